@@ -1,0 +1,166 @@
+/*
+ * mixemt_hip.h -- C ABI of libmixemt_hip.so (MI355X / gfx950).
+ *
+ * The drop-in boundary for mixemt's EM hot path.  The reference has no native
+ * code and no plugin registry: the boundary it offers is four Python functions
+ *   preprocess.build_em_matrix(refseq, phylo, reads, haplogroups, args)   /root/reference/mixemt/preprocess.py:177
+ *   em.em_step(read_hap_mat, weights, ln_props, read_mix_mat)             /root/reference/mixemt/em.py:57
+ *   em.converged(prop, last_prop, tolerance)                              /root/reference/mixemt/em.py:39
+ *   em.run_em(read_hap_mat, weights, args)                                /root/reference/mixemt/em.py:94
+ * Each entry point below names the reference lines whose arithmetic it
+ * replaces.  A Python maintainer binds them with ctypes (INTEGRATION.md shows
+ * the stub); mixemt_amd/{preprocess,em}.py are that binding, re-exposing the
+ * four signatures above.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - `stream` is a hipStream_t passed as void* (NULL = default stream);
+ *     every call only enqueues work on it unless stated otherwise;
+ *   - matrices are row-major with an explicit leading dimension (in elements);
+ *   - return value: 0 = ok, negative = error (text via mxm_last_error());
+ *   - no allocation inside: the caller owns every buffer including `ws`
+ *     (size from mxm_workspace_bytes), so calls are hipGraph-capturable.
+ */
+#ifndef MIXEMT_HIP_H
+#define MIXEMT_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MXM_VERSION 100          /* 0.1.0 */
+
+/* per-restart loop state, written by mxm_m_finalize (16 bytes) */
+typedef struct mxm_em_state {
+    int32_t done;                /* 0 running, 1 converged, 2 max_iter reached */
+    int32_t iters;               /* EM steps executed so far ("Converged! (n)", em.py:135) */
+    double  l1;                  /* last sum_h |p_new - p_cur|  (em.py:53-54) */
+} mxm_em_state;
+
+int         mxm_version(void);
+const char *mxm_last_error(void);
+
+/* Largest haplogroup count the linear-space streaming kernel accepts; above it
+ * (and below MXM_LINEAR_MIN_H) mxm_em_iter runs the generic log-space kernel. */
+int         mxm_linear_supported(int32_t H);
+
+/* Bytes of scratch mxm_em_iter / mxm_em_step / mxm_em_loop need. */
+size_t      mxm_workspace_bytes(int64_t R, int32_t H, int32_t B);
+
+/*
+ * build_em_matrix -- preprocess.py:177-198 (with :69-96 inlined).
+ *   M[r][h] = sum over the row's observations k, IN ORDER, of
+ *             (E[site_k][h] == obs_k ? lhit[site_k] : lmiss[site_k])
+ * E[S][lde]  uint8: the base (ASCII) haplogroup h is expected to show at site s
+ *            (marker if it carries one there, else the reference base; :60-66, :75-83)
+ * lhit/lmiss[S]  log(1-mu_s), log(mu_s/3) computed on the host (:48-51, :80-84)
+ * row_ptr[R+1], site[nnz] (index into the sorted site list), obs[nnz] (ASCII):
+ *            CSR form of the read signatures (:151-160)
+ * lde must be a multiple of 4 and >= H.
+ */
+int mxm_build_em_matrix(const uint8_t *E, int64_t lde,
+                        const double *lhit, const double *lmiss,
+                        const int64_t *row_ptr, const uint16_t *site,
+                        const uint8_t *obs,
+                        int64_t R, int32_t H, int32_t S,
+                        double *M, int64_t ldm, void *stream);
+
+/*
+ * One-time change of variables for the streaming loop:
+ *   rowmax[r] = max_h M[r][h]   (0 if not finite),  P[r][h] = exp(M[r][h] - rowmax[r])
+ * ldp must be even and >= H; pad columns [H, ldp) are written as 0.
+ * (em.py:80-83 evaluated once instead of every iteration; see DESIGN.md.)
+ */
+int mxm_linearize(const double *M, int64_t ldm, int64_t R, int32_t H,
+                  double *P, int64_t ldp, double *rowmax, void *stream);
+
+/*
+ * em_step, E+M fused, this rank's row shard -- em.py:80-88.
+ *   colsum[b][h] = sum_r w[r] * posterior_b[r][h]      (linear space)
+ * where posterior_b is the row-normalised E-step under props[b].
+ * P != NULL and mxm_linear_supported(H): streams P (no transcendental);
+ * otherwise streams M in log space.  Restarts with state[b].done != 0 are
+ * skipped (their colsum is left untouched).
+ * props[B][H] linear proportions (theta_k), w[R] fp64 weights (NULL = all 1).
+ * With several ranks the caller all-reduces (SUM) colsum before mxm_m_finalize.
+ */
+int mxm_em_iter(const double *M, int64_t ldm, const double *P, int64_t ldp,
+                const double *w, const double *props,
+                int64_t R, int32_t H, int32_t B,
+                const mxm_em_state *state, double *colsum,
+                void *ws, size_t ws_bytes, void *stream);
+
+/*
+ * M-step normalisation + convergence test -- em.py:89, :39-54, :133-143.
+ *   p_new = colsum / sum_h colsum ;  l1 = sum_h |p_new - p_cur| ; iters += 1
+ *   l1 < tol -> done = 1 ; else iters >= max_iter -> done = 2 ; else p_cur := p_new
+ * After the loop stops: props_cur = theta_k, props_new = theta_{k+1} -- the pair
+ * the reference returns (posterior one step behind the proportions).
+ */
+int mxm_m_finalize(const double *colsum, double *props_cur, double *props_new,
+                   int32_t H, int32_t B, double tol, int32_t max_iter,
+                   mxm_em_state *state, void *stream);
+
+/*
+ * The run_em inner loop for ONE rank -- em.py:126-143: repeats
+ * {mxm_em_iter; mxm_m_finalize} on `stream` until every restart is done.
+ * Iterations are enqueued in chunks of `check_every`; kernels of a finished
+ * restart are no-ops, so the state freezes on exactly the iteration the
+ * reference would stop on.  Blocks the calling thread (stream sync per chunk).
+ * state_host[B] receives the final states.
+ */
+int mxm_em_loop(const double *M, int64_t ldm, const double *P, int64_t ldp,
+                const double *w, int64_t R, int32_t H, int32_t B,
+                double *props_cur, double *props_new, double *colsum,
+                mxm_em_state *state, double tol, int32_t max_iter,
+                int32_t check_every, void *ws, size_t ws_bytes, void *stream,
+                mxm_em_state *state_host);
+
+/*
+ * E-step with the reference's semantics, writing the posterior -- em.py:80-83:
+ *   out[r][h] = (ln_props[h] + M[r][h]) - logsumexp_h(ln_props + M[r])
+ * mode 0: store; mode 1: out = logaddexp(out, value) (multi-run fold, em.py:156).
+ * colsum (nullable): also the M-step sums sum_r w[r]*exp(out) (em.py:87-88).
+ */
+int mxm_em_step(const double *M, int64_t ldm, const double *w,
+                const double *ln_props, int64_t R, int32_t H,
+                double *out, int64_t ldo, int32_t mode, double *colsum,
+                void *ws, size_t ws_bytes, void *stream);
+
+/* ln_new[h] = log(colsum[h]) - log(sum_h colsum[h])   (em.py:87-89) */
+int mxm_log_normalize(const double *colsum, int32_t H, double *ln_new,
+                      void *stream);
+
+/* l1_out[0] = sum_h |exp(a[h]) - exp(b[h])|   (em.py:53-54) */
+int mxm_l1_exp_diff(const double *a, const double *b, int32_t H,
+                    double *l1_out, void *stream);
+
+/* x[i] += delta over an [R][ld] matrix's first H columns (em.py:161) */
+int mxm_add_scalar(double *x, int64_t ld, int64_t R, int32_t H, double delta,
+                   void *stream);
+
+/*
+ * Row argmax + weighted votes -- assemble.py:115-123 / stats.py:39-40:
+ *   best[r] = first index of max_h X[r][h] ;  votes[h] = sum_{r: best[r]==h} w[r]
+ * votes[H] must be zeroed by the caller; w NULL = 1.
+ */
+int mxm_row_argmax_votes(const double *X, int64_t ldx, const double *w,
+                         int64_t R, int32_t H, int32_t *best, double *votes,
+                         void *stream);
+
+/*
+ * Measurement hook (bench.py): when both handles are non-NULL, mxm_em_iter
+ * records hipEvent_t `ev_start` / `ev_stop` on its stream immediately before /
+ * after the streaming kernel (the dominant one), so its device time can be read
+ * without a profiler.  Pass NULLs to switch it off.  Not part of the reference
+ * boundary.
+ */
+int mxm_set_timing_events(void *ev_start, void *ev_stop);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIXEMT_HIP_H */

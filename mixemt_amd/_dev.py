@@ -1,0 +1,44 @@
+"""
+Device-memory plumbing: PyTorch-ROCm is the allocator / stream model, nothing
+more.  Raw pointers and the current HIP stream are handed to the C ABI.
+"""
+
+import numpy
+
+try:
+    import torch
+except ImportError:          # pragma: no cover - the image always has torch
+    torch = None
+
+
+def require_gpu():
+    """The product path has no CPU fallback: fail loudly without a GPU."""
+    if torch is None:
+        raise RuntimeError("mixemt_amd needs PyTorch-ROCm for device memory")
+    if not torch.cuda.is_available():
+        raise RuntimeError("mixemt_amd: no ROCm GPU visible -- the EM hot path runs only on "
+                           "the HIP kernels (no CPU fallback)")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def current_stream():
+    """hipStream_t of torch's current stream, as an integer for ctypes."""
+    return torch.cuda.current_stream().cuda_stream
+
+
+def as_device(x, dtype, dev):
+    """numpy array / tensor -> contiguous device tensor of `dtype`."""
+    if isinstance(x, torch.Tensor):
+        if dtype == torch.uint16:
+            return x.to(device=dev).contiguous()      # already a 16-bit bit pattern
+        return x.to(device=dev, dtype=dtype).contiguous()
+    arr = numpy.ascontiguousarray(x)
+    if dtype == torch.uint16:
+        # torch has no first-class uint16 arithmetic; only the bytes matter here
+        arr = numpy.ascontiguousarray(arr.astype(numpy.uint16, copy=False))
+        return torch.from_numpy(arr.view(numpy.int16)).to(dev)
+    return torch.from_numpy(arr).to(device=dev).to(dtype).contiguous()
+
+
+def ptr(t):
+    return 0 if t is None else t.data_ptr()

@@ -1,0 +1,83 @@
+"""
+ctypes binding of libmixemt_hip.so (the C ABI in include/mixemt_hip.h).
+
+There is no CPU fallback: if the shared object is missing or a symbol cannot
+be resolved this module raises, and every product entry point raises with it.
+"""
+
+import ctypes
+import os
+
+_PKG = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_PKG, "lib", "libmixemt_hip.so")
+
+c_i32, c_i64, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
+c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
+
+
+class EmState(ctypes.Structure):
+    """mxm_em_state (include/mixemt_hip.h)."""
+    _fields_ = [("done", c_i32), ("iters", c_i32), ("l1", c_f64)]
+
+
+# name -> (restype, argtypes); must list every symbol the header declares
+SIGNATURES = {
+    "mxm_version": (ctypes.c_int, []),
+    "mxm_last_error": (ctypes.c_char_p, []),
+    "mxm_linear_supported": (ctypes.c_int, [c_i32]),
+    "mxm_workspace_bytes": (c_size, [c_i64, c_i32, c_i32]),
+    "mxm_build_em_matrix": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                           c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
+    "mxm_linearize": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
+    "mxm_em_iter": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32,
+                                   c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "mxm_m_finalize": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f64, c_i32, c_ptr,
+                                      c_ptr]),
+    "mxm_em_loop": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32,
+                                   c_ptr, c_ptr, c_ptr, c_ptr, c_f64, c_i32, c_i32, c_ptr, c_size,
+                                   c_ptr, ctypes.POINTER(EmState)]),
+    "mxm_em_step": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_i32,
+                                   c_ptr, c_ptr, c_size, c_ptr]),
+    "mxm_log_normalize": (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_ptr]),
+    "mxm_l1_exp_diff": (ctypes.c_int, [c_ptr, c_ptr, c_i32, c_ptr, c_ptr]),
+    "mxm_add_scalar": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_f64, c_ptr]),
+    "mxm_set_timing_events": (ctypes.c_int, [c_ptr, c_ptr]),
+    "mxm_row_argmax_votes": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
+                                            c_ptr]),
+}
+
+_lib = None
+
+
+class MixemtHipError(RuntimeError):
+    pass
+
+
+def load():
+    """dlopen the library and bind every symbol; raises if anything is missing."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MixemtHipError(
+            "libmixemt_hip.so is not built (%s); run `python -m mixemt_amd.build` -- "
+            "there is no CPU fallback for the EM hot path" % LIB_PATH)
+    # PyTorch-ROCm first: it brings the HIP runtime (soname libamdhip64.so.7) this
+    # library binds to, so both share ONE runtime -- streams and pointers are then
+    # interchangeable.  Loading order matters; a second runtime must not appear.
+    from . import _dev  # noqa: F401
+    lib = ctypes.CDLL(LIB_PATH)
+    for name, (restype, argtypes) in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is absent
+        fn.restype = restype
+        fn.argtypes = argtypes
+    _lib = lib
+    return lib
+
+
+def check(rc, what):
+    """Turn a negative status into the exception the reference's CLI catches
+    (ValueError, bin/mixemt:325-327)."""
+    if rc != 0:
+        msg = load().mxm_last_error().decode("utf-8", "replace")
+        raise ValueError("%s failed (%d): %s" % (what, rc, msg))

@@ -1,0 +1,709 @@
+// mixemt_hip.hip -- gfx950 (MI355X, CDNA4) kernels + C ABI for mixemt's EM hot path.
+//
+// Replaces, behind include/mixemt_hip.h:
+//   preprocess.build_em_matrix   /root/reference/mixemt/preprocess.py:177-198
+//   em.em_step / em.run_em loop  /root/reference/mixemt/em.py:57-91, :126-143
+//
+// Everything here is HBM-bound byte/fp64 streaming + reductions: 64-wide
+// wavefronts, 16-byte coalesced loads, rows held in VGPRs between the row
+// reduction and the column accumulation, deterministic two-stage column sums
+// (no float atomics).  No MFMA: there is no contraction to feed it.
+//
+// Kernel map (DESIGN.md has the roofline of each):
+//   build_em_matrix_kernel  R*H*8 B written, E table served from L2/MALL
+//   linearize_kernel        one-time  P = exp(M - rowmax)
+//   em_iter_wide_kernel     THE hot kernel: R*H*8 B read per EM iteration
+//   estep_log_kernel        reference-semantics E-step (posterior pass, small H)
+//   colreduce_kernel        [nWG][H] partials -> colsum[H], fixed order
+//   finalize_kernel         normalise, L1 test, loop state
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include <math.h>
+
+#include "mixemt_hip.h"
+
+#define MXM_MAX_WG 1024            // upper bound on the persistent grid (workspace sizing)
+#define MXM_WIDE_THREADS 256
+#define MXM_WIDE_MAX_NCH 16        // double2 chunks per thread -> H <= 2*256*16 = 8192
+#define MXM_LINEAR_MIN_H 65        // below this the log-space kernel is used
+
+// ------------------------------------------------------------------------------------------
+// error plumbing
+// ------------------------------------------------------------------------------------------
+static thread_local char g_err[512] = "";
+
+static int fail(int code, const char *fmt, const char *a = "", long long b = 0, long long c = 0) {
+    snprintf(g_err, sizeof(g_err), fmt, a, b, c);
+    return code;
+}
+#define HIP_TRY(expr)                                                                        \
+    do {                                                                                     \
+        hipError_t e_ = (expr);                                                              \
+        if (e_ != hipSuccess) return fail(-2, "HIP error: %s (line %lld)", hipGetErrorString(e_), __LINE__); \
+    } while (0)
+
+static int g_num_cu = 0;
+static int num_cu() {
+    if (g_num_cu == 0) {
+        int dev = 0;
+        hipDeviceProp_t prop;
+        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    }
+    return g_num_cu;
+}
+
+// ------------------------------------------------------------------------------------------
+// wave / workgroup reductions (wave = 64 lanes on gfx950)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+}
+__device__ __forceinline__ double wave_max(double v) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v = fmax(v, __shfl_xor(v, off, 64));
+    return v;
+}
+
+// all threads get the result; `scratch` holds THREADS/64 doubles; two barriers
+template <int THREADS, bool IS_MAX>
+__device__ __forceinline__ double block_reduce(double v, double *scratch) {
+    constexpr int NW = THREADS / 64;
+    v = IS_MAX ? wave_max(v) : wave_sum(v);
+    __syncthreads();                       // scratch free (previous use finished)
+    if ((threadIdx.x & 63) == 0) scratch[threadIdx.x >> 6] = v;
+    __syncthreads();
+    double r = scratch[0];
+#pragma unroll
+    for (int i = 1; i < NW; ++i) r = IS_MAX ? fmax(r, scratch[i]) : r + scratch[i];
+    return r;
+}
+
+__device__ __forceinline__ double logaddexp_f64(double a, double b) {
+    // numpy.logaddexp semantics (em.py:156)
+    if (a == b) return a + 0.693147180559945309417232121458176568;   // covers +-inf ties
+    double d = a - b;
+    if (d > 0) return a + log1p(exp(-d));
+    if (d <= 0) return b + log1p(exp(d));
+    return d;                                                         // NaN
+}
+
+// ------------------------------------------------------------------------------------------
+// K1  build_em_matrix  (preprocess.py:177-198, :69-96)
+// One workgroup per read row (grid-stride); a thread owns 4 adjacent haplogroup
+// columns per 1024-column tile and adds the per-site terms IN SIGNATURE ORDER,
+// so every cell is the same fp64 sum the reference forms.
+// ------------------------------------------------------------------------------------------
+#define BUILD_THREADS 256
+#define BUILD_CAP 512              // observations staged in LDS per pass
+
+__global__ __launch_bounds__(BUILD_THREADS) void build_em_matrix_kernel(
+    const uint8_t *__restrict__ E, int64_t lde, const double *__restrict__ lhit,
+    const double *__restrict__ lmiss, const int64_t *__restrict__ row_ptr,
+    const uint16_t *__restrict__ site, const uint8_t *__restrict__ obs, int64_t R, int H,
+    double *__restrict__ M, int64_t ldm) {
+    __shared__ int64_t s_off[BUILD_CAP];     // site * lde
+    __shared__ uint32_t s_obs[BUILD_CAP];
+    __shared__ double s_hit[BUILD_CAP];
+    __shared__ double s_miss[BUILD_CAP];
+    const int t = threadIdx.x;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const int64_t beg = row_ptr[r], end = row_ptr[r + 1];
+        for (int cb = 0; cb < H; cb += BUILD_THREADS * 4) {
+            const int h = cb + 4 * t;
+            double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+            for (int64_t j0 = beg; j0 < end; j0 += BUILD_CAP) {
+                const int n = (int)((end - j0) < BUILD_CAP ? (end - j0) : BUILD_CAP);
+                __syncthreads();
+                for (int j = t; j < n; j += BUILD_THREADS) {
+                    const int s = site[j0 + j];
+                    s_off[j] = (int64_t)s * lde;
+                    s_obs[j] = obs[j0 + j];
+                    s_hit[j] = lhit[s];
+                    s_miss[j] = lmiss[s];
+                }
+                __syncthreads();
+                if (h < H) {
+                    for (int j = 0; j < n; ++j) {
+                        const uint32_t e4 = *reinterpret_cast<const uint32_t *>(E + s_off[j] + h);
+                        const uint32_t o = s_obs[j];
+                        const double hit = s_hit[j], miss = s_miss[j];
+                        a0 += ((e4 & 0xffu) == o) ? hit : miss;
+                        a1 += (((e4 >> 8) & 0xffu) == o) ? hit : miss;
+                        a2 += (((e4 >> 16) & 0xffu) == o) ? hit : miss;
+                        a3 += ((e4 >> 24) == o) ? hit : miss;
+                    }
+                }
+            }
+            if (h < H) {
+                double *dst = M + r * ldm + h;
+                dst[0] = a0;
+                if (h + 1 < H) dst[1] = a1;
+                if (h + 2 < H) dst[2] = a2;
+                if (h + 3 < H) dst[3] = a3;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K2  linearize:  rowmax[r], P[r][h] = exp(M[r][h] - rowmax[r])   (one-time)
+// ------------------------------------------------------------------------------------------
+#define ROW_THREADS 256
+
+__global__ __launch_bounds__(ROW_THREADS) void linearize_kernel(const double *__restrict__ M,
+                                                                int64_t ldm, int64_t R, int H,
+                                                                double *__restrict__ P, int64_t ldp,
+                                                                double *__restrict__ rowmax) {
+    __shared__ double scratch[ROW_THREADS / 64];
+    const int t = threadIdx.x;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const double *src = M + r * ldm;
+        double m = -INFINITY;
+        for (int h = t; h < H; h += ROW_THREADS) m = fmax(m, src[h]);
+        m = block_reduce<ROW_THREADS, true>(m, scratch);
+        const double shift = isfinite(m) ? m : 0.0;
+        double *dst = P + r * ldp;
+        for (int h = t; h < (int)ldp; h += ROW_THREADS) dst[h] = (h < H) ? exp(src[h] - shift) : 0.0;
+        if (t == 0) rowmax[r] = shift;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3  em_iter_wide: fused E+M step in linear space, one restart.
+//
+//   Z_r      = sum_h p_h P_rh                     (row reduction)
+//   acc_h   += (w_r / Z_r) * P_rh                 (column accumulation, per workgroup)
+//   colsum_h = p_h * sum_wg acc_h                 (colreduce_kernel)
+//
+// which is em.py:80-88 with exp(M - rowmax) hoisted out of the loop:
+//   posterior_rh = p_h P_rh / Z_r,   colsum_h = sum_r w_r posterior_rh.
+//
+// A workgroup (256 threads) owns a contiguous block of rows.  Thread t owns the
+// double2 column pairs {t + 256 k}, k < NCH: one 16-byte load per pair per row
+// (a wave instruction covers 1 KiB contiguous), the row stays in VGPRs between
+// the dot product and the accumulation, so the matrix is read from HBM exactly
+// once per iteration.  T rows are in flight per step and the next step's loads
+// are issued before the current step's reduction (register double buffer).
+// Column partials live in registers for the whole kernel and are written once:
+// partial[wg][h], summed in fixed order afterwards -> bitwise reproducible.
+// ------------------------------------------------------------------------------------------
+typedef double d2 __attribute__((ext_vector_type(2)));
+
+template <int NCH, int T>
+__global__ __launch_bounds__(MXM_WIDE_THREADS) void em_iter_wide_kernel(
+    const double *__restrict__ P, int64_t ldp, const double *__restrict__ w,
+    const double *__restrict__ props, int64_t R, int H, int64_t rows_per_wg,
+    double *__restrict__ partial, int64_t ldpart, const mxm_em_state *__restrict__ state) {
+    constexpr int THREADS = MXM_WIDE_THREADS;
+    constexpr int NW = THREADS / 64;
+    __shared__ double red[2][T][NW];
+    if (state != nullptr && state->done != 0) return;
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int ncol2 = (H + 1) >> 1;                 // d2 pairs per row (pad column is 0 in P)
+
+    d2 p[NCH], acc[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = 2 * (t + k * THREADS);
+        p[k].x = (c < H) ? props[c] : 0.0;
+        p[k].y = (c + 1 < H) ? props[c + 1] : 0.0;
+        acc[k] = d2{0.0, 0.0};
+    }
+
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < R) ? (r0 + rows_per_wg) : R;
+    const bool last_ok = (t + (NCH - 1) * THREADS) < ncol2;
+
+    d2 xa[T][NCH], xb[T][NCH];
+
+    auto load_rows = [&](d2(&x)[T][NCH], int64_t r) {
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            const bool live = (r + i) < r1;
+            const d2 *row = reinterpret_cast<const d2 *>(P + (r + i) * ldp);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const bool ok = live && (k < NCH - 1 || last_ok);
+                x[i][k] = ok ? __builtin_nontemporal_load(row + t + k * THREADS)
+                             : d2{0.0, 0.0};
+            }
+        }
+    };
+
+    int buf = 0;
+    auto process = [&](d2(&x)[T][NCH], int64_t r) {
+        double d[T];
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                s = fma(x[i][k].x, p[k].x, s);
+                s = fma(x[i][k].y, p[k].y, s);
+            }
+            d[i] = s;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) d[i] += __shfl_xor(d[i], off, 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int i = 0; i < T; ++i) red[buf][i][wv] = d[i];
+        }
+        __syncthreads();
+#pragma unroll
+        for (int i = 0; i < T; ++i) {
+            double z = red[buf][i][0];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) z += red[buf][i][q];
+            const bool live = (r + i) < r1;
+            const double wr = live ? (w != nullptr ? w[r + i] : 1.0) : 0.0;
+            const double c = (z > 0.0) ? wr / z : 0.0;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                acc[k].x = fma(c, x[i][k].x, acc[k].x);
+                acc[k].y = fma(c, x[i][k].y, acc[k].y);
+            }
+        }
+        buf ^= 1;
+    };
+
+    load_rows(xa, r0);
+    for (int64_t r = r0; r < r1; r += 2 * T) {
+        load_rows(xb, r + T);
+        process(xa, r);
+        load_rows(xa, r + 2 * T);
+        process(xb, r + T);
+    }
+
+    d2 *dst = reinterpret_cast<d2 *>(partial + (int64_t)blockIdx.x * ldpart);
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c2 = t + k * THREADS;
+        if (c2 < ncol2) dst[c2] = acc[k];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4  colreduce: colsum[h] = scale_h * sum_{g < nwg} partial[g][h]   (fixed order)
+// 64 columns per workgroup; 4 waves take interleaved quarters of the partial rows.
+// scale_h = props[h] for the linear kernel, 1 for the log-space kernel.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void colreduce_kernel(const double *__restrict__ partial,
+                                                        int64_t ldpart, int nwg, int H,
+                                                        const double *__restrict__ props,
+                                                        double *__restrict__ colsum,
+                                                        const mxm_em_state *__restrict__ state) {
+    __shared__ double part[4][64];
+    if (state != nullptr && state->done != 0) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int h = blockIdx.x * 64 + lane;
+    double s = 0.0;
+    if (h < H)
+        for (int g = wv; g < nwg; g += 4) s += partial[(int64_t)g * ldpart + h];
+    part[wv][lane] = s;
+    __syncthreads();
+    if (wv == 0 && h < H) {
+        const double tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        colsum[h] = (props != nullptr) ? props[h] * tot : tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5  finalize: em.py:89 (normalise), :39-54 (L1 test), :133-143 (loop state). One WG per restart.
+// ------------------------------------------------------------------------------------------
+#define FIN_THREADS 1024
+
+__global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(const double *__restrict__ colsum,
+                                                               double *__restrict__ props_cur,
+                                                               double *__restrict__ props_new, int H,
+                                                               double tol, int max_iter,
+                                                               mxm_em_state *__restrict__ state) {
+    __shared__ double scratch[FIN_THREADS / 64];
+    const int b = blockIdx.x;
+    mxm_em_state *st = state + b;
+    if (st->done != 0) return;
+    const double *cs = colsum + (int64_t)b * H;
+    double *pc = props_cur + (int64_t)b * H;
+    double *pn = props_new + (int64_t)b * H;
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int h = t; h < H; h += FIN_THREADS) s += cs[h];
+    const double total = block_reduce<FIN_THREADS, false>(s, scratch);
+    double l1 = 0.0;
+    for (int h = t; h < H; h += FIN_THREADS) {
+        const double v = cs[h] / total;
+        pn[h] = v;
+        l1 += fabs(v - pc[h]);
+    }
+    l1 = block_reduce<FIN_THREADS, false>(l1, scratch);
+    const int iters = st->iters + 1;
+    const bool conv = l1 < tol;
+    const bool stop = conv || iters >= max_iter;
+    if (!stop)
+        for (int h = t; h < H; h += FIN_THREADS) pc[h] = pn[h];
+    __syncthreads();
+    if (t == 0) {
+        st->iters = iters;
+        st->l1 = l1;
+        st->done = conv ? 1 : (stop ? 2 : 0);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6  estep_log: the reference's E-step verbatim in log space (em.py:80-83), optional posterior
+// write / logaddexp fold (em.py:156) and optional M-step sums (em.py:87-88, linear space).
+// One workgroup per row (grid-stride), column sums in LDS (each thread owns its columns).
+// Used for em_step(), the final posterior pass, and EM iterations when H is tiny.
+// ------------------------------------------------------------------------------------------
+template <bool FROM_LINEAR_PROPS>
+__global__ __launch_bounds__(ROW_THREADS) void estep_log_kernel(
+    const double *__restrict__ M, int64_t ldm, const double *__restrict__ w,
+    const double *__restrict__ pvec, int64_t R, int H, double *__restrict__ out, int64_t ldo,
+    int mode, double *__restrict__ partial, int64_t ldpart,
+    const mxm_em_state *__restrict__ state) {
+    extern __shared__ double dyn[];            // [H] column sums (if partial) + [H] ln props
+    __shared__ double scratch[ROW_THREADS / 64];
+    if (state != nullptr && state->done != 0) return;
+    const int t = threadIdx.x;
+    double *lnp = dyn;
+    double *acc = dyn + H;
+    for (int h = t; h < H; h += ROW_THREADS) {
+        lnp[h] = FROM_LINEAR_PROPS ? log(pvec[h]) : pvec[h];
+        if (partial != nullptr) acc[h] = 0.0;
+    }
+    __syncthreads();
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const double *src = M + r * ldm;
+        double m = -INFINITY;
+        for (int h = t; h < H; h += ROW_THREADS) m = fmax(m, lnp[h] + src[h]);
+        m = block_reduce<ROW_THREADS, true>(m, scratch);
+        const double shift = isfinite(m) ? m : 0.0;
+        double s = 0.0;
+        for (int h = t; h < H; h += ROW_THREADS) s += exp((lnp[h] + src[h]) - shift);
+        s = block_reduce<ROW_THREADS, false>(s, scratch);
+        const double lse = log(s) + m;          // m (not shift): -inf rows give -inf, as scipy does
+        const double wr = (w != nullptr) ? w[r] : 1.0;
+        for (int h = t; h < H; h += ROW_THREADS) {
+            const double v = (lnp[h] + src[h]) - lse;
+            if (out != nullptr) {
+                double *o = out + r * ldo + h;
+                *o = (mode == 1) ? logaddexp_f64(*o, v) : v;
+            }
+            if (partial != nullptr) acc[h] += wr * exp(v);
+        }
+    }
+    if (partial != nullptr) {
+        double *dst = partial + (int64_t)blockIdx.x * ldpart;
+        for (int h = t; h < H; h += ROW_THREADS) dst[h] = acc[h];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// small vector kernels (one workgroup)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FIN_THREADS) void log_normalize_kernel(const double *__restrict__ colsum,
+                                                                    int H, double *__restrict__ ln_new) {
+    __shared__ double scratch[FIN_THREADS / 64];
+    double s = 0.0;
+    for (int h = threadIdx.x; h < H; h += FIN_THREADS) s += colsum[h];
+    const double lt = log(block_reduce<FIN_THREADS, false>(s, scratch));
+    for (int h = threadIdx.x; h < H; h += FIN_THREADS) ln_new[h] = log(colsum[h]) - lt;
+}
+
+__global__ __launch_bounds__(FIN_THREADS) void l1_exp_diff_kernel(const double *__restrict__ a,
+                                                                  const double *__restrict__ b, int H,
+                                                                  double *__restrict__ out) {
+    __shared__ double scratch[FIN_THREADS / 64];
+    double s = 0.0;
+    for (int h = threadIdx.x; h < H; h += FIN_THREADS) s += fabs(exp(a[h]) - exp(b[h]));
+    s = block_reduce<FIN_THREADS, false>(s, scratch);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+__global__ __launch_bounds__(256) void add_scalar_kernel(double *__restrict__ x, int64_t ld, int64_t R,
+                                                         int H, double delta) {
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        double *row = x + r * ld;
+        for (int h = threadIdx.x; h < H; h += 256) row[h] += delta;
+    }
+}
+
+// first index of the row maximum (numpy.argmax: a NaN counts as the maximum, first one wins)
+// + weighted votes (assemble.py:115-123).  Candidate order: NaN before numbers, then larger
+// value, then smaller index.
+__device__ __forceinline__ bool cand_better(int an, double av, int ai, int bn, double bv, int bi) {
+    if (an != bn) return an > bn;
+    if (an == 0 && av != bv) return av > bv;
+    return ai < bi;
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void row_argmax_votes_kernel(
+    const double *__restrict__ X, int64_t ldx, const double *__restrict__ w, int64_t R, int H,
+    int32_t *__restrict__ best, double *__restrict__ votes) {
+    constexpr int NW = ROW_THREADS / 64;
+    __shared__ double s_val[NW];
+    __shared__ int s_idx[NW];
+    __shared__ int s_nan[NW];
+    const int t = threadIdx.x;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const double *row = X + r * ldx;
+        int cn = 0, ci = 0x7fffffff;
+        double cv = -INFINITY;
+        for (int h = t; h < H; h += ROW_THREADS) {
+            const double v = row[h];
+            const int vn = (v != v) ? 1 : 0;
+            if (cand_better(vn, v, h, cn, cv, ci)) { cn = vn; cv = v; ci = h; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(cv, off, 64);
+            const int oi = __shfl_xor(ci, off, 64);
+            const int on = __shfl_xor(cn, off, 64);
+            if (cand_better(on, ov, oi, cn, cv, ci)) { cn = on; cv = ov; ci = oi; }
+        }
+        __syncthreads();
+        if ((t & 63) == 0) { s_val[t >> 6] = cv; s_idx[t >> 6] = ci; s_nan[t >> 6] = cn; }
+        __syncthreads();
+        if (t == 0) {
+            for (int q = 1; q < NW; ++q)
+                if (cand_better(s_nan[q], s_val[q], s_idx[q], cn, cv, ci)) { cn = s_nan[q]; cv = s_val[q]; ci = s_idx[q]; }
+            if (ci >= H) ci = 0;
+            best[r] = ci;
+            if (votes != nullptr) atomicAdd(votes + ci, (w != nullptr) ? w[r] : 1.0);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// host side of the C ABI
+// ------------------------------------------------------------------------------------------
+static inline int clamp_grid(int64_t want, int cap) {
+    if (want < 1) want = 1;
+    return (int)(want < cap ? want : cap);
+}
+
+static inline int64_t part_ld(int H) { return ((int64_t)H + 1) & ~(int64_t)1; }
+
+extern "C" int mxm_version(void) { return MXM_VERSION; }
+extern "C" const char *mxm_last_error(void) { return g_err; }
+
+extern "C" int mxm_linear_supported(int32_t H) {
+    return (H >= MXM_LINEAR_MIN_H && H <= 2 * MXM_WIDE_THREADS * MXM_WIDE_MAX_NCH) ? 1 : 0;
+}
+
+extern "C" size_t mxm_workspace_bytes(int64_t R, int32_t H, int32_t B) {
+    (void)R;
+    (void)B;                      // restarts are processed one at a time over the same scratch
+    return (size_t)MXM_MAX_WG * (size_t)part_ld(H) * sizeof(double);
+}
+
+extern "C" int mxm_build_em_matrix(const uint8_t *E, int64_t lde, const double *lhit,
+                                   const double *lmiss, const int64_t *row_ptr, const uint16_t *site,
+                                   const uint8_t *obs, int64_t R, int32_t H, int32_t S, double *M,
+                                   int64_t ldm, void *stream) {
+    if (R < 0 || H <= 0 || S <= 0) return fail(-1, "mxm_build_em_matrix: bad shape R=%s%lld H=%lld", "", R, H);
+    if (lde < (((int64_t)H + 3) & ~(int64_t)3) || (lde & 3) != 0) return fail(-1, "mxm_build_em_matrix: lde must be a multiple of 4 and >= H%s (lde=%lld)", "", lde);
+    if (ldm < H) return fail(-1, "mxm_build_em_matrix: ldm < H%s", "");
+    if (S > 65536) return fail(-1, "mxm_build_em_matrix: more than 65536 variant sites%s", "");
+    if (R == 0) return 0;
+    const int grid = clamp_grid(R, num_cu() * 8);
+    hipLaunchKernelGGL(build_em_matrix_kernel, dim3(grid), dim3(BUILD_THREADS), 0, (hipStream_t)stream, E,
+                       lde, lhit, lmiss, row_ptr, site, obs, R, (int)H, M, ldm);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_linearize(const double *M, int64_t ldm, int64_t R, int32_t H, double *P, int64_t ldp,
+                             double *rowmax, void *stream) {
+    if (R < 0 || H <= 0) return fail(-1, "mxm_linearize: bad shape%s", "");
+    if (ldm < H || ldp < H || (ldp & 1)) return fail(-1, "mxm_linearize: ldp must be even and >= H%s (ldp=%lld)", "", ldp);
+    if (R == 0) return 0;
+    const int grid = clamp_grid(R, num_cu() * 8);
+    hipLaunchKernelGGL(linearize_kernel, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, M, ldm, R,
+                       (int)H, P, ldp, rowmax);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// ---- optional timing hook (bench.py): events recorded right around the dominant kernel --------
+static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+extern "C" int mxm_set_timing_events(void *ev_start, void *ev_stop) {
+    g_ev_start = (hipEvent_t)ev_start;
+    g_ev_stop = (hipEvent_t)ev_stop;
+    return 0;
+}
+
+// ---- wide-kernel dispatch over NCH ------------------------------------------------------------
+#ifndef MXM_WIDE_T
+#define MXM_WIDE_T 1
+#endif
+#ifndef MXM_WIDE_WG_PER_CU
+#define MXM_WIDE_WG_PER_CU 2
+#endif
+
+template <int NCH>
+static void launch_wide(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
+                        int H, int grid, int64_t rows_per_wg, double *partial, int64_t ldpart,
+                        const mxm_em_state *state, hipStream_t stream) {
+    hipLaunchKernelGGL((em_iter_wide_kernel<NCH, MXM_WIDE_T>), dim3(grid), dim3(MXM_WIDE_THREADS), 0,
+                       stream, P, ldp, w, props, R, H, rows_per_wg, partial, ldpart, state);
+}
+
+static int em_iter_one(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
+                       const double *props, int64_t R, int H, const mxm_em_state *state, double *colsum,
+                       double *partial, hipStream_t stream) {
+    const int64_t ldpart = part_ld(H);
+    int nwg;
+    if (P != nullptr && mxm_linear_supported(H)) {
+        const int ncol2 = (H + 1) / 2;
+        const int nch = (ncol2 + MXM_WIDE_THREADS - 1) / MXM_WIDE_THREADS;
+        const int64_t steps = (R + 2 * MXM_WIDE_T - 1) / (2 * MXM_WIDE_T);
+        nwg = clamp_grid(steps, num_cu() * MXM_WIDE_WG_PER_CU < MXM_MAX_WG ? num_cu() * MXM_WIDE_WG_PER_CU : MXM_MAX_WG);
+        int64_t rows_per_wg = (R + nwg - 1) / nwg;
+        rows_per_wg = (rows_per_wg + 2 * MXM_WIDE_T - 1) / (2 * MXM_WIDE_T) * (2 * MXM_WIDE_T);
+        nwg = (int)((R + rows_per_wg - 1) / rows_per_wg);
+        if (g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
+        switch (nch) {
+#define WIDE_CASE(n) case n: launch_wide<n>(P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream); break;
+            WIDE_CASE(1) WIDE_CASE(2) WIDE_CASE(3) WIDE_CASE(4) WIDE_CASE(5) WIDE_CASE(6) WIDE_CASE(7) WIDE_CASE(8)
+            WIDE_CASE(9) WIDE_CASE(10) WIDE_CASE(11) WIDE_CASE(12) WIDE_CASE(13) WIDE_CASE(14) WIDE_CASE(15) WIDE_CASE(16)
+#undef WIDE_CASE
+            default: return fail(-1, "mxm_em_iter: H=%s%lld outside the linear kernel's range", "", H);
+        }
+        HIP_TRY(hipGetLastError());
+        if (g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
+        hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64), dim3(256), 0, stream, partial, ldpart, nwg,
+                           H, props, colsum, state);
+    } else {
+        if (M == nullptr) return fail(-1, "mxm_em_iter: M is NULL and the linear path does not apply%s", "");
+        const size_t lds = 2 * (size_t)H * sizeof(double);
+        if (lds > 150 * 1024) return fail(-1, "mxm_em_iter: H=%s%lld too large for the log-space kernel", "", H);
+        nwg = clamp_grid(R, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
+        hipLaunchKernelGGL((estep_log_kernel<true>), dim3(nwg), dim3(ROW_THREADS), lds, stream, M, ldm, w, props,
+                           R, H, (double *)nullptr, (int64_t)0, 0, partial, ldpart, state);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64), dim3(256), 0, stream, partial, ldpart, nwg,
+                           H, (const double *)nullptr, colsum, state);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_em_iter(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
+                           const double *props, int64_t R, int32_t H, int32_t B, const mxm_em_state *state,
+                           double *colsum, void *ws, size_t ws_bytes, void *stream) {
+    if (R <= 0 || H <= 0 || B <= 0) return fail(-1, "mxm_em_iter: bad shape R=%s%lld H=%lld", "", R, H);
+    if (ws == nullptr || ws_bytes < mxm_workspace_bytes(R, H, B)) return fail(-1, "mxm_em_iter: workspace too small%s", "");
+    if (P != nullptr && ((ldp & 1) || ldp < H)) return fail(-1, "mxm_em_iter: ldp must be even and >= H%s", "");
+    if (M != nullptr && ldm < H) return fail(-1, "mxm_em_iter: ldm < H%s", "");
+    for (int b = 0; b < B; ++b) {
+        const int rc = em_iter_one(M, ldm, P, ldp, w, props + (int64_t)b * H, R, (int)H,
+                                   state ? state + b : nullptr, colsum + (int64_t)b * H, (double *)ws,
+                                   (hipStream_t)stream);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
+extern "C" int mxm_m_finalize(const double *colsum, double *props_cur, double *props_new, int32_t H, int32_t B,
+                              double tol, int32_t max_iter, mxm_em_state *state, void *stream) {
+    if (H <= 0 || B <= 0 || state == nullptr) return fail(-1, "mxm_m_finalize: bad arguments%s", "");
+    hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), 0, (hipStream_t)stream, colsum, props_cur,
+                       props_new, (int)H, tol, (int)max_iter, state);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_em_loop(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
+                           int64_t R, int32_t H, int32_t B, double *props_cur, double *props_new,
+                           double *colsum, mxm_em_state *state, double tol, int32_t max_iter,
+                           int32_t check_every, void *ws, size_t ws_bytes, void *stream,
+                           mxm_em_state *state_host) {
+    if (state_host == nullptr || state == nullptr) return fail(-1, "mxm_em_loop: state pointers required%s", "");
+    if (check_every < 1) check_every = 1;
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
+    HIP_TRY(hipStreamSynchronize(s));
+    int64_t issued = 0;
+    for (;;) {
+        bool all_done = true;
+        for (int b = 0; b < B; ++b) all_done = all_done && (state_host[b].done != 0);
+        if (all_done || issued >= (int64_t)max_iter) break;
+        int64_t n = max_iter - issued;
+        if (n > check_every) n = check_every;
+        for (int64_t i = 0; i < n; ++i) {
+            int rc = mxm_em_iter(M, ldm, P, ldp, w, props_cur, R, H, B, state, colsum, ws, ws_bytes, stream);
+            if (rc != 0) return rc;
+            rc = mxm_m_finalize(colsum, props_cur, props_new, H, B, tol, max_iter, state, stream);
+            if (rc != 0) return rc;
+        }
+        issued += n;
+        HIP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+    }
+    return 0;
+}
+
+extern "C" int mxm_em_step(const double *M, int64_t ldm, const double *w, const double *ln_props, int64_t R,
+                           int32_t H, double *out, int64_t ldo, int32_t mode, double *colsum, void *ws,
+                           size_t ws_bytes, void *stream) {
+    if (R <= 0 || H <= 0 || ldm < H) return fail(-1, "mxm_em_step: bad shape%s", "");
+    if (out != nullptr && ldo < H) return fail(-1, "mxm_em_step: ldo < H%s", "");
+    if (colsum != nullptr && (ws == nullptr || ws_bytes < mxm_workspace_bytes(R, H, 1)))
+        return fail(-1, "mxm_em_step: workspace too small%s", "");
+    const size_t lds = 2 * (size_t)H * sizeof(double);
+    if (lds > 150 * 1024) return fail(-1, "mxm_em_step: H=%s%lld too large", "", H);
+    const int64_t ldpart = part_ld(H);
+    const int nwg = clamp_grid(R, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL((estep_log_kernel<false>), dim3(nwg), dim3(ROW_THREADS), lds, s, M, ldm, w, ln_props, R,
+                       (int)H, out, ldo, (int)mode, colsum ? (double *)ws : (double *)nullptr, ldpart,
+                       (const mxm_em_state *)nullptr);
+    HIP_TRY(hipGetLastError());
+    if (colsum != nullptr) {
+        hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64), dim3(256), 0, s, (const double *)ws, ldpart, nwg,
+                           (int)H, (const double *)nullptr, colsum, (const mxm_em_state *)nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int mxm_log_normalize(const double *colsum, int32_t H, double *ln_new, void *stream) {
+    if (H <= 0) return fail(-1, "mxm_log_normalize: H <= 0%s", "");
+    hipLaunchKernelGGL(log_normalize_kernel, dim3(1), dim3(FIN_THREADS), 0, (hipStream_t)stream, colsum, (int)H, ln_new);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_l1_exp_diff(const double *a, const double *b, int32_t H, double *l1_out, void *stream) {
+    if (H <= 0) return fail(-1, "mxm_l1_exp_diff: H <= 0%s", "");
+    hipLaunchKernelGGL(l1_exp_diff_kernel, dim3(1), dim3(FIN_THREADS), 0, (hipStream_t)stream, a, b, (int)H, l1_out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_add_scalar(double *x, int64_t ld, int64_t R, int32_t H, double delta, void *stream) {
+    if (R <= 0 || H <= 0 || ld < H) return fail(-1, "mxm_add_scalar: bad shape%s", "");
+    hipLaunchKernelGGL(add_scalar_kernel, dim3(clamp_grid(R, num_cu() * 8)), dim3(256), 0, (hipStream_t)stream, x, ld, R, (int)H, delta);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_row_argmax_votes(const double *X, int64_t ldx, const double *w, int64_t R, int32_t H,
+                                    int32_t *best, double *votes, void *stream) {
+    if (R <= 0 || H <= 0 || ldx < H) return fail(-1, "mxm_row_argmax_votes: bad shape%s", "");
+    hipLaunchKernelGGL(row_argmax_votes_kernel, dim3(clamp_grid(R, num_cu() * 8)), dim3(ROW_THREADS), 0,
+                       (hipStream_t)stream, X, ldx, w, R, (int)H, best, votes);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}

@@ -1,0 +1,158 @@
+"""
+Multi-GPU EM: one process per GPU, `torch.distributed` (backend "nccl" = RCCL
+over xGMI on ROCm; "gloo" in the CPU tests).
+
+The reference is single-process (SURVEY.md section 8 e); what shards is the
+matrix's rows: the E-step is row-local (em.py:80-83) and the M-step is a
+weighted column sum over rows (em.py:87-88).  So each rank keeps a contiguous
+row block of the matrix / weights / observations resident, and an EM
+iteration has exactly ONE exchange step:
+
+    colsum_local[b][h] = sum_{r in shard} w_r posterior_b[r][h]   (mxm_em_iter)
+    all-reduce(SUM, fp64, B*H values)                              (RCCL)
+    p' = colsum / sum colsum ; L1 test ; loop state                (mxm_m_finalize)
+
+The all-reduce hands every rank the same bytes, so every rank takes the same
+stop decision on the same iteration; kernels of a finished restart are no-ops,
+which lets the host look at the loop state only every `check_every`
+iterations without overshooting the reference's stopping iteration.
+
+Two modes:
+    run_em_sharded            rows sharded, every restart on every rank (configs 2-4)
+    run_em_restart_parallel   matrix replicated, restarts dealt round-robin
+                              over ranks, no per-iteration traffic (config 5)
+"""
+
+import math
+
+import numpy
+
+from . import em as _em
+
+try:
+    import torch
+    import torch.distributed as dist
+except ImportError:          # pragma: no cover
+    torch = None
+    dist = None
+
+
+def shard_bounds(n_rows, rank, world):
+    """Contiguous row block [lo, hi) of rank `rank`; sizes differ by at most 1."""
+    base, extra = divmod(int(n_rows), int(world))
+    lo = rank * base + min(rank, extra)
+    return lo, lo + base + (1 if rank < extra else 0)
+
+
+def _world(group):
+    if dist is None or not dist.is_available() or not dist.is_initialized():
+        return 0, 1
+    return dist.get_rank(group), dist.get_world_size(group)
+
+
+def broadcast_inits(n_runs, n_haps, alpha, device, group=None, src=0):
+    """
+    The restarts' initial proportions are sequential draws from numpy's global
+    legacy RNG on ONE process (em.py:36, :123); rank `src` draws, all receive.
+    """
+    rank, world = _world(group)
+    if rank == src:
+        host = numpy.stack([_em.init_props(n_haps, alpha=alpha) for _ in range(n_runs)])
+    else:
+        host = numpy.empty((n_runs, n_haps))
+    buf = torch.from_numpy(numpy.ascontiguousarray(host)).to(device)
+    if world > 1:
+        dist.broadcast(buf, src=src, group=group)
+    return buf.cpu().numpy()
+
+
+def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8):
+    """
+    The EM loop over a row-sharded matrix.  `plan` is the rank-local EmPlan (or
+    any object with its em_iter / finalize / alloc / read_state surface -- the
+    CPU tests pass a numpy-backed double).  Returns
+    (props_cur, props_new, [(done, iters, l1)]) -- identical on every rank.
+    """
+    rank, world = _world(group)
+    props_cur = plan.alloc_props(inits)
+    props_new = plan.alloc_props(inits)
+    colsum = plan.alloc_props(numpy.zeros_like(inits))
+    state = plan.alloc_state(inits.shape[0])
+    issued = 0
+    states = plan.read_state(state)
+    while issued < max_iter and not all(s[0] != 0 for s in states):
+        burst = min(check_every, max_iter - issued)
+        for _ in range(burst):
+            plan.em_iter(props_cur, state, colsum)
+            if world > 1:
+                dist.all_reduce(colsum, op=dist.ReduceOp.SUM, group=group)
+            plan.finalize(colsum, props_cur, props_new, state, tolerance, max_iter)
+        issued += burst
+        states = plan.read_state(state)
+    return props_cur, props_new, states
+
+
+def run_em_sharded(local_mat, local_weights, args, inits=None, group=None, want_read_mix=True,
+                   check_every=8):
+    """
+    run_em (em.py:94-165) over a matrix whose rows are spread over the ranks of
+    `group`; each rank passes ITS row block and gets back the global proportions
+    plus ITS block of the posterior matrix.  Same dict as em.run_em_ex.
+    """
+    n_multi = int(args.n_multi)
+    plan = _em.EmPlan(local_mat, local_weights, n_runs=n_multi)
+    if inits is None:
+        inits = broadcast_inits(n_multi, plan.n_haps, args.init_alpha, plan.dev, group)
+    inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
+    props_cur, props_new, states = sharded_em_loop(plan, inits, args.tolerance, args.max_iter,
+                                                   group=group, check_every=check_every)
+    return _em.collect_result(plan, inits, props_cur, props_new, states, want_read_mix)
+
+
+def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_read_mix=True):
+    """
+    Config 5: the matrix is replicated, the n_multi restarts are dealt
+    round-robin over the ranks (run i -> rank i % world) and run with no
+    per-iteration communication.  At the end the per-run log-proportions are
+    summed with one all-reduce; the posterior fold (em.py:156, log-mean-exp over
+    runs) is completed in linear space with one all-reduce of the local folds.
+    Every rank returns the full result.
+    """
+    rank, world = _world(group)
+    n_multi = int(args.n_multi)
+    plan = _em.EmPlan(mat, weights, n_runs=max(1, (n_multi + world - 1) // world))
+    if inits is None:
+        inits = broadcast_inits(n_multi, plan.n_haps, args.init_alpha, plan.dev, group)
+    inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
+    mine = list(range(rank, n_multi, world))
+    n_haps = plan.n_haps
+    ln_sum = torch.zeros(n_haps, dtype=torch.float64, device=plan.dev)
+    iters = torch.zeros(n_multi, dtype=torch.int64, device=plan.dev)
+    run_props = torch.zeros((n_multi, n_haps), dtype=torch.float64, device=plan.dev)
+    fold = None
+    if mine:
+        props_cur, props_new, states = _em.em_loop(plan, inits[mine], args.tolerance, args.max_iter)
+        with numpy.errstate(divide="ignore"):
+            ln_k = numpy.log(props_cur.cpu().numpy())
+        ln_sum += torch.log(props_new).sum(dim=0)
+        for j, run in enumerate(mine):
+            iters[run] = states[j][1]
+            run_props[run] = props_new[j]
+            if want_read_mix:
+                fold = _em.posterior(plan, ln_k[j], out=fold, fold=(j > 0))
+    if world > 1:
+        dist.all_reduce(ln_sum, group=group)
+        dist.all_reduce(iters, group=group)
+        dist.all_reduce(run_props, group=group)
+    read_mix = None
+    if want_read_mix:
+        lin = torch.exp(fold) if fold is not None else torch.zeros(
+            (plan.n_rows, n_haps), dtype=torch.float64, device=plan.dev)
+        if world > 1:
+            dist.all_reduce(lin, group=group)
+        read_mix = torch.log(lin)
+        if n_multi > 1:
+            read_mix -= math.log(n_multi)
+    props = torch.exp(ln_sum / n_multi).cpu().numpy() if n_multi > 1 else run_props[0].cpu().numpy()
+    return {"props": props, "read_mix": read_mix, "iters": [int(x) for x in iters.cpu()],
+            "run_props": run_props.cpu().numpy(), "inits": inits}

@@ -1,0 +1,307 @@
+"""
+EM mixture estimation on the GPU: the drop-in for `mixemt.em`
+(reference: mixemt/em.py).  Same four entry points, same argument meaning:
+
+    init_props(nhaps, alpha)                                   em.py:23
+    converged(prop, last_prop, tolerance)                      em.py:39
+    em_step(read_hap_mat, weights, ln_props, read_mix_mat)     em.py:57
+    run_em(read_hap_mat, weights, args)                        em.py:94
+
+Matrices may be numpy arrays (uploaded, results downloaded: drop-in behaviour)
+or ROCm tensors (stay resident; `read_mix` comes back as a device tensor).
+
+How the loop runs on the device (DESIGN.md has the derivation):
+  * once per run_em:  P = exp(M - rowmax)            (mxm_linearize)
+  * per iteration:    Z_r = sum_h p_h P_rh ; colsum_h = p_h sum_r w_r P_rh / Z_r
+                      (mxm_em_iter, one read of P, no transcendental)
+                      p' = colsum / sum colsum ; L1 test ; loop state on device
+                      (mxm_m_finalize)
+  * after the loop:   posterior under theta_k in log space from M itself
+                      (mxm_em_step), folded over runs with logaddexp.
+All restarts of a multi-run advance in one device loop (mxm_em_loop); their
+initial proportions are drawn on the host, sequentially, from numpy's global
+legacy RNG exactly as the reference does (em.py:36, :123).
+"""
+
+import ctypes
+import math
+import sys
+
+import numpy
+
+from . import _lib
+from ._dev import as_device, current_stream, ptr, require_gpu, torch
+
+
+def init_props(nhaps, alpha=1.0):
+    """
+    Random initial proportions (reference: em.py:23-36).  Stays on the host so
+    the draw consumes numpy's process-global legacy stream like the reference
+    (numpy.random.seed(args.seed) at bin/mixemt:507-508 must keep its meaning).
+    """
+    if alpha == float("inf"):
+        return numpy.array([1.0 / nhaps] * nhaps)
+    return numpy.random.dirichlet([alpha] * nhaps)
+
+
+def converged(prop, last_prop, tolerance=0.0001):
+    """
+    sum_h |exp(prop_h) - exp(last_prop_h)| < tolerance on two LOG-proportion
+    vectors (reference: em.py:39-54), evaluated by mxm_l1_exp_diff.
+    """
+    lib = _lib.load()
+    dev = require_gpu()
+    a = as_device(prop, torch.float64, dev)
+    b = as_device(last_prop, torch.float64, dev)
+    if a.numel() != b.numel():
+        raise ValueError("operands could not be broadcast together")
+    out = torch.empty(1, dtype=torch.float64, device=dev)
+    _lib.check(lib.mxm_l1_exp_diff(a.data_ptr(), b.data_ptr(), a.numel(), out.data_ptr(),
+                                   current_stream()), "mxm_l1_exp_diff")
+    return bool(out.item() < tolerance)
+
+
+def _workspace(lib, n_rows, n_haps, n_runs, dev):
+    nbytes = lib.mxm_workspace_bytes(n_rows, n_haps, n_runs)
+    return torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=dev), nbytes
+
+
+def em_step(read_hap_mat, weights, ln_props, read_mix_mat):
+    """
+    One EM step with the reference's semantics (em.py:57-91): fills
+    `read_mix_mat` with the row-normalised log posterior and returns it with the
+    new LOG proportions.  numpy in -> numpy out (read_mix_mat written in place);
+    device tensors in -> device tensors out.
+    """
+    lib = _lib.load()
+    dev = require_gpu()
+    on_host = not isinstance(read_hap_mat, torch.Tensor)
+    mat = as_device(read_hap_mat, torch.float64, dev)
+    n_rows, n_haps = mat.shape
+    wts = as_device(weights, torch.float64, dev)
+    lnp = as_device(ln_props, torch.float64, dev)
+    if wts.numel() != n_rows or lnp.numel() != n_haps:
+        raise ValueError("em_step: weights/ln_props do not match the matrix shape")
+    if on_host:
+        out = torch.empty_like(mat)
+    else:
+        out = read_mix_mat
+        if out.shape != mat.shape or out.dtype != torch.float64 or out.stride(1) != 1:
+            raise ValueError("em_step: read_mix_mat must be a float64 matrix like read_hap_mat")
+    colsum = torch.empty(n_haps, dtype=torch.float64, device=dev)
+    ln_new = torch.empty(n_haps, dtype=torch.float64, device=dev)
+    ws, ws_bytes = _workspace(lib, n_rows, n_haps, 1, dev)
+    stream = current_stream()
+    _lib.check(lib.mxm_em_step(mat.data_ptr(), mat.stride(0), wts.data_ptr(), lnp.data_ptr(),
+                               n_rows, n_haps, out.data_ptr(), out.stride(0), 0,
+                               colsum.data_ptr(), ws.data_ptr(), ws_bytes, stream),
+               "mxm_em_step")
+    _lib.check(lib.mxm_log_normalize(colsum.data_ptr(), n_haps, ln_new.data_ptr(), stream),
+               "mxm_log_normalize")
+    if on_host:
+        read_mix_mat[...] = out.cpu().numpy()
+        return read_mix_mat, ln_new.cpu().numpy()
+    return out, ln_new
+
+
+class EmPlan(object):
+    """
+    Device-resident inputs of the EM loop for one (rank-local) matrix:
+    the log matrix, fp64 weights, the linearised copy and scratch.
+    """
+
+    def __init__(self, read_hap_mat, weights, n_runs=1, keep_log_matrix=True):
+        self.lib = _lib.load()
+        self.dev = require_gpu()
+        self.mat = as_device(read_hap_mat, torch.float64, self.dev)
+        if self.mat.dim() != 2:
+            raise ValueError("read_hap_mat must be 2-D")
+        self.n_rows, self.n_haps = self.mat.shape
+        self.wts = as_device(weights, torch.float64, self.dev)
+        if self.wts.numel() != self.n_rows:
+            raise ValueError("weights do not match the matrix height")
+        self.n_runs = n_runs
+        self.ws, self.ws_bytes = _workspace(self.lib, self.n_rows, self.n_haps, n_runs, self.dev)
+        self.lin = None
+        self.rowmax = None
+        if self.lib.mxm_linear_supported(self.n_haps) and self.n_rows > 0:
+            ldp = (self.n_haps + 1) // 2 * 2
+            self.lin = torch.empty((self.n_rows, ldp), dtype=torch.float64, device=self.dev)
+            self.rowmax = torch.empty(self.n_rows, dtype=torch.float64, device=self.dev)
+            _lib.check(self.lib.mxm_linearize(self.mat.data_ptr(), self.mat.stride(0),
+                                              self.n_rows, self.n_haps, self.lin.data_ptr(),
+                                              self.lin.stride(0), self.rowmax.data_ptr(),
+                                              current_stream()), "mxm_linearize")
+        if not keep_log_matrix and self.lin is not None:
+            self.mat = None
+
+    # pointers for the C ABI ------------------------------------------------
+    def mat_args(self):
+        if self.mat is None:
+            return 0, 0
+        return self.mat.data_ptr(), self.mat.stride(0)
+
+    def lin_args(self):
+        if self.lin is None:
+            return 0, 0
+        return self.lin.data_ptr(), self.lin.stride(0)
+
+    # buffers (the surface dist.sharded_em_loop drives) ----------------------
+    def alloc_props(self, host):
+        return torch.from_numpy(numpy.ascontiguousarray(host, dtype=numpy.float64)).to(self.dev)
+
+    def alloc_state(self, n_runs):
+        return new_state(n_runs, self.dev)
+
+    def read_state(self, state):
+        return read_state(state)
+
+    def em_iter(self, props, state, colsum):
+        """Enqueue one fused E+M step for every restart (mxm_em_iter)."""
+        m_ptr, ldm = self.mat_args()
+        p_ptr, ldp = self.lin_args()
+        _lib.check(self.lib.mxm_em_iter(m_ptr, ldm, p_ptr, ldp, self.wts.data_ptr(),
+                                        props.data_ptr(), self.n_rows, self.n_haps,
+                                        props.shape[0], ptr(state), colsum.data_ptr(),
+                                        self.ws.data_ptr(), self.ws_bytes, current_stream()),
+                   "mxm_em_iter")
+
+    def finalize(self, colsum, props_cur, props_new, state, tol, max_iter):
+        """Enqueue the M-step normalisation + convergence test (mxm_m_finalize)."""
+        _lib.check(self.lib.mxm_m_finalize(colsum.data_ptr(), props_cur.data_ptr(),
+                                           props_new.data_ptr(), self.n_haps,
+                                           props_cur.shape[0], float(tol), int(max_iter),
+                                           state.data_ptr(), current_stream()),
+                   "mxm_m_finalize")
+
+
+def new_state(n_runs, dev):
+    """Device array of mxm_em_state (16 bytes each), zeroed."""
+    return torch.zeros(n_runs * 2, dtype=torch.int64, device=dev)
+
+
+def read_state(state):
+    """Device mxm_em_state array -> list of (done, iters, l1)."""
+    raw = state.cpu().numpy().tobytes()
+    n = len(raw) // ctypes.sizeof(_lib.EmState)
+    arr = (_lib.EmState * n).from_buffer_copy(raw)
+    return [(s.done, s.iters, s.l1) for s in arr]
+
+
+def em_loop(plan, inits, tolerance, max_iter, check_every=16):
+    """
+    The run_em inner loop (em.py:126-143) for all restarts at once on one GPU.
+    inits: [B][H] linear initial proportions.  Returns
+    (props_cur = theta_k, props_new = theta_{k+1}, [(done, iters, l1)] per run).
+    """
+    lib, dev = plan.lib, plan.dev
+    inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
+    n_runs, n_haps = inits.shape
+    props_cur = torch.from_numpy(inits).to(dev)
+    props_new = props_cur.clone()
+    colsum = torch.zeros_like(props_cur)
+    state = new_state(n_runs, dev)
+    host_state = (_lib.EmState * n_runs)()
+    if max_iter > 0:
+        m_ptr, ldm = plan.mat_args()
+        p_ptr, ldp = plan.lin_args()
+        _lib.check(lib.mxm_em_loop(m_ptr, ldm, p_ptr, ldp, plan.wts.data_ptr(), plan.n_rows,
+                                   n_haps, n_runs, props_cur.data_ptr(), props_new.data_ptr(),
+                                   colsum.data_ptr(), state.data_ptr(), float(tolerance),
+                                   int(max_iter), int(check_every), plan.ws.data_ptr(),
+                                   plan.ws_bytes, current_stream(), host_state),
+                   "mxm_em_loop")
+    states = [(s.done, s.iters, s.l1) for s in host_state]
+    return props_cur, props_new, states
+
+
+def posterior(plan, ln_theta, out=None, fold=False):
+    """
+    Log posterior under log-proportions `ln_theta` (em.py:80-83) written to
+    `out` (mode store) or folded into it with logaddexp (em.py:156).
+    """
+    if plan.mat is None:
+        raise ValueError("posterior pass needs the log matrix (keep_log_matrix=True)")
+    lnp = as_device(ln_theta, torch.float64, plan.dev)
+    if out is None:
+        out = torch.empty((plan.n_rows, plan.n_haps), dtype=torch.float64, device=plan.dev)
+    _lib.check(plan.lib.mxm_em_step(plan.mat.data_ptr(), plan.mat.stride(0), 0, lnp.data_ptr(),
+                                    plan.n_rows, plan.n_haps, out.data_ptr(), out.stride(0),
+                                    1 if fold else 0, 0, 0, 0, current_stream()),
+               "mxm_em_step")
+    return out
+
+
+def collect_result(plan, inits, props_cur, props_new, states, want_read_mix=True,
+                   verbose=False):
+    """
+    What run_em does after its loops (em.py:145-165): posterior under theta_k
+    per run, folded with logaddexp, minus log n; proportions = exp(mean of the
+    runs' LOG proportions) -- a geometric mean that is not renormalised.
+    """
+    n_multi, n_haps = inits.shape
+    theta_k = props_cur.cpu().numpy()
+    theta_next = props_new.cpu().numpy()
+    if verbose:
+        for run, (done, iters, _) in enumerate(states):
+            sys.stderr.write("Starting EM run %d...\n" % (run + 1))
+            sys.stderr.write("." * (iters // 10))
+            if done == 1:
+                sys.stderr.write("\nConverged! (%d)\n" % iters)
+    read_mix = None
+    with numpy.errstate(divide="ignore"):
+        ln_k = numpy.log(theta_k)
+        ln_next = numpy.log(theta_next)
+    if want_read_mix:
+        for run in range(n_multi):
+            read_mix = posterior(plan, ln_k[run], out=read_mix, fold=(run > 0))
+        if n_multi > 1:
+            _lib.check(plan.lib.mxm_add_scalar(read_mix.data_ptr(), read_mix.stride(0),
+                                               plan.n_rows, n_haps, -math.log(n_multi),
+                                               current_stream()), "mxm_add_scalar")
+    if n_multi > 1:
+        res = ln_next[0].copy()
+        for run in range(1, n_multi):
+            res += ln_next[run]
+        res /= n_multi
+        props = numpy.exp(res)
+    else:
+        props = theta_next[0].copy()
+    return {"props": props, "read_mix": read_mix, "iters": [s[1] for s in states],
+            "done": [s[0] for s in states], "run_props": theta_next, "inits": inits,
+            "l1": [s[2] for s in states]}
+
+
+def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True):
+    """
+    run_em with the parity observables exposed.  Returns a dict:
+        props      [H] numpy, linear (geometric mean over runs, em.py:155-163)
+        read_mix   [R][H] device tensor, log (None if want_read_mix=False)
+        iters      per-run iteration counts ("Converged! (n)", em.py:135)
+        run_props  [n_multi][H] numpy, each run's theta_{k+1}
+        inits      [n_multi][H] numpy, the initial draws
+        done       per-run stop reason (1 converged, 2 max_iter)
+    """
+    n_multi = int(args.n_multi)
+    plan = EmPlan(read_hap_mat, weights, n_runs=n_multi)
+    if inits is None:
+        # sequential draws in run order: same RNG consumption as em.py:123
+        inits = numpy.stack([init_props(plan.n_haps, alpha=args.init_alpha)
+                             for _ in range(n_multi)])
+    inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
+    props_cur, props_new, states = em_loop(plan, inits, args.tolerance, args.max_iter)
+    return collect_result(plan, inits, props_cur, props_new, states, want_read_mix,
+                          getattr(args, "verbose", False))
+
+
+def run_em(read_hap_mat, weights, args):
+    """
+    Drop-in for mixemt.em.run_em (em.py:94-165): returns (props, read_mix) --
+    linear proportions [H] (numpy) and the log posterior matrix [R][H]
+    (numpy if the input was numpy, else a device tensor).
+    """
+    res = run_em_ex(read_hap_mat, weights, args)
+    read_mix = res["read_mix"]
+    if not isinstance(read_hap_mat, torch.Tensor):
+        read_mix = read_mix.cpu().numpy()
+    return res["props"], read_mix

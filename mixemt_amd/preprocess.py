@@ -1,0 +1,175 @@
+"""
+EM input construction on the GPU: the drop-in for
+`mixemt.preprocess.build_em_matrix` (reference: mixemt/preprocess.py:177-198)
+plus the host-side encoders that turn the reference's dictionaries and
+signature strings into the flat tables the kernel reads.
+
+Host (numpy, one-time, small):
+    HapVarTables.build   <- HapVarBaseMatrix.__init__/add_hap_markers (:39-67)
+    encode_signatures    <- pos_obs_from_sig (:151-160)
+Device (libmixemt_hip.so):
+    mxm_build_em_matrix  <- the R x H x k loop (:188-191) with _prob (:69-84)
+                            and prob_for_vars (:86-96) inlined
+
+The expected-base table stores the ASCII code of the base a haplogroup should
+show at a site, observations are ASCII codes too, so "hit" is byte equality --
+exactly the reference's string comparison, for any alphabet ('N' included).
+"""
+
+import math
+import sys
+
+import numpy
+
+from . import _lib
+from . import phylotree
+from ._dev import as_device, current_stream, require_gpu, torch
+
+MUT_WT = 0.01       # preprocess.py:39 defaults; not CLI flags (build_em_matrix :182)
+MUT_MAX = 0.5
+
+
+class HapVarTables(object):
+    """
+    Flat form of HapVarBaseMatrix for a fixed haplogroup (column) order.
+
+        sites[S]      sorted 0-based variant sites (phylotree.py:221-229)
+        expected[S][lde] uint8: ord(base) haplogroup h is expected to show at
+                      site s -- its marker where it carries a non-reference
+                      allele (:60-66), else the reference base (:80-82);
+                      columns [H, lde) are padding (0 never equals a base)
+        lhit[S]       math.log(1 - mu_s)        (:77, :82 with :94)
+        lmiss[S]      math.log(mu_s / 3.0)      (:84 with :94)
+        mu_s = min(mut_max, mut_wt * sum(variants[pos].values()))  (:48-51)
+    """
+
+    def __init__(self, sites, expected, lhit, lmiss, haplogroups, n_haps):
+        self.sites = sites
+        self.expected = expected
+        self.lhit = lhit
+        self.lmiss = lmiss
+        self.haplogroups = haplogroups
+        self.n_haps = n_haps
+        self.site_index = {int(p): k for k, p in enumerate(sites)}
+        self._dev = None
+
+    @classmethod
+    def build(cls, refseq, phylo, haplogroups, mut_wt=MUT_WT, mut_max=MUT_MAX):
+        sites = numpy.array(sorted(phylo.variants.keys()), dtype=numpy.int64)
+        n_sites, n_haps = len(sites), len(haplogroups)
+        if n_sites > 65536:
+            raise ValueError("more than 65536 variant sites (%d)" % n_sites)
+        where = {int(p): k for k, p in enumerate(sites)}
+        lde = (n_haps + 15) // 16 * 16
+        expected = numpy.zeros((n_sites, lde), dtype=numpy.uint8)
+        ref_codes = numpy.array([ord(refseq[int(p)]) for p in sites], dtype=numpy.uint8)
+        expected[:, :n_haps] = ref_codes[:, None]
+        for j, hap in enumerate(haplogroups):
+            for var in phylo.hap_var[hap]:
+                pos = phylotree.pos_from_var(var)
+                der = phylotree.der_allele(var)
+                k = where.get(pos)
+                if k is not None and der != refseq[pos]:
+                    # a derived allele equal to the reference base leaves no
+                    # marker (:63-66): the expected base stays whatever it was
+                    expected[k, j] = ord(der)
+        lhit = numpy.empty(n_sites)
+        lmiss = numpy.empty(n_sites)
+        for k, pos in enumerate(sites):
+            mu = min(mut_max, mut_wt * sum(phylo.variants[int(pos)].values()))
+            lhit[k] = math.log(1.0 - mu)
+            lmiss[k] = math.log(mu / 3.0)
+        return cls(sites, expected, lhit, lmiss, list(haplogroups), n_haps)
+
+    def device(self):
+        """Upload once; returns (expected, lhit, lmiss) as device tensors."""
+        if self._dev is None:
+            dev = require_gpu()
+            self._dev = (torch.from_numpy(self.expected).to(dev),
+                         torch.from_numpy(self.lhit).to(dev),
+                         torch.from_numpy(self.lmiss).to(dev))
+        return self._dev
+
+
+def encode_signatures(reads, tables):
+    """
+    Signature strings 'pos:base,pos:base,...' (preprocess.py:142-160) -> CSR
+        row_ptr[R+1] int64, site[nnz] uint16 (index into tables.sites),
+        obs[nnz] uint8 (ASCII; a multi-character observation can never equal a
+        base and is stored as 0)
+    Order inside a row is the signature's order: the kernel adds in that order.
+    """
+    row_ptr = numpy.zeros(len(reads) + 1, dtype=numpy.int64)
+    site, obs = [], []
+    index = tables.site_index
+    for i, sig in enumerate(reads):
+        if sig == "":
+            # the reference dies in int('') here (preprocess.py:156-160)
+            raise ValueError("empty read signature at row %d" % i)
+        for item in sig.split(","):
+            pos, base = item.split(":")
+            try:
+                site.append(index[int(pos)])
+            except KeyError:
+                raise KeyError(int(pos))      # reference: self.mut_prob[pos] (:84)
+            obs.append(ord(base) if len(base) == 1 else 0)
+        row_ptr[i + 1] = len(site)
+    return (row_ptr, numpy.array(site, dtype=numpy.uint16),
+            numpy.array(obs, dtype=numpy.uint8))
+
+
+def build_em_matrix_device(tables, row_ptr, site, obs, out=None):
+    """
+    CSR observations (numpy or device tensors) -> device tensor M[R][H] float64.
+    Wraps mxm_build_em_matrix; `out` may supply a preallocated [R][>=H] tensor.
+    """
+    lib = _lib.load()
+    dev = require_gpu()
+    exp_d, lhit_d, lmiss_d = tables.device()
+    row_ptr_d = as_device(row_ptr, torch.int64, dev)
+    site_d = as_device(site, torch.uint16, dev)
+    obs_d = as_device(obs, torch.uint8, dev)
+    n_rows = row_ptr_d.numel() - 1
+    n_haps = tables.n_haps
+    if out is None:
+        out = torch.empty((n_rows, n_haps), dtype=torch.float64, device=dev)
+    if n_rows == 0:
+        return out
+    _lib.check(lib.mxm_build_em_matrix(
+        exp_d.data_ptr(), exp_d.stride(0), lhit_d.data_ptr(), lmiss_d.data_ptr(),
+        row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(),
+        n_rows, n_haps, len(tables.sites), out.data_ptr(), out.stride(0),
+        current_stream()), "mxm_build_em_matrix")
+    return out
+
+
+def build_em_matrix(refseq, phylo, reads, haplogroups, args, as_device_tensor=False):
+    """
+    Drop-in for mixemt.preprocess.build_em_matrix (preprocess.py:177-198):
+    returns the float64 [len(reads), len(haplogroups)] log-likelihood matrix
+    (C-order numpy array; a device tensor if as_device_tensor=True).
+    """
+    verbose = getattr(args, "verbose", False)
+    if verbose:
+        sys.stderr.write("Building EM input matrix...\n")
+    tables = HapVarTables.build(refseq, phylo, haplogroups)
+    row_ptr, site, obs = encode_signatures(reads, tables)
+    mat = build_em_matrix_device(tables, row_ptr, site, obs)
+    if verbose:
+        sys.stderr.write("  processed %d fragments...\nDone.\n\n" % len(reads))
+    if as_device_tensor:
+        return mat
+    return mat.cpu().numpy()
+
+
+def reduce_em_matrix(em_mat, haplogroups, contrib_props):
+    """
+    Column subset for the refinement EM (preprocess.py:230-251); works on numpy
+    arrays and device tensors alike.
+    """
+    keep = {con[1] for con in contrib_props}
+    idx = [i for i, hap in enumerate(haplogroups) if hap in keep]
+    names = [haplogroups[i] for i in idx]
+    if torch is not None and isinstance(em_mat, torch.Tensor):
+        return em_mat[:, torch.tensor(idx, device=em_mat.device)].contiguous(), names
+    return em_mat[:, idx], names

@@ -1,0 +1,66 @@
+"""
+The C-ABI library: builds for gfx950 without a GPU, loads, and exports every
+symbol include/mixemt_hip.h declares.  No compute calls here (CPU box).
+"""
+import ctypes
+import os
+import re
+
+import pytest
+
+from conftest import ROOT
+
+
+@pytest.fixture(scope="module")
+def lib_path():
+    from mixemt_amd import build
+    return build.build()
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "mixemt_hip.h")).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(mxm_[a-z0-9_]+)\s*\(", text)))
+
+
+def test_header_declares_the_boundary():
+    names = _declared()
+    for must in ("mxm_build_em_matrix", "mxm_em_iter", "mxm_m_finalize", "mxm_em_loop",
+                 "mxm_em_step", "mxm_workspace_bytes", "mxm_last_error", "mxm_version"):
+        assert must in names
+
+
+def test_library_exports_every_declared_symbol(lib_path):
+    lib = ctypes.CDLL(lib_path)
+    for name in _declared():
+        assert hasattr(lib, name), "missing export: %s" % name
+
+
+def test_binding_table_matches_header(lib_path):
+    from mixemt_amd import _lib
+    assert sorted(_lib.SIGNATURES) == _declared()
+    lib = _lib.load()
+    assert lib.mxm_version() == 100
+    assert ctypes.sizeof(_lib.EmState) == 16
+    assert lib.mxm_linear_supported(5408) == 1 and lib.mxm_linear_supported(3) == 0
+    assert lib.mxm_linear_supported(8192) == 1 and lib.mxm_linear_supported(8193) == 0
+    assert lib.mxm_workspace_bytes(1000000, 5408, 1) >= 1024 * 5408 * 8
+
+
+def test_code_object_is_gfx950(lib_path):
+    blob = open(lib_path, "rb").read()
+    assert b"gfx950" in blob
+    assert b"em_iter_wide_kernel" in blob and b"build_em_matrix_kernel" in blob
+
+
+def test_product_fails_loudly_without_gpu():
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    import numpy
+    from conftest import em_args
+    from mixemt_amd import em
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        em.run_em(numpy.zeros((4, 3)), numpy.ones(4), em_args())
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        em.converged(numpy.zeros(3), numpy.zeros(3))

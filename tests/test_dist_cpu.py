@@ -1,0 +1,94 @@
+"""
+world_size-2 gloo runs of the row-sharded EM loop (mixemt_amd.dist) on CPU:
+the orchestration -- shard bounds, one all-reduce of the column sums per
+iteration, identical stop decision on every rank, init broadcast -- with the
+oracle-backed CpuPlan standing in for the device kernels.
+"""
+import os
+import socket
+
+import numpy
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+from conftest import em_args, golden
+from mixemt_amd import dist as mdist
+
+
+def test_shard_bounds_cover_rows_exactly():
+    for n, world in ((10, 3), (7, 8), (1000000, 8), (0, 2), (5, 1)):
+        spans = [mdist.shard_bounds(n, r, world) for r in range(world)]
+        assert spans[0][0] == 0 and spans[-1][1] == n
+        assert all(a[1] == b[0] for a, b in zip(spans, spans[1:]))
+        sizes = [hi - lo for lo, hi in spans]
+        assert max(sizes) - min(sizes) <= 1
+
+
+def test_single_process_loop_matches_oracle_run():
+    """world = 1 (no process group): the loop alone reproduces the oracle's run_em."""
+    from _cpu_plan import CpuPlan
+    from oracle import em_oracle
+    g = golden("g7_config1")
+    mat, wts = g["mat"][:200], numpy.ones(200)
+    numpy.random.seed(3)
+    init = numpy.random.dirichlet([1.0] * mat.shape[1])[None, :]
+    cur, new, states = mdist.sharded_em_loop(CpuPlan(mat, wts), init, 1e-4, 10000, check_every=5)
+    trace = []
+    numpy.random.seed(3)
+    props, _ = em_oracle.run_em(mat, wts, em_args(), trace=trace)
+    assert states[0][0] == 1 and states[0][1] == trace[0]["iters"]
+    assert numpy.abs(new[0].numpy() - props).max() < 1e-12
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _cpu_plan import CpuPlan
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        g = numpy.load(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "g7_config1.npz"))
+        mat = g["mat"][:301]
+        wts = (numpy.arange(301) % 3 + 1).astype(numpy.float64)
+        lo, hi = mdist.shard_bounds(301, rank, world)
+        plan = CpuPlan(mat[lo:hi], wts[lo:hi])
+        numpy.random.seed(100 + rank)            # ranks deliberately disagree: rank 0's draw must win
+        inits = mdist.broadcast_inits(2, mat.shape[1], 1.0, torch.device("cpu"))
+        cur, new, states = mdist.sharded_em_loop(plan, inits, 1e-4, 10000, check_every=7)
+        numpy.savez(os.path.join(out_dir, "rank%d.npz" % rank), inits=inits, cur=cur.numpy(),
+                    new=new.numpy(), states=numpy.array(states), calls=plan.calls)
+    finally:
+        dist.destroy_process_group()
+
+
+def test_two_rank_gloo_matches_single_process(tmp_path):
+    from _cpu_plan import CpuPlan
+    world = 2
+    mp.spawn(_worker, args=(world, _free_port(), str(tmp_path)), nprocs=world, join=True)
+    res = [numpy.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(world)]
+    # every rank saw rank 0's init draws and took identical decisions
+    numpy.random.seed(100)
+    want_inits = numpy.stack([numpy.random.dirichlet([1.0] * 100) for _ in range(2)])
+    for r in res:
+        assert numpy.array_equal(r["inits"], want_inits)
+        assert numpy.array_equal(r["states"], res[0]["states"])
+        assert numpy.array_equal(r["new"], res[0]["new"]) and numpy.array_equal(r["cur"], res[0]["cur"])
+        assert int(r["calls"]) == int(res[0]["calls"])
+    # and the sharded result equals the unsharded one
+    g = golden("g7_config1")
+    mat = g["mat"][:301]
+    wts = (numpy.arange(301) % 3 + 1).astype(numpy.float64)
+    cur, new, states = mdist.sharded_em_loop(CpuPlan(mat, wts), want_inits, 1e-4, 10000, check_every=7)
+    assert [s[1] for s in states] == [int(s[1]) for s in res[0]["states"]]
+    assert all(s[0] == 1 for s in states)
+    assert numpy.abs(new.numpy() - res[0]["new"]).max() < 1e-12
+    assert numpy.abs(cur.numpy() - res[0]["cur"]).max() < 1e-12

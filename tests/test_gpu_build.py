@@ -1,0 +1,135 @@
+"""
+GPU parity of build_em_matrix (mxm_build_em_matrix through the drop-in wrapper)
+against the oracle and the reference-derived golden matrices.  Bit-exact: the
+kernel adds the same fp64 terms in the same order as preprocess.py:86-96.
+"""
+import hashlib
+
+import numpy
+import pytest
+
+from conftest import em_args, golden
+from oracle import build_oracle, c_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+def _sha(arr):
+    return hashlib.sha256(numpy.ascontiguousarray(arr).tobytes()).hexdigest()
+
+
+def test_toy_matrices_bitwise(toy):
+    from mixemt_amd import preprocess
+    ref, phy, haps = toy
+    g = golden("g1_toy")
+    for key, mkey in (("reads", "mat"), ("reads_b", "mat_b")):
+        reads = str(g[key]).split("\n")
+        mat = preprocess.build_em_matrix(ref, phy, reads, haps, em_args())
+        assert mat.dtype == numpy.float64 and mat.flags["C_CONTIGUOUS"]
+        assert mat.shape == (len(reads), len(haps))
+        assert numpy.array_equal(mat, g[mkey])
+
+
+def test_reference_hand_computed_values(toy):
+    """preprocess_test.py:268-284."""
+    from mixemt_amd import preprocess
+    ref, phy, haps = toy
+    reads = ["1:A,2:C", "1:T,2:C", "3:T,4:T", "2:A,4:T"]
+    r1 = [(0.01 / 3) * (0.01 / 3)] + [0.99 * (0.01 / 3)] * 8
+    r2 = [0.99 * (0.01 / 3)] + [(0.01 / 3) * (0.01 / 3)] * 8
+    r3 = ([0.98 * (0.02 / 3)] + [(0.02 / 3) * 0.98] + [(0.02 / 3) * (0.02 / 3)] + [(0.02 / 3) * 0.98]
+          + [0.98 * 0.98] + [(0.02 / 3) * 0.98] * 3 + [(0.02 / 3) * (0.02 / 3)])
+    r4 = ([0.99 * (0.02 / 3)] + [(0.01 / 3) * 0.98] + [(0.01 / 3) * (0.02 / 3)]
+          + [(0.01 / 3) * 0.98] * 5 + [0.99 * (0.02 / 3)])
+    mat = preprocess.build_em_matrix(ref, phy, reads, haps, em_args())
+    assert numpy.allclose(mat, numpy.log(numpy.array([r1, r2, r3, r4])))
+
+
+def test_build17_golden_bitwise(b17):
+    from mixemt_amd import preprocess
+    refseq, phy, haps, tables = b17
+    g = golden("g2_build_b17")
+    mat = preprocess.build_em_matrix_device(tables, g["row_ptr"], g["site"], g["obs"]).cpu().numpy()
+    assert mat.shape == (1032, 5408)
+    assert numpy.array_equal(mat[:32], g["mat32"])
+    assert _sha(mat) == str(g["mat_sha256"])
+    assert numpy.array_equal(mat.sum(axis=1), g["row_sum"])
+    assert numpy.array_equal(mat.argmax(axis=1), g["row_argmax"])
+
+
+def test_drop_in_signature_strings(b17):
+    """The reference's own call shape: refseq, phylo, signature strings, hap names, args."""
+    from mixemt_amd import preprocess, synth
+    refseq, phy, haps, tables = b17
+    g = golden("g2_build_b17")
+    sigs = synth.signatures(tables, g["row_ptr"][:9], g["site"], g["obs"])
+    mat = preprocess.build_em_matrix(refseq, phy, sigs, haps, em_args())
+    assert numpy.array_equal(mat, g["mat32"][:8])
+
+
+@pytest.mark.parametrize("n_rows,seed", [(1, 5), (257, 6), (5000, 7)])
+def test_against_c_oracle_bitwise(b17, n_rows, seed):
+    from mixemt_amd import preprocess, synth
+    refseq, phy, haps, tables = b17
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=seed)
+    got = preprocess.build_em_matrix_device(tables, row_ptr, site, obs).cpu().numpy()
+    want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, row_ptr, site, obs,
+                                    len(haps))
+    assert numpy.array_equal(got, want)
+
+
+@pytest.mark.parametrize("n_cols", [1, 3, 5, 100, 1023, 1025])
+def test_ragged_column_counts(b17, n_cols):
+    """H not a multiple of 4 / of the 1024-column tile; H = #contributors sized subsets."""
+    from mixemt_amd import preprocess, synth
+    refseq, phy, haps, tables = b17
+    sub = haps[:n_cols]
+    sub_tables = preprocess.HapVarTables.build(refseq, phy, sub)
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 40, seed=8)
+    got = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs).cpu().numpy()
+    want = c_oracle.build_em_matrix(sub_tables.expected, sub_tables.lhit, sub_tables.lmiss, row_ptr,
+                                    site, obs, n_cols)
+    assert got.shape == (40, n_cols) and numpy.array_equal(got, want)
+
+
+def test_long_reads_more_observations_than_one_lds_pass(b17):
+    """A 3 kb fragment covers > 512 variant sites: the kernel stages them in several passes."""
+    from mixemt_amd import preprocess, synth
+    refseq, phy, haps, tables = b17
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 6, seed=9, read_len=3000)
+    assert numpy.diff(row_ptr).max() > 512
+    got = preprocess.build_em_matrix_device(tables, row_ptr, site, obs).cpu().numpy()
+    want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, row_ptr, site, obs,
+                                    len(haps))
+    assert numpy.array_equal(got, want)
+
+
+def test_unusual_observations_and_errors(b17):
+    from mixemt_amd import preprocess
+    refseq, phy, haps, tables = b17
+    s0, s1 = int(tables.sites[0]), int(tables.sites[1])
+    reads = ["%d:N,%d:a" % (s0, s1), "%d:%s" % (s0, refseq[s0])]
+    got = preprocess.build_em_matrix(refseq, phy, reads, haps, em_args())
+    want = build_oracle.build_em_matrix_np(refseq, phy, reads, haps)
+    assert numpy.array_equal(got, want)
+    with pytest.raises(ValueError):
+        preprocess.build_em_matrix(refseq, phy, [""], haps, em_args())
+    with pytest.raises(KeyError):
+        preprocess.build_em_matrix(refseq, phy, ["0:A"], haps, em_args())
+    empty = preprocess.build_em_matrix(refseq, phy, [], haps, em_args())
+    assert empty.shape == (0, len(haps))
+
+
+def test_reference_phylotree_object_is_accepted(toy):
+    """Duck-typing: any object with .variants and .hap_var works (the drop-in claim)."""
+    from mixemt_amd import preprocess
+
+    class Bare(object):
+        pass
+    ref, phy, haps = toy
+    bare = Bare()
+    bare.variants = {p: dict(c) for p, c in phy.variants.items()}
+    bare.hap_var = dict(phy.hap_var)
+    g = golden("g1_toy")
+    reads = str(g["reads"]).split("\n")
+    assert numpy.array_equal(preprocess.build_em_matrix(ref, bare, reads, haps, em_args()), g["mat"])

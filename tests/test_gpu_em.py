@@ -1,0 +1,260 @@
+"""
+GPU parity of the EM core (em_step / converged / run_em through the drop-in
+wrappers over the C ABI) against the oracle and the reference-derived goldens.
+
+Tolerances (north_star: identical haplogroup calls, proportions within 1e-6):
+the tests hold the HIP path to 1e-9 on proportions (linear-space loop vs the
+reference's log-space loop differ by rounding only), identical iteration
+counts, identical row argmax.
+"""
+import numpy
+import pytest
+
+from conftest import em_args, golden
+from oracle import c_oracle, em_oracle
+
+pytestmark = pytest.mark.gpu
+
+PROPS_ATOL = 1e-9          # << the 1e-6 parity bar
+LOGMIX_ATOL = 1e-9
+
+
+def _b17_matrix(tables, g, n_haps):
+    return c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, g["row_ptr"],
+                                    g["site"], g["obs"], n_haps)
+
+
+def test_converged_truth_table():
+    """em_test.py:22-33."""
+    from mixemt_amd import em
+    prev = numpy.log(numpy.ones(10))
+    cur = numpy.log(numpy.full(10, 2.0))
+    assert em.converged(cur, cur) and em.converged(prev, prev)
+    assert not em.converged(prev, cur) and not em.converged(cur, prev)
+    close = cur.copy()
+    close[3] = numpy.log(2.0001)
+    assert em.converged(cur, prev, 20.0)
+    assert not em.converged(cur, close)
+    assert em.converged(cur, close, 0.001)
+
+
+def test_init_props_uses_numpy_global_stream():
+    """em_test.py:17-20 + the seeding contract of bin/mixemt:507-508."""
+    from mixemt_amd import em
+    numpy.random.seed(3)
+    mine = em.init_props(10)
+    numpy.random.seed(3)
+    assert numpy.array_equal(mine, numpy.random.dirichlet([1.0] * 10))
+    assert abs(mine.sum() - 1.0) < 1e-9
+    assert numpy.array_equal(em.init_props(4, float("inf")), numpy.full(4, 0.25))
+
+
+@pytest.mark.parametrize("wts,want", [([1, 1, 1], [1.0, 1.0, 1.0]), ([2, 1, 1], [2.0, 1.0, 1.0])])
+def test_em_step_identity_with_minus_inf(wts, want):
+    """em_test.py:35-65: output matrix == input, props == log(w / sum w)."""
+    from mixemt_amd import em
+    inf = float("inf")
+    in_mat = numpy.array([[0.0, -inf, -inf], [-inf, 0.0, -inf], [-inf, -inf, 0.0]])
+    props = numpy.log(numpy.array([0.6, 0.2, 0.2]))
+    mix = numpy.empty_like(in_mat)
+    res_mat, res_props = em.em_step(in_mat, numpy.array(wts), props, mix)
+    assert res_mat is mix
+    assert numpy.all(in_mat == mix)
+    want = numpy.log(numpy.array(want) / sum(want))
+    assert numpy.allclose(res_props, want, rtol=0, atol=1e-15)
+
+
+def test_em_step_b17_golden(b17):
+    from mixemt_amd import em
+    refseq, phy, haps, tables = b17
+    g = golden("g3_em_step")
+    mat = _b17_matrix(tables, g, len(haps))
+    mix = numpy.empty_like(mat)
+    res_mat, new_props = em.em_step(mat, g["wts"], g["lnp"], mix)
+    assert numpy.allclose(mix[:8], g["mix_rows"], rtol=0, atol=LOGMIX_ATOL)
+    assert numpy.array_equal(mix.argmax(axis=1), g["mix_argmax"])
+    assert numpy.allclose(mix.max(axis=1), g["mix_rowmax"], rtol=0, atol=LOGMIX_ATOL)
+    assert numpy.allclose(new_props, g["new_props"], rtol=0, atol=1e-10)
+    assert numpy.allclose(numpy.exp(new_props), numpy.exp(g["new_props"]), rtol=0, atol=1e-13)
+    # rows of the posterior are normalised
+    assert numpy.allclose(numpy.exp(mix).sum(axis=1), 1.0, atol=1e-12)
+
+
+@pytest.mark.parametrize("n_multi", [1, 3])
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_run_em_toy_golden(n_multi, seed):
+    """9 haplogroups: the generic log-space kernel path (H below the streaming kernel's range)."""
+    from mixemt_amd import em
+    g = golden("g1_toy")
+    key = "m%d_s%d" % (n_multi, seed)
+    numpy.random.seed(seed)
+    res = em.run_em_ex(g["mat"], numpy.ones(10), em_args(n_multi=n_multi, max_iter=1000))
+    assert numpy.array_equal(res["inits"], g[key + "_inits"])
+    assert res["iters"] == list(g[key + "_iters"])
+    assert numpy.allclose(res["props"], g[key + "_props"], rtol=0, atol=PROPS_ATOL)
+    mix = res["read_mix"].cpu().numpy()
+    assert numpy.allclose(numpy.exp(mix), numpy.exp(g[key + "_mix"]), rtol=0, atol=1e-9)
+    assert numpy.array_equal(mix.argmax(axis=1), g[key + "_mix"].argmax(axis=1))
+
+
+def test_run_em_reference_test_tolerances():
+    """em_test.py:104-116 verbatim expectations (n_multi 1 and 10)."""
+    from mixemt_amd import em
+    g = golden("g1_toy")
+    true_props = numpy.array([0.0, 0.8, 0.0, 0.0, 0.2, 0.0, 0.0, 0.0, 0.0])
+    true_haps = numpy.full((10, 9), -numpy.inf)
+    true_haps[0:8, 1] = 0.0
+    true_haps[8:10, 4] = 0.0
+    for n_multi in (1, 10):
+        props, read_mix = em.run_em(g["mat"], numpy.ones(10), em_args(n_multi=n_multi, max_iter=1000))
+        assert isinstance(read_mix, numpy.ndarray) and read_mix.shape == (10, 9)
+        assert numpy.allclose(props, true_props, atol=0.02)
+        assert numpy.allclose(numpy.exp(read_mix), numpy.exp(true_haps), atol=0.05)
+
+
+def test_run_em_config1_golden():
+    """BASELINE config 1: 1000 x 100 (the streaming linear-space kernel, NCH = 1)."""
+    from mixemt_amd import em
+    g = golden("g7_config1")
+    numpy.random.seed(7)
+    res = em.run_em_ex(g["mat"], numpy.ones(1000, dtype=numpy.int64), em_args())
+    assert res["iters"] == [int(g["iters"][0])]
+    assert numpy.allclose(res["props"], g["props"], rtol=0, atol=PROPS_ATOL)
+    mix = res["read_mix"].cpu().numpy()
+    assert numpy.array_equal(mix.argmax(axis=1), g["mix"].argmax(axis=1))
+    assert numpy.allclose(numpy.exp(mix), numpy.exp(g["mix"]), rtol=0, atol=1e-9)
+
+
+def test_run_em_b17_golden(b17):
+    """600 x 5408, default flags: iteration count, proportions, calls, votes."""
+    from mixemt_amd import em
+    refseq, phy, haps, tables = b17
+    g = golden("g4_run_em")
+    mat = _b17_matrix(tables, g, len(haps))
+    numpy.random.seed(7)
+    res = em.run_em_ex(mat, g["wts"], em_args())
+    assert numpy.array_equal(res["inits"], g["inits"])
+    assert res["iters"] == list(g["iters"])
+    assert numpy.abs(res["props"] - g["props"]).max() < PROPS_ATOL
+    mix = res["read_mix"].cpu().numpy()
+    best = mix.argmax(axis=1)
+    assert numpy.array_equal(best, g["mix_argmax"])                 # identical haplogroup calls
+    votes = numpy.zeros(len(haps))
+    numpy.add.at(votes, best, g["wts"])
+    assert numpy.array_equal(votes, g["votes"])
+    assert numpy.array_equal(numpy.flatnonzero(votes >= 10), g["contributors"])
+    assert numpy.allclose(mix[:4], g["mix_rows"], rtol=0, atol=1e-8)
+    assert numpy.allclose(mix.max(axis=1), g["mix_rowmax"], rtol=0, atol=1e-8)
+
+
+def test_run_em_b17_multi_golden(b17):
+    """n_multi = 3: sequential init draws, geometric-mean proportions (sum != 1), folded posterior."""
+    from mixemt_amd import em
+    refseq, phy, haps, tables = b17
+    g = golden("g5_run_em_multi")
+    mat = _b17_matrix(tables, g, len(haps))
+    numpy.random.seed(11)
+    res = em.run_em_ex(mat, g["wts"], em_args(n_multi=3))
+    assert numpy.array_equal(res["inits"], g["inits"])
+    assert res["iters"] == list(g["iters"])
+    assert numpy.abs(res["props"] - g["props"]).max() < PROPS_ATOL
+    assert abs(res["props"].sum() - g["props"].sum()) < 1e-9
+    mix = res["read_mix"].cpu().numpy()
+    assert numpy.array_equal(mix.argmax(axis=1), g["mix_argmax"])
+    assert numpy.allclose(mix[:16], g["mix_rows"], rtol=0, atol=1e-8)
+
+
+def test_run_em_refinement_shape_golden(b17):
+    """600 x 5 contributor columns (bin/mixemt:311-320): tiny H."""
+    from mixemt_amd import em, preprocess
+    refseq, phy, haps, tables = b17
+    g = golden("g6_refine")
+    mat = _b17_matrix(tables, g, len(haps))
+    contribs = [["hap%d" % (i + 1), haps[c], 0.0] for i, c in enumerate(g["cols"])]
+    sub, names = preprocess.reduce_em_matrix(mat, haps, contribs)
+    assert names == [haps[c] for c in g["cols"]]
+    numpy.random.seed(5)
+    res = em.run_em_ex(sub, g["wts"], em_args())
+    assert res["iters"] == list(g["iters"])
+    assert numpy.abs(res["props"] - g["props"]).max() < PROPS_ATOL
+    mix = res["read_mix"].cpu().numpy()
+    assert numpy.allclose(numpy.exp(mix), numpy.exp(g["mix"]), rtol=0, atol=1e-9)
+
+
+@pytest.mark.parametrize("n_rows,n_haps,seed", [(37, 66, 1), (500, 513, 2), (300, 1000, 3), (64, 2049, 4),
+                                                (33, 8192, 5), (129, 5408, 6)])
+def test_em_iterations_vs_oracle_random_shapes(n_rows, n_haps, seed):
+    """A few EM steps on random matrices across the streaming kernel's NCH range, odd H included."""
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(seed)
+    mat = rng.normal(-25.0, 8.0, size=(n_rows, n_haps))
+    mat[rng.random(mat.shape) < 0.01] = -numpy.inf
+    wts = rng.integers(1, 5, size=n_rows)
+    init = rng.dirichlet([1.0] * n_haps)
+    res = em.run_em_ex(mat, wts, em_args(max_iter=5, tolerance=0.0), inits=init[None, :],
+                       want_read_mix=True)
+    assert res["iters"] == [5] and res["done"] == [2]
+    theta = numpy.log(init)
+    buf = numpy.empty_like(mat)
+    for _ in range(5):
+        buf, theta = em_oracle.em_step(mat, wts, theta, buf)
+    assert numpy.abs(res["props"] - numpy.exp(theta)).max() < 1e-12
+    mix = res["read_mix"].cpu().numpy()
+    fin = numpy.isfinite(buf)
+    assert numpy.array_equal(numpy.isfinite(mix), fin)
+    assert numpy.allclose(mix[fin], buf[fin], rtol=0, atol=1e-9)
+
+
+def test_max_iter_exhaustion_matches_reference_semantics():
+    """for-else at em.py:141-143: result is (theta_{k+1}, E-step under theta_k) also when not converged."""
+    from mixemt_amd import em
+    g = golden("g7_config1")
+    mat, wts = g["mat"], numpy.ones(1000)
+    numpy.random.seed(21)
+    res = em.run_em_ex(mat, wts, em_args(max_iter=7))
+    numpy.random.seed(21)
+    props, mix = em_oracle.run_em(mat, wts, em_args(max_iter=7))
+    assert res["iters"] == [7] and res["done"] == [2]
+    assert numpy.abs(res["props"] - props).max() < 1e-12
+    assert numpy.allclose(numpy.exp(res["read_mix"].cpu().numpy()), numpy.exp(mix), rtol=0, atol=1e-10)
+
+
+def test_device_resident_pipeline(b17):
+    """CSR -> device matrix -> run_em on tensors: nothing but proportions leaves the GPU."""
+    import torch
+    from mixemt_amd import em, preprocess
+    refseq, phy, haps, tables = b17
+    g = golden("g4_run_em")
+    mat = preprocess.build_em_matrix_device(tables, g["row_ptr"], g["site"], g["obs"])
+    assert mat.is_cuda
+    keep = mat.clone()
+    numpy.random.seed(7)
+    props, read_mix = em.run_em(mat, torch.from_numpy(g["wts"]).cuda(), em_args())
+    assert isinstance(read_mix, torch.Tensor) and read_mix.is_cuda
+    assert torch.equal(mat, keep)                                   # caller's matrix untouched
+    assert numpy.abs(props - g["props"]).max() < PROPS_ATOL
+    assert numpy.array_equal(read_mix.argmax(dim=1).cpu().numpy(), g["mix_argmax"])
+
+
+def test_row_argmax_votes_kernel(b17):
+    """assemble.py:115-123 / stats.py:39-40 on device (first max wins, weighted votes)."""
+    import torch
+    from mixemt_amd import _lib
+    from mixemt_amd._dev import current_stream
+    rng = numpy.random.default_rng(12)
+    mat = rng.normal(size=(300, 777))
+    mat[5, 100] = mat[5, 600] = 9.0          # tie -> first index
+    mat[6, :] = -numpy.inf
+    wts = rng.integers(1, 4, size=300).astype(numpy.float64)
+    x = torch.from_numpy(mat).cuda()
+    w = torch.from_numpy(wts).cuda()
+    best = torch.empty(300, dtype=torch.int32, device="cuda")
+    votes = torch.zeros(777, dtype=torch.float64, device="cuda")
+    lib = _lib.load()
+    _lib.check(lib.mxm_row_argmax_votes(x.data_ptr(), x.stride(0), w.data_ptr(), 300, 777,
+                                        best.data_ptr(), votes.data_ptr(), current_stream()), "argmax")
+    want = mat.argmax(axis=1)
+    assert numpy.array_equal(best.cpu().numpy(), want)
+    want_votes = numpy.zeros(777)
+    numpy.add.at(want_votes, want, wts)
+    assert numpy.array_equal(votes.cpu().numpy(), want_votes)

@@ -1,0 +1,120 @@
+"""
+Host logic of the product package against the reference-derived fixtures:
+Phylotree parsing, table encoding, signature encoding, the synthetic generator.
+CPU only (no kernels are called).
+"""
+import hashlib
+
+import numpy
+import pytest
+
+from conftest import golden
+from mixemt_amd import phylotree, preprocess, synth
+
+
+def test_toy_tree_matches_reference_docstring(toy):
+    """phylotree.py:491-499 lists the toy tree's hap_var."""
+    _, phy, _ = toy
+    want = {'A': ['A1G', 'A2T', 'A4T'], 'B': ['A1G', 'A3T', 'A5T', 'A6T', 'A8T'],
+            'C': ['A1G', 'A3T', 'T5A', 'A6T'], 'D': ['A1G', 'A3T', 'A5T', 'A7T', 'A9T'],
+            'E': ['A1G', 'A3T', 'A4T', 'A5T', 'A7T'], 'F': ['A1G', 'A3T', 'A5T', 'A6T'],
+            'G': ['A1G', 'A3T', 'A5T', 'A7T'], 'H': ['A1G', 'A3T', 'A5T'], 'I': ['A1G']}
+    assert phy.hap_var == want
+    assert phy.get_variant_pos() == list(range(9))
+    assert phy.variants[4] == {'T': 1, 'A': 1} and phy.variants[3] == {'T': 2}
+
+
+def test_toy_markers_match_reference_test(toy):
+    """preprocess_test.py:34-50: marker table of the toy tree."""
+    ref, phy, haps = toy
+    tables = preprocess.HapVarTables.build(ref, phy, haps)
+    markers = {'A': {1: 'T', 3: 'T', 0: 'G'}, 'B': {0: 'G', 2: 'T', 4: 'T', 5: 'T', 7: 'T'},
+               'C': {0: 'G', 2: 'T', 5: 'T'}, 'D': {0: 'G', 2: 'T', 4: 'T', 6: 'T', 8: 'T'},
+               'E': {0: 'G', 2: 'T', 3: 'T', 4: 'T', 6: 'T'}, 'F': {0: 'G', 2: 'T', 4: 'T', 5: 'T'},
+               'G': {0: 'G', 2: 'T', 4: 'T', 6: 'T'}, 'H': {0: 'G', 2: 'T', 4: 'T'}, 'I': {0: 'G'}}
+    for j, hap in enumerate(haps):
+        for pos in range(9):
+            want = markers[hap].get(pos, 'A')
+            assert chr(tables.expected[pos, j]) == want
+    # mut_prob scaling (preprocess_test.py:64-74 uses other weights; defaults here)
+    assert numpy.allclose(numpy.exp(tables.lhit), 1 - numpy.minimum(0.5, 0.01 * numpy.array(
+        [sum(phy.variants[p].values()) for p in range(9)])))
+
+
+def test_line_parser_anonymous_nodes():
+    rows = ["R, A1G ,,", ",, A2T ,,", ",,, A3T ,,", ",N, A4T ,,", ",,, A5T ,,"]
+    phy = phylotree.Phylotree(rows, anon_haps=True)
+    assert phy.names == ["R", "R[1]", "R[1][1]", "N", "N[1]"]
+    assert phy.parent == [-1, 0, 1, 0, 3]
+    assert phy.hap_var["R[1][1]"] == ["A1G", "A2T", "A3T"]
+    phy2 = phylotree.Phylotree(rows, anon_haps=False)
+    assert sorted(phy2.hap_var) == ["N", "R"]
+
+
+def test_annotations_and_filters():
+    rows = ["R, (A1G) A2T! C3d 4.1T a5c ,,", ",K, G1A T2A ,,"]
+    phy = phylotree.Phylotree(rows)
+    assert phy.hap_var["R"] == ["A1G", "A2T", "A5C"]        # indels dropped, annotations stripped
+    assert phy.hap_var["K"] == ["G1A", "T2A", "A5C"]        # newer mutation masks the older
+    assert phylotree.Phylotree(rows, rm_unstable=True).get_variant_pos() == [1, 4]
+    assert phylotree.Phylotree(rows, rm_unstable=True, rm_backmut=True).get_variant_pos() == [4]
+    assert phylotree.pos_from_var("(A95c)") == 94 and phylotree.der_allele("(A95c)") == "C"
+    assert phylotree.der_allele("A263G!") == "G" and phylotree.anc_allele("(A95c)") == "A"
+    phy.add_custom_hap("mine", ["A1T", "G9A"])
+    with pytest.raises(ValueError):
+        phy.add_custom_hap("mine", ["A1T"])
+    phy.ignore_sites("1,4-5")
+    assert phy.get_variant_pos() == [1]
+    assert phy.variants[1]["T"] == 2                         # counters accumulate (reference quirk)
+
+
+def test_build17_tables_match_reference(b17):
+    refseq, phy, haps, tables = b17
+    g = golden("g0_tables_b17")
+    assert len(refseq) == 16569
+    assert haps == str(g["hap_names"]).split("\n")
+    assert int(g["n_haps"]) == 5408 and int(g["n_sites"]) == 4070
+    assert numpy.array_equal(tables.sites, g["sites"])
+    dense = numpy.empty((len(tables.sites), len(haps)), dtype=numpy.uint8)
+    dense[:, :] = g["ref_codes"][:, None]
+    dense[g["marker_site"], g["marker_hap"]] = g["marker_base"]
+    assert len(g["marker_hap"]) == 263826
+    assert numpy.array_equal(tables.expected[:, :len(haps)], dense)
+    assert hashlib.sha256(dense.tobytes()).hexdigest() == str(g["dense_sha256"])
+    assert not tables.expected[:, len(haps):].any()
+    assert numpy.array_equal(tables.lhit, numpy.log(1.0 - g["mut_prob"]))
+    assert numpy.array_equal(tables.lmiss, numpy.log(g["mut_prob"] / 3.0))
+
+
+def test_encode_signatures_roundtrip_and_errors(b17):
+    refseq, phy, haps, tables = b17
+    row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), 50, seed=9)
+    sigs = synth.signatures(tables, row_ptr, site, obs)
+    rp, si, ob = preprocess.encode_signatures(sigs, tables)
+    assert numpy.array_equal(rp, row_ptr) and numpy.array_equal(si, site) and numpy.array_equal(ob, obs)
+    assert rp.dtype == numpy.int64 and si.dtype == numpy.uint16 and ob.dtype == numpy.uint8
+    with pytest.raises(ValueError):
+        preprocess.encode_signatures(["%d:A" % tables.sites[0], ""], tables)          # reference: int('') ValueError
+    with pytest.raises(KeyError):
+        preprocess.encode_signatures(["0:A"], tables)              # position 0 is not a variant site
+    rp, si, ob = preprocess.encode_signatures(["%d:N,%d:ac" % (tables.sites[0], tables.sites[1])], tables)
+    assert list(ob) == [ord("N"), 0]
+
+
+def test_synth_v1_is_pinned(b17):
+    """The generator's stream is part of the bench definition: same seed, same bytes."""
+    refseq, phy, haps, tables = b17
+    g = golden("g2_build_b17")
+    row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), 1032, seed=2)
+    assert numpy.array_equal(row_ptr, g["row_ptr"])
+    assert numpy.array_equal(site, g["site"]) and numpy.array_equal(obs, g["obs"])
+    counts = numpy.diff(row_ptr)
+    assert counts.min() >= 1 and 30 < counts.mean() < 45
+    assert set(numpy.unique(obs)) <= set(b"ACGTN")
+
+
+def test_reduce_em_matrix_numpy():
+    """preprocess.py:230-251."""
+    mat = numpy.arange(12.0).reshape(3, 4)
+    sub, names = preprocess.reduce_em_matrix(mat, list("WXYZ"), [["hap1", "Y", 0.7], ["hap2", "W", 0.3]])
+    assert names == ["W", "Y"] and numpy.array_equal(sub, mat[:, [0, 2]])

@@ -1,0 +1,241 @@
+#!/usr/bin/env python
+"""
+Golden-vector generator: runs ONLY in the build container, where the reference
+is mounted at /root/reference.  It imports the reference's own modules (through
+a package shim, because `import mixemt` pulls in pysam via assemble.py:22) and
+records inputs + outputs of the hot path as small .npz fixtures under
+tests/golden/.  Only the fixtures travel; no reference code does.
+
+    python tools/gen_golden.py [--only g0,g1,...] [--out tests/golden]
+
+Fixtures (SURVEY.md section 8 c):
+    g0  Build-17 + RSRS tables: haplogroup order, sites, mut_prob, sparse markers
+    g1  9-haplogroup toy tree: signatures -> matrix, run_em for seeds x n_multi
+    g2  Build 17: 32 synthetic rows -> full matrix; 1000 more rows -> row stats
+    g3  em_step on 64 x 5408 (+ the two exact -inf cases of em_test.py:35-65)
+    g4  run_em on 600 x 5408, n_multi = 1
+    g5  run_em on the same matrix, n_multi = 3
+    g6  refinement shape: 600 x 5 contributor columns
+    g7  config 1: 1000 x 100
+"""
+
+import argparse
+import hashlib
+import io
+import os
+import re
+import sys
+import time
+import types
+
+import numpy
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+REF = "/root/reference"
+
+
+def load_reference():
+    pkg = types.ModuleType("mixemt")
+    pkg.__path__ = [os.path.join(REF, "mixemt")]
+    sys.modules["mixemt"] = pkg
+    import mixemt.em
+    import mixemt.phylotree
+    import mixemt.preprocess
+    return pkg
+
+
+def ns(**kw):
+    args = argparse.Namespace(init_alpha=1.0, tolerance=0.0001, max_iter=10000,
+                              n_multi=1, verbose=False)
+    for key, val in kw.items():
+        setattr(args, key, val)
+    return args
+
+
+def sha(arr):
+    return hashlib.sha256(numpy.ascontiguousarray(arr).tobytes()).hexdigest()
+
+
+def ref_run_em(ref, mat, wts, seed, **kw):
+    """Reference run_em with the iteration counts scraped from its -v output."""
+    args = ns(verbose=True, **kw)
+    numpy.random.seed(seed)
+    inits = numpy.stack([numpy.random.dirichlet([args.init_alpha] * mat.shape[1])
+                         for _ in range(args.n_multi)])
+    numpy.random.seed(seed)
+    err, sys.stderr = sys.stderr, io.StringIO()
+    try:
+        props, read_mix = ref.em.run_em(mat, wts, args)
+        log = sys.stderr.getvalue()
+    finally:
+        sys.stderr = err
+    iters = [int(x) for x in re.findall(r"Converged! \((\d+)\)", log)]
+    assert len(iters) == args.n_multi, log[-200:]
+    return props, read_mix, numpy.array(iters), inits
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--only", default="")
+    ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    opts = ap.parse_args()
+    only = set(x for x in opts.only.split(",") if x)
+    os.makedirs(opts.out, exist_ok=True)
+
+    def want(name):
+        return not only or name in only
+
+    def save(name, **arrays):
+        path = os.path.join(opts.out, name + ".npz")
+        numpy.savez_compressed(path, **arrays)
+        print("%-4s %8.1f KB  %s" % (name, os.path.getsize(path) / 1024.0, path))
+
+    ref = load_reference()
+    from mixemt_amd import phylotree as my_phy
+    from mixemt_amd import preprocess as my_pre
+    from mixemt_amd import synth
+
+    refseq = my_phy.read_fasta_first(os.path.join(REF, "mixemt/ref/RSRS.mtDNA.fa"))
+    with open(os.path.join(REF, "mixemt/phylotree/mtDNA_tree_Build_17.csv")) as fin:
+        phy = ref.phylotree.Phylotree(fin, refseq=refseq, anon_haps=True)
+    haps = sorted(phy.hap_var)
+    # encoder only (host tables for the generator); checked against the reference in g0
+    tables = my_pre.HapVarTables.build(refseq, phy, haps)
+    quiet = ns()
+
+    if want("g0"):
+        hvb = ref.preprocess.HapVarBaseMatrix(refseq, phy)
+        sites = numpy.array(phy.get_variant_pos(), dtype=numpy.int64)
+        where = {int(p): k for k, p in enumerate(sites)}
+        mh, ms, mb = [], [], []
+        dense = numpy.empty((len(sites), len(haps)), dtype=numpy.uint8)
+        dense[:, :] = numpy.array([ord(refseq[p]) for p in sites], dtype=numpy.uint8)[:, None]
+        for j, hap in enumerate(haps):
+            for pos, base in sorted(hvb.markers[hap].items()):
+                mh.append(j); ms.append(where[pos]); mb.append(ord(base))
+                dense[where[pos], j] = ord(base)
+        mut = numpy.array([hvb.mut_prob[int(p)] for p in sites])
+        save("g0_tables_b17",
+             hap_names=numpy.array("\n".join(haps)),
+             sites=sites, mut_prob=mut,
+             marker_hap=numpy.array(mh, dtype=numpy.uint16),
+             marker_site=numpy.array(ms, dtype=numpy.uint16),
+             marker_base=numpy.array(mb, dtype=numpy.uint8),
+             ref_codes=numpy.array([ord(refseq[p]) for p in sites], dtype=numpy.uint8),
+             dense_sha256=numpy.array(sha(dense)),
+             n_haps=numpy.array(len(haps)), n_sites=numpy.array(len(sites)))
+
+    if want("g1"):
+        toy = ref.phylotree.example()
+        toy_ref = "AAAAAAAAA"
+        reads = ["1:A,2:T,3:A", "2:T,3:A", "3:A,4:T,5:T", "5:T,6:A", "6:A,7:T",
+                 "6:A,7:T,8:A", "7:T,8:A", "4:T,5:T", "1:A,2:T,3:T,4:T", "5:A,6:T,7:A,8:A"]
+        thaps = list("ABCDEFGHI")
+        mat = ref.preprocess.build_em_matrix(toy_ref, toy, reads, thaps, quiet)
+        reads_b = ["1:A,2:C", "1:T,2:C", "3:T,4:T", "2:A,4:T"]     # preprocess_test.py:269
+        mat_b = ref.preprocess.build_em_matrix(toy_ref, toy, reads_b, thaps, quiet)
+        out = dict(reads=numpy.array("\n".join(reads)), reads_b=numpy.array("\n".join(reads_b)),
+                   mat=mat, mat_b=mat_b)
+        for n_multi in (1, 3):
+            for seed in (1, 2, 3):
+                props, mix, iters, inits = ref_run_em(ref, mat, numpy.ones(len(reads)), seed,
+                                                      n_multi=n_multi, max_iter=1000)
+                key = "m%d_s%d" % (n_multi, seed)
+                out[key + "_props"] = props
+                out[key + "_mix"] = mix
+                out[key + "_iters"] = iters
+                out[key + "_inits"] = inits
+        save("g1_toy", **out)
+
+    if want("g2"):
+        row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), 1032, seed=2)
+        sigs = synth.signatures(tables, row_ptr, site, obs)
+        t0 = time.time()
+        mat = ref.preprocess.build_em_matrix(refseq, phy, sigs, haps, quiet)
+        print("g2: reference built 1032 x %d in %.0f s" % (len(haps), time.time() - t0))
+        save("g2_build_b17", row_ptr=row_ptr, site=site, obs=obs,
+             mat32=mat[:32].copy(),
+             row_sum=mat.sum(axis=1), row_min=mat.min(axis=1), row_max=mat.max(axis=1),
+             row_argmax=mat.argmax(axis=1).astype(numpy.int32),
+             col_sum=mat.sum(axis=0), mat_sha256=numpy.array(sha(mat)))
+
+    if want("g3"):
+        row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), 64, seed=3)
+        sigs = synth.signatures(tables, row_ptr, site, obs)
+        mat = ref.preprocess.build_em_matrix(refseq, phy, sigs, haps, quiet)
+        rng = numpy.random.default_rng(33)
+        wts = rng.integers(1, 6, size=64).astype(numpy.int64)
+        lnp = numpy.log(rng.dirichlet([1.0] * len(haps)))
+        mix = numpy.empty_like(mat)
+        mix, new_props = ref.em.em_step(mat, wts, lnp, mix)
+        inf = float("inf")
+        ident = numpy.array([[0.0, -inf, -inf], [-inf, 0.0, -inf], [-inf, -inf, 0.0]])
+        p3 = numpy.log(numpy.array([0.6, 0.2, 0.2]))
+        r1 = ref.em.em_step(ident, numpy.array([1, 1, 1]), p3, numpy.empty_like(ident))
+        r2 = ref.em.em_step(ident, numpy.array([2, 1, 1]), p3, numpy.empty_like(ident))
+        save("g3_em_step", row_ptr=row_ptr, site=site, obs=obs, mat_sha256=numpy.array(sha(mat)),
+             wts=wts, lnp=lnp, mix_rows=mix[:8].copy(), mix_sha256=numpy.array(sha(mix)),
+             mix_rowmax=mix.max(axis=1), mix_argmax=mix.argmax(axis=1).astype(numpy.int32),
+             new_props=new_props,
+             ident=ident, ident_lnp=p3, ident_mix1=r1[0], ident_new1=r1[1],
+             ident_mix2=r2[0], ident_new2=r2[1])
+
+    mat600 = None
+    if want("g4") or want("g5") or want("g6"):
+        row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), 600, seed=4)
+        sigs = synth.signatures(tables, row_ptr, site, obs)
+        t0 = time.time()
+        mat600 = ref.preprocess.build_em_matrix(refseq, phy, sigs, haps, quiet)
+        print("g4-6: reference built 600 x %d in %.0f s" % (len(haps), time.time() - t0))
+        wts600 = numpy.random.default_rng(44).integers(1, 4, size=600).astype(numpy.int64)
+        common = dict(row_ptr=row_ptr, site=site, obs=obs, who=who, wts=wts600,
+                      mat_sha256=numpy.array(sha(mat600)))
+
+    def votes_of(mix, wts, n):
+        best = mix.argmax(axis=1)
+        votes = numpy.zeros(n)
+        numpy.add.at(votes, best, wts)          # assemble.py:115-123
+        return best.astype(numpy.int32), votes
+
+    if want("g4"):
+        t0 = time.time()
+        props, mix, iters, inits = ref_run_em(ref, mat600, wts600, 7)
+        print("g4: reference run_em %d iterations in %.0f s" % (iters[0], time.time() - t0))
+        best, votes = votes_of(mix, wts600, len(haps))
+        save("g4_run_em", props=props, iters=iters, inits=inits, mix_rows=mix[:4].copy(),
+             mix_argmax=best, votes=votes, mix_rowmax=mix.max(axis=1),
+             contributors=numpy.flatnonzero(votes >= 10).astype(numpy.int32), **common)
+
+    if want("g5"):
+        t0 = time.time()
+        props, mix, iters, inits = ref_run_em(ref, mat600, wts600, 11, n_multi=3)
+        print("g5: reference run_em x3 %s iterations in %.0f s" % (iters, time.time() - t0))
+        best, votes = votes_of(mix, wts600, len(haps))
+        save("g5_run_em_multi", props=props, iters=iters, inits=inits, mix_rows=mix[:16].copy(),
+             mix_argmax=best, votes=votes, mix_rowmax=mix.max(axis=1), **common)
+
+    if want("g6"):
+        contribs = [["hap1", haps[10], 0.6], ["hap2", haps[2000], 0.3], ["hap3", haps[4000], 0.1],
+                    ["hap4", haps[11], 0.0], ["hap5", haps[3000], 0.0]]
+        sub, names = ref.preprocess.reduce_em_matrix(mat600, haps, contribs)
+        props, mix, iters, inits = ref_run_em(ref, sub, wts600, 5)
+        save("g6_refine", cols=numpy.array([haps.index(n) for n in names], dtype=numpy.int32),
+             props=props, iters=iters, inits=inits, mix=mix, **common)
+
+    if want("g7"):
+        cols = list(range(0, 5400, 54))
+        sub_haps = [haps[c] for c in cols]
+        contrib = (cols[10], cols[40], cols[80])
+        row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), 1000, seed=1,
+                                                    contrib=contrib)
+        sigs = synth.signatures(tables, row_ptr, site, obs)
+        mat = ref.preprocess.build_em_matrix(refseq, phy, sigs, sub_haps, quiet)
+        wts = numpy.ones(1000, dtype=numpy.int64)
+        props, mix, iters, inits = ref_run_em(ref, mat, wts, 7)
+        save("g7_config1", cols=numpy.array(cols, dtype=numpy.int32), row_ptr=row_ptr, site=site,
+             obs=obs, who=who, mat=mat, props=props, iters=iters, inits=inits, mix=mix)
+
+
+if __name__ == "__main__":
+    main()
