@@ -1,0 +1,52 @@
+#!/usr/bin/env python
+"""
+Summarise rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, collected in
+separate runs as MI355X_MICROARCH.md prescribes) into per-kernel HBM traffic.
+
+    python tools/pmc_summary.py FETCH.csv WRITE.csv > profiles/rNN/pmc_traffic.json
+
+Units and corrections (MI355X_MICROARCH.md, section HBM):
+  * both counters count units of 1024 B;
+  * on gfx950 FETCH_SIZE reports exactly 1/2 of the bytes of a wide coalesced
+    streaming read (16 B/lane), so it is doubled for kernels that read that way
+    (listed in WIDE_READERS); other access widths are uncalibrated and reported
+    raw (correction 1.0);
+  * WRITE_SIZE is exact for 16-B-per-lane streaming stores.
+"""
+import collections
+import csv
+import json
+import sys
+
+# kernels whose reads are 16 B/lane coalesced streams (FETCH_SIZE x2 applies)
+WIDE_READERS = ("em_iter_wide_kernel", "em_iter_batch_kernel")
+
+
+def per_kernel(path):
+    acc = collections.defaultdict(list)
+    for row in csv.DictReader(open(path)):
+        name = row["Kernel_Name"].split("(")[0].replace("void ", "").strip()
+        acc[name].append(float(row["Counter_Value"]))
+    return {k: (sum(v) / len(v), len(v)) for k, v in acc.items()}
+
+
+def main():
+    fetch, write = per_kernel(sys.argv[1]), per_kernel(sys.argv[2])
+    out = {}
+    for name in sorted(set(fetch) | set(write)):
+        if "_kernel" not in name or name.startswith("at::"):
+            continue
+        f, nf = fetch.get(name, (0.0, 0))
+        w, nw = write.get(name, (0.0, 0))
+        corr = 2.0 if name.startswith(WIDE_READERS) else 1.0
+        out[name] = {"launches": max(nf, nw), "FETCH_SIZE_raw": f, "WRITE_SIZE_raw": w,
+                     "fetch_correction": corr,
+                     "hbm_read_bytes_per_launch": f * 1024.0 * corr,
+                     "hbm_write_bytes_per_launch": w * 1024.0,
+                     "hbm_bytes_per_launch": f * 1024.0 * corr + w * 1024.0}
+    json.dump(out, sys.stdout, indent=1)
+    sys.stdout.write("\n")
+
+
+if __name__ == "__main__":
+    main()
