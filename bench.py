@@ -92,6 +92,9 @@ def main():
     ap.add_argument("--cpu-iters", type=int, default=2)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to test the "
+                         "multi-process path on a single GPU)")
     opts = ap.parse_args()
 
     import torch
@@ -103,11 +106,17 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != opts.gpus:
         log("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (opts.gpus, world))
-    torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
+    n_dev = torch.cuda.device_count()
+    if opts.backend == "nccl" and world > n_dev:
+        raise SystemExit("bench: %d ranks but %d GPU(s) visible" % (world, n_dev))
+    dev = torch.device("cuda", local_rank % max(n_dev, 1))
+    torch.cuda.set_device(dev)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        if opts.backend == "nccl":
+            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        else:
+            dist.init_process_group(opts.backend, rank=rank, world_size=world)
     lib = _lib.load()
 
     # ---- inputs: Build 17 + RSRS tables, synth-v1 reads, matrix built on the device -------------
