@@ -160,6 +160,13 @@ int mxm_row_argmax_votes(const double *X, int64_t ldx, const double *w,
  */
 int mxm_set_timing_events(void *ev_start, void *ev_stop);
 
+/*
+ * How many restarts share one pass over the matrix in mxm_em_iter (1..3,
+ * default 3).  1 reproduces the unbatched schedule (B passes per iteration).
+ * Results do not depend on it beyond rounding of the reduction order.
+ */
+int mxm_set_batch_tile(int32_t bt);
+
 #ifdef __cplusplus
 }
 #endif

@@ -187,109 +187,127 @@ __global__ __launch_bounds__(ROW_THREADS) void linearize_kernel(const double *__
 // double2 column pairs {t + 256 k}, k < NCH: one 16-byte load per pair per row
 // (a wave instruction covers 1 KiB contiguous), the row stays in VGPRs between
 // the dot product and the accumulation, so the matrix is read from HBM exactly
-// once per iteration.  T rows are in flight per step and the next step's loads
-// are issued before the current step's reduction (register double buffer).
+// once per iteration.  The next row's loads are issued before the current row's
+// reduction (register double buffer).  BT restarts can share each row: every
+// restart adds its own p / accumulator registers, the bytes read stay the same
+// (BT = 1: 256 threads, 2 workgroups per CU; BT = 2, 3: 512 threads, 1 per CU).
 // Column partials live in registers for the whole kernel and are written once:
 // partial[wg][h], summed in fixed order afterwards -> bitwise reproducible.
 // ------------------------------------------------------------------------------------------
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-template <int NCH, int T>
-__global__ __launch_bounds__(MXM_WIDE_THREADS) void em_iter_wide_kernel(
+template <int THREADS, int NCH, int BT>
+__global__ __launch_bounds__(THREADS) void em_iter_wide_kernel(
     const double *__restrict__ P, int64_t ldp, const double *__restrict__ w,
     const double *__restrict__ props, int64_t R, int H, int64_t rows_per_wg,
     double *__restrict__ partial, int64_t ldpart, const mxm_em_state *__restrict__ state) {
-    constexpr int THREADS = MXM_WIDE_THREADS;
     constexpr int NW = THREADS / 64;
-    __shared__ double red[2][T][NW];
-    if (state != nullptr && state->done != 0) return;
+    __shared__ double red[2][BT][NW];
+    if (state != nullptr) {
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < BT; ++b) any = any || (state[b].done == 0);
+        if (!any) return;                           // every restart of this tile has stopped
+    }
 
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6;
     const int ncol2 = (H + 1) >> 1;                 // d2 pairs per row (pad column is 0 in P)
 
-    d2 p[NCH], acc[NCH];
+    // proportions: registers for a single restart; for a batch they sit in LDS as
+    // [b][k][thread] pairs (one conflict-free ds_read_b128 per use) so that the VGPR
+    // budget goes to the accumulators and the row double buffer
+    extern __shared__ d2 lds_p[];
+    d2 p[BT == 1 ? NCH : 1], acc[BT][NCH];
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const int c = 2 * (t + k * THREADS);
-        p[k].x = (c < H) ? props[c] : 0.0;
-        p[k].y = (c + 1 < H) ? props[c + 1] : 0.0;
-        acc[k] = d2{0.0, 0.0};
+    for (int b = 0; b < BT; ++b) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = 2 * (t + k * THREADS);
+            d2 v;
+            v.x = (c < H) ? props[(int64_t)b * H + c] : 0.0;
+            v.y = (c + 1 < H) ? props[(int64_t)b * H + c + 1] : 0.0;
+            if constexpr (BT == 1) p[k] = v;
+            else lds_p[(b * NCH + k) * THREADS + t] = v;
+            acc[b][k] = d2{0.0, 0.0};
+        }
     }
 
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
     const int64_t r1 = (r0 + rows_per_wg < R) ? (r0 + rows_per_wg) : R;
     const bool last_ok = (t + (NCH - 1) * THREADS) < ncol2;
 
-    d2 xa[T][NCH], xb[T][NCH];
+    d2 xa[NCH], xb[NCH];
 
-    auto load_rows = [&](d2(&x)[T][NCH], int64_t r) {
+    auto load_row = [&](d2(&x)[NCH], int64_t r) {
+        const bool live = r < r1;
+        const d2 *row = reinterpret_cast<const d2 *>(P + r * ldp);
 #pragma unroll
-        for (int i = 0; i < T; ++i) {
-            const bool live = (r + i) < r1;
-            const d2 *row = reinterpret_cast<const d2 *>(P + (r + i) * ldp);
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                const bool ok = live && (k < NCH - 1 || last_ok);
-                x[i][k] = ok ? __builtin_nontemporal_load(row + t + k * THREADS)
-                             : d2{0.0, 0.0};
-            }
+        for (int k = 0; k < NCH; ++k) {
+            const bool ok = live && (k < NCH - 1 || last_ok);
+            x[k] = ok ? __builtin_nontemporal_load(row + t + k * THREADS) : d2{0.0, 0.0};
         }
     };
 
     int buf = 0;
-    auto process = [&](d2(&x)[T][NCH], int64_t r) {
-        double d[T];
+    auto process = [&](d2(&x)[NCH], int64_t r) {
+        double d[BT];
 #pragma unroll
-        for (int i = 0; i < T; ++i) {
+        for (int b = 0; b < BT; ++b) {
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                s = fma(x[i][k].x, p[k].x, s);
-                s = fma(x[i][k].y, p[k].y, s);
+                d2 pk;
+                if constexpr (BT == 1) pk = p[k];
+                else pk = lds_p[(b * NCH + k) * THREADS + t];     // own slot: no barrier needed
+                s = fma(x[k].x, pk.x, s);
+                s = fma(x[k].y, pk.y, s);
             }
-            d[i] = s;
+            d[b] = s;
         }
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
-            for (int i = 0; i < T; ++i) d[i] += __shfl_xor(d[i], off, 64);
+            for (int b = 0; b < BT; ++b) d[b] += __shfl_xor(d[b], off, 64);
         }
         if (lane == 0) {
 #pragma unroll
-            for (int i = 0; i < T; ++i) red[buf][i][wv] = d[i];
+            for (int b = 0; b < BT; ++b) red[buf][b][wv] = d[b];
         }
         __syncthreads();
+        const bool live = r < r1;
+        const double wr = live ? (w != nullptr ? w[r] : 1.0) : 0.0;
 #pragma unroll
-        for (int i = 0; i < T; ++i) {
-            double z = red[buf][i][0];
+        for (int b = 0; b < BT; ++b) {
+            double z = red[buf][b][0];
 #pragma unroll
-            for (int q = 1; q < NW; ++q) z += red[buf][i][q];
-            const bool live = (r + i) < r1;
-            const double wr = live ? (w != nullptr ? w[r + i] : 1.0) : 0.0;
+            for (int q = 1; q < NW; ++q) z += red[buf][b][q];
             const double c = (z > 0.0) ? wr / z : 0.0;
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                acc[k].x = fma(c, x[i][k].x, acc[k].x);
-                acc[k].y = fma(c, x[i][k].y, acc[k].y);
+                acc[b][k].x = fma(c, x[k].x, acc[b][k].x);
+                acc[b][k].y = fma(c, x[k].y, acc[b][k].y);
             }
         }
         buf ^= 1;
     };
 
-    load_rows(xa, r0);
-    for (int64_t r = r0; r < r1; r += 2 * T) {
-        load_rows(xb, r + T);
+    load_row(xa, r0);
+    for (int64_t r = r0; r < r1; r += 2) {
+        load_row(xb, r + 1);
         process(xa, r);
-        load_rows(xa, r + 2 * T);
-        process(xb, r + T);
+        load_row(xa, r + 2);
+        process(xb, r + 1);
     }
 
-    d2 *dst = reinterpret_cast<d2 *>(partial + (int64_t)blockIdx.x * ldpart);
 #pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-        const int c2 = t + k * THREADS;
-        if (c2 < ncol2) dst[c2] = acc[k];
+    for (int b = 0; b < BT; ++b) {
+        d2 *dst = reinterpret_cast<d2 *>(partial + ((int64_t)blockIdx.x * BT + b) * ldpart);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c2 = t + k * THREADS;
+            if (c2 < ncol2) dst[c2] = acc[b][k];
+        }
     }
 }
 
@@ -299,22 +317,24 @@ __global__ __launch_bounds__(MXM_WIDE_THREADS) void em_iter_wide_kernel(
 // scale_h = props[h] for the linear kernel, 1 for the log-space kernel.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void colreduce_kernel(const double *__restrict__ partial,
-                                                        int64_t ldpart, int nwg, int H,
+                                                        int64_t ldpart, int nwg, int nb, int H,
                                                         const double *__restrict__ props,
                                                         double *__restrict__ colsum,
                                                         const mxm_em_state *__restrict__ state) {
+    // grid = (ceil(H/64), nb); partial is [nwg][nb][ldpart]; props / colsum are [nb][H]
     __shared__ double part[4][64];
-    if (state != nullptr && state->done != 0) return;
+    const int b = blockIdx.y;
+    if (state != nullptr && state[b].done != 0) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int h = blockIdx.x * 64 + lane;
     double s = 0.0;
     if (h < H)
-        for (int g = wv; g < nwg; g += 4) s += partial[(int64_t)g * ldpart + h];
+        for (int g = wv; g < nwg; g += 4) s += partial[((int64_t)g * nb + b) * ldpart + h];
     part[wv][lane] = s;
     __syncthreads();
     if (wv == 0 && h < H) {
         const double tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
-        colsum[h] = (props != nullptr) ? props[h] * tot : tot;
+        colsum[(int64_t)b * H + h] = (props != nullptr) ? props[(int64_t)b * H + h] * tot : tot;
     }
 }
 
@@ -503,8 +523,8 @@ extern "C" int mxm_linear_supported(int32_t H) {
 
 extern "C" size_t mxm_workspace_bytes(int64_t R, int32_t H, int32_t B) {
     (void)R;
-    (void)B;                      // restarts are processed one at a time over the same scratch
-    return (size_t)MXM_MAX_WG * (size_t)part_ld(H) * sizeof(double);
+    (void)B;                      // restart tiles are processed one after another over the same scratch
+    return (size_t)MXM_MAX_WG * 3 * (size_t)part_ld(H) * sizeof(double);
 }
 
 extern "C" int mxm_build_em_matrix(const uint8_t *E, int64_t lde, const double *lhit,
@@ -537,64 +557,114 @@ extern "C" int mxm_linearize(const double *M, int64_t ldm, int64_t R, int32_t H,
 
 // ---- optional timing hook (bench.py): events recorded right around the dominant kernel --------
 static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
+static int g_max_bt = 3;              // restarts per matrix pass (1..MXM_MAX_BT); see mxm_set_batch_tile
 extern "C" int mxm_set_timing_events(void *ev_start, void *ev_stop) {
     g_ev_start = (hipEvent_t)ev_start;
     g_ev_stop = (hipEvent_t)ev_stop;
     return 0;
 }
 
-// ---- wide-kernel dispatch over NCH ------------------------------------------------------------
-#ifndef MXM_WIDE_T
-#define MXM_WIDE_T 1
-#endif
-#ifndef MXM_WIDE_WG_PER_CU
-#define MXM_WIDE_WG_PER_CU 2
-#endif
+extern "C" int mxm_set_batch_tile(int32_t bt) {
+    if (bt < 1 || bt > 3) return fail(-1, "mxm_set_batch_tile: tile must be 1..3%s", "");
+    g_max_bt = bt;
+    return 0;
+}
 
-template <int NCH>
+// ---- wide-kernel dispatch over NCH ------------------------------------------------------------
+#define MXM_BATCH2_THREADS 512        // workgroup of the BT = 2 variant (1 per CU)
+#ifndef MXM_BATCH3_THREADS
+#define MXM_BATCH3_THREADS 512        // workgroup of the BT = 3 variant (1 per CU)
+#endif
+#define MXM_MAX_BT 3                  // restarts sharing one read of the matrix
+
+#define MXM_LDS_BUDGET (156 * 1024)  // of the CU's 160 KiB, leaving room for the exchange buffers
+
+static size_t batch_lds_bytes(int H, int nb) {
+    const int threads = (nb == 2) ? MXM_BATCH2_THREADS : MXM_BATCH3_THREADS;
+    const int nch = ((H + 1) / 2 + threads - 1) / threads;
+    return (size_t)nb * nch * threads * 16;
+}
+
+template <int THREADS, int NCH, int BT>
 static void launch_wide(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
                         int H, int grid, int64_t rows_per_wg, double *partial, int64_t ldpart,
                         const mxm_em_state *state, hipStream_t stream) {
-    hipLaunchKernelGGL((em_iter_wide_kernel<NCH, MXM_WIDE_T>), dim3(grid), dim3(MXM_WIDE_THREADS), 0,
-                       stream, P, ldp, w, props, R, H, rows_per_wg, partial, ldpart, state);
+    const size_t lds = (BT == 1) ? 0 : (size_t)BT * NCH * THREADS * sizeof(d2);
+    if (BT > 1) {
+        static bool raised = false;     // > 64 KiB of dynamic LDS must be opted into, once per kernel
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&em_iter_wide_kernel<THREADS, NCH, BT>),
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+            raised = true;
+        }
+    }
+    hipLaunchKernelGGL((em_iter_wide_kernel<THREADS, NCH, BT>), dim3(grid), dim3(THREADS), lds, stream, P,
+                       ldp, w, props, R, H, rows_per_wg, partial, ldpart, state);
 }
 
-static int em_iter_one(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
-                       const double *props, int64_t R, int H, const mxm_em_state *state, double *colsum,
-                       double *partial, hipStream_t stream) {
-    const int64_t ldpart = part_ld(H);
-    int nwg;
-    if (P != nullptr && mxm_linear_supported(H)) {
-        const int ncol2 = (H + 1) / 2;
-        const int nch = (ncol2 + MXM_WIDE_THREADS - 1) / MXM_WIDE_THREADS;
-        const int64_t steps = (R + 2 * MXM_WIDE_T - 1) / (2 * MXM_WIDE_T);
-        nwg = clamp_grid(steps, num_cu() * MXM_WIDE_WG_PER_CU < MXM_MAX_WG ? num_cu() * MXM_WIDE_WG_PER_CU : MXM_MAX_WG);
-        int64_t rows_per_wg = (R + nwg - 1) / nwg;
-        rows_per_wg = (rows_per_wg + 2 * MXM_WIDE_T - 1) / (2 * MXM_WIDE_T) * (2 * MXM_WIDE_T);
-        nwg = (int)((R + rows_per_wg - 1) / rows_per_wg);
-        if (g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
-        switch (nch) {
-#define WIDE_CASE(n) case n: launch_wide<n>(P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream); break;
-            WIDE_CASE(1) WIDE_CASE(2) WIDE_CASE(3) WIDE_CASE(4) WIDE_CASE(5) WIDE_CASE(6) WIDE_CASE(7) WIDE_CASE(8)
-            WIDE_CASE(9) WIDE_CASE(10) WIDE_CASE(11) WIDE_CASE(12) WIDE_CASE(13) WIDE_CASE(14) WIDE_CASE(15) WIDE_CASE(16)
-#undef WIDE_CASE
-            default: return fail(-1, "mxm_em_iter: H=%s%lld outside the linear kernel's range", "", H);
-        }
-        HIP_TRY(hipGetLastError());
-        if (g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
-        hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64), dim3(256), 0, stream, partial, ldpart, nwg,
-                           H, props, colsum, state);
-    } else {
-        if (M == nullptr) return fail(-1, "mxm_em_iter: M is NULL and the linear path does not apply%s", "");
-        const size_t lds = 2 * (size_t)H * sizeof(double);
-        if (lds > 150 * 1024) return fail(-1, "mxm_em_iter: H=%s%lld too large for the log-space kernel", "", H);
-        nwg = clamp_grid(R, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
-        hipLaunchKernelGGL((estep_log_kernel<true>), dim3(nwg), dim3(ROW_THREADS), lds, stream, M, ldm, w, props,
-                           R, H, (double *)nullptr, (int64_t)0, 0, partial, ldpart, state);
-        HIP_TRY(hipGetLastError());
-        hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64), dim3(256), 0, stream, partial, ldpart, nwg,
-                           H, (const double *)nullptr, colsum, state);
+template <int THREADS, int BT>
+static int dispatch_wide(int nch, const double *P, int64_t ldp, const double *w, const double *props,
+                         int64_t R, int H, int grid, int64_t rows_per_wg, double *partial,
+                         int64_t ldpart, const mxm_em_state *state, hipStream_t stream) {
+    switch (nch) {
+#define WIDE_CASE(n) case n: launch_wide<THREADS, n, BT>(P, ldp, w, props, R, H, grid, rows_per_wg, partial, ldpart, state, stream); return 0;
+        WIDE_CASE(1) WIDE_CASE(2) WIDE_CASE(3) WIDE_CASE(4) WIDE_CASE(5) WIDE_CASE(6) WIDE_CASE(7) WIDE_CASE(8)
+        default: break;
     }
+    if (THREADS == MXM_WIDE_THREADS && BT == 1) {
+        switch (nch) {
+            WIDE_CASE(9) WIDE_CASE(10) WIDE_CASE(11) WIDE_CASE(12) WIDE_CASE(13) WIDE_CASE(14) WIDE_CASE(15) WIDE_CASE(16)
+            default: break;
+        }
+    }
+#undef WIDE_CASE
+    return fail(-1, "mxm_em_iter: H=%s%lld outside the linear kernel's range", "", H);
+}
+
+// One tile of nb (<= MXM_MAX_BT) restarts over the linear matrix: streaming kernel + column reduce.
+static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
+                               int H, int nb, const mxm_em_state *state, double *colsum, double *partial,
+                               hipStream_t stream, bool timed) {
+    const int64_t ldpart = part_ld(H);
+    const int ncol2 = (H + 1) / 2;
+    const int threads = (nb == 1) ? MXM_WIDE_THREADS : (nb == 2 ? MXM_BATCH2_THREADS : MXM_BATCH3_THREADS);
+    const int wg_per_cu = (nb == 1) ? 2 : 1;
+    const int nch = (ncol2 + threads - 1) / threads;
+    int cap = num_cu() * wg_per_cu;
+    if (cap > MXM_MAX_WG) cap = MXM_MAX_WG;
+    int nwg = clamp_grid((R + 1) / 2, cap);
+    int64_t rows_per_wg = (R + nwg - 1) / nwg;
+    rows_per_wg = (rows_per_wg + 1) / 2 * 2;
+    nwg = (int)((R + rows_per_wg - 1) / rows_per_wg);
+    if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
+    int rc;
+    if (nb == 1)
+        rc = dispatch_wide<MXM_WIDE_THREADS, 1>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
+    else if (nb == 2)
+        rc = dispatch_wide<MXM_BATCH2_THREADS, 2>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
+    else
+        rc = dispatch_wide<MXM_BATCH3_THREADS, 3>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
+    if (rc != 0) return rc;
+    HIP_TRY(hipGetLastError());
+    if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
+    hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, nb), dim3(256), 0, stream, partial, ldpart, nwg, nb,
+                       H, props, colsum, state);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int em_iter_log_one(const double *M, int64_t ldm, const double *w, const double *props, int64_t R, int H,
+                           const mxm_em_state *state, double *colsum, double *partial, hipStream_t stream) {
+    if (M == nullptr) return fail(-1, "mxm_em_iter: M is NULL and the linear path does not apply%s", "");
+    const size_t lds = 2 * (size_t)H * sizeof(double);
+    if (lds > 150 * 1024) return fail(-1, "mxm_em_iter: H=%s%lld too large for the log-space kernel", "", H);
+    const int64_t ldpart = part_ld(H);
+    const int nwg = clamp_grid(R, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
+    hipLaunchKernelGGL((estep_log_kernel<true>), dim3(nwg), dim3(ROW_THREADS), lds, stream, M, ldm, w, props,
+                       R, H, (double *)nullptr, (int64_t)0, 0, partial, ldpart, state);
+    HIP_TRY(hipGetLastError());
+    hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(256), 0, stream, partial, ldpart, nwg, 1,
+                       H, (const double *)nullptr, colsum, state);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -606,11 +676,25 @@ extern "C" int mxm_em_iter(const double *M, int64_t ldm, const double *P, int64_
     if (ws == nullptr || ws_bytes < mxm_workspace_bytes(R, H, B)) return fail(-1, "mxm_em_iter: workspace too small%s", "");
     if (P != nullptr && ((ldp & 1) || ldp < H)) return fail(-1, "mxm_em_iter: ldp must be even and >= H%s", "");
     if (M != nullptr && ldm < H) return fail(-1, "mxm_em_iter: ldm < H%s", "");
-    for (int b = 0; b < B; ++b) {
-        const int rc = em_iter_one(M, ldm, P, ldp, w, props + (int64_t)b * H, R, (int)H,
-                                   state ? state + b : nullptr, colsum + (int64_t)b * H, (double *)ws,
-                                   (hipStream_t)stream);
+    const bool linear = (P != nullptr) && mxm_linear_supported(H);
+    // restarts are taken in tiles of up to g_max_bt that share one pass over the matrix; the
+    // scratch is reused tile after tile (same stream, so the passes are ordered)
+    const int max_bt = (linear && H <= 2 * MXM_BATCH2_THREADS * 8) ? g_max_bt : 1;
+    for (int b = 0; b < B;) {
+        int nb = B - b;
+        if (nb > max_bt) nb = max_bt;
+        // a batch keeps nb proportion vectors in LDS: shrink the tile until they fit
+        while (nb > 1 && batch_lds_bytes((int)H, nb) > MXM_LDS_BUDGET) --nb;
+        const mxm_em_state *st = state ? state + b : nullptr;
+        int rc;
+        if (linear)
+            rc = em_iter_linear_tile(P, ldp, w, props + (int64_t)b * H, R, (int)H, nb, st,
+                                     colsum + (int64_t)b * H, (double *)ws, (hipStream_t)stream, b == 0);
+        else
+            rc = em_iter_log_one(M, ldm, w, props + (int64_t)b * H, R, (int)H, st, colsum + (int64_t)b * H,
+                                 (double *)ws, (hipStream_t)stream);
         if (rc != 0) return rc;
+        b += nb;
     }
     return 0;
 }
@@ -671,8 +755,8 @@ extern "C" int mxm_em_step(const double *M, int64_t ldm, const double *w, const 
                        (const mxm_em_state *)nullptr);
     HIP_TRY(hipGetLastError());
     if (colsum != nullptr) {
-        hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64), dim3(256), 0, s, (const double *)ws, ldpart, nwg,
-                           (int)H, (const double *)nullptr, colsum, (const mxm_em_state *)nullptr);
+        hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(256), 0, s, (const double *)ws, ldpart, nwg,
+                           1, (int)H, (const double *)nullptr, colsum, (const mxm_em_state *)nullptr);
         HIP_TRY(hipGetLastError());
     }
     return 0;

@@ -258,3 +258,54 @@ def test_row_argmax_votes_kernel(b17):
     want_votes = numpy.zeros(777)
     numpy.add.at(want_votes, want, wts)
     assert numpy.array_equal(votes.cpu().numpy(), want_votes)
+
+
+@pytest.mark.parametrize("n_rows,n_haps,n_runs,seed", [(200, 5408, 3, 1), (150, 1000, 5, 2), (90, 8192, 3, 3),
+                                                      (64, 6200, 4, 4), (300, 66, 2, 5)])
+def test_batched_restarts_share_matrix_reads(n_rows, n_haps, n_runs, seed):
+    """
+    Restarts advance in tiles of up to 3 that share one pass over the matrix
+    (LDS-resident proportions).  Every restart must come out as if run alone:
+    compared with the oracle and with the unbatched schedule (tile = 1).
+    """
+    from mixemt_amd import _lib, em
+    lib = _lib.load()
+    rng = numpy.random.default_rng(seed)
+    mat = rng.normal(-25.0, 8.0, size=(n_rows, n_haps))
+    wts = rng.integers(1, 5, size=n_rows)
+    inits = rng.dirichlet([1.0] * n_haps, size=n_runs)
+    args = em_args(max_iter=4, tolerance=0.0, n_multi=n_runs)
+    try:
+        lib.mxm_set_batch_tile(3)
+        batched = em.run_em_ex(mat, wts, args, inits=inits, want_read_mix=False)
+        lib.mxm_set_batch_tile(1)
+        single = em.run_em_ex(mat, wts, args, inits=inits, want_read_mix=False)
+    finally:
+        lib.mxm_set_batch_tile(3)
+    assert batched["iters"] == [4] * n_runs
+    for run in range(n_runs):
+        theta = numpy.log(inits[run])
+        buf = numpy.empty_like(mat)
+        for _ in range(4):
+            buf, theta = em_oracle.em_step(mat, wts, theta, buf)
+        assert numpy.abs(batched["run_props"][run] - numpy.exp(theta)).max() < 1e-12
+    assert numpy.abs(batched["run_props"] - single["run_props"]).max() < 1e-13
+
+
+def test_batched_restarts_stop_independently(b17):
+    """Restarts of one tile converge on different iterations; finished ones freeze (g5: 391/446/454)."""
+    from mixemt_amd import _lib, em
+    refseq, phy, haps, tables = b17
+    g = golden("g5_run_em_multi")
+    mat = _b17_matrix(tables, g, len(haps))
+    lib = _lib.load()
+    out = {}
+    for tile in (3, 2, 1):
+        lib.mxm_set_batch_tile(tile)
+        try:
+            numpy.random.seed(11)
+            out[tile] = em.run_em_ex(mat, g["wts"], em_args(n_multi=3), want_read_mix=False)
+        finally:
+            lib.mxm_set_batch_tile(3)
+        assert out[tile]["iters"] == list(g["iters"])
+        assert numpy.abs(out[tile]["props"] - g["props"]).max() < PROPS_ATOL
