@@ -9,7 +9,8 @@ import ctypes
 import os
 
 _PKG = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_PKG, "lib", "libmixemt_hip.so")
+# MXM_LIB points at an alternative build of the same ABI (kernel-shape tuning runs)
+LIB_PATH = os.environ.get("MXM_LIB") or os.path.join(_PKG, "lib", "libmixemt_hip.so")
 
 c_i32, c_i64, c_f64 = ctypes.c_int32, ctypes.c_int64, ctypes.c_double
 c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t

@@ -39,8 +39,11 @@ def _digest(flags):
     return h.hexdigest()
 
 
-def build(force=False, defines=(), verbose=False):
-    """Compile csrc/mixemt_hip.hip -> lib/libmixemt_hip.so; returns the path."""
+def build(force=False, defines=(), verbose=False, out=None):
+    """Compile csrc/mixemt_hip.hip -> lib/libmixemt_hip.so (or `out`); returns the path."""
+    global LIB
+    if out is not None:
+        LIB = os.path.abspath(out)
     flags = ["--offload-arch=%s" % ARCH, "-O3", "-std=c++17", "-shared", "-fPIC",
              "-I" + os.path.join(_ROOT, "include")]
     flags += ["-D%s" % d for d in defines]
@@ -50,7 +53,7 @@ def build(force=False, defines=(), verbose=False):
         with open(stamp) as fin:
             if fin.read().strip() == want:
                 return LIB
-    os.makedirs(LIB_DIR, exist_ok=True)
+    os.makedirs(os.path.dirname(LIB), exist_ok=True)
     cmd = [_hipcc()] + flags + [SRC, "-o", LIB]
     if verbose:
         sys.stderr.write(" ".join(cmd) + "\n")
@@ -75,4 +78,5 @@ if __name__ == "__main__":
             i += 1
         else:
             i += 1
-    print(build(force="--force" in argv, defines=defs, verbose=True))
+    out_path = argv[argv.index("--out") + 1] if "--out" in argv else None
+    print(build(force="--force" in argv, defines=defs, verbose=True, out=out_path))

@@ -196,8 +196,21 @@ __global__ __launch_bounds__(ROW_THREADS) void linearize_kernel(const double *__
 // ------------------------------------------------------------------------------------------
 typedef double d2 __attribute__((ext_vector_type(2)));
 
-template <int THREADS, int NCH, int BT>
-__global__ __launch_bounds__(THREADS) void em_iter_wide_kernel(
+#ifndef MXM_V1_MINW
+#define MXM_V1_MINW 2                 // min waves/SIMD the BT = 1 shape is compiled for (2 WGs of 256 per CU)
+#endif
+#ifndef MXM_V1_P_LDS
+#define MXM_V1_P_LDS 0                // 1: the single-restart shape also keeps its proportions in LDS
+#endif
+#ifndef MXM_SCHED_FENCE
+#define MXM_SCHED_FENCE 0
+#endif
+#ifndef MXM_VB_MINW
+#define MXM_VB_MINW 2                 // batched shapes: one 512-thread workgroup per CU
+#endif
+
+template <int THREADS, int NCH, int BT, int NBUF>
+__global__ __launch_bounds__(THREADS, (BT == 1 ? MXM_V1_MINW : MXM_VB_MINW)) void em_iter_wide_kernel(
     const double *__restrict__ P, int64_t ldp, const double *__restrict__ w,
     const double *__restrict__ props, int64_t R, int H, int64_t rows_per_wg,
     double *__restrict__ partial, int64_t ldpart, const mxm_em_state *__restrict__ state) {
@@ -218,7 +231,8 @@ __global__ __launch_bounds__(THREADS) void em_iter_wide_kernel(
     // [b][k][thread] pairs (one conflict-free ds_read_b128 per use) so that the VGPR
     // budget goes to the accumulators and the row double buffer
     extern __shared__ d2 lds_p[];
-    d2 p[BT == 1 ? NCH : 1], acc[BT][NCH];
+    constexpr bool P_IN_LDS = (BT > 1) || (MXM_V1_P_LDS != 0);
+    d2 p[P_IN_LDS ? 1 : NCH], acc[BT][NCH];
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
 #pragma unroll
@@ -227,7 +241,7 @@ __global__ __launch_bounds__(THREADS) void em_iter_wide_kernel(
             d2 v;
             v.x = (c < H) ? props[(int64_t)b * H + c] : 0.0;
             v.y = (c + 1 < H) ? props[(int64_t)b * H + c + 1] : 0.0;
-            if constexpr (BT == 1) p[k] = v;
+            if constexpr (!P_IN_LDS) p[k] = v;
             else lds_p[(b * NCH + k) * THREADS + t] = v;
             acc[b][k] = d2{0.0, 0.0};
         }
@@ -235,33 +249,51 @@ __global__ __launch_bounds__(THREADS) void em_iter_wide_kernel(
 
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
     const int64_t r1 = (r0 + rows_per_wg < R) ? (r0 + rows_per_wg) : R;
-    const bool last_ok = (t + (NCH - 1) * THREADS) < ncol2;
+    if (r0 >= r1) return;
 
-    d2 xa[NCH], xb[NCH];
+    // Row loads: buffer_load_dwordx4 through one descriptor over this workgroup's row block.
+    // Per-lane offset = one VGPR (t * 16), row and chunk offsets are scalar, so no 64-bit
+    // per-load addresses and no exec-masked branches: rows past the block and column pairs
+    // past the row are CLAMPED to a valid element instead of skipped -- a clamped row gets
+    // weight 0 below, a clamped column has p = 0 and its accumulator is never stored.
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(P + r0 * ldp), 0, (int)((r1 - r0) * ldp * 8), 0x00020000);
+    const int row_bytes = (int)(ldp * 8);
+    const int voff = t * 16;
+    int last_c2 = t + (NCH - 1) * THREADS;
+    if (last_c2 > ncol2 - 1) last_c2 = ncol2 - 1;
+    const int voff_last = last_c2 * 16;
 
-    auto load_row = [&](d2(&x)[NCH], int64_t r) {
-        const bool live = r < r1;
-        const d2 *row = reinterpret_cast<const d2 *>(P + r * ldp);
+    d2 x[NBUF][NCH];                                // register ring: NBUF - 1 rows in flight
+
+    auto load_row = [&](d2(&xr)[NCH], int64_t r) {
+        const int64_t rr = (r < r1) ? r : (r1 - 1);
+        const int soff = (int)(rr - r0) * row_bytes;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const bool ok = live && (k < NCH - 1 || last_ok);
-            x[k] = ok ? __builtin_nontemporal_load(row + t + k * THREADS) : d2{0.0, 0.0};
-        }
+        for (int k = 0; k < NCH - 1; ++k)
+            xr[k] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(
+                                               rsrc, voff, soff + k * THREADS * 16, 2 /* nt */));
+        xr[NCH - 1] = __builtin_bit_cast(
+            d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, soff, 2 /* nt */));
     };
 
     int buf = 0;
-    auto process = [&](d2(&x)[NCH], int64_t r) {
+    auto process = [&](d2(&xr)[NCH], int64_t r) {
         double d[BT];
+        // keep the batch's proportions IN LDS: without this the loads are loop-invariant
+        // and get hoisted back into (BT * NCH * 4) VGPRs
+        if constexpr (P_IN_LDS) asm volatile("" ::: "memory");
 #pragma unroll
         for (int b = 0; b < BT; ++b) {
             double s = 0.0;
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 d2 pk;
-                if constexpr (BT == 1) pk = p[k];
+                if constexpr (!P_IN_LDS) pk = p[k];
                 else pk = lds_p[(b * NCH + k) * THREADS + t];     // own slot: no barrier needed
-                s = fma(x[k].x, pk.x, s);
-                s = fma(x[k].y, pk.y, s);
+                s = fma(xr[k].x, pk.x, s);
+                s = fma(xr[k].y, pk.y, s);
             }
             d[b] = s;
         }
@@ -285,19 +317,29 @@ __global__ __launch_bounds__(THREADS) void em_iter_wide_kernel(
             const double c = (z > 0.0) ? wr / z : 0.0;
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                acc[b][k].x = fma(c, x[k].x, acc[b][k].x);
-                acc[b][k].y = fma(c, x[k].y, acc[b][k].y);
+                acc[b][k].x = fma(c, xr[k].x, acc[b][k].x);
+                acc[b][k].y = fma(c, xr[k].y, acc[b][k].y);
             }
         }
         buf ^= 1;
     };
 
-    load_row(xa, r0);
-    for (int64_t r = r0; r < r1; r += 2) {
-        load_row(xb, r + 1);
-        process(xa, r);
-        load_row(xa, r + 2);
-        process(xb, r + 1);
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j) load_row(x[j], r0 + j);
+    for (int64_t r = r0; r < r1; r += NBUF) {
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) {
+            load_row(x[(j + NBUF - 1) % NBUF], r + j + NBUF - 1);
+#if MXM_SCHED_FENCE
+            // keep the scheduler from hoisting these loads above the previous row's last
+            // uses of the same ring slot (it would need a second register set for it)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            process(x[j], r + j);
+#if MXM_SCHED_FENCE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
     }
 
 #pragma unroll
@@ -518,7 +560,7 @@ extern "C" int mxm_version(void) { return MXM_VERSION; }
 extern "C" const char *mxm_last_error(void) { return g_err; }
 
 extern "C" int mxm_linear_supported(int32_t H) {
-    return (H >= MXM_LINEAR_MIN_H && H <= 2 * MXM_WIDE_THREADS * MXM_WIDE_MAX_NCH) ? 1 : 0;
+    return (H >= MXM_LINEAR_MIN_H && H <= 8192) ? 1 : 0;
 }
 
 extern "C" size_t mxm_workspace_bytes(int64_t R, int32_t H, int32_t B) {
@@ -571,53 +613,77 @@ extern "C" int mxm_set_batch_tile(int32_t bt) {
 }
 
 // ---- wide-kernel dispatch over NCH ------------------------------------------------------------
-#define MXM_BATCH2_THREADS 512        // workgroup of the BT = 2 variant (1 per CU)
-#ifndef MXM_BATCH3_THREADS
-#define MXM_BATCH3_THREADS 512        // workgroup of the BT = 3 variant (1 per CU)
+// Tuned shapes of the streaming kernel per batch size: workgroup threads, register ring depth
+// (rows in flight = NBUF - 1 per workgroup), workgroups per CU of the persistent grid.
+#ifndef MXM_V1_THREADS
+#define MXM_V1_THREADS 256
+#endif
+#ifndef MXM_V1_NBUF
+#define MXM_V1_NBUF 2
+#endif
+#ifndef MXM_V1_WG_PER_CU
+#define MXM_V1_WG_PER_CU 2
+#endif
+#ifndef MXM_V2_THREADS
+#define MXM_V2_THREADS 512
+#endif
+#ifndef MXM_V2_NBUF
+#define MXM_V2_NBUF 3                 // measured: 6.22 ms vs 6.67 ms per pass at 1M x 5408 (profiles/r01/tune_sweep.txt)
+#endif
+#ifndef MXM_V3_THREADS
+#define MXM_V3_THREADS 512
+#endif
+#ifndef MXM_V3_NBUF
+#define MXM_V3_NBUF 2
 #endif
 #define MXM_MAX_BT 3                  // restarts sharing one read of the matrix
+#define MXM_MAX_COL2 4096             // column pairs per row the register tiling covers (H <= 8192)
+#define MXM_LDS_BUDGET (156 * 1024)   // of the CU's 160 KiB, leaving room for the exchange buffers
 
-#define MXM_LDS_BUDGET (156 * 1024)  // of the CU's 160 KiB, leaving room for the exchange buffers
+static inline int variant_threads(int nb) { return nb == 1 ? MXM_V1_THREADS : (nb == 2 ? MXM_V2_THREADS : MXM_V3_THREADS); }
+static inline int variant_nbuf(int nb) { return nb == 1 ? MXM_V1_NBUF : (nb == 2 ? MXM_V2_NBUF : MXM_V3_NBUF); }
 
 static size_t batch_lds_bytes(int H, int nb) {
-    const int threads = (nb == 2) ? MXM_BATCH2_THREADS : MXM_BATCH3_THREADS;
+    const int threads = variant_threads(nb);
     const int nch = ((H + 1) / 2 + threads - 1) / threads;
     return (size_t)nb * nch * threads * 16;
 }
 
-template <int THREADS, int NCH, int BT>
-static void launch_wide(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
-                        int H, int grid, int64_t rows_per_wg, double *partial, int64_t ldpart,
-                        const mxm_em_state *state, hipStream_t stream) {
-    const size_t lds = (BT == 1) ? 0 : (size_t)BT * NCH * THREADS * sizeof(d2);
-    if (BT > 1) {
-        static bool raised = false;     // > 64 KiB of dynamic LDS must be opted into, once per kernel
-        if (!raised) {
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&em_iter_wide_kernel<THREADS, NCH, BT>),
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-            raised = true;
+template <int THREADS, int NCH, int BT, int NBUF>
+static int launch_wide(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
+                       int H, int grid, int64_t rows_per_wg, double *partial, int64_t ldpart,
+                       const mxm_em_state *state, hipStream_t stream) {
+    if constexpr (NCH * THREADS > MXM_MAX_COL2) {
+        return fail(-1, "mxm_em_iter: H=%s%lld outside the linear kernel's range", "", H);
+    } else {
+        const bool p_in_lds = (BT > 1) || (MXM_V1_P_LDS != 0);
+        const size_t lds = p_in_lds ? (size_t)BT * NCH * THREADS * sizeof(d2) : 0;
+        if (p_in_lds) {
+            static bool raised = false;     // > 64 KiB of dynamic LDS must be opted into, once per kernel
+            if (!raised) {
+                (void)hipFuncSetAttribute(
+                    reinterpret_cast<const void *>(&em_iter_wide_kernel<THREADS, NCH, BT, NBUF>),
+                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+                raised = true;
+            }
         }
+        hipLaunchKernelGGL((em_iter_wide_kernel<THREADS, NCH, BT, NBUF>), dim3(grid), dim3(THREADS), lds,
+                           stream, P, ldp, w, props, R, H, rows_per_wg, partial, ldpart, state);
+        return 0;
     }
-    hipLaunchKernelGGL((em_iter_wide_kernel<THREADS, NCH, BT>), dim3(grid), dim3(THREADS), lds, stream, P,
-                       ldp, w, props, R, H, rows_per_wg, partial, ldpart, state);
 }
 
-template <int THREADS, int BT>
+template <int THREADS, int BT, int NBUF>
 static int dispatch_wide(int nch, const double *P, int64_t ldp, const double *w, const double *props,
                          int64_t R, int H, int grid, int64_t rows_per_wg, double *partial,
                          int64_t ldpart, const mxm_em_state *state, hipStream_t stream) {
     switch (nch) {
-#define WIDE_CASE(n) case n: launch_wide<THREADS, n, BT>(P, ldp, w, props, R, H, grid, rows_per_wg, partial, ldpart, state, stream); return 0;
+#define WIDE_CASE(n) case n: return launch_wide<THREADS, n, BT, NBUF>(P, ldp, w, props, R, H, grid, rows_per_wg, partial, ldpart, state, stream);
         WIDE_CASE(1) WIDE_CASE(2) WIDE_CASE(3) WIDE_CASE(4) WIDE_CASE(5) WIDE_CASE(6) WIDE_CASE(7) WIDE_CASE(8)
+        WIDE_CASE(9) WIDE_CASE(10) WIDE_CASE(11) WIDE_CASE(12) WIDE_CASE(13) WIDE_CASE(14) WIDE_CASE(15) WIDE_CASE(16)
+#undef WIDE_CASE
         default: break;
     }
-    if (THREADS == MXM_WIDE_THREADS && BT == 1) {
-        switch (nch) {
-            WIDE_CASE(9) WIDE_CASE(10) WIDE_CASE(11) WIDE_CASE(12) WIDE_CASE(13) WIDE_CASE(14) WIDE_CASE(15) WIDE_CASE(16)
-            default: break;
-        }
-    }
-#undef WIDE_CASE
     return fail(-1, "mxm_em_iter: H=%s%lld outside the linear kernel's range", "", H);
 }
 
@@ -627,23 +693,24 @@ static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, co
                                hipStream_t stream, bool timed) {
     const int64_t ldpart = part_ld(H);
     const int ncol2 = (H + 1) / 2;
-    const int threads = (nb == 1) ? MXM_WIDE_THREADS : (nb == 2 ? MXM_BATCH2_THREADS : MXM_BATCH3_THREADS);
-    const int wg_per_cu = (nb == 1) ? 2 : 1;
+    const int threads = variant_threads(nb);
+    const int nbuf = variant_nbuf(nb);
+    const int wg_per_cu = (nb == 1) ? MXM_V1_WG_PER_CU : 1;
     const int nch = (ncol2 + threads - 1) / threads;
     int cap = num_cu() * wg_per_cu;
     if (cap > MXM_MAX_WG) cap = MXM_MAX_WG;
-    int nwg = clamp_grid((R + 1) / 2, cap);
+    int nwg = clamp_grid((R + nbuf - 1) / nbuf, cap);
     int64_t rows_per_wg = (R + nwg - 1) / nwg;
-    rows_per_wg = (rows_per_wg + 1) / 2 * 2;
+    rows_per_wg = (rows_per_wg + nbuf - 1) / nbuf * nbuf;
     nwg = (int)((R + rows_per_wg - 1) / rows_per_wg);
     if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
     int rc;
     if (nb == 1)
-        rc = dispatch_wide<MXM_WIDE_THREADS, 1>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V1_THREADS, 1, MXM_V1_NBUF>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
     else if (nb == 2)
-        rc = dispatch_wide<MXM_BATCH2_THREADS, 2>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V2_THREADS, 2, MXM_V2_NBUF>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
     else
-        rc = dispatch_wide<MXM_BATCH3_THREADS, 3>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V3_THREADS, 3, MXM_V3_NBUF>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
     if (rc != 0) return rc;
     HIP_TRY(hipGetLastError());
     if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
@@ -679,7 +746,7 @@ extern "C" int mxm_em_iter(const double *M, int64_t ldm, const double *P, int64_
     const bool linear = (P != nullptr) && mxm_linear_supported(H);
     // restarts are taken in tiles of up to g_max_bt that share one pass over the matrix; the
     // scratch is reused tile after tile (same stream, so the passes are ordered)
-    const int max_bt = (linear && H <= 2 * MXM_BATCH2_THREADS * 8) ? g_max_bt : 1;
+    const int max_bt = linear ? g_max_bt : 1;
     for (int b = 0; b < B;) {
         int nb = B - b;
         if (nb > max_bt) nb = max_bt;
