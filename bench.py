@@ -97,6 +97,7 @@ def main():
                          "iteration of EVERY restart and value counts cells x restarts")
     ap.add_argument("--batch-tile", type=int, default=3,
                     help="restarts sharing one pass over the matrix (1 = unbatched schedule)")
+    ap.add_argument("--build-kernel", default="auto", choices=["auto", "packed", "bytes"])
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to test the "
                          "multi-process path on a single GPU)")
@@ -140,9 +141,11 @@ def main():
     obs_d = torch.from_numpy(obs).to(dev)
     mat = torch.empty((n_rows, n_haps), dtype=torch.float64, device=dev)
     tables.device()
+    if opts.build_kernel == "packed":
+        tables.packed_device()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    preprocess.build_em_matrix_device(tables, row_ptr_d, site_d, obs_d, out=mat)
+    preprocess.build_em_matrix_device(tables, row_ptr_d, site_d, obs_d, out=mat, kernel=opts.build_kernel)
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
     wts = torch.ones(n_rows, dtype=torch.float64, device=dev)

@@ -59,7 +59,7 @@ size_t      mxm_workspace_bytes(int64_t R, int32_t H, int32_t B);
  * lhit/lmiss[S]  log(1-mu_s), log(mu_s/3) computed on the host (:48-51, :80-84)
  * row_ptr[R+1], site[nnz] (index into the sorted site list), obs[nnz] (ASCII):
  *            CSR form of the read signatures (:151-160)
- * lde must be a multiple of 4 and >= H.
+ * lde must be a multiple of 8 and >= H rounded up to 8; E 8-byte aligned (pad bytes 0).
  */
 int mxm_build_em_matrix(const uint8_t *E, int64_t lde,
                         const double *lhit, const double *lmiss,
@@ -67,6 +67,27 @@ int mxm_build_em_matrix(const uint8_t *E, int64_t lde,
                         const uint8_t *obs,
                         int64_t R, int32_t H, int32_t S,
                         double *M, int64_t ldm, void *stream);
+
+/*
+ * build_em_matrix, packed-table fast path -- same arithmetic, same order, same bits as
+ * mxm_build_em_matrix; the tables are pre-encoded by the host so that one 64-column slice
+ * fits a CU's LDS:
+ *   Epk[ntiles][S][8]  uint32: 4-bit expected-base codes, 8 columns per dword, 64 columns
+ *                      per tile (ntiles = ceil(H/64)); column c of a tile sits in dword
+ *                      (c%16)/2, nibble 2*(c/16) + c%2 (bits 4*nibble..+3), so that the 8 lanes
+ *                      of a row store whole 128-byte lines.  Codes 1..14 name the alphabet, 0 pads.
+ *   muidx[S]           uint8: index of site s's (log hit, log miss) pair
+ *   pairs[n_mu][2]     f64:   (lhit, lmiss) per distinct mutation probability, n_mu <= 255
+ *   obsmap[256]        uint8: observation byte -> code (15 = matches nothing)
+ * Needs mxm_build_packed_lds_bytes(S, n_mu) <= 158 KiB (S <= ~4900); otherwise call
+ * mxm_build_em_matrix.
+ */
+size_t mxm_build_packed_lds_bytes(int32_t S, int32_t n_mu);
+int mxm_build_em_matrix_packed(const uint32_t *Epk, const uint8_t *muidx, const double *pairs,
+                               int32_t n_mu, const uint8_t *obsmap,
+                               const int64_t *row_ptr, const uint16_t *site,
+                               const uint8_t *obs, int64_t R, int32_t H, int32_t S,
+                               double *M, int64_t ldm, void *stream);
 
 /*
  * One-time change of variables for the streaming loop:

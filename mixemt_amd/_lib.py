@@ -29,6 +29,9 @@ SIGNATURES = {
     "mxm_workspace_bytes": (c_size, [c_i64, c_i32, c_i32]),
     "mxm_build_em_matrix": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                            c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
+    "mxm_build_packed_lds_bytes": (c_size, [c_i32, c_i32]),
+    "mxm_build_em_matrix_packed": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
+                                                  c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     "mxm_linearize": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
     "mxm_em_iter": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32,
                                    c_ptr, c_ptr, c_ptr, c_size, c_ptr]),

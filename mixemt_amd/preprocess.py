@@ -52,6 +52,8 @@ class HapVarTables(object):
         self.n_haps = n_haps
         self.site_index = {int(p): k for k, p in enumerate(sites)}
         self._dev = None
+        self._packed = None          # None = not tried, False = does not qualify
+        self._packed_dev = None
 
     @classmethod
     def build(cls, refseq, phylo, haplogroups, mut_wt=MUT_WT, mut_max=MUT_MAX):
@@ -80,6 +82,61 @@ class HapVarTables(object):
             lhit[k] = math.log(1.0 - mu)
             lmiss[k] = math.log(mu / 3.0)
         return cls(sites, expected, lhit, lmiss, list(haplogroups), n_haps)
+
+    def packed(self):
+        """
+        The LDS-staged kernel's encoding of the same tables (include/mixemt_hip.h,
+        mxm_build_em_matrix_packed), or None if they do not qualify (more than 14
+        distinct expected bases, more than 256 distinct mutation probabilities,
+        or a site count whose 64-column slice does not fit a CU's LDS):
+            epk[ntiles][S][8] uint32  4-bit codes, 8 columns per dword (permuted, see header)
+            muidx[S] uint8, pairs[n_mu][2] f64 (lhit, lmiss), obsmap[256] uint8
+        """
+        if self._packed is not None:
+            return self._packed or None
+        n_sites, n_haps = len(self.sites), self.n_haps
+        body = self.expected[:, :n_haps]
+        alphabet = numpy.unique(body)
+        alphabet = alphabet[alphabet != 0]
+        keys = numpy.stack([self.lhit, self.lmiss], axis=1)
+        uniq, inverse = numpy.unique(keys, axis=0, return_inverse=True)
+        lds = (n_sites + 1) * 32 + (len(uniq) + 1) * 16 + 256 + (n_sites + 4) // 4 * 4
+        if len(alphabet) > 14 or len(uniq) > 255 or lds > 158 * 1024 or n_sites == 0:
+            self._packed = False
+            return None
+        code_of = numpy.zeros(256, dtype=numpy.uint8)
+        code_of[alphabet] = numpy.arange(1, len(alphabet) + 1, dtype=numpy.uint8)
+        obsmap = numpy.full(256, 15, dtype=numpy.uint8)
+        obsmap[alphabet] = code_of[alphabet]
+        ntiles = (n_haps + 63) // 64
+        codes = numpy.zeros((n_sites, ntiles * 64), dtype=numpy.uint8)
+        codes[:, :n_haps] = code_of[body]
+        # tile-local column c -> dword (c % 16) // 2, nibble 2 * (c // 16) + c % 2
+        c = numpy.arange(64)
+        slot = ((c % 16) // 2) * 8 + 2 * (c // 16) + (c % 2)      # nibble slot 0..63 in the tile
+        by_slot = numpy.empty_like(codes).reshape(n_sites, ntiles, 64)
+        by_slot[:, :, slot] = codes.reshape(n_sites, ntiles, 64)
+        nibbles = (by_slot[:, :, 0::2] | (by_slot[:, :, 1::2] << 4)).astype(numpy.uint8)  # [S][ntiles][32]
+        epk = numpy.ascontiguousarray(nibbles.transpose(1, 0, 2)).view(numpy.uint32)
+        self._packed = {"epk": epk.reshape(ntiles, n_sites, 8),
+                        "muidx": inverse.reshape(-1).astype(numpy.uint8),
+                        "pairs": numpy.ascontiguousarray(uniq, dtype=numpy.float64),
+                        "obsmap": obsmap}
+        return self._packed
+
+    def packed_device(self):
+        """Device copies of packed(), uploaded once; None if the tables do not qualify."""
+        pk = self.packed()
+        if pk is None:
+            return None
+        if self._packed_dev is None:
+            dev = require_gpu()
+            self._packed_dev = {
+                "epk": torch.from_numpy(pk["epk"].view(numpy.int32)).to(dev),
+                "muidx": torch.from_numpy(pk["muidx"]).to(dev),
+                "pairs": torch.from_numpy(pk["pairs"]).to(dev),
+                "obsmap": torch.from_numpy(pk["obsmap"]).to(dev)}
+        return self._packed_dev
 
     def device(self):
         """Upload once; returns (expected, lhit, lmiss) as device tensors."""
@@ -118,13 +175,36 @@ def encode_signatures(reads, tables):
             numpy.array(obs, dtype=numpy.uint8))
 
 
-def build_em_matrix_device(tables, row_ptr, site, obs, out=None):
+def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto"):
     """
     CSR observations (numpy or device tensors) -> device tensor M[R][H] float64.
-    Wraps mxm_build_em_matrix; `out` may supply a preallocated [R][>=H] tensor.
+    `out` may supply a preallocated [R][>=H] tensor.  kernel: "bytes" is the
+    byte-table kernel (mxm_build_em_matrix, table served from L2 / Infinity
+    Cache), "packed" the LDS-staged 4-bit-table kernel
+    (mxm_build_em_matrix_packed).  Both give the same bits; "auto" takes the
+    faster one as measured on MI355X at 1M x 5408 (bytes: 40.4 ms, packed:
+    76.8 ms -- profiles/r01/build_kernels.txt).
     """
     lib = _lib.load()
     dev = require_gpu()
+    packed = tables.packed_device() if kernel == "packed" else None
+    if kernel == "packed" and packed is None:
+        raise ValueError("tables do not qualify for the packed-table kernel")
+    if packed is not None:
+        row_ptr_d = as_device(row_ptr, torch.int64, dev)
+        site_d = as_device(site, torch.uint16, dev)
+        obs_d = as_device(obs, torch.uint8, dev)
+        n_rows = row_ptr_d.numel() - 1
+        if out is None:
+            out = torch.empty((n_rows, tables.n_haps), dtype=torch.float64, device=dev)
+        if n_rows == 0:
+            return out
+        _lib.check(lib.mxm_build_em_matrix_packed(
+            packed["epk"].data_ptr(), packed["muidx"].data_ptr(), packed["pairs"].data_ptr(),
+            packed["pairs"].shape[0], packed["obsmap"].data_ptr(), row_ptr_d.data_ptr(),
+            site_d.data_ptr(), obs_d.data_ptr(), n_rows, tables.n_haps, len(tables.sites),
+            out.data_ptr(), out.stride(0), current_stream()), "mxm_build_em_matrix_packed")
+        return out
     exp_d, lhit_d, lmiss_d = tables.device()
     row_ptr_d = as_device(row_ptr, torch.int64, dev)
     site_d = as_device(site, torch.uint16, dev)

@@ -133,3 +133,65 @@ def test_reference_phylotree_object_is_accepted(toy):
     g = golden("g1_toy")
     reads = str(g["reads"]).split("\n")
     assert numpy.array_equal(preprocess.build_em_matrix(ref, bare, reads, haps, em_args()), g["mat"])
+
+
+@pytest.mark.parametrize("kernel", ["packed", "bytes"])
+def test_both_kernels_give_reference_bits(b17, kernel):
+    """The LDS-staged packed-table kernel and the byte-table kernel are interchangeable."""
+    from mixemt_amd import preprocess
+    refseq, phy, haps, tables = b17
+    g = golden("g2_build_b17")
+    mat = preprocess.build_em_matrix_device(tables, g["row_ptr"], g["site"], g["obs"],
+                                            kernel=kernel).cpu().numpy()
+    assert numpy.array_equal(mat[:32], g["mat32"])
+    assert _sha(mat) == str(g["mat_sha256"])
+
+
+@pytest.mark.parametrize("n_cols", [1, 7, 63, 64, 65, 129, 1000])
+def test_packed_kernel_ragged_tiles_and_rows(b17, n_cols):
+    """Column counts around the 64-column tile, row counts around the 8-row / 128-row steps."""
+    from mixemt_amd import preprocess, synth
+    refseq, phy, haps, tables = b17
+    sub = haps[100:100 + n_cols]
+    sub_tables = preprocess.HapVarTables.build(refseq, phy, sub)
+    assert sub_tables.packed() is not None
+    for n_rows, seed in ((1, 1), (9, 2), (127, 3), (130, 4), (1000, 5)):
+        row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=seed)
+        got = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="packed").cpu().numpy()
+        want = c_oracle.build_em_matrix(sub_tables.expected, sub_tables.lhit, sub_tables.lmiss, row_ptr,
+                                        site, obs, n_cols)
+        assert numpy.array_equal(got, want), (n_cols, n_rows)
+
+
+def test_packed_kernel_long_reads_unusual_bases_and_strided_output(b17):
+    import torch
+    from mixemt_amd import preprocess, synth
+    refseq, phy, haps, tables = b17
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 5, seed=9, read_len=3000)
+    obs = obs.copy()
+    obs[::17] = ord("N")                 # never matches an expected base
+    obs[5::29] = ord("a")                # lower case is a different string in the reference
+    obs[3::31] = 0                       # multi-character observation (encoded as 0)
+    want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, row_ptr, site, obs,
+                                    len(haps))
+    got = preprocess.build_em_matrix_device(tables, row_ptr, site, obs, kernel="packed").cpu().numpy()
+    assert numpy.array_equal(got, want)
+    # odd leading dimension: the kernel must fall back to 8-byte stores
+    out = torch.full((5, len(haps) + 3), -1.0, dtype=torch.float64, device="cuda")
+    preprocess.build_em_matrix_device(tables, row_ptr, site, obs, out=out, kernel="packed")
+    host = out.cpu().numpy()
+    assert numpy.array_equal(host[:, :len(haps)], want) and (host[:, len(haps):] == -1.0).all()
+
+
+def test_tables_that_do_not_qualify_fall_back(b17, toy):
+    from mixemt_amd import preprocess
+    ref, phy, haps = toy
+    tables = preprocess.HapVarTables.build(ref, phy, haps)
+    tables._packed = False               # as if the alphabet / LDS budget check had failed
+    g = golden("g1_toy")
+    reads = str(g["reads"]).split("\n")
+    rp, si, ob = preprocess.encode_signatures(reads, tables)
+    got = preprocess.build_em_matrix_device(tables, rp, si, ob).cpu().numpy()
+    assert numpy.array_equal(got, g["mat"])
+    with pytest.raises(ValueError):
+        preprocess.build_em_matrix_device(tables, rp, si, ob, kernel="packed")
