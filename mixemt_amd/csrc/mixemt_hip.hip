@@ -479,24 +479,40 @@ __global__ __launch_bounds__(THREADS, (BT == 1 ? MXM_V1_MINW : MXM_VB_MINW)) voi
 // 64 columns per workgroup; 4 waves take interleaved quarters of the partial rows.
 // scale_h = props[h] for the linear kernel, 1 for the log-space kernel.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void colreduce_kernel(const double *__restrict__ partial,
-                                                        int64_t ldpart, int nwg, int nb, int H,
-                                                        const double *__restrict__ props,
-                                                        double *__restrict__ colsum,
-                                                        const mxm_em_state *__restrict__ state) {
-    // grid = (ceil(H/64), nb); partial is [nwg][nb][ldpart]; props / colsum are [nb][H]
-    __shared__ double part[4][64];
+#define COLRED_THREADS 1024
+__global__ __launch_bounds__(COLRED_THREADS) void colreduce_kernel(const double *__restrict__ partial,
+                                                                   int64_t ldpart, int nwg, int nb, int H,
+                                                                   const double *__restrict__ props,
+                                                                   double *__restrict__ colsum,
+                                                                   const mxm_em_state *__restrict__ state) {
+    // grid = (ceil(H/64), nb); partial is [nwg][nb][ldpart]; props / colsum are [nb][H].
+    // 16 waves take interleaved sixteenths of the partial rows, four independent chains each
+    // (the loads are what this kernel waits for); every order below is fixed -> deterministic.
+    constexpr int NW = COLRED_THREADS / 64;
+    __shared__ double part[NW][64];
     const int b = blockIdx.y;
     if (state != nullptr && state[b].done != 0) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int h = blockIdx.x * 64 + lane;
-    double s = 0.0;
-    if (h < H)
-        for (int g = wv; g < nwg; g += 4) s += partial[((int64_t)g * nb + b) * ldpart + h];
-    part[wv][lane] = s;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (h < H) {
+        const double *src = partial + (int64_t)b * ldpart + h;
+        const int64_t step = (int64_t)nb * ldpart;
+        int g = wv;
+        for (; g + 3 * NW < nwg; g += 4 * NW) {
+            s0 += src[(int64_t)g * step];
+            s1 += src[(int64_t)(g + NW) * step];
+            s2 += src[(int64_t)(g + 2 * NW) * step];
+            s3 += src[(int64_t)(g + 3 * NW) * step];
+        }
+        for (; g < nwg; g += NW) s0 += src[(int64_t)g * step];
+    }
+    part[wv][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
     if (wv == 0 && h < H) {
-        const double tot = ((part[0][lane] + part[1][lane]) + part[2][lane]) + part[3][lane];
+        double tot = part[0][lane];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) tot += part[q][lane];
         colsum[(int64_t)b * H + h] = (props != nullptr) ? props[(int64_t)b * H + h] * tot : tot;
     }
 }
@@ -588,6 +604,146 @@ __global__ __launch_bounds__(ROW_THREADS) void estep_log_kernel(
     if (partial != nullptr) {
         double *dst = partial + (int64_t)blockIdx.x * ldpart;
         for (int h = t; h < H; h += ROW_THREADS) dst[h] = acc[h];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6b estep_wide: the same E-step (em.py:80-83, fold :156, M-step sums :87-88) for wide rows,
+// one HBM read + one write per cell: the row is held in VGPRs across the two row reductions
+// (max, then sum of exp), exactly like the streaming kernel holds it across its dot product.
+// Needs H even, 16-byte aligned rows in M and out; everything else takes estep_log_kernel.
+// ------------------------------------------------------------------------------------------
+template <int NCH, bool COLSUM>
+__global__ __launch_bounds__(256, 2) void estep_wide_kernel(
+    const double *__restrict__ M, int64_t ldm, const double *__restrict__ w,
+    const double *__restrict__ lnp_in, int64_t R, int H, int64_t rows_per_wg,
+    double *__restrict__ out, int64_t ldo, int mode, double *__restrict__ partial, int64_t ldpart) {
+    constexpr int THREADS = 256, NW = THREADS / 64;
+    __shared__ double red[2][2][NW];               // [ring][max|sum][wave]
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int ncol2 = H >> 1;
+
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < R) ? (r0 + rows_per_wg) : R;
+    if (r0 >= r1) return;
+
+    // with the M-step sums the exponentials have to survive the second reduction: that variant
+    // gives up the register double buffer (two workgroups per CU still overlap load and math)
+    constexpr int NBUF = COLSUM ? 1 : 2;
+    d2 lp[NCH], acc[COLSUM ? NCH : 1];
+    bool own[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c2 = t + k * THREADS;
+        own[k] = c2 < ncol2;
+        // a clamped (not owned) lane carries -inf log-proportions: it adds exp(-inf) = 0
+        lp[k].x = own[k] ? lnp_in[2 * c2] : -INFINITY;
+        lp[k].y = own[k] ? lnp_in[2 * c2 + 1] : -INFINITY;
+        if constexpr (COLSUM) acc[k] = d2{0.0, 0.0};
+    }
+
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(M + r0 * ldm), 0,
+                                                        (int)((r1 - r0) * ldm * 8), 0x00020000);
+    const int row_bytes = (int)(ldm * 8);
+    const int voff = t * 16;
+    int last_c2 = t + (NCH - 1) * THREADS;
+    if (last_c2 > ncol2 - 1) last_c2 = ncol2 - 1;
+    const int voff_last = last_c2 * 16;
+
+    d2 x[NBUF][NCH];
+    auto load_row = [&](d2(&xr)[NCH], int64_t r) {
+        const int64_t rr = (r < r1) ? r : (r1 - 1);
+        const int soff = (int)(rr - r0) * row_bytes;
+#pragma unroll
+        for (int k = 0; k < NCH - 1; ++k)
+            xr[k] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(
+                                               rsrc, voff, soff + k * THREADS * 16, 2));
+        xr[NCH - 1] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, soff, 2));
+    };
+
+    int ring = 0;
+    auto process = [&](d2(&xr)[NCH], int64_t r) {
+        const bool live = r < r1;
+        double m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            xr[k].x += lp[k].x;                    // z = ln p + M   (em.py:80)
+            xr[k].y += lp[k].y;
+            m = fmax(m, fmax(xr[k].x, xr[k].y));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+        if (lane == 0) red[ring][0][wv] = m;
+        __syncthreads();
+        m = red[ring][0][0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) m = fmax(m, red[ring][0][q]);
+        const double shift = isfinite(m) ? m : 0.0;
+        d2 e[COLSUM ? NCH : 1];
+        double ssum = 0.0;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const double ex = exp(xr[k].x - shift), ey = exp(xr[k].y - shift);
+            if constexpr (COLSUM) e[k] = d2{ex, ey};
+            ssum += ex + ey;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ssum += __shfl_xor(ssum, off, 64);
+        if (lane == 0) red[ring][1][wv] = ssum;
+        __syncthreads();
+        ssum = red[ring][1][0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) ssum += red[ring][1][q];
+        ring ^= 1;
+        const double lse = log(ssum) + m;          // em.py:81-83 (m, not shift: -inf rows stay -inf)
+        if (out != nullptr && live) {
+            d2 *orow = reinterpret_cast<d2 *>(out + r * ldo);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                if (own[k]) {
+                    d2 v = d2{xr[k].x - lse, xr[k].y - lse};
+                    d2 *dst = orow + t + k * THREADS;
+                    if (mode == 1) {
+                        const d2 old = *dst;
+                        v.x = logaddexp_f64(old.x, v.x);
+                        v.y = logaddexp_f64(old.y, v.y);
+                    }
+                    __builtin_nontemporal_store(v, dst);
+                }
+            }
+        }
+        if constexpr (COLSUM) {
+            const double wr = live ? (w != nullptr ? w[r] : 1.0) : 0.0;
+            const double c = (ssum > 0.0) ? wr / ssum : 0.0;     // w * exp(z - lse) = w * e / sum
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                acc[k].x = fma(c, e[k].x, acc[k].x);
+                acc[k].y = fma(c, e[k].y, acc[k].y);
+            }
+        }
+    };
+
+    if constexpr (NBUF == 2) {
+        load_row(x[0], r0);
+        for (int64_t r = r0; r < r1; r += 2) {
+            load_row(x[1], r + 1);
+            process(x[0], r);
+            load_row(x[0], r + 2);
+            process(x[1], r + 1);
+        }
+    } else {
+        for (int64_t r = r0; r < r1; ++r) {
+            load_row(x[0], r);
+            process(x[0], r);
+        }
+    }
+    if constexpr (COLSUM) {
+        d2 *dst = reinterpret_cast<d2 *>(partial + (int64_t)blockIdx.x * ldpart);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+            if (own[k]) dst[t + k * THREADS] = acc[k];
     }
 }
 
@@ -875,7 +1031,7 @@ static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, co
     if (rc != 0) return rc;
     HIP_TRY(hipGetLastError());
     if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
-    hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, nb), dim3(256), 0, stream, partial, ldpart, nwg, nb,
+    hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, nb), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg, nb,
                        H, props, colsum, state);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -891,7 +1047,7 @@ static int em_iter_log_one(const double *M, int64_t ldm, const double *w, const 
     hipLaunchKernelGGL((estep_log_kernel<true>), dim3(nwg), dim3(ROW_THREADS), lds, stream, M, ldm, w, props,
                        R, H, (double *)nullptr, (int64_t)0, 0, partial, ldpart, state);
     HIP_TRY(hipGetLastError());
-    hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(256), 0, stream, partial, ldpart, nwg, 1,
+    hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg, 1,
                        H, (const double *)nullptr, colsum, state);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -966,6 +1122,18 @@ extern "C" int mxm_em_loop(const double *M, int64_t ldm, const double *P, int64_
     return 0;
 }
 
+template <int NCH>
+static void launch_estep_wide(const double *M, int64_t ldm, const double *w, const double *lnp, int64_t R, int H,
+                              int grid, int64_t rows_per_wg, double *out, int64_t ldo, int mode, double *partial,
+                              int64_t ldpart, hipStream_t s) {
+    if (partial != nullptr)
+        hipLaunchKernelGGL((estep_wide_kernel<NCH, true>), dim3(grid), dim3(256), 0, s, M, ldm, w, lnp, R, H,
+                           rows_per_wg, out, ldo, mode, partial, ldpart);
+    else
+        hipLaunchKernelGGL((estep_wide_kernel<NCH, false>), dim3(grid), dim3(256), 0, s, M, ldm, w, lnp, R, H,
+                           rows_per_wg, out, ldo, mode, partial, ldpart);
+}
+
 extern "C" int mxm_em_step(const double *M, int64_t ldm, const double *w, const double *ln_props, int64_t R,
                            int32_t H, double *out, int64_t ldo, int32_t mode, double *colsum, void *ws,
                            size_t ws_bytes, void *stream) {
@@ -973,17 +1141,39 @@ extern "C" int mxm_em_step(const double *M, int64_t ldm, const double *w, const 
     if (out != nullptr && ldo < H) return fail(-1, "mxm_em_step: ldo < H%s", "");
     if (colsum != nullptr && (ws == nullptr || ws_bytes < mxm_workspace_bytes(R, H, 1)))
         return fail(-1, "mxm_em_step: workspace too small%s", "");
-    const size_t lds = 2 * (size_t)H * sizeof(double);
-    if (lds > 150 * 1024) return fail(-1, "mxm_em_step: H=%s%lld too large", "", H);
     const int64_t ldpart = part_ld(H);
-    const int nwg = clamp_grid(R, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL((estep_log_kernel<false>), dim3(nwg), dim3(ROW_THREADS), lds, s, M, ldm, w, ln_props, R,
-                       (int)H, out, ldo, (int)mode, colsum ? (double *)ws : (double *)nullptr, ldpart,
-                       (const mxm_em_state *)nullptr);
+    double *partial = colsum ? (double *)ws : (double *)nullptr;
+    int nwg;
+    const bool aligned = ((H & 1) == 0) && ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0) &&
+                         (out == nullptr || (((ldo & 1) == 0) && ((reinterpret_cast<uintptr_t>(out) & 15) == 0)));
+    const int nch = (H / 2 + 255) / 256;
+    // register budget of estep_wide_kernel (spill-free instances only): 13 column chunks per
+    // thread without the M-step sums, 10 with them
+    if (aligned && mxm_linear_supported(H) && nch <= (colsum != nullptr ? 10 : 13)) {
+        // wide rows: one read + one write per cell, rows held in registers
+        int cap = num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG;
+        nwg = clamp_grid((R + 1) / 2, cap);
+        int64_t rows_per_wg = (R + nwg - 1) / nwg;
+        rows_per_wg = (rows_per_wg + 1) / 2 * 2;
+        nwg = (int)((R + rows_per_wg - 1) / rows_per_wg);
+        switch (nch) {
+#define EW_CASE(n) case n: launch_estep_wide<n>(M, ldm, w, ln_props, R, (int)H, nwg, rows_per_wg, out, ldo, (int)mode, partial, ldpart, s); break;
+            EW_CASE(1) EW_CASE(2) EW_CASE(3) EW_CASE(4) EW_CASE(5) EW_CASE(6) EW_CASE(7) EW_CASE(8)
+            EW_CASE(9) EW_CASE(10) EW_CASE(11) EW_CASE(12) EW_CASE(13) EW_CASE(14) EW_CASE(15) EW_CASE(16)
+#undef EW_CASE
+            default: return fail(-1, "mxm_em_step: H=%s%lld outside the wide kernel's range", "", H);
+        }
+    } else {
+        const size_t lds = 2 * (size_t)H * sizeof(double);
+        if (lds > 150 * 1024) return fail(-1, "mxm_em_step: H=%s%lld too large", "", H);
+        nwg = clamp_grid(R, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
+        hipLaunchKernelGGL((estep_log_kernel<false>), dim3(nwg), dim3(ROW_THREADS), lds, s, M, ldm, w, ln_props, R,
+                           (int)H, out, ldo, (int)mode, partial, ldpart, (const mxm_em_state *)nullptr);
+    }
     HIP_TRY(hipGetLastError());
     if (colsum != nullptr) {
-        hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(256), 0, s, (const double *)ws, ldpart, nwg,
+        hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, s, (const double *)ws, ldpart, nwg,
                            1, (int)H, (const double *)nullptr, colsum, (const mxm_em_state *)nullptr);
         HIP_TRY(hipGetLastError());
     }

@@ -309,3 +309,40 @@ def test_batched_restarts_stop_independently(b17):
             lib.mxm_set_batch_tile(3)
         assert out[tile]["iters"] == list(g["iters"])
         assert numpy.abs(out[tile]["props"] - g["props"]).max() < PROPS_ATOL
+
+
+@pytest.mark.parametrize("n_rows,n_haps,seed", [(50, 66, 1), (257, 512, 2), (100, 2560, 3), (64, 5408, 4),
+                                                (40, 6656, 5), (33, 8192, 6), (20, 1001, 7)])
+def test_em_step_wide_and_generic_kernels_vs_oracle(n_rows, n_haps, seed):
+    """em_step across the register-resident (wide) and the generic E-step kernels, -inf included."""
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(seed)
+    mat = rng.normal(-30.0, 10.0, size=(n_rows, n_haps))
+    mat[rng.random(mat.shape) < 0.02] = -numpy.inf
+    wts = rng.integers(1, 4, size=n_rows)
+    lnp = numpy.log(rng.dirichlet([0.5] * n_haps))
+    want_mix, want_new = em_oracle.em_step(mat, wts, lnp, numpy.empty_like(mat))
+    got_mix = numpy.empty_like(mat)
+    _, got_new = em.em_step(mat, wts, lnp, got_mix)
+    fin = numpy.isfinite(want_mix)
+    assert numpy.array_equal(numpy.isfinite(got_mix), fin)
+    assert numpy.allclose(got_mix[fin], want_mix[fin], rtol=0, atol=1e-10)
+    assert numpy.allclose(numpy.exp(got_new), numpy.exp(want_new), rtol=0, atol=1e-13)
+
+
+def test_posterior_fold_matches_logaddexp():
+    """mode 1 of mxm_em_step: out = logaddexp(out, E-step) (em.py:156), wide kernel."""
+    import torch
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(8)
+    mat = rng.normal(-30.0, 10.0, size=(70, 5408))
+    plan = em.EmPlan(mat, numpy.ones(70))
+    lnp_a = numpy.log(rng.dirichlet([1.0] * 5408))
+    lnp_b = numpy.log(rng.dirichlet([1.0] * 5408))
+    out = em.posterior(plan, lnp_a)
+    first = out.cpu().numpy().copy()
+    out = em.posterior(plan, lnp_b, out=out, fold=True)
+    second, _ = em_oracle.em_step(mat, numpy.ones(70), lnp_b, numpy.empty_like(mat))
+    want_first, _ = em_oracle.em_step(mat, numpy.ones(70), lnp_a, numpy.empty_like(mat))
+    assert numpy.allclose(first, want_first, rtol=0, atol=1e-10)
+    assert numpy.allclose(out.cpu().numpy(), numpy.logaddexp(want_first, second), rtol=0, atol=1e-10)
