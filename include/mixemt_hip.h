@@ -173,6 +173,16 @@ int mxm_row_argmax_votes(const double *X, int64_t ldx, const double *w,
                          void *stream);
 
 /*
+ * Read -> contributor assignment -- assemble.py:284-334 (_find_best_n_for_read :267-281 inlined):
+ *   v_c = X[r][c] - log_props[c] for the nC contributor columns cols[];
+ *   assigned[r] = ordinal (0..nC-1) of the largest v_c if it beats the runner-up by at least
+ *   log_min_fold, else -1 ("unassigned").  nC == 1 is the caller's trivial case.
+ */
+int mxm_assign_reads(const double *X, int64_t ldx, const double *log_props,
+                     const int32_t *cols, int32_t nC, int64_t R, int32_t H,
+                     double log_min_fold, int32_t *assigned, void *stream);
+
+/*
  * Measurement hook (bench.py): when both handles are non-NULL, mxm_em_iter
  * records hipEvent_t `ev_start` / `ev_stop` on its stream immediately before /
  * after the streaming kernel (the dominant one), so its device time can be read

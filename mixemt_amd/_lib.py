@@ -45,6 +45,7 @@ SIGNATURES = {
     "mxm_log_normalize": (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_ptr]),
     "mxm_l1_exp_diff": (ctypes.c_int, [c_ptr, c_ptr, c_i32, c_ptr, c_ptr]),
     "mxm_add_scalar": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_f64, c_ptr]),
+    "mxm_assign_reads": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_f64, c_ptr, c_ptr]),
     "mxm_set_timing_events": (ctypes.c_int, [c_ptr, c_ptr]),
     "mxm_set_batch_tile": (ctypes.c_int, [c_i32]),
     "mxm_row_argmax_votes": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_ptr,

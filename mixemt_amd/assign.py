@@ -1,0 +1,126 @@
+"""
+Consumers of the EM result that reduce the [R][H] posterior matrix to one small
+value per read -- the "next" rows f-1..f-3 of SURVEY.md section 8.  On the
+device they are single streaming / gather passes over a matrix that is already
+resident, and they remove the 43 GB device->host copy of `read_mix` the
+reference's NumPy versions would need:
+
+    find_contribs_from_reads   <- assemble._find_contribs_from_reads  assemble.py:103-123
+    read_votes / report_read_votes <- stats.report_read_votes          stats.py:34-45
+    update_contribs            <- assemble.update_contribs             assemble.py:211-230
+    assign_read_indexes        <- assemble.assign_read_indexes         assemble.py:284-334
+                                  (with _find_best_n_for_read :267-281)
+
+Matrices may be numpy arrays (uploaded) or ROCm tensors.
+"""
+
+import collections
+import sys
+
+import numpy
+
+from . import _lib
+from ._dev import as_device, current_stream, ptr, require_gpu, torch
+
+
+def row_argmax_votes(read_hap_mat, wts=None):
+    """
+    best[r] = first index of the row maximum (numpy.argmax semantics) and
+    votes[h] = sum of wts over the rows that picked h (mxm_row_argmax_votes).
+    Returns (best int32[R], votes float64[H]) as numpy arrays.
+    """
+    lib = _lib.load()
+    dev = require_gpu()
+    mat = as_device(read_hap_mat, torch.float64, dev)
+    n_rows, n_haps = mat.shape
+    w_d = None if wts is None else as_device(wts, torch.float64, dev)
+    best = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    votes = torch.zeros(n_haps, dtype=torch.float64, device=dev)
+    if n_rows:
+        _lib.check(lib.mxm_row_argmax_votes(mat.data_ptr(), mat.stride(0), ptr(w_d), n_rows, n_haps,
+                                            best.data_ptr(), votes.data_ptr(), current_stream()),
+                   "mxm_row_argmax_votes")
+    return best.cpu().numpy(), votes.cpu().numpy()
+
+
+def _first_seen_order(best):
+    """Column indexes in the order they first appear in `best` (dict insertion order
+    of the reference's vote table, assemble.py:116-119)."""
+    uniq, first = numpy.unique(best, return_index=True)
+    return uniq[numpy.argsort(first, kind="stable")]
+
+
+def find_contribs_from_reads(read_hap_mat, wts, args):
+    """
+    Haplogroup columns that are the most probable source of at least
+    args.min_reads fragments (assemble.py:103-123), in the reference's order
+    (first appearance among the rows).
+    """
+    best, votes = row_argmax_votes(read_hap_mat, wts)
+    return [int(h) for h in _first_seen_order(best) if votes[h] >= args.min_reads]
+
+
+def read_votes(read_hap_mat):
+    """Counter {column: number of rows voting for it}, unweighted (stats.py:39-40),
+    with the reference's insertion order so that most_common() breaks ties alike."""
+    best, votes = row_argmax_votes(read_hap_mat, None)
+    counter = collections.Counter()
+    for h in _first_seen_order(best):
+        counter[int(h)] = int(votes[h])
+    return counter
+
+
+def report_read_votes(haplogroups, read_hap_mat, top_n=10):
+    """stats.report_read_votes (stats.py:34-45), same text on stderr."""
+    sys.stderr.write("\nTop 10 haplogroups by read probabilities...\n")
+    for hap_i, count in read_votes(read_hap_mat).most_common(top_n):
+        sys.stderr.write("%s\t%d\n" % (haplogroups[hap_i], count))
+    sys.stderr.write("\n")
+
+
+def update_contribs(contribs, em_results, haps):
+    """assemble.update_contribs (assemble.py:211-230): refined proportions by name."""
+    props, _ = em_results
+    by_hap = {haps[i]: props[i] for i in range(len(haps))}
+    for con in contribs:
+        con[2] = by_hap[con[1]]
+    return contribs
+
+
+def assign_read_indexes(contribs, em_results, haps, reads, min_fold):
+    """
+    assemble.assign_read_indexes (assemble.py:284-334): contributor name -> set
+    of row indexes, plus 'unassigned'; a row goes to its best contributor when,
+    after dividing out the mixture proportions, it beats the runner-up by
+    min_fold.  One gather kernel (mxm_assign_reads) instead of an argsort of
+    all H columns per row.
+    """
+    props, read_hap_mat = em_results
+    out = collections.defaultdict(set)
+    n_rows = len(reads)
+    if len(contribs) <= 1:
+        out[contribs[0][0]].update(range(n_rows))
+        return out
+    lib = _lib.load()
+    dev = require_gpu()
+    mat = as_device(read_hap_mat, torch.float64, dev)
+    with numpy.errstate(divide="ignore"):
+        log_props = numpy.log(numpy.asarray(props, dtype=numpy.float64))
+    cols = numpy.array([haps.index(group) for _, group, _ in contribs], dtype=numpy.int32)
+    names = [hap_n for hap_n, _, _ in contribs]
+    lp_d = torch.from_numpy(log_props).to(dev)
+    cols_d = torch.from_numpy(cols).to(dev)
+    assigned = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    if n_rows:
+        _lib.check(lib.mxm_assign_reads(mat.data_ptr(), mat.stride(0), lp_d.data_ptr(), cols_d.data_ptr(),
+                                        len(cols), n_rows, mat.shape[1], float(numpy.log(min_fold)),
+                                        assigned.data_ptr(), current_stream()), "mxm_assign_reads")
+    host = assigned.cpu().numpy()
+    for i, name in enumerate(names):
+        mine = numpy.flatnonzero(host == i)
+        if mine.size:                      # like the reference's defaultdict: no key without reads
+            out[name].update(mine.tolist())
+    rest = numpy.flatnonzero(host < 0)
+    if rest.size:
+        out["unassigned"].update(rest.tolist())
+    return out

@@ -823,6 +823,32 @@ __global__ __launch_bounds__(ROW_THREADS) void row_argmax_votes_kernel(
     }
 }
 
+// Read -> contributor assignment (assemble.py:284-334): per row, among the contributor columns
+// only, the two largest  X[r][c] - log p_c ; assigned to the best one if the gap reaches
+// log(min_fold), else unassigned (-1).  One thread per row; the row touches nC scattered cells.
+// Order among exactly equal values follows numpy.argsort(...)[::-1]: the larger column wins.
+__global__ __launch_bounds__(256) void assign_reads_kernel(const double *__restrict__ X, int64_t ldx,
+                                                           const double *__restrict__ log_props,
+                                                           const int32_t *__restrict__ cols, int nC, int64_t R,
+                                                           double log_min_fold, int32_t *__restrict__ assigned) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const double *row = X + r * ldx;
+    double v1 = -INFINITY, v2 = -INFINITY;      // best, runner-up
+    int i1 = -1, c1 = -1, c2 = -1;
+    for (int i = 0; i < nC; ++i) {
+        const int c = cols[i];
+        const double v = row[c] - log_props[c];
+        if (i1 < 0 || v > v1 || (v == v1 && c > c1)) {
+            v2 = v1; c2 = c1;
+            v1 = v; c1 = c; i1 = i;
+        } else if (c2 < 0 || v > v2 || (v == v2 && c > c2)) {
+            v2 = v; c2 = c;
+        }
+    }
+    assigned[r] = (nC >= 2 && (v1 - v2) >= log_min_fold) ? i1 : -1;
+}
+
 // ------------------------------------------------------------------------------------------
 // host side of the C ABI
 // ------------------------------------------------------------------------------------------
@@ -1197,6 +1223,16 @@ extern "C" int mxm_l1_exp_diff(const double *a, const double *b, int32_t H, doub
 extern "C" int mxm_add_scalar(double *x, int64_t ld, int64_t R, int32_t H, double delta, void *stream) {
     if (R <= 0 || H <= 0 || ld < H) return fail(-1, "mxm_add_scalar: bad shape%s", "");
     hipLaunchKernelGGL(add_scalar_kernel, dim3(clamp_grid(R, num_cu() * 8)), dim3(256), 0, (hipStream_t)stream, x, ld, R, (int)H, delta);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_assign_reads(const double *X, int64_t ldx, const double *log_props, const int32_t *cols,
+                                int32_t nC, int64_t R, int32_t H, double log_min_fold, int32_t *assigned,
+                                void *stream) {
+    if (R <= 0 || H <= 0 || nC <= 0 || ldx < H) return fail(-1, "mxm_assign_reads: bad shape%s", "");
+    hipLaunchKernelGGL(assign_reads_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
+                       ldx, log_props, cols, (int)nC, R, log_min_fold, assigned);
     HIP_TRY(hipGetLastError());
     return 0;
 }

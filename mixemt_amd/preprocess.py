@@ -16,6 +16,7 @@ show at a site, observations are ASCII codes too, so "hit" is byte equality --
 exactly the reference's string comparison, for any alphabet ('N' included).
 """
 
+import collections
 import math
 import sys
 
@@ -240,6 +241,88 @@ def build_em_matrix(refseq, phylo, reads, haplogroups, args, as_device_tensor=Fa
     if as_device_tensor:
         return mat
     return mat.cpu().numpy()
+
+
+# --------------------------------------------------------------------------
+# host front end: alignments -> signatures -> EM input  
+# --------------------------------------------------------------------------
+
+def process_reads(alns, var_pos, min_mq, min_bq):
+    """
+    Alignments -> {fragment id: {0-based variant site: observed base}}
+    (reference: preprocess.py:99-139).  `alns` yields pysam.AlignedSegment-like
+    objects: mapping_quality, query_name, query_sequence, query_qualities and
+    get_aligned_pairs(matches_only=True).  Mates share a fragment id; a site seen
+    with two different bases becomes 'N' and is dropped at the end.
+    """
+    wanted = set(var_pos)
+    frags = collections.defaultdict(dict)
+    for aln in alns:
+        if aln.mapping_quality < min_mq:
+            continue
+        quals = aln.query_qualities
+        seq = aln.query_sequence
+        for qpos, rpos in aln.get_aligned_pairs(matches_only=True):
+            qpos, rpos = int(qpos), int(rpos)
+            if rpos not in wanted:
+                continue
+            if quals is not None and quals[qpos] < min_bq:
+                continue
+            base = seq[qpos].upper()
+            seen = frags[aln.query_name]
+            if rpos in seen and seen[rpos] != base:
+                base = "N"
+            seen[rpos] = base
+    return {name: {pos: base for pos, base in obs.items() if base != "N"}
+            for name, obs in frags.items()}
+
+
+def read_signature(obs_by_pos):
+    """{site: base} -> 'site:base,site:base' by ascending site (preprocess.py:142-148)."""
+    return ",".join("%d:%s" % (pos, obs_by_pos[pos]) for pos in sorted(obs_by_pos))
+
+
+def pos_obs_from_sig(read_sig):
+    """'site:base,...' -> [(int site, base)] (preprocess.py:151-160)."""
+    out = []
+    for item in read_sig.split(","):
+        pos, base = item.split(":")
+        out.append((int(pos), base))
+    return out
+
+
+def reduce_reads(read_obs):
+    """{fragment id: observations} -> {signature: [fragment ids]} (preprocess.py:163-174)."""
+    by_sig = collections.defaultdict(list)
+    for read_id, obs in read_obs.items():
+        by_sig[read_signature(obs)].append(read_id)
+    return by_sig
+
+
+def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False):
+    """
+    Drop-in for mixemt.preprocess.build_em_input (preprocess.py:201-227):
+    (em_matrix, weights, haplogroups, read_ids) with rows = sorted distinct
+    signatures, weights = fragments per signature, columns = sorted(hap_var).
+    A fragment whose every site was conflicted away has the empty signature, on
+    which the reference dies (int('') at :156-160); it is skipped here.
+    """
+    var_pos = phylo.get_variant_pos()
+    read_obs = process_reads(bamfile.fetch(), var_pos, args.min_mq, args.min_bq)
+    read_sigs = reduce_reads(read_obs)
+    dropped = read_sigs.pop("", None)
+    if getattr(args, "verbose", False):
+        sys.stderr.write("Using %d aligned fragments (MQ>=%d) (%d distinct sub-haplotypes)\n\n"
+                         % (len(read_obs), args.min_mq, len(read_sigs)))
+        if dropped:
+            sys.stderr.write("Skipped %d fragment(s) without a usable site.\n" % len(dropped))
+    haplogroups = sorted(phylo.hap_var)
+    reads = sorted(read_sigs)
+    weights = numpy.array([len(read_sigs[r]) for r in reads])
+    em_matrix = build_em_matrix(refseq, phylo, reads, haplogroups, args,
+                                as_device_tensor=as_device_tensor)
+    read_ids = [read_sigs[r] for r in reads]
+    return em_matrix, weights, haplogroups, read_ids
 
 
 def reduce_em_matrix(em_mat, haplogroups, contrib_props):

@@ -1,0 +1,40 @@
+"""
+Minimal stand-in for pysam.AlignedSegment / AlignmentFile for the front-end
+tests (the reference's own tests build pysam objects in memory,
+preprocess_test.py:102-124; pysam is not installed here).  Supports M/=/X, I,
+D/N, S cigar operations -- what get_aligned_pairs(matches_only=True) needs.
+"""
+import re
+
+
+class FakeAln(object):
+    def __init__(self, name, start=0, mq=0, seq=None, quals=None, cigar=None):
+        self.query_name = name
+        self.reference_start = start
+        self.mapping_quality = mq
+        self.query_sequence = seq
+        self.query_qualities = quals
+        self.cigarstring = cigar
+
+    def get_aligned_pairs(self, matches_only=False):
+        assert matches_only
+        pairs, q, r = [], 0, self.reference_start
+        for n, op in re.findall(r"(\d+)([MIDNS=X])", self.cigarstring or ""):
+            n = int(n)
+            if op in "M=X":
+                pairs.extend((q + i, r + i) for i in range(n))
+                q += n
+                r += n
+            elif op in "IS":
+                q += n
+            else:
+                r += n
+        return pairs
+
+
+class FakeBam(object):
+    def __init__(self, alns):
+        self.alns = list(alns)
+
+    def fetch(self):
+        return iter(self.alns)

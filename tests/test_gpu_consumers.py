@@ -1,0 +1,147 @@
+"""
+"Next" rows f-1..f-4 on the GPU against reference-derived golden g8 (the
+reference's assemble/stats functions run on its own run_em result): contributor
+votes, read assignment, refinement EM + update_contribs, front end -> matrix,
+device-streamed save files.
+"""
+import argparse
+import io
+import sys
+
+import numpy
+import pytest
+
+from conftest import em_args, golden
+from oracle import build_oracle, c_oracle
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def run600(b17):
+    """The g4 run on the device: matrix, weights, result kept resident."""
+    import torch
+    from mixemt_amd import em, preprocess
+    refseq, phy, haps, tables = b17
+    g = golden("g4_run_em")
+    mat = preprocess.build_em_matrix_device(tables, g["row_ptr"], g["site"], g["obs"])
+    wts = g["wts"]
+    numpy.random.seed(7)
+    props, read_mix = em.run_em(mat, torch.from_numpy(wts).cuda(), em_args())
+    return dict(haps=haps, mat=mat, wts=wts, props=props, read_mix=read_mix)
+
+
+def test_contributors_from_read_votes(run600):
+    """assemble.py:103-123: same columns, same (first-appearance) order."""
+    from mixemt_amd import assign
+    g8 = golden("g8_consumers")
+    args = argparse.Namespace(min_reads=10)
+    got = assign.find_contribs_from_reads(run600["read_mix"], run600["wts"], args)
+    assert got == list(g8["contributors"])
+    # numpy input takes the same path after an upload
+    got_np = assign.find_contribs_from_reads(run600["read_mix"].cpu().numpy(), run600["wts"], args)
+    assert got_np == got
+
+
+def test_report_read_votes_text(run600):
+    """stats.py:34-45: identical stderr text (counts, order, tie order)."""
+    from mixemt_amd import assign
+    g8 = golden("g8_consumers")
+    err, sys.stderr = sys.stderr, io.StringIO()
+    try:
+        assign.report_read_votes(run600["haps"], run600["read_mix"], 10)
+        text = sys.stderr.getvalue()
+    finally:
+        sys.stderr = err
+    assert text == str(g8["vote_text"])
+
+
+def _contribs(g8):
+    return [[n, h, p] for n, h, p in zip(str(g8["contrib_names"]).split("\n"),
+                                          str(g8["contrib_haps"]).split("\n"), g8["contrib_props"])]
+
+
+def test_assign_read_indexes(run600):
+    """assemble.py:284-334 on the full-width posterior."""
+    from mixemt_amd import assign
+    g8 = golden("g8_consumers")
+    contribs = _contribs(g8)
+    reads = [[str(i)] for i in range(600)]
+    table = assign.assign_read_indexes(contribs, (run600["props"], run600["read_mix"]), run600["haps"],
+                                       reads, 2.0)
+    names = [c[0] for c in contribs]
+    got = numpy.full(600, -2, dtype=numpy.int32)
+    for key, idxs in table.items():
+        got[sorted(idxs)] = -1 if key == "unassigned" else names.index(key)
+    assert numpy.array_equal(got, g8["assigned"])
+    assert sum(len(v) for v in table.values()) == 600
+    # a single contributor takes every read (assemble.py:331-334)
+    one = assign.assign_read_indexes(contribs[:1], (run600["props"], run600["read_mix"]), run600["haps"],
+                                     reads, 2.0)
+    assert one == {contribs[0][0]: set(range(600))}
+
+
+def test_refinement_round(run600):
+    """bin/mixemt:311-320: reduce_em_matrix -> run_em on R x #contributors -> update_contribs -> assign."""
+    from mixemt_amd import assign, em, preprocess
+    g8 = golden("g8_consumers")
+    contribs = _contribs(g8)
+    sub, sub_names = preprocess.reduce_em_matrix(run600["mat"], run600["haps"], contribs)
+    assert sub.shape == (600, len(contribs)) and sub.is_cuda
+    numpy.random.seed(13)
+    res = em.run_em_ex(sub, run600["wts"], em_args())
+    assert numpy.array_equal(res["inits"], g8["refined_inits"])
+    assert res["iters"] == list(g8["refined_iters"])
+    refined = assign.update_contribs([list(c) for c in contribs], (res["props"], res["read_mix"]), sub_names)
+    assert numpy.abs(numpy.array([c[2] for c in refined]) - g8["refined_props"]).max() < 1e-9
+    table = assign.assign_read_indexes(refined, (res["props"], res["read_mix"]), sub_names,
+                                       [[str(i)] for i in range(600)], 2.0)
+    names = [c[0] for c in contribs]
+    got = numpy.full(600, -2, dtype=numpy.int32)
+    for key, idxs in table.items():
+        got[sorted(idxs)] = -1 if key == "unassigned" else names.index(key)
+    assert numpy.array_equal(got, g8["refined_assigned"])
+
+
+def test_front_end_to_matrix(b17):
+    """build_em_input (preprocess.py:201-227) on in-memory alignments: sorted distinct signatures,
+    weights, and a matrix equal to the oracle's for those signatures."""
+    import sys as _sys
+    import os
+    _sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _fake_aln import FakeAln, FakeBam
+    from mixemt_amd import preprocess
+    refseq, phy, haps, tables = b17
+    rng = numpy.random.default_rng(5)
+    alns = []
+    for i in range(60):
+        start = int(rng.integers(0, len(refseq) - 400))
+        for mate, off in ((0, 0), (1, 180)):
+            seq = list(refseq[start + off:start + off + 150])
+            for k in rng.integers(0, 150, size=2):
+                seq[k] = "ACGT"[int(rng.integers(0, 4))]
+            alns.append(FakeAln("frag%d" % (i % 50), start + off, 40, "".join(seq), [35] * 150, "150M"))
+    args = argparse.Namespace(min_mq=30, min_bq=30, verbose=False)
+    mat, wts, hap_order, read_ids = preprocess.build_em_input(FakeBam(alns), refseq, phy, args)
+    assert hap_order == haps
+    obs = preprocess.process_reads(alns, phy.get_variant_pos(), 30, 30)
+    sigs = preprocess.reduce_reads(obs)
+    sigs.pop("", None)
+    order = sorted(sigs)
+    assert read_ids == [sigs[s] for s in order] and list(wts) == [len(sigs[s]) for s in order]
+    assert mat.shape == (len(order), len(haps))
+    want = build_oracle.build_em_matrix_np(refseq, phy, order, haps)
+    assert numpy.array_equal(mat, want)
+
+
+def test_save_files_stream_from_device(tmp_path, run600):
+    """dump_all with device tensors writes numpy.save-compatible files (bin/mixemt:239-242)."""
+    from mixemt_amd import io as mio
+    prefix = str(tmp_path / "state")
+    reads = [["id%d" % i] for i in range(600)]
+    mio.dump_all(prefix, run600["haps"], reads, run600["mat"], (run600["props"], run600["read_mix"]))
+    haps, r2, wts, init, (props, mix) = mio.load_prev(prefix)
+    assert haps == run600["haps"] and r2 == reads and wts.sum() == 600
+    assert numpy.array_equal(init, run600["mat"].cpu().numpy())
+    assert numpy.array_equal(mix, run600["read_mix"].cpu().numpy())
+    assert numpy.array_equal(props, run600["props"])

@@ -17,6 +17,7 @@ Fixtures (SURVEY.md section 8 c):
     g5  run_em on the same matrix, n_multi = 3
     g6  refinement shape: 600 x 5 contributor columns
     g7  config 1: 1000 x 100
+    g8  consumers of the result on the g4 run: contributor votes, read assignment, refinement
 """
 
 import argparse
@@ -182,6 +183,7 @@ def main():
              ident_mix2=r2[0], ident_new2=r2[1])
 
     mat600 = None
+    wts600 = None
     if want("g4") or want("g5") or want("g6"):
         row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), 600, seed=4)
         sigs = synth.signatures(tables, row_ptr, site, obs)
@@ -222,6 +224,54 @@ def main():
         props, mix, iters, inits = ref_run_em(ref, sub, wts600, 5)
         save("g6_refine", cols=numpy.array([haps.index(n) for n in names], dtype=numpy.int32),
              props=props, iters=iters, inits=inits, mix=mix, **common)
+
+    if want("g8"):
+        # consumers of the EM result (assemble.py / stats.py); assemble imports pysam and Bio at
+        # module level only for its writers, so empty stand-in modules are enough to import it
+        for name in ("pysam", "Bio", "Bio.Seq", "Bio.SeqRecord", "Bio.SeqIO"):
+            sys.modules.setdefault(name, types.ModuleType(name))
+        sys.modules["Bio"].SeqIO = sys.modules["Bio.SeqIO"]
+        sys.modules["Bio.Seq"].Seq = object
+        sys.modules["Bio.SeqRecord"].SeqRecord = object
+        import mixemt.assemble
+        import mixemt.stats
+        if mat600 is None:
+            row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), 600, seed=4)
+            sigs = synth.signatures(tables, row_ptr, site, obs)
+            mat600 = ref.preprocess.build_em_matrix(refseq, phy, sigs, haps, quiet)
+            wts600 = numpy.random.default_rng(44).integers(1, 4, size=600).astype(numpy.int64)
+        props, mix, iters, inits = ref_run_em(ref, mat600, wts600, 7)
+        asm_args = ns(min_reads=10, contributors=None, var_check=False, min_fold=2.0)
+        cons = ref.assemble._find_contribs_from_reads(mix, wts600, asm_args)
+        contribs = ref.assemble.get_contributors(phy, None, haps, wts600, (props, mix), asm_args)
+        reads_stub = [[str(i)] for i in range(600)]
+        table = ref.assemble.assign_read_indexes(contribs, (props, mix), haps, reads_stub, 2.0)
+        assigned = numpy.full(600, -2, dtype=numpy.int32)
+        names = [c[0] for c in contribs]
+        for key, idxs in table.items():
+            assigned[sorted(idxs)] = -1 if key == "unassigned" else names.index(key)
+        err, sys.stderr = sys.stderr, io.StringIO()
+        try:
+            ref.stats.report_read_votes(haps, mix, 10)
+            vote_text = sys.stderr.getvalue()
+        finally:
+            sys.stderr = err
+        # refinement on the contributor columns (bin/mixemt:311-320)
+        sub, sub_names = ref.preprocess.reduce_em_matrix(mat600, haps, contribs)
+        rprops, rmix, riters, rinits = ref_run_em(ref, sub, wts600, 13)
+        refined = ref.assemble.update_contribs([list(c) for c in contribs], (rprops, rmix), sub_names)
+        rtable = ref.assemble.assign_read_indexes(refined, (rprops, rmix), sub_names, reads_stub, 2.0)
+        rassigned = numpy.full(600, -2, dtype=numpy.int32)
+        for key, idxs in rtable.items():
+            rassigned[sorted(idxs)] = -1 if key == "unassigned" else names.index(key)
+        save("g8_consumers", contributors=numpy.array(cons, dtype=numpy.int32),
+             contrib_names=numpy.array("\n".join(names)),
+             contrib_haps=numpy.array("\n".join(c[1] for c in contribs)),
+             contrib_props=numpy.array([c[2] for c in contribs]),
+             assigned=assigned, vote_text=numpy.array(vote_text),
+             refined_props=numpy.array([c[2] for c in refined]), refined_iters=riters,
+             refined_inits=rinits, refined_assigned=rassigned,
+             props=props, iters=iters)
 
     if want("g7"):
         cols = list(range(0, 5400, 54))
