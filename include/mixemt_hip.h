@@ -192,6 +192,13 @@ int mxm_assign_reads(const double *X, int64_t ldx, const double *log_props,
 int mxm_set_timing_events(void *ev_start, void *ev_stop);
 
 /*
+ * mxm_em_loop replays its chunk of iterations from a hipGraph when that pays
+ * (launch-bound sizes): mode -1 = automatic (R*H*B < 6.4e7 cells), 0 = never,
+ * 1 = always.  Results are identical either way.
+ */
+int mxm_set_loop_graph(int32_t mode);
+
+/*
  * How many restarts share one pass over the matrix in mxm_em_iter (1..3,
  * default 3).  1 reproduces the unbatched schedule (B passes per iteration).
  * Results do not depend on it beyond rounding of the reduction order.

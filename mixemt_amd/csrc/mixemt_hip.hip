@@ -1118,6 +1118,30 @@ extern "C" int mxm_m_finalize(const double *colsum, double *props_cur, double *p
     return 0;
 }
 
+// ---- the run_em inner loop (em.py:126-143) as a native driver -----------------------------------
+// Iterations are enqueued in chunks; for small matrices the chunk is captured once into a
+// hipGraph and replayed (the loop is launch-bound there: 3 kernels of a few microseconds each),
+// for large ones plain launches already run ahead of the GPU.  Either way the kernels of a
+// finished restart are no-ops, so the state freezes on the iteration the reference stops on.
+static int g_loop_graph = -1;          // -1 auto (graph when R*H*B is small), 0 never, 1 always
+extern "C" int mxm_set_loop_graph(int32_t mode) {
+    g_loop_graph = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+    return 0;
+}
+
+static int enqueue_iterations(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
+                              int64_t R, int32_t H, int32_t B, double *props_cur, double *props_new,
+                              double *colsum, mxm_em_state *state, double tol, int32_t max_iter, int64_t n,
+                              void *ws, size_t ws_bytes, hipStream_t s) {
+    for (int64_t i = 0; i < n; ++i) {
+        int rc = mxm_em_iter(M, ldm, P, ldp, w, props_cur, R, H, B, state, colsum, ws, ws_bytes, s);
+        if (rc != 0) return rc;
+        rc = mxm_m_finalize(colsum, props_cur, props_new, H, B, tol, max_iter, state, s);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
 extern "C" int mxm_em_loop(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
                            int64_t R, int32_t H, int32_t B, double *props_cur, double *props_new,
                            double *colsum, mxm_em_state *state, double tol, int32_t max_iter,
@@ -1125,27 +1149,80 @@ extern "C" int mxm_em_loop(const double *M, int64_t ldm, const double *P, int64_
                            mxm_em_state *state_host) {
     if (state_host == nullptr || state == nullptr) return fail(-1, "mxm_em_loop: state pointers required%s", "");
     if (check_every < 1) check_every = 1;
-    hipStream_t s = (hipStream_t)stream;
-    HIP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
-    HIP_TRY(hipStreamSynchronize(s));
-    int64_t issued = 0;
-    for (;;) {
-        bool all_done = true;
-        for (int b = 0; b < B; ++b) all_done = all_done && (state_host[b].done != 0);
-        if (all_done || issued >= (int64_t)max_iter) break;
-        int64_t n = max_iter - issued;
-        if (n > check_every) n = check_every;
-        for (int64_t i = 0; i < n; ++i) {
-            int rc = mxm_em_iter(M, ldm, P, ldp, w, props_cur, R, H, B, state, colsum, ws, ws_bytes, stream);
-            if (rc != 0) return rc;
-            rc = mxm_m_finalize(colsum, props_cur, props_new, H, B, tol, max_iter, state, stream);
-            if (rc != 0) return rc;
+    hipStream_t caller = (hipStream_t)stream;
+    (void)num_cu();                                    // device query outside any capture
+    const bool want_graph = g_loop_graph == 1 ||
+                            (g_loop_graph == -1 && (double)R * (double)H * (double)B < 6.4e7);
+
+    // the loop runs on a private stream (the caller's may be the legacy default stream, which
+    // cannot be captured); it is ordered after / before the caller's stream with events
+    hipStream_t s = nullptr;
+    hipEvent_t ev = nullptr;
+    HIP_TRY(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+    HIP_TRY(hipEventCreateWithFlags(&ev, hipEventDisableTiming));
+    int rc = 0;
+    hipGraph_t graph = nullptr;
+    hipGraphExec_t exec = nullptr;
+    int64_t graph_iters = 0;
+#define LOOP_TRY(expr)                                                                        \
+    do {                                                                                      \
+        hipError_t e_ = (expr);                                                               \
+        if (e_ != hipSuccess) { rc = fail(-2, "HIP error: %s (line %lld)", hipGetErrorString(e_), __LINE__); goto done; } \
+    } while (0)
+    LOOP_TRY(hipEventRecord(ev, caller));
+    LOOP_TRY(hipStreamWaitEvent(s, ev, 0));
+    LOOP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
+    LOOP_TRY(hipStreamSynchronize(s));
+    {
+        int64_t issued = 0;
+        for (;;) {
+            bool all_done = true;
+            for (int b = 0; b < B; ++b) all_done = all_done && (state_host[b].done != 0);
+            if (all_done || issued >= (int64_t)max_iter) break;
+            int64_t n = (int64_t)max_iter - issued;
+            if (n > check_every) n = check_every;
+            bool launched = false;
+            if (want_graph) {
+                if (exec == nullptr || graph_iters != n) {
+                    if (exec != nullptr) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
+                    if (graph != nullptr) { (void)hipGraphDestroy(graph); graph = nullptr; }
+                    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                        const int crc = enqueue_iterations(M, ldm, P, ldp, w, R, H, B, props_cur, props_new, colsum,
+                                                           state, tol, max_iter, n, ws, ws_bytes, s);
+                        const hipError_t ee = hipStreamEndCapture(s, &graph);
+                        if (crc == 0 && ee == hipSuccess &&
+                            hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                            graph_iters = n;
+                        } else {
+                            exec = nullptr;            // capture unavailable: plain launches below
+                            (void)hipGetLastError();
+                        }
+                    }
+                }
+                if (exec != nullptr) {
+                    LOOP_TRY(hipGraphLaunch(exec, s));
+                    launched = true;
+                }
+            }
+            if (!launched) {
+                rc = enqueue_iterations(M, ldm, P, ldp, w, R, H, B, props_cur, props_new, colsum, state, tol,
+                                        max_iter, n, ws, ws_bytes, s);
+                if (rc != 0) goto done;
+            }
+            issued += n;
+            LOOP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
+            LOOP_TRY(hipStreamSynchronize(s));
         }
-        issued += n;
-        HIP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
-        HIP_TRY(hipStreamSynchronize(s));
     }
-    return 0;
+    LOOP_TRY(hipEventRecord(ev, s));
+    LOOP_TRY(hipStreamWaitEvent(caller, ev, 0));
+done:
+#undef LOOP_TRY
+    if (exec != nullptr) (void)hipGraphExecDestroy(exec);
+    if (graph != nullptr) (void)hipGraphDestroy(graph);
+    if (s != nullptr) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
+    if (ev != nullptr) (void)hipEventDestroy(ev);
+    return rc;
 }
 
 template <int NCH>
