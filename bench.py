@@ -97,6 +97,9 @@ def main():
                          "iteration of EVERY restart and value counts cells x restarts")
     ap.add_argument("--batch-tile", type=int, default=3,
                     help="restarts sharing one pass over the matrix (1 = unbatched schedule)")
+    ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
+                    help="element type of the streamed matrix; f32 is a labelled opt-in variant "
+                         "(fp64 math on float-stored P), never the default")
     ap.add_argument("--build-kernel", default="auto", choices=["auto", "packed", "bytes"])
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to test the "
@@ -149,12 +152,13 @@ def main():
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
     wts = torch.ones(n_rows, dtype=torch.float64, device=dev)
-    plan = em.EmPlan(mat, wts, n_runs=opts.restarts)          # allocates P and linearises once (untimed: hipMalloc)
+    plan = em.EmPlan(mat, wts, n_runs=opts.restarts, storage=opts.storage)          # allocates P and linearises once (untimed: hipMalloc)
     torch.cuda.synchronize()
     t0 = time.perf_counter()                      # timed again on the now-resident buffers
-    _lib.check(lib.mxm_linearize(mat.data_ptr(), mat.stride(0), n_rows, n_haps, plan.lin.data_ptr(),
-                                 plan.lin.stride(0), plan.rowmax.data_ptr(),
-                                 torch.cuda.current_stream().cuda_stream), "mxm_linearize")
+    lin_fn = lib.mxm_linearize_f32 if opts.storage == "f32" else lib.mxm_linearize
+    _lib.check(lin_fn(mat.data_ptr(), mat.stride(0), n_rows, n_haps, plan.lin.data_ptr(),
+                      plan.lin.stride(0), plan.rowmax.data_ptr(),
+                      torch.cuda.current_stream().cuda_stream), "mxm_linearize")
     torch.cuda.synchronize()
     linearize_s = time.perf_counter() - t0
     if rank == 0:
@@ -246,9 +250,10 @@ def main():
 
     if rank == 0:
         cells = float(n_rows) * n_haps
-        algo_bytes = cells * 8.0                      # fp64 matrix read once per iteration
+        elem = 4.0 if opts.storage == "f32" else 8.0
+        algo_bytes = cells * elem                     # the stored matrix is read once per iteration
         achieved = algo_bytes / (kernel_ms.mean() * 1e-3)
-        traffic = pmc_traffic(n_rows, n_haps)
+        traffic = pmc_traffic(n_rows, n_haps) if (opts.storage == "f64" and n_runs == 1) else None
         line = {
             "metric": "read x hap cells/sec through one EM iteration (E+M fused), whole job",
             "value": cells * world * n_runs * opts.steps / elapsed,
@@ -257,10 +262,12 @@ def main():
             "n_gpus": world, "steps": opts.steps, "warmup": opts.warmup,
             "ms_per_step": elapsed / opts.steps * 1e3,
             "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic (synth-v1 reads, matrix built on device)",
+            "dtype": "f64" if opts.storage == "f64" else "f64 arithmetic on f32-stored matrix (opt-in variant)",
+            "data": "synthetic (synth-v1 reads, matrix built on device)",
             "config": {"workload": "%d reads x %d haplogroups per GPU (Phylotree B17 + RSRS), "
-                                   "%d EM restart(s) advanced together (tile %d), fp64 matrix"
-                                   % (n_rows, n_haps, n_runs, opts.batch_tile),
+                                   "%d EM restart(s) advanced together (tile %d), %s matrix"
+                                   % (n_rows, n_haps, n_runs, opts.batch_tile,
+                                      "fp64" if opts.storage == "f64" else "fp32-stored"),
                        "rows_per_gpu": n_rows, "haps": n_haps, "restarts": n_runs,
                        "sharding": "rows over %d rank(s), 1 all-reduce of %d fp64 per iteration"
                                    % (world, n_haps)},
@@ -268,7 +275,7 @@ def main():
                          "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S,
                          "traffic": traffic[0] if traffic else None,
                          "traffic_source": traffic[1] if traffic else None,
-                         "kernel": "em_iter_wide_kernel", "kernel_ms": float(kernel_ms.mean()),
+                         "kernel": "em_iter_wide_kernel" if opts.storage == "f64" else "em_iter_wide_f32_kernel", "kernel_ms": float(kernel_ms.mean()),
                          "algorithmic_bytes_per_launch": algo_bytes},
             "cpu_baseline": cpu,
             "matrix_build_cells_per_s": cells / build_s,

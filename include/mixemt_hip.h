@@ -126,6 +126,23 @@ int mxm_m_finalize(const double *colsum, double *props_cur, double *props_new,
                    mxm_em_state *state, void *stream);
 
 /*
+ * fp32-STORAGE variant of the loop (opt-in; NOT the reference's arithmetic type for the stored
+ * matrix): P is kept as float -- half the HBM bytes per iteration -- while every product, row sum
+ * and column sum stays fp64.  One restart per pass.  ldp (floats) a multiple of 4, pad columns 0.
+ * Everything else (w, props, colsum, state, finalize, posterior from the fp64 M) is unchanged.
+ */
+int mxm_linearize_f32(const double *M, int64_t ldm, int64_t R, int32_t H,
+                      float *P, int64_t ldp, double *rowmax, void *stream);
+int mxm_em_iter_f32(const float *P, int64_t ldp, const double *w, const double *props,
+                    int64_t R, int32_t H, int32_t B, const mxm_em_state *state,
+                    double *colsum, void *ws, size_t ws_bytes, void *stream);
+int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int64_t R, int32_t H,
+                    int32_t B, double *props_cur, double *props_new, double *colsum,
+                    mxm_em_state *state, double tol, int32_t max_iter,
+                    int32_t check_every, void *ws, size_t ws_bytes, void *stream,
+                    mxm_em_state *state_host);
+
+/*
  * The run_em inner loop for ONE rank -- em.py:126-143: repeats
  * {mxm_em_iter; mxm_m_finalize} on `stream` until every restart is done.
  * Iterations are enqueued in chunks of `check_every`; kernels of a finished

@@ -475,6 +475,127 @@ __global__ __launch_bounds__(THREADS, (BT == 1 ? MXM_V1_MINW : MXM_VB_MINW)) voi
 }
 
 // ------------------------------------------------------------------------------------------
+// K3f  fp32-STORAGE variant of the streaming kernel (opt-in, labelled as such everywhere):
+// P is kept as float (half the HBM bytes per iteration), every product and sum stays fp64.
+// Same structure as em_iter_wide_kernel with 4 columns per 16-byte load; one restart per pass.
+// ------------------------------------------------------------------------------------------
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int THREADS, int NCH, int NBUF>
+__global__ __launch_bounds__(THREADS, 2) void em_iter_wide_f32_kernel(
+    const float *__restrict__ P, int64_t ldp, const double *__restrict__ w,
+    const double *__restrict__ props, int64_t R, int H, int64_t rows_per_wg,
+    double *__restrict__ partial, int64_t ldpart, const mxm_em_state *__restrict__ state) {
+    constexpr int NW = THREADS / 64;
+    __shared__ double red[2][NW];
+    if (state != nullptr && state->done != 0) return;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int ncol4 = (H + 3) >> 2;                 // float4 groups per row (pad columns are 0 in P)
+
+    double p[NCH][4], acc[NCH][4];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (t + k * THREADS) + e;
+            p[k][e] = (c < H) ? props[c] : 0.0;
+            acc[k][e] = 0.0;
+        }
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < R) ? (r0 + rows_per_wg) : R;
+    if (r0 >= r1) return;
+
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P + r0 * ldp), 0,
+                                                        (int)((r1 - r0) * ldp * 4), 0x00020000);
+    const int row_bytes = (int)(ldp * 4);
+    const int voff = t * 16;
+    int last_c4 = t + (NCH - 1) * THREADS;
+    if (last_c4 > ncol4 - 1) last_c4 = ncol4 - 1;
+    const int voff_last = last_c4 * 16;
+
+    f4 x[NBUF][NCH];
+    auto load_row = [&](f4(&xr)[NCH], int64_t r) {
+        const int64_t rr = (r < r1) ? r : (r1 - 1);
+        const int soff = (int)(rr - r0) * row_bytes;
+#pragma unroll
+        for (int k = 0; k < NCH - 1; ++k)
+            xr[k] = __builtin_bit_cast(f4, (u4)__builtin_amdgcn_raw_buffer_load_b128(
+                                               rsrc, voff, soff + k * THREADS * 16, 2));
+        xr[NCH - 1] = __builtin_bit_cast(f4, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, soff, 2));
+    };
+
+    int buf = 0;
+    auto process = [&](f4(&xr)[NCH], int64_t r) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fma((double)xr[k][e], p[k][e], s);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[buf][wv] = s;
+        __syncthreads();
+        double z = red[buf][0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) z += red[buf][q];
+        buf ^= 1;
+        const bool live = r < r1;
+        const double wr = live ? (w != nullptr ? w[r] : 1.0) : 0.0;
+        const double c = (z > 0.0) ? wr / z : 0.0;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // re-convert from the float (1 v_cvt) instead of keeping the doubles of the dot
+                // product alive across the barrier (2 VGPRs each): opaque to CSE on purpose
+                float xf = xr[k][e];
+                asm volatile("" : "+v"(xf));
+                acc[k][e] = fma(c, (double)xf, acc[k][e]);
+            }
+        }
+    };
+
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j) load_row(x[j], r0 + j);
+    for (int64_t r = r0; r < r1; r += NBUF) {
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) {
+            load_row(x[(j + NBUF - 1) % NBUF], r + j + NBUF - 1);
+            process(x[j], r + j);
+        }
+    }
+    double *dst = partial + (int64_t)blockIdx.x * ldpart;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = 4 * (t + k * THREADS);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < (int)ldpart) dst[c + e] = acc[k][e];
+    }
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void linearize_f32_kernel(const double *__restrict__ M, int64_t ldm,
+                                                                    int64_t R, int H, float *__restrict__ P,
+                                                                    int64_t ldp, double *__restrict__ rowmax) {
+    __shared__ double scratch[ROW_THREADS / 64];
+    const int t = threadIdx.x;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const double *src = M + r * ldm;
+        double m = -INFINITY;
+        for (int h = t; h < H; h += ROW_THREADS) m = fmax(m, src[h]);
+        m = block_reduce<ROW_THREADS, true>(m, scratch);
+        const double shift = isfinite(m) ? m : 0.0;
+        float *dst = P + r * ldp;
+        for (int h = t; h < (int)ldp; h += ROW_THREADS) dst[h] = (h < H) ? (float)exp(src[h] - shift) : 0.0f;
+        if (t == 0) rowmax[r] = shift;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K4  colreduce: colsum[h] = scale_h * sum_{g < nwg} partial[g][h]   (fixed order)
 // 64 columns per workgroup; 4 waves take interleaved quarters of the partial rows.
 // scale_h = props[h] for the linear kernel, 1 for the log-space kernel.
@@ -1063,6 +1184,57 @@ static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, co
     return 0;
 }
 
+#ifndef MXM_F32_THREADS
+#define MXM_F32_THREADS 256
+#endif
+#ifndef MXM_F32_NBUF
+#define MXM_F32_NBUF 2
+#endif
+#ifndef MXM_F32_WG_PER_CU
+#define MXM_F32_WG_PER_CU 2
+#endif
+
+template <int NCH>
+static int launch_wide_f32(const float *P, int64_t ldp, const double *w, const double *props, int64_t R, int H,
+                           int grid, int64_t rows_per_wg, double *partial, int64_t ldpart,
+                           const mxm_em_state *state, hipStream_t stream) {
+    if constexpr (NCH * MXM_F32_THREADS > 2048) {
+        return fail(-1, "mxm_em_iter_f32: H=%s%lld outside the kernel's range", "", H);
+    } else {
+        hipLaunchKernelGGL((em_iter_wide_f32_kernel<MXM_F32_THREADS, NCH, MXM_F32_NBUF>), dim3(grid),
+                           dim3(MXM_F32_THREADS), 0, stream, P, ldp, w, props, R, H, rows_per_wg, partial, ldpart,
+                           state);
+        return 0;
+    }
+}
+
+static int em_iter_f32_one(const float *P, int64_t ldp, const double *w, const double *props, int64_t R, int H,
+                           const mxm_em_state *state, double *colsum, double *partial, hipStream_t stream,
+                           bool timed) {
+    const int64_t ldpart = part_ld(H);
+    const int nch = ((H + 3) / 4 + MXM_F32_THREADS - 1) / MXM_F32_THREADS;
+    const int nbuf = MXM_F32_NBUF;
+    int cap = num_cu() * MXM_F32_WG_PER_CU;
+    if (cap > MXM_MAX_WG) cap = MXM_MAX_WG;
+    int nwg = clamp_grid((R + nbuf - 1) / nbuf, cap);
+    int64_t rows_per_wg = (R + nwg - 1) / nwg;
+    rows_per_wg = (rows_per_wg + nbuf - 1) / nbuf * nbuf;
+    nwg = (int)((R + rows_per_wg - 1) / rows_per_wg);
+    if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
+    switch (nch) {
+#define F32_CASE(n) case n: { const int lrc = launch_wide_f32<n>(P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream); if (lrc != 0) return lrc; } break;
+        F32_CASE(1) F32_CASE(2) F32_CASE(3) F32_CASE(4) F32_CASE(5) F32_CASE(6) F32_CASE(7) F32_CASE(8)
+#undef F32_CASE
+        default: return fail(-1, "mxm_em_iter_f32: H=%s%lld outside the kernel's range", "", H);
+    }
+    HIP_TRY(hipGetLastError());
+    if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
+    hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg,
+                       1, H, props, colsum, state);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static int em_iter_log_one(const double *M, int64_t ldm, const double *w, const double *props, int64_t R, int H,
                            const mxm_em_state *state, double *colsum, double *partial, hipStream_t stream) {
     if (M == nullptr) return fail(-1, "mxm_em_iter: M is NULL and the linear path does not apply%s", "");
@@ -1109,6 +1281,33 @@ extern "C" int mxm_em_iter(const double *M, int64_t ldm, const double *P, int64_
     return 0;
 }
 
+extern "C" int mxm_linearize_f32(const double *M, int64_t ldm, int64_t R, int32_t H, float *P, int64_t ldp,
+                                 double *rowmax, void *stream) {
+    if (R < 0 || H <= 0) return fail(-1, "mxm_linearize_f32: bad shape%s", "");
+    if (ldm < H || ldp < H || (ldp & 3)) return fail(-1, "mxm_linearize_f32: ldp must be a multiple of 4 and >= H%s (ldp=%lld)", "", ldp);
+    if (R == 0) return 0;
+    const int grid = clamp_grid(R, num_cu() * 8);
+    hipLaunchKernelGGL(linearize_f32_kernel, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, M, ldm, R, (int)H,
+                       P, ldp, rowmax);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_em_iter_f32(const float *P, int64_t ldp, const double *w, const double *props, int64_t R,
+                               int32_t H, int32_t B, const mxm_em_state *state, double *colsum, void *ws,
+                               size_t ws_bytes, void *stream) {
+    if (R <= 0 || H <= 0 || B <= 0) return fail(-1, "mxm_em_iter_f32: bad shape R=%s%lld H=%lld", "", R, H);
+    if (!mxm_linear_supported(H)) return fail(-1, "mxm_em_iter_f32: H=%s%lld outside the linear kernel's range", "", H);
+    if (P == nullptr || (ldp & 3) || ldp < H) return fail(-1, "mxm_em_iter_f32: ldp must be a multiple of 4 and >= H%s", "");
+    if (ws == nullptr || ws_bytes < mxm_workspace_bytes(R, H, B)) return fail(-1, "mxm_em_iter_f32: workspace too small%s", "");
+    for (int b = 0; b < B; ++b) {
+        const int rc = em_iter_f32_one(P, ldp, w, props + (int64_t)b * H, R, (int)H, state ? state + b : nullptr,
+                                       colsum + (int64_t)b * H, (double *)ws, (hipStream_t)stream, b == 0);
+        if (rc != 0) return rc;
+    }
+    return 0;
+}
+
 extern "C" int mxm_m_finalize(const double *colsum, double *props_cur, double *props_new, int32_t H, int32_t B,
                               double tol, int32_t max_iter, mxm_em_state *state, void *stream) {
     if (H <= 0 || B <= 0 || state == nullptr) return fail(-1, "mxm_m_finalize: bad arguments%s", "");
@@ -1132,9 +1331,11 @@ extern "C" int mxm_set_loop_graph(int32_t mode) {
 static int enqueue_iterations(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
                               int64_t R, int32_t H, int32_t B, double *props_cur, double *props_new,
                               double *colsum, mxm_em_state *state, double tol, int32_t max_iter, int64_t n,
-                              void *ws, size_t ws_bytes, hipStream_t s) {
+                              void *ws, size_t ws_bytes, hipStream_t s, bool p_is_f32) {
     for (int64_t i = 0; i < n; ++i) {
-        int rc = mxm_em_iter(M, ldm, P, ldp, w, props_cur, R, H, B, state, colsum, ws, ws_bytes, s);
+        int rc = p_is_f32 ? mxm_em_iter_f32(reinterpret_cast<const float *>(P), ldp, w, props_cur, R, H, B, state,
+                                            colsum, ws, ws_bytes, s)
+                          : mxm_em_iter(M, ldm, P, ldp, w, props_cur, R, H, B, state, colsum, ws, ws_bytes, s);
         if (rc != 0) return rc;
         rc = mxm_m_finalize(colsum, props_cur, props_new, H, B, tol, max_iter, state, s);
         if (rc != 0) return rc;
@@ -1142,11 +1343,11 @@ static int enqueue_iterations(const double *M, int64_t ldm, const double *P, int
     return 0;
 }
 
-extern "C" int mxm_em_loop(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
-                           int64_t R, int32_t H, int32_t B, double *props_cur, double *props_new,
-                           double *colsum, mxm_em_state *state, double tol, int32_t max_iter,
-                           int32_t check_every, void *ws, size_t ws_bytes, void *stream,
-                           mxm_em_state *state_host) {
+static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
+                        int64_t R, int32_t H, int32_t B, double *props_cur, double *props_new,
+                        double *colsum, mxm_em_state *state, double tol, int32_t max_iter,
+                        int32_t check_every, void *ws, size_t ws_bytes, void *stream,
+                        mxm_em_state *state_host, bool p_is_f32) {
     if (state_host == nullptr || state == nullptr) return fail(-1, "mxm_em_loop: state pointers required%s", "");
     if (check_every < 1) check_every = 1;
     hipStream_t caller = (hipStream_t)stream;
@@ -1188,7 +1389,7 @@ extern "C" int mxm_em_loop(const double *M, int64_t ldm, const double *P, int64_
                     if (graph != nullptr) { (void)hipGraphDestroy(graph); graph = nullptr; }
                     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
                         const int crc = enqueue_iterations(M, ldm, P, ldp, w, R, H, B, props_cur, props_new, colsum,
-                                                           state, tol, max_iter, n, ws, ws_bytes, s);
+                                                           state, tol, max_iter, n, ws, ws_bytes, s, p_is_f32);
                         const hipError_t ee = hipStreamEndCapture(s, &graph);
                         if (crc == 0 && ee == hipSuccess &&
                             hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
@@ -1206,7 +1407,7 @@ extern "C" int mxm_em_loop(const double *M, int64_t ldm, const double *P, int64_
             }
             if (!launched) {
                 rc = enqueue_iterations(M, ldm, P, ldp, w, R, H, B, props_cur, props_new, colsum, state, tol,
-                                        max_iter, n, ws, ws_bytes, s);
+                                        max_iter, n, ws, ws_bytes, s, p_is_f32);
                 if (rc != 0) goto done;
             }
             issued += n;
@@ -1223,6 +1424,23 @@ done:
     if (s != nullptr) { (void)hipStreamSynchronize(s); (void)hipStreamDestroy(s); }
     if (ev != nullptr) (void)hipEventDestroy(ev);
     return rc;
+}
+
+extern "C" int mxm_em_loop(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
+                           int64_t R, int32_t H, int32_t B, double *props_cur, double *props_new,
+                           double *colsum, mxm_em_state *state, double tol, int32_t max_iter,
+                           int32_t check_every, void *ws, size_t ws_bytes, void *stream,
+                           mxm_em_state *state_host) {
+    return em_loop_impl(M, ldm, P, ldp, w, R, H, B, props_cur, props_new, colsum, state, tol, max_iter,
+                        check_every, ws, ws_bytes, stream, state_host, false);
+}
+
+extern "C" int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int64_t R, int32_t H, int32_t B,
+                               double *props_cur, double *props_new, double *colsum, mxm_em_state *state,
+                               double tol, int32_t max_iter, int32_t check_every, void *ws, size_t ws_bytes,
+                               void *stream, mxm_em_state *state_host) {
+    return em_loop_impl(nullptr, 0, reinterpret_cast<const double *>(P), ldp, w, R, H, B, props_cur, props_new,
+                        colsum, state, tol, max_iter, check_every, ws, ws_bytes, stream, state_host, true);
 }
 
 template <int NCH>

@@ -110,7 +110,18 @@ class EmPlan(object):
     the log matrix, fp64 weights, the linearised copy and scratch.
     """
 
-    def __init__(self, read_hap_mat, weights, n_runs=1, keep_log_matrix=True):
+    def __init__(self, read_hap_mat, weights, n_runs=1, keep_log_matrix=True, storage="f64"):
+        """
+        storage: element type of the linearised matrix the loop streams.
+        "f64" (default) is the reference's arithmetic type end to end; "f32" is
+        an opt-in variant that stores P as float (half the HBM traffic per
+        iteration) and still multiplies and sums in fp64 -- measured within
+        ~1e-8 of the fp64 path on the goldens, inside the 1e-6 parity bar, but
+        NOT what the headline benchmark runs.
+        """
+        if storage not in ("f64", "f32"):
+            raise ValueError("storage must be 'f64' or 'f32'")
+        self.storage = storage
         self.lib = _lib.load()
         self.dev = require_gpu()
         self.mat = as_device(read_hap_mat, torch.float64, self.dev)
@@ -125,13 +136,23 @@ class EmPlan(object):
         self.lin = None
         self.rowmax = None
         if self.lib.mxm_linear_supported(self.n_haps) and self.n_rows > 0:
-            ldp = (self.n_haps + 1) // 2 * 2
-            self.lin = torch.empty((self.n_rows, ldp), dtype=torch.float64, device=self.dev)
             self.rowmax = torch.empty(self.n_rows, dtype=torch.float64, device=self.dev)
-            _lib.check(self.lib.mxm_linearize(self.mat.data_ptr(), self.mat.stride(0),
-                                              self.n_rows, self.n_haps, self.lin.data_ptr(),
-                                              self.lin.stride(0), self.rowmax.data_ptr(),
-                                              current_stream()), "mxm_linearize")
+            if storage == "f32":
+                ldp = (self.n_haps + 3) // 4 * 4
+                self.lin = torch.empty((self.n_rows, ldp), dtype=torch.float32, device=self.dev)
+                _lib.check(self.lib.mxm_linearize_f32(self.mat.data_ptr(), self.mat.stride(0),
+                                                      self.n_rows, self.n_haps, self.lin.data_ptr(),
+                                                      self.lin.stride(0), self.rowmax.data_ptr(),
+                                                      current_stream()), "mxm_linearize_f32")
+            else:
+                ldp = (self.n_haps + 1) // 2 * 2
+                self.lin = torch.empty((self.n_rows, ldp), dtype=torch.float64, device=self.dev)
+                _lib.check(self.lib.mxm_linearize(self.mat.data_ptr(), self.mat.stride(0),
+                                                  self.n_rows, self.n_haps, self.lin.data_ptr(),
+                                                  self.lin.stride(0), self.rowmax.data_ptr(),
+                                                  current_stream()), "mxm_linearize")
+        elif storage == "f32":
+            self.storage = "f64"             # narrow matrices iterate the fp64 log-space kernel
         if not keep_log_matrix and self.lin is not None:
             self.mat = None
 
@@ -160,6 +181,12 @@ class EmPlan(object):
         """Enqueue one fused E+M step for every restart (mxm_em_iter)."""
         m_ptr, ldm = self.mat_args()
         p_ptr, ldp = self.lin_args()
+        if self.storage == "f32":
+            _lib.check(self.lib.mxm_em_iter_f32(p_ptr, ldp, self.wts.data_ptr(), props.data_ptr(),
+                                                self.n_rows, self.n_haps, props.shape[0], ptr(state),
+                                                colsum.data_ptr(), self.ws.data_ptr(), self.ws_bytes,
+                                                current_stream()), "mxm_em_iter_f32")
+            return
         _lib.check(self.lib.mxm_em_iter(m_ptr, ldm, p_ptr, ldp, self.wts.data_ptr(),
                                         props.data_ptr(), self.n_rows, self.n_haps,
                                         props.shape[0], ptr(state), colsum.data_ptr(),
@@ -202,7 +229,14 @@ def em_loop(plan, inits, tolerance, max_iter, check_every=16):
     colsum = torch.zeros_like(props_cur)
     state = new_state(n_runs, dev)
     host_state = (_lib.EmState * n_runs)()
-    if max_iter > 0:
+    if max_iter > 0 and plan.storage == "f32":
+        p_ptr, ldp = plan.lin_args()
+        _lib.check(lib.mxm_em_loop_f32(p_ptr, ldp, plan.wts.data_ptr(), plan.n_rows, n_haps, n_runs,
+                                       props_cur.data_ptr(), props_new.data_ptr(), colsum.data_ptr(),
+                                       state.data_ptr(), float(tolerance), int(max_iter),
+                                       int(check_every), plan.ws.data_ptr(), plan.ws_bytes,
+                                       current_stream(), host_state), "mxm_em_loop_f32")
+    elif max_iter > 0:
         m_ptr, ldm = plan.mat_args()
         p_ptr, ldp = plan.lin_args()
         _lib.check(lib.mxm_em_loop(m_ptr, ldm, p_ptr, ldp, plan.wts.data_ptr(), plan.n_rows,
@@ -272,7 +306,7 @@ def collect_result(plan, inits, props_cur, props_new, states, want_read_mix=True
             "l1": [s[2] for s in states]}
 
 
-def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True):
+def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, storage=None):
     """
     run_em with the parity observables exposed.  Returns a dict:
         props      [H] numpy, linear (geometric mean over runs, em.py:155-163)
@@ -283,7 +317,8 @@ def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True):
         done       per-run stop reason (1 converged, 2 max_iter)
     """
     n_multi = int(args.n_multi)
-    plan = EmPlan(read_hap_mat, weights, n_runs=n_multi)
+    storage = storage or getattr(args, "storage", "f64")
+    plan = EmPlan(read_hap_mat, weights, n_runs=n_multi, storage=storage)
     if inits is None:
         # sequential draws in run order: same RNG consumption as em.py:123
         inits = numpy.stack([init_props(plan.n_haps, alpha=args.init_alpha)
