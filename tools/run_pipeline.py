@@ -1,0 +1,86 @@
+#!/usr/bin/env python
+"""
+The in-scope part of bin/mixemt's process_and_report (bin/mixemt:248-342) on
+synthetic reads, device-resident end to end:
+
+    CSR observations -> build_em_matrix_device -> run_em -> contributors from read votes
+    -> refinement EM on the contributor columns -> read assignment -> contributor table
+
+    python tools/run_pipeline.py [--reads N] [--seed S] [--multi M]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+
+import numpy
+import torch
+
+from mixemt_amd import assign, em, phylotree, preprocess, synth
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reads", type=int, default=20000)
+    ap.add_argument("--seed", type=int, default=7)
+    ap.add_argument("--multi", type=int, default=1)
+    opts = ap.parse_args()
+    args = argparse.Namespace(init_alpha=1.0, tolerance=1e-4, max_iter=10000, n_multi=opts.multi,
+                              verbose=True, min_reads=10, min_fold=2.0)
+    numpy.random.seed(opts.seed)                       # bin/mixemt:507-508
+
+    t0 = time.perf_counter()
+    refseq = phylotree.load_rsrs()
+    phy = phylotree.load_build17(refseq)
+    haps = sorted(phy.hap_var)
+    tables = preprocess.HapVarTables.build(refseq, phy, haps)
+    row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), opts.reads, seed=1)
+    sys.stderr.write("Using %d variant sites from %d haplogroups; %d synthetic fragments (%.1f s)\n"
+                     % (len(tables.sites), len(haps), opts.reads, time.perf_counter() - t0))
+
+    t0 = time.perf_counter()
+    em_mat = preprocess.build_em_matrix_device(tables, row_ptr, site, obs)
+    wts = torch.ones(opts.reads, dtype=torch.float64, device="cuda")
+    torch.cuda.synchronize()
+    sys.stderr.write("EM input matrix %d x %d built on the device in %.1f ms\n"
+                     % (em_mat.shape[0], em_mat.shape[1], (time.perf_counter() - t0) * 1e3))
+
+    t0 = time.perf_counter()
+    props, read_mix = em.run_em(em_mat, wts, args)
+    torch.cuda.synchronize()
+    sys.stderr.write("run_em: %.1f ms\n" % ((time.perf_counter() - t0) * 1e3))
+
+    order = numpy.argsort(props)[::-1]
+    sys.stderr.write("\nTop 10 haplogroups by proportion...\n")
+    for i in range(10):
+        sys.stderr.write("%d\t%0.6f\t%s\n" % (i + 1, props[order[i]], haps[order[i]]))
+    assign.report_read_votes(haps, read_mix, 10)
+
+    cons = assign.find_contribs_from_reads(read_mix, wts, args)
+    contribs = sorted(([haps[c], props[c]] for c in cons), key=lambda c: c[1], reverse=True)
+    fmt = "hap%%0%dd" % len(str(len(contribs) + 1))
+    contribs = [[fmt % (i + 1)] + c for i, c in enumerate(contribs)]
+    if not contribs:
+        sys.stderr.write("\n0 contributors passed filtering steps.\n")
+        return 1
+
+    sys.stderr.write("Refining contribution estimates...\n")
+    sub, sub_haps = preprocess.reduce_em_matrix(em_mat, haps, contribs)
+    results = em.run_em(sub, wts, args)
+    contribs = assign.update_contribs(contribs, results, sub_haps)
+    reads = [[str(i)] for i in range(opts.reads)]
+    table = assign.assign_read_indexes(contribs, results, sub_haps, reads, args.min_fold)
+
+    print("hap#   Haplogroup      Contribution   Reads")
+    print("-------------------------------------------")
+    for hap_id, group, prop in contribs:
+        print("%s %s %s %s" % (hap_id.ljust(6), group.ljust(15), ("%.4f" % prop).rjust(12),
+                               ("%d" % len(table.get(hap_id, ()))).rjust(7)))
+    print("unassigned %d" % len(table.get("unassigned", ())))
+    return 0
+
+
+if __name__ == "__main__":
+    sys.exit(main())
