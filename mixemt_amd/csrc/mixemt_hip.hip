@@ -102,6 +102,9 @@ __device__ __forceinline__ double logaddexp_f64(double a, double b) {
 // ------------------------------------------------------------------------------------------
 #define BUILD_THREADS 256
 #define BUILD_CAP 512              // observations staged in LDS per pass
+#ifndef BUILD_UNROLL
+#define BUILD_UNROLL 8             // table loads in flight per wave
+#endif
 #define BUILD_CPL 4                // haplogroup columns per lane (one 4-byte table load per site;
                                    // 8 per lane measured slower: 56 ms vs 40.6 ms at 1M x 5408)
 
@@ -135,7 +138,7 @@ __global__ __launch_bounds__(BUILD_THREADS) void build_em_matrix_kernel(
                 __syncthreads();
                 if (h < H) {
                     // independent table loads: unrolled so several are in flight per wave
-#pragma unroll 8
+#pragma unroll BUILD_UNROLL
                     for (int j = 0; j < n; ++j) {
                         const uint32_t *src = reinterpret_cast<const uint32_t *>(E + s_off[j] + h);
                         uint32_t e4[BUILD_CPL / 4];
@@ -1167,6 +1170,10 @@ static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, co
     int64_t rows_per_wg = (R + nwg - 1) / nwg;
     rows_per_wg = (rows_per_wg + nbuf - 1) / nbuf * nbuf;
     nwg = (int)((R + rows_per_wg - 1) / rows_per_wg);
+    // a workgroup addresses its row block through one buffer descriptor with 32-bit offsets
+    if ((double)rows_per_wg * (double)ldp * 8.0 >= 2147483648.0)
+        return fail(-1, "mxm_em_iter: %s%lld rows of %lld doubles per workgroup exceed the 2 GiB descriptor range", "",
+                    (long long)rows_per_wg, (long long)ldp);
     if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
     int rc;
     if (nb == 1)
