@@ -209,6 +209,15 @@ int mxm_assign_reads(const double *X, int64_t ldx, const double *log_props,
 int mxm_set_timing_events(void *ev_start, void *ev_stop);
 
 /*
+ * Diagnostic, not part of the reference boundary: a bare streaming read of `bytes` bytes
+ * (16 B per lane, 8 loads in flight per lane, `wg_per_cu` workgroups of 256 per CU; blocked = 0:
+ * grid-stride plain loads, 1: one contiguous block per workgroup, non-temporal loads) to measure
+ * the practical HBM read ceiling on the device at hand (tools/stream_ceiling.py).
+ */
+int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_per_cu, int32_t blocked,
+                         void *sink, void *stream);
+
+/*
  * mxm_em_loop replays its chunk of iterations from a hipGraph when that pays
  * (launch-bound sizes): mode -1 = automatic (R*H*B < 6.4e7 cells), 0 = never,
  * 1 = always.  Results are identical either way.

@@ -329,12 +329,10 @@ __global__ __launch_bounds__(ROW_THREADS) void linearize_kernel(const double *__
 #ifndef MXM_SCHED_FENCE
 #define MXM_SCHED_FENCE 0
 #endif
-#ifndef MXM_VB_MINW
-#define MXM_VB_MINW 2                 // batched shapes: one 512-thread workgroup per CU
-#endif
+// batched shapes run one workgroup per CU: min waves/SIMD = THREADS / 256
 
 template <int THREADS, int NCH, int BT, int NBUF>
-__global__ __launch_bounds__(THREADS, (BT == 1 ? MXM_V1_MINW : MXM_VB_MINW)) void em_iter_wide_kernel(
+__global__ __launch_bounds__(THREADS, (BT == 1 ? MXM_V1_MINW : THREADS / 256)) void em_iter_wide_kernel(
     const double *__restrict__ P, int64_t ldp, const double *__restrict__ w,
     const double *__restrict__ props, int64_t R, int H, int64_t rows_per_wg,
     double *__restrict__ partial, int64_t ldpart, const mxm_em_state *__restrict__ state) {
@@ -973,6 +971,51 @@ __global__ __launch_bounds__(256) void assign_reads_kernel(const double *__restr
     assigned[r] = (nC >= 2 && (v1 - v2) >= log_min_fold) ? i1 : -1;
 }
 
+// Diagnostic only: bare streaming reads (16 B/lane, 8 loads in flight per lane, xor-folded so
+// nothing is optimised away) -- the practical HBM read ceiling the streaming kernel's roofline
+// fraction is judged against (tools/stream_ceiling.py).  BLOCKED = false: grid-stride, plain
+// loads (the textbook pattern); true: one contiguous block per workgroup, non-temporal loads
+// (the EM kernel's pattern).
+template <bool BLOCKED>
+__global__ __launch_bounds__(256) void diag_stream_read_kernel(const uint4 *__restrict__ src_in, int64_t n16,
+                                                               unsigned int *__restrict__ sink) {
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u4v *src = reinterpret_cast<const u4v *>(src_in);
+    unsigned int acc = 0;
+    if (BLOCKED) {
+        const int64_t per_wg = (n16 + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * per_wg;
+        const int64_t hi = (lo + per_wg < n16) ? lo + per_wg : n16;
+        int64_t i = lo + threadIdx.x;
+        for (; i + 7 * 256 < hi; i += 8 * 256) {
+            u4v v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load(src + i + q * 256);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc ^= v[q].x ^ v[q].y ^ v[q].z ^ v[q].w;
+        }
+        for (; i < hi; i += 256) {
+            const u4v v = __builtin_nontemporal_load(src + i);
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    } else {
+        const int64_t stride = (int64_t)gridDim.x * 256;
+        int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 7 * stride < n16; i += 8 * stride) {
+            u4v v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = src[i + q * stride];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc ^= v[q].x ^ v[q].y ^ v[q].z ^ v[q].w;
+        }
+        for (; i < n16; i += stride) {
+            const u4v v = src[i];
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;          // practically never: keeps the loads alive
+}
+
 // ------------------------------------------------------------------------------------------
 // host side of the C ABI
 // ------------------------------------------------------------------------------------------
@@ -1535,6 +1578,19 @@ extern "C" int mxm_assign_reads(const double *X, int64_t ldx, const double *log_
     if (R <= 0 || H <= 0 || nC <= 0 || ldx < H) return fail(-1, "mxm_assign_reads: bad shape%s", "");
     hipLaunchKernelGGL(assign_reads_kernel, dim3((unsigned)((R + 255) / 256)), dim3(256), 0, (hipStream_t)stream, X,
                        ldx, log_props, cols, (int)nC, R, log_min_fold, assigned);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_per_cu, int32_t blocked, void *sink,
+                                    void *stream) {
+    if (src == nullptr || sink == nullptr || bytes < 16 || wg_per_cu < 1) return fail(-1, "mxm_diag_stream_read: bad arguments%s", "");
+    if (blocked)
+        hipLaunchKernelGGL(diag_stream_read_kernel<true>, dim3(num_cu() * wg_per_cu), dim3(256), 0, (hipStream_t)stream,
+                           (const uint4 *)src, (int64_t)(bytes / 16), (unsigned int *)sink);
+    else
+        hipLaunchKernelGGL(diag_stream_read_kernel<false>, dim3(num_cu() * wg_per_cu), dim3(256), 0, (hipStream_t)stream,
+                           (const uint4 *)src, (int64_t)(bytes / 16), (unsigned int *)sink);
     HIP_TRY(hipGetLastError());
     return 0;
 }

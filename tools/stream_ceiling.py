@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""
+Practical HBM read ceiling of the device at hand: a bare streaming-read kernel over a 43 GB
+buffer (the size of the 1M x 5408 fp64 matrix), for several grid sizes.  The streaming EM
+kernel's roofline fraction is quoted against the 8 TB/s spec; this number says how much of the
+gap is the kernel's and how much is the memory system's.
+"""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from mixemt_amd import _lib
+from mixemt_amd._dev import current_stream
+
+lib = _lib.load()
+nbytes = int(float(sys.argv[1])) if len(sys.argv) > 1 else 43264000000
+buf = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda").uniform_()
+sink = torch.zeros(4, dtype=torch.int32, device="cuda")
+for blocked in (0, 1):
+    for wg in (1, 2, 4, 8, 16):
+        times = []
+        for rep in range(6):
+            a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            a.record()
+            _lib.check(lib.mxm_diag_stream_read(buf.data_ptr(), nbytes, wg, blocked, sink.data_ptr(),
+                                                current_stream()), "diag")
+            b.record()
+            torch.cuda.synchronize()
+            times.append(a.elapsed_time(b))
+        best, med = min(times[1:]), sorted(times[1:])[len(times[1:]) // 2]
+        print("bare read (%s), %2d WG/CU: median %.3f ms = %.2f TB/s (best %.3f ms = %.2f TB/s)"
+              % ("blocked, nt" if blocked else "grid-stride", wg, med, nbytes / med / 1e9, best,
+                 nbytes / best / 1e9))
