@@ -100,6 +100,7 @@ def main():
     ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
                     help="element type of the streamed matrix; f32 is a labelled opt-in variant "
                          "(fp64 math on float-stored P), never the default")
+    ap.add_argument("--min-rows-per-wg", type=int, default=0, help="tuning knob (0 = library default)")
     ap.add_argument("--build-kernel", default="auto", choices=["auto", "packed", "bytes"])
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to test the "
@@ -169,6 +170,8 @@ def main():
     # ---- loop state: one restart, init = first Dirichlet draw after numpy.random.seed(7) --------
     n_runs = opts.restarts
     lib.mxm_set_batch_tile(opts.batch_tile)
+    if opts.min_rows_per_wg > 0:
+        lib.mxm_set_min_rows_per_wg(opts.min_rows_per_wg)
     numpy.random.seed(7)
     init = numpy.stack([em.init_props(n_haps, 1.0) for _ in range(n_runs)])   # sequential draws
     props_cur = torch.from_numpy(init).to(dev)

@@ -231,6 +231,9 @@ int mxm_set_loop_graph(int32_t mode);
  */
 int mxm_set_batch_tile(int32_t bt);
 
+/* Tuning knob: rows a workgroup of the streaming kernel handles at least (grid = min(cap, R / n)). */
+int mxm_set_min_rows_per_wg(int32_t n);
+
 #ifdef __cplusplus
 }
 #endif
