@@ -30,9 +30,14 @@ def _hipcc():
     raise RuntimeError("hipcc not found (set HIPCC or add /opt/rocm/bin to PATH)")
 
 
+def _sources():
+    csrc = os.path.dirname(SRC)
+    return sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))) + [HDR]
+
+
 def _digest(flags):
     h = hashlib.sha256()
-    for path in (SRC, HDR):
+    for path in _sources():
         with open(path, "rb") as fin:
             h.update(fin.read())
     h.update(" ".join(flags).encode())
@@ -45,7 +50,7 @@ def build(force=False, defines=(), verbose=False, out=None):
     if out is not None:
         LIB = os.path.abspath(out)
     flags = ["--offload-arch=%s" % ARCH, "-O3", "-std=c++17", "-shared", "-fPIC",
-             "-I" + os.path.join(_ROOT, "include")]
+             "-I" + os.path.join(_ROOT, "include"), "-I" + os.path.dirname(SRC)]
     flags += ["-D%s" % d for d in defines]
     stamp = LIB + ".stamp"
     want = _digest(flags)

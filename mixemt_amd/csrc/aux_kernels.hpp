@@ -1,0 +1,153 @@
+// aux_kernels.hpp -- part of libmixemt_hip.so (gfx950); included by mixemt_hip.hip only.
+// Small vector kernels, consumers of the posterior (assemble.py:103-123, :284-334) and the bare-read diagnostic.
+#ifndef MIXEMT_AUX_KERNELS_HPP
+#define MIXEMT_AUX_KERNELS_HPP
+
+// ------------------------------------------------------------------------------------------
+// small vector kernels (one workgroup)
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(FIN_THREADS) void log_normalize_kernel(const double *__restrict__ colsum,
+                                                                    int H, double *__restrict__ ln_new) {
+    __shared__ double scratch[FIN_THREADS / 64];
+    double s = 0.0;
+    for (int h = threadIdx.x; h < H; h += FIN_THREADS) s += colsum[h];
+    const double lt = log(block_reduce<FIN_THREADS, false>(s, scratch));
+    for (int h = threadIdx.x; h < H; h += FIN_THREADS) ln_new[h] = log(colsum[h]) - lt;
+}
+
+__global__ __launch_bounds__(FIN_THREADS) void l1_exp_diff_kernel(const double *__restrict__ a,
+                                                                  const double *__restrict__ b, int H,
+                                                                  double *__restrict__ out) {
+    __shared__ double scratch[FIN_THREADS / 64];
+    double s = 0.0;
+    for (int h = threadIdx.x; h < H; h += FIN_THREADS) s += fabs(exp(a[h]) - exp(b[h]));
+    s = block_reduce<FIN_THREADS, false>(s, scratch);
+    if (threadIdx.x == 0) out[0] = s;
+}
+
+__global__ __launch_bounds__(256) void add_scalar_kernel(double *__restrict__ x, int64_t ld, int64_t R,
+                                                         int H, double delta) {
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        double *row = x + r * ld;
+        for (int h = threadIdx.x; h < H; h += 256) row[h] += delta;
+    }
+}
+
+// first index of the row maximum (numpy.argmax: a NaN counts as the maximum, first one wins)
+// + weighted votes (assemble.py:115-123).  Candidate order: NaN before numbers, then larger
+// value, then smaller index.
+__device__ __forceinline__ bool cand_better(int an, double av, int ai, int bn, double bv, int bi) {
+    if (an != bn) return an > bn;
+    if (an == 0 && av != bv) return av > bv;
+    return ai < bi;
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void row_argmax_votes_kernel(
+    const double *__restrict__ X, int64_t ldx, const double *__restrict__ w, int64_t R, int H,
+    int32_t *__restrict__ best, double *__restrict__ votes) {
+    constexpr int NW = ROW_THREADS / 64;
+    __shared__ double s_val[NW];
+    __shared__ int s_idx[NW];
+    __shared__ int s_nan[NW];
+    const int t = threadIdx.x;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const double *row = X + r * ldx;
+        int cn = 0, ci = 0x7fffffff;
+        double cv = -INFINITY;
+        for (int h = t; h < H; h += ROW_THREADS) {
+            const double v = row[h];
+            const int vn = (v != v) ? 1 : 0;
+            if (cand_better(vn, v, h, cn, cv, ci)) { cn = vn; cv = v; ci = h; }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(cv, off, 64);
+            const int oi = __shfl_xor(ci, off, 64);
+            const int on = __shfl_xor(cn, off, 64);
+            if (cand_better(on, ov, oi, cn, cv, ci)) { cn = on; cv = ov; ci = oi; }
+        }
+        __syncthreads();
+        if ((t & 63) == 0) { s_val[t >> 6] = cv; s_idx[t >> 6] = ci; s_nan[t >> 6] = cn; }
+        __syncthreads();
+        if (t == 0) {
+            for (int q = 1; q < NW; ++q)
+                if (cand_better(s_nan[q], s_val[q], s_idx[q], cn, cv, ci)) { cn = s_nan[q]; cv = s_val[q]; ci = s_idx[q]; }
+            if (ci >= H) ci = 0;
+            best[r] = ci;
+            if (votes != nullptr) atomicAdd(votes + ci, (w != nullptr) ? w[r] : 1.0);
+        }
+    }
+}
+
+// Read -> contributor assignment (assemble.py:284-334): per row, among the contributor columns
+// only, the two largest  X[r][c] - log p_c ; assigned to the best one if the gap reaches
+// log(min_fold), else unassigned (-1).  One thread per row; the row touches nC scattered cells.
+// Order among exactly equal values follows numpy.argsort(...)[::-1]: the larger column wins.
+__global__ __launch_bounds__(256) void assign_reads_kernel(const double *__restrict__ X, int64_t ldx,
+                                                           const double *__restrict__ log_props,
+                                                           const int32_t *__restrict__ cols, int nC, int64_t R,
+                                                           double log_min_fold, int32_t *__restrict__ assigned) {
+    const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const double *row = X + r * ldx;
+    double v1 = -INFINITY, v2 = -INFINITY;      // best, runner-up
+    int i1 = -1, c1 = -1, c2 = -1;
+    for (int i = 0; i < nC; ++i) {
+        const int c = cols[i];
+        const double v = row[c] - log_props[c];
+        if (i1 < 0 || v > v1 || (v == v1 && c > c1)) {
+            v2 = v1; c2 = c1;
+            v1 = v; c1 = c; i1 = i;
+        } else if (c2 < 0 || v > v2 || (v == v2 && c > c2)) {
+            v2 = v; c2 = c;
+        }
+    }
+    assigned[r] = (nC >= 2 && (v1 - v2) >= log_min_fold) ? i1 : -1;
+}
+
+// Diagnostic only: bare streaming reads (16 B/lane, 8 loads in flight per lane, xor-folded so
+// nothing is optimised away) -- the practical HBM read ceiling the streaming kernel's roofline
+// fraction is judged against (tools/stream_ceiling.py).  BLOCKED = false: grid-stride, plain
+// loads (the textbook pattern); true: one contiguous block per workgroup, non-temporal loads
+// (the EM kernel's pattern).
+template <bool BLOCKED>
+__global__ __launch_bounds__(256) void diag_stream_read_kernel(const uint4 *__restrict__ src_in, int64_t n16,
+                                                               unsigned int *__restrict__ sink) {
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    const u4v *src = reinterpret_cast<const u4v *>(src_in);
+    unsigned int acc = 0;
+    if (BLOCKED) {
+        const int64_t per_wg = (n16 + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * per_wg;
+        const int64_t hi = (lo + per_wg < n16) ? lo + per_wg : n16;
+        int64_t i = lo + threadIdx.x;
+        for (; i + 7 * 256 < hi; i += 8 * 256) {
+            u4v v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = __builtin_nontemporal_load(src + i + q * 256);
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc ^= v[q].x ^ v[q].y ^ v[q].z ^ v[q].w;
+        }
+        for (; i < hi; i += 256) {
+            const u4v v = __builtin_nontemporal_load(src + i);
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    } else {
+        const int64_t stride = (int64_t)gridDim.x * 256;
+        int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+        for (; i + 7 * stride < n16; i += 8 * stride) {
+            u4v v[8];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) v[q] = src[i + q * stride];
+#pragma unroll
+            for (int q = 0; q < 8; ++q) acc ^= v[q].x ^ v[q].y ^ v[q].z ^ v[q].w;
+        }
+        for (; i < n16; i += stride) {
+            const u4v v = src[i];
+            acc ^= v.x ^ v.y ^ v.z ^ v.w;
+        }
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;          // practically never: keeps the loads alive
+}
+
+#endif  // MIXEMT_AUX_KERNELS_HPP

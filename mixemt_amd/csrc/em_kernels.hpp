@@ -1,0 +1,410 @@
+// em_kernels.hpp -- part of libmixemt_hip.so (gfx950); included by mixemt_hip.hip only.
+// The EM iteration (em.py:57-91, :126-143): linearise, fused E+M streaming kernels, column reduce, finalize.
+#ifndef MIXEMT_EM_KERNELS_HPP
+#define MIXEMT_EM_KERNELS_HPP
+
+// ------------------------------------------------------------------------------------------
+// K2  linearize:  rowmax[r], P[r][h] = exp(M[r][h] - rowmax[r])   (one-time)
+// ------------------------------------------------------------------------------------------
+#define ROW_THREADS 256
+
+__global__ __launch_bounds__(ROW_THREADS) void linearize_kernel(const double *__restrict__ M,
+                                                                int64_t ldm, int64_t R, int H,
+                                                                double *__restrict__ P, int64_t ldp,
+                                                                double *__restrict__ rowmax) {
+    __shared__ double scratch[ROW_THREADS / 64];
+    const int t = threadIdx.x;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const double *src = M + r * ldm;
+        double m = -INFINITY;
+        for (int h = t; h < H; h += ROW_THREADS) m = fmax(m, src[h]);
+        m = block_reduce<ROW_THREADS, true>(m, scratch);
+        const double shift = isfinite(m) ? m : 0.0;
+        double *dst = P + r * ldp;
+        for (int h = t; h < (int)ldp; h += ROW_THREADS) dst[h] = (h < H) ? exp(src[h] - shift) : 0.0;
+        if (t == 0) rowmax[r] = shift;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3  em_iter_wide: fused E+M step in linear space, one restart.
+//
+//   Z_r      = sum_h p_h P_rh                     (row reduction)
+//   acc_h   += (w_r / Z_r) * P_rh                 (column accumulation, per workgroup)
+//   colsum_h = p_h * sum_wg acc_h                 (colreduce_kernel)
+//
+// which is em.py:80-88 with exp(M - rowmax) hoisted out of the loop:
+//   posterior_rh = p_h P_rh / Z_r,   colsum_h = sum_r w_r posterior_rh.
+//
+// A workgroup (256 threads) owns a contiguous block of rows.  Thread t owns the
+// double2 column pairs {t + 256 k}, k < NCH: one 16-byte load per pair per row
+// (a wave instruction covers 1 KiB contiguous), the row stays in VGPRs between
+// the dot product and the accumulation, so the matrix is read from HBM exactly
+// once per iteration.  The next row's loads are issued before the current row's
+// reduction (register double buffer).  BT restarts can share each row: every
+// restart adds its own p / accumulator registers, the bytes read stay the same
+// (BT = 1: 256 threads, 2 workgroups per CU; BT = 2, 3: 512 threads, 1 per CU).
+// Column partials live in registers for the whole kernel and are written once:
+// partial[wg][h], summed in fixed order afterwards -> bitwise reproducible.
+// ------------------------------------------------------------------------------------------
+#ifndef MXM_V1_MINW
+#define MXM_V1_MINW 2                 // min waves/SIMD the BT = 1 shape is compiled for (2 WGs of 256 per CU)
+#endif
+#ifndef MXM_V1_P_LDS
+#define MXM_V1_P_LDS 0                // 1: the single-restart shape also keeps its proportions in LDS
+#endif
+#ifndef MXM_SCHED_FENCE
+#define MXM_SCHED_FENCE 0
+#endif
+// batched shapes run one workgroup per CU: min waves/SIMD = THREADS / 256
+
+template <int THREADS, int NCH, int BT, int NBUF>
+__global__ __launch_bounds__(THREADS, (BT == 1 ? MXM_V1_MINW : THREADS / 256)) void em_iter_wide_kernel(
+    const double *__restrict__ P, int64_t ldp, const double *__restrict__ w,
+    const double *__restrict__ props, int64_t R, int H, int64_t rows_per_wg,
+    double *__restrict__ partial, int64_t ldpart, const mxm_em_state *__restrict__ state) {
+    constexpr int NW = THREADS / 64;
+    __shared__ double red[2][BT][NW];
+    if (state != nullptr) {
+        bool any = false;
+#pragma unroll
+        for (int b = 0; b < BT; ++b) any = any || (state[b].done == 0);
+        if (!any) return;                           // every restart of this tile has stopped
+    }
+
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int ncol2 = (H + 1) >> 1;                 // d2 pairs per row (pad column is 0 in P)
+
+    // proportions: registers for a single restart; for a batch they sit in LDS as
+    // [b][k][thread] pairs (one conflict-free ds_read_b128 per use) so that the VGPR
+    // budget goes to the accumulators and the row double buffer
+    extern __shared__ d2 lds_p[];
+    constexpr bool P_IN_LDS = (BT > 1) || (MXM_V1_P_LDS != 0);
+    d2 p[P_IN_LDS ? 1 : NCH], acc[BT][NCH];
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = 2 * (t + k * THREADS);
+            d2 v;
+            v.x = (c < H) ? props[(int64_t)b * H + c] : 0.0;
+            v.y = (c + 1 < H) ? props[(int64_t)b * H + c + 1] : 0.0;
+            if constexpr (!P_IN_LDS) p[k] = v;
+            else lds_p[(b * NCH + k) * THREADS + t] = v;
+            acc[b][k] = d2{0.0, 0.0};
+        }
+    }
+
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < R) ? (r0 + rows_per_wg) : R;
+    if (r0 >= r1) return;
+
+    // Row loads: buffer_load_dwordx4 through one descriptor over this workgroup's row block.
+    // Per-lane offset = one VGPR (t * 16), row and chunk offsets are scalar, so no 64-bit
+    // per-load addresses and no exec-masked branches: rows past the block and column pairs
+    // past the row are CLAMPED to a valid element instead of skipped -- a clamped row gets
+    // weight 0 below, a clamped column has p = 0 and its accumulator is never stored.
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<double *>(P + r0 * ldp), 0, (int)((r1 - r0) * ldp * 8), 0x00020000);
+    const int row_bytes = (int)(ldp * 8);
+    const int voff = t * 16;
+    int last_c2 = t + (NCH - 1) * THREADS;
+    if (last_c2 > ncol2 - 1) last_c2 = ncol2 - 1;
+    const int voff_last = last_c2 * 16;
+
+    d2 x[NBUF][NCH];                                // register ring: NBUF - 1 rows in flight
+
+    auto load_row = [&](d2(&xr)[NCH], int64_t r) {
+        const int64_t rr = (r < r1) ? r : (r1 - 1);
+        const int soff = (int)(rr - r0) * row_bytes;
+#pragma unroll
+        for (int k = 0; k < NCH - 1; ++k)
+            xr[k] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(
+                                               rsrc, voff, soff + k * THREADS * 16, 2 /* nt */));
+        xr[NCH - 1] = __builtin_bit_cast(
+            d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, soff, 2 /* nt */));
+    };
+
+    int buf = 0;
+    auto process = [&](d2(&xr)[NCH], int64_t r) {
+        double d[BT];
+        // keep the batch's proportions IN LDS: without this the loads are loop-invariant
+        // and get hoisted back into (BT * NCH * 4) VGPRs
+        if constexpr (P_IN_LDS) asm volatile("" ::: "memory");
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            double s = 0.0;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                d2 pk;
+                if constexpr (!P_IN_LDS) pk = p[k];
+                else pk = lds_p[(b * NCH + k) * THREADS + t];     // own slot: no barrier needed
+                s = fma(xr[k].x, pk.x, s);
+                s = fma(xr[k].y, pk.y, s);
+            }
+            d[b] = s;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+#pragma unroll
+            for (int b = 0; b < BT; ++b) d[b] += __shfl_xor(d[b], off, 64);
+        }
+        if (lane == 0) {
+#pragma unroll
+            for (int b = 0; b < BT; ++b) red[buf][b][wv] = d[b];
+        }
+        __syncthreads();
+        const bool live = r < r1;
+        const double wr = live ? (w != nullptr ? w[r] : 1.0) : 0.0;
+#pragma unroll
+        for (int b = 0; b < BT; ++b) {
+            double z = red[buf][b][0];
+#pragma unroll
+            for (int q = 1; q < NW; ++q) z += red[buf][b][q];
+            const double c = (z > 0.0) ? wr / z : 0.0;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                acc[b][k].x = fma(c, xr[k].x, acc[b][k].x);
+                acc[b][k].y = fma(c, xr[k].y, acc[b][k].y);
+            }
+        }
+        buf ^= 1;
+    };
+
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j) load_row(x[j], r0 + j);
+    for (int64_t r = r0; r < r1; r += NBUF) {
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) {
+            load_row(x[(j + NBUF - 1) % NBUF], r + j + NBUF - 1);
+#if MXM_SCHED_FENCE
+            // keep the scheduler from hoisting these loads above the previous row's last
+            // uses of the same ring slot (it would need a second register set for it)
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+            process(x[j], r + j);
+#if MXM_SCHED_FENCE
+            __builtin_amdgcn_sched_barrier(0);
+#endif
+        }
+    }
+
+#pragma unroll
+    for (int b = 0; b < BT; ++b) {
+        d2 *dst = reinterpret_cast<d2 *>(partial + ((int64_t)blockIdx.x * BT + b) * ldpart);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c2 = t + k * THREADS;
+            if (c2 < ncol2) dst[c2] = acc[b][k];
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3f  fp32-STORAGE variant of the streaming kernel (opt-in, labelled as such everywhere):
+// P is kept as float (half the HBM bytes per iteration), every product and sum stays fp64.
+// Same structure as em_iter_wide_kernel with 4 columns per 16-byte load; one restart per pass.
+// ------------------------------------------------------------------------------------------
+typedef float f4 __attribute__((ext_vector_type(4)));
+
+template <int THREADS, int NCH, int NBUF>
+__global__ __launch_bounds__(THREADS, 2) void em_iter_wide_f32_kernel(
+    const float *__restrict__ P, int64_t ldp, const double *__restrict__ w,
+    const double *__restrict__ props, int64_t R, int H, int64_t rows_per_wg,
+    double *__restrict__ partial, int64_t ldpart, const mxm_em_state *__restrict__ state) {
+    constexpr int NW = THREADS / 64;
+    __shared__ double red[2][NW];
+    if (state != nullptr && state->done != 0) return;
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int ncol4 = (H + 3) >> 2;                 // float4 groups per row (pad columns are 0 in P)
+
+    double p[NCH][4], acc[NCH][4];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (t + k * THREADS) + e;
+            p[k][e] = (c < H) ? props[c] : 0.0;
+            acc[k][e] = 0.0;
+        }
+    }
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < R) ? (r0 + rows_per_wg) : R;
+    if (r0 >= r1) return;
+
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P + r0 * ldp), 0,
+                                                        (int)((r1 - r0) * ldp * 4), 0x00020000);
+    const int row_bytes = (int)(ldp * 4);
+    const int voff = t * 16;
+    int last_c4 = t + (NCH - 1) * THREADS;
+    if (last_c4 > ncol4 - 1) last_c4 = ncol4 - 1;
+    const int voff_last = last_c4 * 16;
+
+    f4 x[NBUF][NCH];
+    auto load_row = [&](f4(&xr)[NCH], int64_t r) {
+        const int64_t rr = (r < r1) ? r : (r1 - 1);
+        const int soff = (int)(rr - r0) * row_bytes;
+#pragma unroll
+        for (int k = 0; k < NCH - 1; ++k)
+            xr[k] = __builtin_bit_cast(f4, (u4)__builtin_amdgcn_raw_buffer_load_b128(
+                                               rsrc, voff, soff + k * THREADS * 16, 2));
+        xr[NCH - 1] = __builtin_bit_cast(f4, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, soff, 2));
+    };
+
+    int buf = 0;
+    auto process = [&](f4(&xr)[NCH], int64_t r) {
+        double s = 0.0;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s = fma((double)xr[k][e], p[k][e], s);
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
+        if (lane == 0) red[buf][wv] = s;
+        __syncthreads();
+        double z = red[buf][0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) z += red[buf][q];
+        buf ^= 1;
+        const bool live = r < r1;
+        const double wr = live ? (w != nullptr ? w[r] : 1.0) : 0.0;
+        const double c = (z > 0.0) ? wr / z : 0.0;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                // re-convert from the float (1 v_cvt) instead of keeping the doubles of the dot
+                // product alive across the barrier (2 VGPRs each): opaque to CSE on purpose
+                float xf = xr[k][e];
+                asm volatile("" : "+v"(xf));
+                acc[k][e] = fma(c, (double)xf, acc[k][e]);
+            }
+        }
+    };
+
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j) load_row(x[j], r0 + j);
+    for (int64_t r = r0; r < r1; r += NBUF) {
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) {
+            load_row(x[(j + NBUF - 1) % NBUF], r + j + NBUF - 1);
+            process(x[j], r + j);
+        }
+    }
+    double *dst = partial + (int64_t)blockIdx.x * ldpart;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = 4 * (t + k * THREADS);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < (int)ldpart) dst[c + e] = acc[k][e];
+    }
+}
+
+__global__ __launch_bounds__(ROW_THREADS) void linearize_f32_kernel(const double *__restrict__ M, int64_t ldm,
+                                                                    int64_t R, int H, float *__restrict__ P,
+                                                                    int64_t ldp, double *__restrict__ rowmax) {
+    __shared__ double scratch[ROW_THREADS / 64];
+    const int t = threadIdx.x;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const double *src = M + r * ldm;
+        double m = -INFINITY;
+        for (int h = t; h < H; h += ROW_THREADS) m = fmax(m, src[h]);
+        m = block_reduce<ROW_THREADS, true>(m, scratch);
+        const double shift = isfinite(m) ? m : 0.0;
+        float *dst = P + r * ldp;
+        for (int h = t; h < (int)ldp; h += ROW_THREADS) dst[h] = (h < H) ? (float)exp(src[h] - shift) : 0.0f;
+        if (t == 0) rowmax[r] = shift;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K4  colreduce: colsum[h] = scale_h * sum_{g < nwg} partial[g][h]   (fixed order)
+// 64 columns per workgroup; 4 waves take interleaved quarters of the partial rows.
+// scale_h = props[h] for the linear kernel, 1 for the log-space kernel.
+// ------------------------------------------------------------------------------------------
+#define COLRED_THREADS 1024
+__global__ __launch_bounds__(COLRED_THREADS) void colreduce_kernel(const double *__restrict__ partial,
+                                                                   int64_t ldpart, int nwg, int nb, int H,
+                                                                   const double *__restrict__ props,
+                                                                   double *__restrict__ colsum,
+                                                                   const mxm_em_state *__restrict__ state) {
+    // grid = (ceil(H/64), nb); partial is [nwg][nb][ldpart]; props / colsum are [nb][H].
+    // 16 waves take interleaved sixteenths of the partial rows, four independent chains each
+    // (the loads are what this kernel waits for); every order below is fixed -> deterministic.
+    constexpr int NW = COLRED_THREADS / 64;
+    __shared__ double part[NW][64];
+    const int b = blockIdx.y;
+    if (state != nullptr && state[b].done != 0) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int h = blockIdx.x * 64 + lane;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (h < H) {
+        const double *src = partial + (int64_t)b * ldpart + h;
+        const int64_t step = (int64_t)nb * ldpart;
+        int g = wv;
+        for (; g + 3 * NW < nwg; g += 4 * NW) {
+            s0 += src[(int64_t)g * step];
+            s1 += src[(int64_t)(g + NW) * step];
+            s2 += src[(int64_t)(g + 2 * NW) * step];
+            s3 += src[(int64_t)(g + 3 * NW) * step];
+        }
+        for (; g < nwg; g += NW) s0 += src[(int64_t)g * step];
+    }
+    part[wv][lane] = (s0 + s1) + (s2 + s3);
+    __syncthreads();
+    if (wv == 0 && h < H) {
+        double tot = part[0][lane];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) tot += part[q][lane];
+        colsum[(int64_t)b * H + h] = (props != nullptr) ? props[(int64_t)b * H + h] * tot : tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K5  finalize: em.py:89 (normalise), :39-54 (L1 test), :133-143 (loop state). One WG per restart.
+// ------------------------------------------------------------------------------------------
+#define FIN_THREADS 1024
+
+__global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(const double *__restrict__ colsum,
+                                                               double *__restrict__ props_cur,
+                                                               double *__restrict__ props_new, int H,
+                                                               double tol, int max_iter,
+                                                               mxm_em_state *__restrict__ state) {
+    __shared__ double scratch[FIN_THREADS / 64];
+    const int b = blockIdx.x;
+    mxm_em_state *st = state + b;
+    if (st->done != 0) return;
+    const double *cs = colsum + (int64_t)b * H;
+    double *pc = props_cur + (int64_t)b * H;
+    double *pn = props_new + (int64_t)b * H;
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int h = t; h < H; h += FIN_THREADS) s += cs[h];
+    const double total = block_reduce<FIN_THREADS, false>(s, scratch);
+    double l1 = 0.0;
+    for (int h = t; h < H; h += FIN_THREADS) {
+        const double v = cs[h] / total;
+        pn[h] = v;
+        l1 += fabs(v - pc[h]);
+    }
+    l1 = block_reduce<FIN_THREADS, false>(l1, scratch);
+    const int iters = st->iters + 1;
+    const bool conv = l1 < tol;
+    const bool stop = conv || iters >= max_iter;
+    if (!stop)
+        for (int h = t; h < H; h += FIN_THREADS) pc[h] = pn[h];
+    __syncthreads();
+    if (t == 0) {
+        st->iters = iters;
+        st->l1 = l1;
+        st->done = conv ? 1 : (stop ? 2 : 0);
+    }
+}
+
+#endif  // MIXEMT_EM_KERNELS_HPP

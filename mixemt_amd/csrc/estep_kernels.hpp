@@ -1,0 +1,195 @@
+// estep_kernels.hpp -- part of libmixemt_hip.so (gfx950); included by mixemt_hip.hip only.
+// The E-step with the reference's log-space semantics (em.py:80-83, fold :156): generic and register-resident forms.
+#ifndef MIXEMT_ESTEP_KERNELS_HPP
+#define MIXEMT_ESTEP_KERNELS_HPP
+
+// ------------------------------------------------------------------------------------------
+// K6  estep_log: the reference's E-step verbatim in log space (em.py:80-83), optional posterior
+// write / logaddexp fold (em.py:156) and optional M-step sums (em.py:87-88, linear space).
+// One workgroup per row (grid-stride), column sums in LDS (each thread owns its columns).
+// Used for em_step(), the final posterior pass, and EM iterations when H is tiny.
+// ------------------------------------------------------------------------------------------
+template <bool FROM_LINEAR_PROPS>
+__global__ __launch_bounds__(ROW_THREADS) void estep_log_kernel(
+    const double *__restrict__ M, int64_t ldm, const double *__restrict__ w,
+    const double *__restrict__ pvec, int64_t R, int H, double *__restrict__ out, int64_t ldo,
+    int mode, double *__restrict__ partial, int64_t ldpart,
+    const mxm_em_state *__restrict__ state) {
+    extern __shared__ double dyn[];            // [H] column sums (if partial) + [H] ln props
+    __shared__ double scratch[ROW_THREADS / 64];
+    if (state != nullptr && state->done != 0) return;
+    const int t = threadIdx.x;
+    double *lnp = dyn;
+    double *acc = dyn + H;
+    for (int h = t; h < H; h += ROW_THREADS) {
+        lnp[h] = FROM_LINEAR_PROPS ? log(pvec[h]) : pvec[h];
+        if (partial != nullptr) acc[h] = 0.0;
+    }
+    __syncthreads();
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const double *src = M + r * ldm;
+        double m = -INFINITY;
+        for (int h = t; h < H; h += ROW_THREADS) m = fmax(m, lnp[h] + src[h]);
+        m = block_reduce<ROW_THREADS, true>(m, scratch);
+        const double shift = isfinite(m) ? m : 0.0;
+        double s = 0.0;
+        for (int h = t; h < H; h += ROW_THREADS) s += exp((lnp[h] + src[h]) - shift);
+        s = block_reduce<ROW_THREADS, false>(s, scratch);
+        const double lse = log(s) + m;          // m (not shift): -inf rows give -inf, as scipy does
+        const double wr = (w != nullptr) ? w[r] : 1.0;
+        for (int h = t; h < H; h += ROW_THREADS) {
+            const double v = (lnp[h] + src[h]) - lse;
+            if (out != nullptr) {
+                double *o = out + r * ldo + h;
+                *o = (mode == 1) ? logaddexp_f64(*o, v) : v;
+            }
+            if (partial != nullptr) acc[h] += wr * exp(v);
+        }
+    }
+    if (partial != nullptr) {
+        double *dst = partial + (int64_t)blockIdx.x * ldpart;
+        for (int h = t; h < H; h += ROW_THREADS) dst[h] = acc[h];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K6b estep_wide: the same E-step (em.py:80-83, fold :156, M-step sums :87-88) for wide rows,
+// one HBM read + one write per cell: the row is held in VGPRs across the two row reductions
+// (max, then sum of exp), exactly like the streaming kernel holds it across its dot product.
+// Needs H even, 16-byte aligned rows in M and out; everything else takes estep_log_kernel.
+// ------------------------------------------------------------------------------------------
+template <int NCH, bool COLSUM>
+__global__ __launch_bounds__(256, 2) void estep_wide_kernel(
+    const double *__restrict__ M, int64_t ldm, const double *__restrict__ w,
+    const double *__restrict__ lnp_in, int64_t R, int H, int64_t rows_per_wg,
+    double *__restrict__ out, int64_t ldo, int mode, double *__restrict__ partial, int64_t ldpart) {
+    constexpr int THREADS = 256, NW = THREADS / 64;
+    __shared__ double red[2][2][NW];               // [ring][max|sum][wave]
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int ncol2 = H >> 1;
+
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < R) ? (r0 + rows_per_wg) : R;
+    if (r0 >= r1) return;
+
+    // with the M-step sums the exponentials have to survive the second reduction: that variant
+    // gives up the register double buffer (two workgroups per CU still overlap load and math)
+    constexpr int NBUF = COLSUM ? 1 : 2;
+    d2 lp[NCH], acc[COLSUM ? NCH : 1];
+    bool own[NCH];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c2 = t + k * THREADS;
+        own[k] = c2 < ncol2;
+        // a clamped (not owned) lane carries -inf log-proportions: it adds exp(-inf) = 0
+        lp[k].x = own[k] ? lnp_in[2 * c2] : -INFINITY;
+        lp[k].y = own[k] ? lnp_in[2 * c2 + 1] : -INFINITY;
+        if constexpr (COLSUM) acc[k] = d2{0.0, 0.0};
+    }
+
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(M + r0 * ldm), 0,
+                                                        (int)((r1 - r0) * ldm * 8), 0x00020000);
+    const int row_bytes = (int)(ldm * 8);
+    const int voff = t * 16;
+    int last_c2 = t + (NCH - 1) * THREADS;
+    if (last_c2 > ncol2 - 1) last_c2 = ncol2 - 1;
+    const int voff_last = last_c2 * 16;
+
+    d2 x[NBUF][NCH];
+    auto load_row = [&](d2(&xr)[NCH], int64_t r) {
+        const int64_t rr = (r < r1) ? r : (r1 - 1);
+        const int soff = (int)(rr - r0) * row_bytes;
+#pragma unroll
+        for (int k = 0; k < NCH - 1; ++k)
+            xr[k] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(
+                                               rsrc, voff, soff + k * THREADS * 16, 2));
+        xr[NCH - 1] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, soff, 2));
+    };
+
+    int ring = 0;
+    auto process = [&](d2(&xr)[NCH], int64_t r) {
+        const bool live = r < r1;
+        double m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            xr[k].x += lp[k].x;                    // z = ln p + M   (em.py:80)
+            xr[k].y += lp[k].y;
+            m = fmax(m, fmax(xr[k].x, xr[k].y));
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+        if (lane == 0) red[ring][0][wv] = m;
+        __syncthreads();
+        m = red[ring][0][0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) m = fmax(m, red[ring][0][q]);
+        const double shift = isfinite(m) ? m : 0.0;
+        d2 e[COLSUM ? NCH : 1];
+        double ssum = 0.0;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const double ex = exp(xr[k].x - shift), ey = exp(xr[k].y - shift);
+            if constexpr (COLSUM) e[k] = d2{ex, ey};
+            ssum += ex + ey;
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) ssum += __shfl_xor(ssum, off, 64);
+        if (lane == 0) red[ring][1][wv] = ssum;
+        __syncthreads();
+        ssum = red[ring][1][0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) ssum += red[ring][1][q];
+        ring ^= 1;
+        const double lse = log(ssum) + m;          // em.py:81-83 (m, not shift: -inf rows stay -inf)
+        if (out != nullptr && live) {
+            d2 *orow = reinterpret_cast<d2 *>(out + r * ldo);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                if (own[k]) {
+                    d2 v = d2{xr[k].x - lse, xr[k].y - lse};
+                    d2 *dst = orow + t + k * THREADS;
+                    if (mode == 1) {
+                        const d2 old = *dst;
+                        v.x = logaddexp_f64(old.x, v.x);
+                        v.y = logaddexp_f64(old.y, v.y);
+                    }
+                    __builtin_nontemporal_store(v, dst);
+                }
+            }
+        }
+        if constexpr (COLSUM) {
+            const double wr = live ? (w != nullptr ? w[r] : 1.0) : 0.0;
+            const double c = (ssum > 0.0) ? wr / ssum : 0.0;     // w * exp(z - lse) = w * e / sum
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                acc[k].x = fma(c, e[k].x, acc[k].x);
+                acc[k].y = fma(c, e[k].y, acc[k].y);
+            }
+        }
+    };
+
+    if constexpr (NBUF == 2) {
+        load_row(x[0], r0);
+        for (int64_t r = r0; r < r1; r += 2) {
+            load_row(x[1], r + 1);
+            process(x[0], r);
+            load_row(x[0], r + 2);
+            process(x[1], r + 1);
+        }
+    } else {
+        for (int64_t r = r0; r < r1; ++r) {
+            load_row(x[0], r);
+            process(x[0], r);
+        }
+    }
+    if constexpr (COLSUM) {
+        d2 *dst = reinterpret_cast<d2 *>(partial + (int64_t)blockIdx.x * ldpart);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+            if (own[k]) dst[t + k * THREADS] = acc[k];
+    }
+}
+
+#endif  // MIXEMT_ESTEP_KERNELS_HPP
