@@ -14,52 +14,96 @@
 #ifndef BUILD_UNROLL
 #define BUILD_UNROLL 8             // table loads in flight per wave
 #endif
-#define BUILD_CPL 4                // haplogroup columns per lane (one 4-byte table load per site;
-                                   // 8 per lane measured slower: 56 ms vs 40.6 ms at 1M x 5408)
 
 __global__ __launch_bounds__(BUILD_THREADS) void build_em_matrix_kernel(
     const uint8_t *__restrict__ E, int64_t lde, const double *__restrict__ lhit,
     const double *__restrict__ lmiss, const int64_t *__restrict__ row_ptr,
     const uint16_t *__restrict__ site, const uint8_t *__restrict__ obs, int64_t R, int H,
     double *__restrict__ M, int64_t ldm, int vec_ok) {
-    __shared__ int64_t s_off[BUILD_CAP];     // site * lde
-    __shared__ uint32_t s_obs[BUILD_CAP];
-    __shared__ double s_hit[BUILD_CAP];
-    __shared__ double s_miss[BUILD_CAP];
+    constexpr int BUILD_CPL = 4;                // columns per lane: one 4-byte table load per site
+                                                // (8 per lane, as bytes or as 4-bit codes, measured slower)
+    // The row's (table offset, observation, log hit, log miss) list lives in LDS, double
+    // buffered: while row r is being added up, the threads fetch row r + grid's list (two
+    // dependent global loads: site -> lhit[site]) and park it in the other buffer, so that
+    // latency is never exposed.  Rows with more than BUILD_THREADS observations (multi-kb
+    // fragments) take the staged-in-passes path below.
+    __shared__ int64_t s_off[2][BUILD_CAP];     // site * lde
+    __shared__ uint32_t s_obs[2][BUILD_CAP];
+    __shared__ double s_hit[2][BUILD_CAP];
+    __shared__ double s_miss[2][BUILD_CAP];
     const int t = threadIdx.x;
-    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+    int cur = 0;
+    bool have = false;                          // buffer[cur] already holds this row's list
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x, cur ^= 1) {
         const int64_t beg = row_ptr[r], end = row_ptr[r + 1];
+        const int64_t n_all = end - beg;
+        const bool fast = n_all <= BUILD_THREADS;
+        const int64_t rn = r + gridDim.x;
+        const int64_t begn = (rn < R) ? row_ptr[rn] : 0;
+        const int nn = (rn < R) ? (int)((row_ptr[rn + 1] - begn) <= BUILD_THREADS ? (row_ptr[rn + 1] - begn) : 0) : 0;
+        if (fast && !have && t < (int)n_all) {
+            const int s0 = site[beg + t];
+            s_off[cur][t] = (int64_t)s0 * lde;
+            s_obs[cur][t] = obs[beg + t];
+            s_hit[cur][t] = lhit[s0];
+            s_miss[cur][t] = lmiss[s0];
+        }
+        __syncthreads();
+        // next row's list, first hop
+        int sv = 0;
+        uint32_t ov = 0;
+        double hv = 0.0, mv = 0.0;
+        if (t < nn) {
+            sv = site[begn + t];
+            ov = obs[begn + t];
+        }
         for (int cb = 0; cb < H; cb += BUILD_THREADS * BUILD_CPL) {
             const int h = cb + BUILD_CPL * t;
             double a[BUILD_CPL];
 #pragma unroll
             for (int c = 0; c < BUILD_CPL; ++c) a[c] = 0.0;
-            for (int64_t j0 = beg; j0 < end; j0 += BUILD_CAP) {
-                const int n = (int)((end - j0) < BUILD_CAP ? (end - j0) : BUILD_CAP);
-                __syncthreads();
-                for (int j = t; j < n; j += BUILD_THREADS) {
-                    const int s = site[j0 + j];
-                    s_off[j] = (int64_t)s * lde;
-                    s_obs[j] = obs[j0 + j];
-                    s_hit[j] = lhit[s];
-                    s_miss[j] = lmiss[s];
-                }
-                __syncthreads();
+            if (fast) {
+                const int n = (int)n_all;
                 if (h < H) {
                     // independent table loads: unrolled so several are in flight per wave
 #pragma unroll BUILD_UNROLL
                     for (int j = 0; j < n; ++j) {
-                        const uint32_t *src = reinterpret_cast<const uint32_t *>(E + s_off[j] + h);
-                        uint32_t e4[BUILD_CPL / 4];
-#pragma unroll
-                        for (int q = 0; q < BUILD_CPL / 4; ++q) e4[q] = src[q];
-                        const uint32_t o = s_obs[j];
-                        const double hit = s_hit[j], miss = s_miss[j];
+                        const uint32_t e = *reinterpret_cast<const uint32_t *>(E + s_off[cur][j] + h);
+                        const uint32_t o = s_obs[cur][j];
+                        const double hit = s_hit[cur][j], miss = s_miss[cur][j];
 #pragma unroll
                         for (int c = 0; c < BUILD_CPL; ++c)
-                            a[c] += (((e4[c / 4] >> (8 * (c % 4))) & 0xffu) == o) ? hit : miss;
+                            a[c] += (((e >> (8 * c)) & 0xffu) == o) ? hit : miss;
                     }
                 }
+            } else {
+                for (int64_t j0 = beg; j0 < end; j0 += BUILD_CAP) {
+                    const int n = (int)((end - j0) < BUILD_CAP ? (end - j0) : BUILD_CAP);
+                    __syncthreads();
+                    for (int j = t; j < n; j += BUILD_THREADS) {
+                        const int s0 = site[j0 + j];
+                        s_off[cur][j] = (int64_t)s0 * lde;
+                        s_obs[cur][j] = obs[j0 + j];
+                        s_hit[cur][j] = lhit[s0];
+                        s_miss[cur][j] = lmiss[s0];
+                    }
+                    __syncthreads();
+                    if (h < H) {
+#pragma unroll BUILD_UNROLL
+                        for (int j = 0; j < n; ++j) {
+                            const uint32_t e = *reinterpret_cast<const uint32_t *>(E + s_off[cur][j] + h);
+                            const uint32_t o = s_obs[cur][j];
+                            const double hit = s_hit[cur][j], miss = s_miss[cur][j];
+#pragma unroll
+                            for (int c = 0; c < BUILD_CPL; ++c)
+                                a[c] += (((e >> (8 * c)) & 0xffu) == o) ? hit : miss;
+                        }
+                    }
+                }
+            }
+            if (cb == 0 && t < nn) {            // second hop of the next row's list
+                hv = lhit[sv];
+                mv = lmiss[sv];
             }
             if (h < H) {
                 double *dst = M + r * ldm + h;
@@ -73,6 +117,13 @@ __global__ __launch_bounds__(BUILD_THREADS) void build_em_matrix_kernel(
                 }
             }
         }
+        if (t < nn) {
+            s_off[cur ^ 1][t] = (int64_t)sv * lde;
+            s_obs[cur ^ 1][t] = ov;
+            s_hit[cur ^ 1][t] = hv;
+            s_miss[cur ^ 1][t] = mv;
+        }
+        have = nn > 0;
     }
 }
 
