@@ -27,6 +27,87 @@ __global__ __launch_bounds__(ROW_THREADS) void linearize_kernel(const double *__
 }
 
 // ------------------------------------------------------------------------------------------
+// K2w linearize for wide, 16-byte aligned rows: one read + one write per cell (the row waits in
+// VGPRs for its maximum, like the streaming kernel's row waits for its dot product).
+// ST = double or float (the opt-in storage variant).  H even, M rows 16-byte aligned.
+// ------------------------------------------------------------------------------------------
+template <int NCH, typename ST>
+__global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__restrict__ M, int64_t ldm,
+                                                                int64_t R, int H, int64_t rows_per_wg,
+                                                                ST *__restrict__ P, int64_t ldp,
+                                                                double *__restrict__ rowmax) {
+    constexpr int THREADS = 256, NW = THREADS / 64;
+    __shared__ double red[2][NW];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int ncol2 = H >> 1;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
+    const int64_t r1 = (r0 + rows_per_wg < R) ? (r0 + rows_per_wg) : R;
+    if (r0 >= r1) return;
+
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(M + r0 * ldm), 0,
+                                                        (int)((r1 - r0) * ldm * 8), 0x00020000);
+    const int row_bytes = (int)(ldm * 8);
+    const int voff = t * 16;
+    int last_c2 = t + (NCH - 1) * THREADS;
+    const bool last_own = last_c2 < ncol2;
+    if (!last_own) last_c2 = ncol2 - 1;
+    const int voff_last = last_c2 * 16;
+
+    d2 x[2][NCH];
+    auto load_row = [&](d2(&xr)[NCH], int64_t r) {
+        const int64_t rr = (r < r1) ? r : (r1 - 1);
+        const int soff = (int)(rr - r0) * row_bytes;
+#pragma unroll
+        for (int k = 0; k < NCH - 1; ++k)
+            xr[k] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(
+                                               rsrc, voff, soff + k * THREADS * 16, 2));
+        xr[NCH - 1] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, soff, 2));
+    };
+    int ring = 0;
+    auto process = [&](d2(&xr)[NCH], int64_t r) {
+        double m = -INFINITY;                   // a clamped lane repeats a real element: harmless for a max
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) m = fmax(m, fmax(xr[k].x, xr[k].y));
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
+        if (lane == 0) red[ring][wv] = m;
+        __syncthreads();
+        m = red[ring][0];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) m = fmax(m, red[ring][q]);
+        ring ^= 1;
+        if (r >= r1) return;
+        const double shift = isfinite(m) ? m : 0.0;
+        if (t == 0) rowmax[r] = shift;
+        ST *prow = P + r * ldp;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (k < NCH - 1 || last_own) {
+                const int c = 2 * (t + k * THREADS);
+                const double ex = exp(xr[k].x - shift), ey = exp(xr[k].y - shift);
+                if constexpr (sizeof(ST) == 8) {
+                    __builtin_nontemporal_store(d2{ex, ey}, reinterpret_cast<d2 *>(prow + c));
+                } else {
+                    typedef float f2 __attribute__((ext_vector_type(2)));
+                    __builtin_nontemporal_store(f2{(float)ex, (float)ey}, reinterpret_cast<f2 *>(prow + c));
+                }
+            }
+        }
+        // pad columns [H, ldp) of P are zero by contract
+        for (int c = H + t; c < (int)ldp; c += THREADS) prow[c] = (ST)0;
+    };
+    load_row(x[0], r0);
+    for (int64_t r = r0; r < r1; r += 2) {
+        load_row(x[1], r + 1);
+        process(x[0], r);
+        load_row(x[0], r + 2);
+        process(x[1], r + 1);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K3  em_iter_wide: fused E+M step in linear space, one restart.
 //
 //   Z_r      = sum_h p_h P_rh                     (row reduction)

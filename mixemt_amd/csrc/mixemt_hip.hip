@@ -113,11 +113,40 @@ extern "C" int mxm_build_em_matrix_packed(const uint32_t *Epk, const uint8_t *mu
     return 0;
 }
 
+template <typename ST>
+static int linearize_wide(const double *M, int64_t ldm, int64_t R, int H, ST *P, int64_t ldp, double *rowmax,
+                          hipStream_t s) {
+    const int nch = (H / 2 + 255) / 256;
+    int cap = num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG;
+    int nwg = clamp_grid((R + 1) / 2, cap);
+    int64_t rows_per_wg = (R + nwg - 1) / nwg;
+    rows_per_wg = (rows_per_wg + 1) / 2 * 2;
+    nwg = (int)((R + rows_per_wg - 1) / rows_per_wg);
+    if ((double)rows_per_wg * (double)ldm * 8.0 >= 2147483648.0) return 1;      // caller falls back
+    switch (nch) {
+#define LW_CASE(n) case n: hipLaunchKernelGGL((linearize_wide_kernel<n, ST>), dim3(nwg), dim3(256), 0, s, M, ldm, R, H, rows_per_wg, P, ldp, rowmax); break;
+        LW_CASE(1) LW_CASE(2) LW_CASE(3) LW_CASE(4) LW_CASE(5) LW_CASE(6) LW_CASE(7) LW_CASE(8)
+        LW_CASE(9) LW_CASE(10) LW_CASE(11) LW_CASE(12) LW_CASE(13) LW_CASE(14) LW_CASE(15) LW_CASE(16)
+#undef LW_CASE
+        default: return 1;
+    }
+    return 0;
+}
+
+static inline bool wide_rows_ok(const void *M, int64_t ldm, int H) {
+    return ((H & 1) == 0) && ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0) && H >= 64 && H <= 8192;
+}
+
 extern "C" int mxm_linearize(const double *M, int64_t ldm, int64_t R, int32_t H, double *P, int64_t ldp,
                              double *rowmax, void *stream) {
     if (R < 0 || H <= 0) return fail(-1, "mxm_linearize: bad shape%s", "");
     if (ldm < H || ldp < H || (ldp & 1)) return fail(-1, "mxm_linearize: ldp must be even and >= H%s (ldp=%lld)", "", ldp);
     if (R == 0) return 0;
+    if (wide_rows_ok(M, ldm, H) && (reinterpret_cast<uintptr_t>(P) & 15) == 0 &&
+        linearize_wide<double>(M, ldm, R, (int)H, P, ldp, rowmax, (hipStream_t)stream) == 0) {
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const int grid = clamp_grid(R, num_cu() * 8);
     hipLaunchKernelGGL(linearize_kernel, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, M, ldm, R,
                        (int)H, P, ldp, rowmax);
@@ -363,6 +392,11 @@ extern "C" int mxm_linearize_f32(const double *M, int64_t ldm, int64_t R, int32_
     if (R < 0 || H <= 0) return fail(-1, "mxm_linearize_f32: bad shape%s", "");
     if (ldm < H || ldp < H || (ldp & 3)) return fail(-1, "mxm_linearize_f32: ldp must be a multiple of 4 and >= H%s (ldp=%lld)", "", ldp);
     if (R == 0) return 0;
+    if (wide_rows_ok(M, ldm, H) && (reinterpret_cast<uintptr_t>(P) & 7) == 0 && (ldp & 1) == 0 &&
+        linearize_wide<float>(M, ldm, R, (int)H, P, ldp, rowmax, (hipStream_t)stream) == 0) {
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     const int grid = clamp_grid(R, num_cu() * 8);
     hipLaunchKernelGGL(linearize_f32_kernel, dim3(grid), dim3(ROW_THREADS), 0, (hipStream_t)stream, M, ldm, R, (int)H,
                        P, ldp, rowmax);
