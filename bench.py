@@ -174,10 +174,13 @@ def main():
         lib.mxm_set_min_rows_per_wg(opts.min_rows_per_wg)
     numpy.random.seed(7)
     init = numpy.stack([em.init_props(n_haps, 1.0) for _ in range(n_runs)])   # sequential draws
-    props_cur = torch.from_numpy(init).to(dev)
+    ln0, p0 = em.log_inits(init)
+    props_cur = torch.from_numpy(p0).to(dev)
+    ln_cur = torch.from_numpy(ln0).to(dev)
     if world > 1:
-        dist.broadcast(props_cur, src=0)
-    props_new = props_cur.clone()
+        dist.broadcast(ln_cur, src=0)
+        props_cur = torch.exp(ln_cur)
+    ln_new = ln_cur.clone()
     colsum = torch.zeros_like(props_cur)
     state = em.new_state(n_runs, dev)
     total = opts.warmup + opts.steps
@@ -190,12 +193,12 @@ def main():
     def step(pair=None):
         if pair is not None:
             lib.mxm_set_timing_events(pair[0].cuda_event, pair[1].cuda_event)
-        plan.em_iter(props_cur, state, colsum)
+        plan.em_iter(props_cur, ln_cur, state, colsum)
         if pair is not None:
             lib.mxm_set_timing_events(None, None)
         if world > 1:
             dist.all_reduce(colsum, op=dist.ReduceOp.SUM)
-        plan.finalize(colsum, props_cur, props_new, state, 0.0, total + 1)
+        plan.finalize(colsum, ln_cur, ln_new, props_cur, state, 0.0, total + 1)
 
     def fence():
         if world > 1:
@@ -217,7 +220,12 @@ def main():
 
     kernel_ms = numpy.array([a.elapsed_time(b) for a, b in evs])
     st = em.read_state(state)[0]
-    mass = float(colsum.sum().item())
+    # sanity (untimed): one more E+M pass; the M-step sums  sum_h p_h T_h  must add up to the
+    # total weight of all ranks' rows, once per restart
+    plan.em_iter(props_cur, ln_cur, state, colsum)
+    if world > 1:
+        dist.all_reduce(colsum, op=dist.ReduceOp.SUM)
+    mass = float((props_cur * colsum).sum().item())
     sane = (st[1] == total) and abs(mass - n_rows * world * n_runs) < 1e-6 * n_rows * world * n_runs
     if rank == 0:
         log("%d steps in %.4f s; streaming kernel avg %.4f ms (min %.4f, max %.4f); "
@@ -229,7 +237,7 @@ def main():
     try:
         out = torch.empty((n_rows, n_haps), dtype=torch.float64, device=dev)
         with numpy.errstate(divide="ignore"):
-            ln_theta = torch.from_numpy(numpy.log(props_cur[0].cpu().numpy())).to(dev)
+            ln_theta = ln_cur[0].clone()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         em.posterior(plan, ln_theta, out=out)

@@ -100,30 +100,35 @@ int mxm_linearize(const double *M, int64_t ldm, int64_t R, int32_t H,
 
 /*
  * em_step, E+M fused, this rank's row shard -- em.py:80-88.
- *   colsum[b][h] = sum_r w[r] * posterior_b[r][h]      (linear space)
- * where posterior_b is the row-normalised E-step under props[b].
- * P != NULL and mxm_linear_supported(H): streams P (no transcendental);
- * otherwise streams M in log space.  Restarts with state[b].done != 0 are
- * skipped (their colsum is left untouched).
- * props[B][H] linear proportions (theta_k), w[R] fp64 weights (NULL = all 1).
+ *   colsum[b][h] = T_bh = sum_r w[r] * P[r][h] / Z_b[r],   Z_b[r] = sum_h props[b][h] * P[r][h]
+ * i.e. the M-step sums WITHOUT their factor props[b][h]:  sum_r w[r] * posterior_b[r][h] =
+ * props[b][h] * T_bh.  The factor is left out so that a proportion that underflows in linear
+ * space still gets an exact log update in mxm_m_finalize (the reference keeps log proportions).
+ * P != NULL and mxm_linear_supported(H): streams P (no transcendental), reads `props`;
+ * otherwise streams M in log space and reads `ln_props` (must then be non-NULL).
+ * Restarts with state[b].done != 0 are skipped (their colsum is left untouched).
+ * props[B][H] = exp(ln_props[B][H]) (theta_k), w[R] fp64 weights (NULL = all 1).
  * With several ranks the caller all-reduces (SUM) colsum before mxm_m_finalize.
  */
 int mxm_em_iter(const double *M, int64_t ldm, const double *P, int64_t ldp,
-                const double *w, const double *props,
+                const double *w, const double *props, const double *ln_props,
                 int64_t R, int32_t H, int32_t B,
                 const mxm_em_state *state, double *colsum,
                 void *ws, size_t ws_bytes, void *stream);
 
 /*
- * M-step normalisation + convergence test -- em.py:89, :39-54, :133-143.
- *   p_new = colsum / sum_h colsum ;  l1 = sum_h |p_new - p_cur| ; iters += 1
- *   l1 < tol -> done = 1 ; else iters >= max_iter -> done = 2 ; else p_cur := p_new
- * After the loop stops: props_cur = theta_k, props_new = theta_{k+1} -- the pair
- * the reference returns (posterior one step behind the proportions).
+ * M-step normalisation + convergence test -- em.py:87-89, :39-54, :133-143, in the reference's
+ * own variable, the LOG proportions:
+ *   ln_new = ln_cur + log(colsum) - log(sum_h props_cur * colsum)
+ *   l1 = sum_h |exp(ln_new) - props_cur| ;  iters += 1
+ *   l1 < tol -> done = 1 ; else iters >= max_iter -> done = 2 ;
+ *   else ln_cur := ln_new, props_cur := exp(ln_new)
+ * After the loop stops: ln_cur = log theta_k, ln_new = log theta_{k+1} -- the pair the
+ * reference returns (posterior one step behind the proportions).  props_cur = exp(ln_cur).
  */
-int mxm_m_finalize(const double *colsum, double *props_cur, double *props_new,
-                   int32_t H, int32_t B, double tol, int32_t max_iter,
-                   mxm_em_state *state, void *stream);
+int mxm_m_finalize(const double *colsum, double *ln_cur, double *ln_new,
+                   double *props_cur, int32_t H, int32_t B, double tol,
+                   int32_t max_iter, mxm_em_state *state, void *stream);
 
 /*
  * fp32-STORAGE variant of the loop (opt-in; NOT the reference's arithmetic type for the stored
@@ -137,8 +142,8 @@ int mxm_em_iter_f32(const float *P, int64_t ldp, const double *w, const double *
                     int64_t R, int32_t H, int32_t B, const mxm_em_state *state,
                     double *colsum, void *ws, size_t ws_bytes, void *stream);
 int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int64_t R, int32_t H,
-                    int32_t B, double *props_cur, double *props_new, double *colsum,
-                    mxm_em_state *state, double tol, int32_t max_iter,
+                    int32_t B, double *props_cur, double *ln_cur, double *ln_new,
+                    double *colsum, mxm_em_state *state, double tol, int32_t max_iter,
                     int32_t check_every, void *ws, size_t ws_bytes, void *stream,
                     mxm_em_state *state_host);
 
@@ -152,7 +157,7 @@ int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int64_t R, int
  */
 int mxm_em_loop(const double *M, int64_t ldm, const double *P, int64_t ldp,
                 const double *w, int64_t R, int32_t H, int32_t B,
-                double *props_cur, double *props_new, double *colsum,
+                double *props_cur, double *ln_cur, double *ln_new, double *colsum,
                 mxm_em_state *state, double tol, int32_t max_iter,
                 int32_t check_every, void *ws, size_t ws_bytes, void *stream,
                 mxm_em_state *state_host);

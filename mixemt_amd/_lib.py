@@ -33,18 +33,19 @@ SIGNATURES = {
     "mxm_build_em_matrix_packed": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
                                                   c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     "mxm_linearize": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
-    "mxm_em_iter": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32,
+    "mxm_em_iter": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32,
                                    c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
-    "mxm_m_finalize": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f64, c_i32, c_ptr,
+    "mxm_m_finalize": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_f64, c_i32, c_ptr,
                                       c_ptr]),
     "mxm_em_loop": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32,
-                                   c_ptr, c_ptr, c_ptr, c_ptr, c_f64, c_i32, c_i32, c_ptr, c_size,
+                                   c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_f64, c_i32, c_i32, c_ptr, c_size,
                                    c_ptr, ctypes.POINTER(EmState)]),
     "mxm_linearize_f32": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
     "mxm_em_iter_f32": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr,
                                        c_size, c_ptr]),
     "mxm_em_loop_f32": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
-                                       c_f64, c_i32, c_i32, c_ptr, c_size, c_ptr, ctypes.POINTER(EmState)]),
+                                       c_ptr, c_f64, c_i32, c_i32, c_ptr, c_size, c_ptr,
+                                       ctypes.POINTER(EmState)]),
     "mxm_em_step": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_i32,
                                    c_ptr, c_ptr, c_size, c_ptr]),
     "mxm_log_normalize": (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_ptr]),

@@ -407,7 +407,8 @@ __global__ __launch_bounds__(ROW_THREADS) void linearize_f32_kernel(const double
 // ------------------------------------------------------------------------------------------
 // K4  colreduce: colsum[h] = scale_h * sum_{g < nwg} partial[g][h]   (fixed order)
 // 64 columns per workgroup; 4 waves take interleaved quarters of the partial rows.
-// scale_h = props[h] for the linear kernel, 1 for the log-space kernel.
+// scale_h = props[h] where the caller wants the M-step sums themselves (em_step), 1 in the loop
+// (the loop's finalize works from the unscaled sums, see finalize_kernel).
 // ------------------------------------------------------------------------------------------
 #define COLRED_THREADS 1024
 __global__ __launch_bounds__(COLRED_THREADS) void colreduce_kernel(const double *__restrict__ partial,
@@ -453,33 +454,45 @@ __global__ __launch_bounds__(COLRED_THREADS) void colreduce_kernel(const double 
 #define FIN_THREADS 1024
 
 __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(const double *__restrict__ colsum,
-                                                               double *__restrict__ props_cur,
-                                                               double *__restrict__ props_new, int H,
+                                                               double *__restrict__ ln_cur,
+                                                               double *__restrict__ ln_new,
+                                                               double *__restrict__ props_cur, int H,
                                                                double tol, int max_iter,
                                                                mxm_em_state *__restrict__ state) {
+    // The state of the loop is the LOG proportions, as in the reference (em.py:123-124, :140):
+    //   colsum_h = T_h = sum_r (w_r / Z_r) P_rh      (no p_h factor: representable however small p_h is)
+    //   ln p'_h  = ln p_h + ln T_h - ln sum_h p_h T_h        == em.py:87-89
+    //   l1       = sum_h |exp(ln p'_h) - exp(ln p_h)|        == em.py:53-54
+    // so a proportion that underflows in linear space keeps a finite log, exactly like the
+    // reference's; props_cur = exp(ln_cur) is what the streaming kernel multiplies with.
     __shared__ double scratch[FIN_THREADS / 64];
     const int b = blockIdx.x;
     mxm_em_state *st = state + b;
     if (st->done != 0) return;
     const double *cs = colsum + (int64_t)b * H;
+    double *lc = ln_cur + (int64_t)b * H;
+    double *ln = ln_new + (int64_t)b * H;
     double *pc = props_cur + (int64_t)b * H;
-    double *pn = props_new + (int64_t)b * H;
     const int t = threadIdx.x;
     double s = 0.0;
-    for (int h = t; h < H; h += FIN_THREADS) s += cs[h];
-    const double total = block_reduce<FIN_THREADS, false>(s, scratch);
+    for (int h = t; h < H; h += FIN_THREADS) s += pc[h] * cs[h];
+    const double ltot = log(block_reduce<FIN_THREADS, false>(s, scratch));
     double l1 = 0.0;
     for (int h = t; h < H; h += FIN_THREADS) {
-        const double v = cs[h] / total;
-        pn[h] = v;
-        l1 += fabs(v - pc[h]);
+        const double v = lc[h] + log(cs[h]) - ltot;
+        ln[h] = v;
+        l1 += fabs(exp(v) - pc[h]);
     }
     l1 = block_reduce<FIN_THREADS, false>(l1, scratch);
     const int iters = st->iters + 1;
     const bool conv = l1 < tol;
     const bool stop = conv || iters >= max_iter;
     if (!stop)
-        for (int h = t; h < H; h += FIN_THREADS) pc[h] = pn[h];
+        for (int h = t; h < H; h += FIN_THREADS) {
+            const double v = ln[h];
+            lc[h] = v;
+            pc[h] = exp(v);
+        }
     __syncthreads();
     if (t == 0) {
         st->iters = iters;

@@ -9,41 +9,59 @@
 // One workgroup per row (grid-stride), column sums in LDS (each thread owns its columns).
 // Used for em_step(), the final posterior pass, and EM iterations when H is tiny.
 // ------------------------------------------------------------------------------------------
-template <bool FROM_LINEAR_PROPS>
+template <bool ITER>
 __global__ __launch_bounds__(ROW_THREADS) void estep_log_kernel(
     const double *__restrict__ M, int64_t ldm, const double *__restrict__ w,
-    const double *__restrict__ pvec, int64_t R, int H, double *__restrict__ out, int64_t ldo,
+    const double *__restrict__ ln_props, int64_t R, int H, double *__restrict__ out, int64_t ldo,
     int mode, double *__restrict__ partial, int64_t ldpart,
     const mxm_em_state *__restrict__ state) {
-    extern __shared__ double dyn[];            // [H] column sums (if partial) + [H] ln props
+    // ITER = false: the reference's E-step verbatim (posterior written / folded; `partial` gets the
+    //               M-step sums  sum_r w_r exp(posterior)).
+    // ITER = true:  one loop iteration for narrow matrices, nothing written but `partial`, which
+    //               gets the UNSCALED sums T_h = sum_r (w_r / Z_r) exp(M_rh - rowmax_r) with
+    //               Z_r = sum_h exp(ln p_h + M_rh - rowmax_r)  -- same quantity as the streaming
+    //               kernel's, so finalize_kernel treats both alike.
+    extern __shared__ double dyn[];            // [H] ln props + [H] column sums
     __shared__ double scratch[ROW_THREADS / 64];
     if (state != nullptr && state->done != 0) return;
     const int t = threadIdx.x;
     double *lnp = dyn;
     double *acc = dyn + H;
     for (int h = t; h < H; h += ROW_THREADS) {
-        lnp[h] = FROM_LINEAR_PROPS ? log(pvec[h]) : pvec[h];
+        lnp[h] = ln_props[h];
         if (partial != nullptr) acc[h] = 0.0;
     }
     __syncthreads();
     for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
         const double *src = M + r * ldm;
-        double m = -INFINITY;
-        for (int h = t; h < H; h += ROW_THREADS) m = fmax(m, lnp[h] + src[h]);
-        m = block_reduce<ROW_THREADS, true>(m, scratch);
-        const double shift = isfinite(m) ? m : 0.0;
-        double s = 0.0;
-        for (int h = t; h < H; h += ROW_THREADS) s += exp((lnp[h] + src[h]) - shift);
-        s = block_reduce<ROW_THREADS, false>(s, scratch);
-        const double lse = log(s) + m;          // m (not shift): -inf rows give -inf, as scipy does
         const double wr = (w != nullptr) ? w[r] : 1.0;
-        for (int h = t; h < H; h += ROW_THREADS) {
-            const double v = (lnp[h] + src[h]) - lse;
-            if (out != nullptr) {
-                double *o = out + r * ldo + h;
-                *o = (mode == 1) ? logaddexp_f64(*o, v) : v;
+        if constexpr (ITER) {
+            double m = -INFINITY;
+            for (int h = t; h < H; h += ROW_THREADS) m = fmax(m, src[h]);
+            m = block_reduce<ROW_THREADS, true>(m, scratch);
+            const double shift = isfinite(m) ? m : 0.0;
+            double z = 0.0;
+            for (int h = t; h < H; h += ROW_THREADS) z += exp(lnp[h] + (src[h] - shift));
+            z = block_reduce<ROW_THREADS, false>(z, scratch);
+            const double c = (z > 0.0) ? wr / z : 0.0;
+            for (int h = t; h < H; h += ROW_THREADS) acc[h] += c * exp(src[h] - shift);
+        } else {
+            double m = -INFINITY;
+            for (int h = t; h < H; h += ROW_THREADS) m = fmax(m, lnp[h] + src[h]);
+            m = block_reduce<ROW_THREADS, true>(m, scratch);
+            const double shift = isfinite(m) ? m : 0.0;
+            double s = 0.0;
+            for (int h = t; h < H; h += ROW_THREADS) s += exp((lnp[h] + src[h]) - shift);
+            s = block_reduce<ROW_THREADS, false>(s, scratch);
+            const double lse = log(s) + m;          // m (not shift): -inf rows give -inf, as scipy does
+            for (int h = t; h < H; h += ROW_THREADS) {
+                const double v = (lnp[h] + src[h]) - lse;
+                if (out != nullptr) {
+                    double *o = out + r * ldo + h;
+                    *o = (mode == 1) ? logaddexp_f64(*o, v) : v;
+                }
+                if (partial != nullptr) acc[h] += wr * exp(v);
             }
-            if (partial != nullptr) acc[h] += wr * exp(v);
         }
     }
     if (partial != nullptr) {

@@ -285,7 +285,7 @@ static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, co
     HIP_TRY(hipGetLastError());
     if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
     hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, nb), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg, nb,
-                       H, props, colsum, state);
+                       H, (const double *)nullptr, colsum, state);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -336,19 +336,20 @@ static int em_iter_f32_one(const float *P, int64_t ldp, const double *w, const d
     HIP_TRY(hipGetLastError());
     if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
     hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg,
-                       1, H, props, colsum, state);
+                       1, H, (const double *)nullptr, colsum, state);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-static int em_iter_log_one(const double *M, int64_t ldm, const double *w, const double *props, int64_t R, int H,
+static int em_iter_log_one(const double *M, int64_t ldm, const double *w, const double *ln_props, int64_t R, int H,
                            const mxm_em_state *state, double *colsum, double *partial, hipStream_t stream) {
     if (M == nullptr) return fail(-1, "mxm_em_iter: M is NULL and the linear path does not apply%s", "");
+    if (ln_props == nullptr) return fail(-1, "mxm_em_iter: ln_props is NULL and the log-space path needs it%s", "");
     const size_t lds = 2 * (size_t)H * sizeof(double);
     if (lds > 150 * 1024) return fail(-1, "mxm_em_iter: H=%s%lld too large for the log-space kernel", "", H);
     const int64_t ldpart = part_ld(H);
     const int nwg = clamp_grid(R, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
-    hipLaunchKernelGGL((estep_log_kernel<true>), dim3(nwg), dim3(ROW_THREADS), lds, stream, M, ldm, w, props,
+    hipLaunchKernelGGL((estep_log_kernel<true>), dim3(nwg), dim3(ROW_THREADS), lds, stream, M, ldm, w, ln_props,
                        R, H, (double *)nullptr, (int64_t)0, 0, partial, ldpart, state);
     HIP_TRY(hipGetLastError());
     hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg, 1,
@@ -358,8 +359,8 @@ static int em_iter_log_one(const double *M, int64_t ldm, const double *w, const 
 }
 
 extern "C" int mxm_em_iter(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
-                           const double *props, int64_t R, int32_t H, int32_t B, const mxm_em_state *state,
-                           double *colsum, void *ws, size_t ws_bytes, void *stream) {
+                           const double *props, const double *ln_props, int64_t R, int32_t H, int32_t B,
+                           const mxm_em_state *state, double *colsum, void *ws, size_t ws_bytes, void *stream) {
     if (R <= 0 || H <= 0 || B <= 0) return fail(-1, "mxm_em_iter: bad shape R=%s%lld H=%lld", "", R, H);
     if (ws == nullptr || ws_bytes < mxm_workspace_bytes(R, H, B)) return fail(-1, "mxm_em_iter: workspace too small%s", "");
     if (P != nullptr && ((ldp & 1) || ldp < H)) return fail(-1, "mxm_em_iter: ldp must be even and >= H%s", "");
@@ -379,8 +380,8 @@ extern "C" int mxm_em_iter(const double *M, int64_t ldm, const double *P, int64_
             rc = em_iter_linear_tile(P, ldp, w, props + (int64_t)b * H, R, (int)H, nb, st,
                                      colsum + (int64_t)b * H, (double *)ws, (hipStream_t)stream, b == 0);
         else
-            rc = em_iter_log_one(M, ldm, w, props + (int64_t)b * H, R, (int)H, st, colsum + (int64_t)b * H,
-                                 (double *)ws, (hipStream_t)stream);
+            rc = em_iter_log_one(M, ldm, w, ln_props ? ln_props + (int64_t)b * H : nullptr, R, (int)H, st,
+                                 colsum + (int64_t)b * H, (double *)ws, (hipStream_t)stream);
         if (rc != 0) return rc;
         b += nb;
     }
@@ -419,11 +420,11 @@ extern "C" int mxm_em_iter_f32(const float *P, int64_t ldp, const double *w, con
     return 0;
 }
 
-extern "C" int mxm_m_finalize(const double *colsum, double *props_cur, double *props_new, int32_t H, int32_t B,
-                              double tol, int32_t max_iter, mxm_em_state *state, void *stream) {
+extern "C" int mxm_m_finalize(const double *colsum, double *ln_cur, double *ln_new, double *props_cur, int32_t H,
+                              int32_t B, double tol, int32_t max_iter, mxm_em_state *state, void *stream) {
     if (H <= 0 || B <= 0 || state == nullptr) return fail(-1, "mxm_m_finalize: bad arguments%s", "");
-    hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), 0, (hipStream_t)stream, colsum, props_cur,
-                       props_new, (int)H, tol, (int)max_iter, state);
+    hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), 0, (hipStream_t)stream, colsum, ln_cur, ln_new,
+                       props_cur, (int)H, tol, (int)max_iter, state);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -440,22 +441,22 @@ extern "C" int mxm_set_loop_graph(int32_t mode) {
 }
 
 static int enqueue_iterations(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
-                              int64_t R, int32_t H, int32_t B, double *props_cur, double *props_new,
+                              int64_t R, int32_t H, int32_t B, double *props_cur, double *ln_cur, double *ln_new,
                               double *colsum, mxm_em_state *state, double tol, int32_t max_iter, int64_t n,
                               void *ws, size_t ws_bytes, hipStream_t s, bool p_is_f32) {
     for (int64_t i = 0; i < n; ++i) {
         int rc = p_is_f32 ? mxm_em_iter_f32(reinterpret_cast<const float *>(P), ldp, w, props_cur, R, H, B, state,
                                             colsum, ws, ws_bytes, s)
-                          : mxm_em_iter(M, ldm, P, ldp, w, props_cur, R, H, B, state, colsum, ws, ws_bytes, s);
+                          : mxm_em_iter(M, ldm, P, ldp, w, props_cur, ln_cur, R, H, B, state, colsum, ws, ws_bytes, s);
         if (rc != 0) return rc;
-        rc = mxm_m_finalize(colsum, props_cur, props_new, H, B, tol, max_iter, state, s);
+        rc = mxm_m_finalize(colsum, ln_cur, ln_new, props_cur, H, B, tol, max_iter, state, s);
         if (rc != 0) return rc;
     }
     return 0;
 }
 
 static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
-                        int64_t R, int32_t H, int32_t B, double *props_cur, double *props_new,
+                        int64_t R, int32_t H, int32_t B, double *props_cur, double *ln_cur, double *ln_new,
                         double *colsum, mxm_em_state *state, double tol, int32_t max_iter,
                         int32_t check_every, void *ws, size_t ws_bytes, void *stream,
                         mxm_em_state *state_host, bool p_is_f32) {
@@ -499,7 +500,7 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
                     if (exec != nullptr) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
                     if (graph != nullptr) { (void)hipGraphDestroy(graph); graph = nullptr; }
                     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                        const int crc = enqueue_iterations(M, ldm, P, ldp, w, R, H, B, props_cur, props_new, colsum,
+                        const int crc = enqueue_iterations(M, ldm, P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, colsum,
                                                            state, tol, max_iter, n, ws, ws_bytes, s, p_is_f32);
                         const hipError_t ee = hipStreamEndCapture(s, &graph);
                         if (crc == 0 && ee == hipSuccess &&
@@ -517,7 +518,7 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
                 }
             }
             if (!launched) {
-                rc = enqueue_iterations(M, ldm, P, ldp, w, R, H, B, props_cur, props_new, colsum, state, tol,
+                rc = enqueue_iterations(M, ldm, P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, colsum, state, tol,
                                         max_iter, n, ws, ws_bytes, s, p_is_f32);
                 if (rc != 0) goto done;
             }
@@ -538,19 +539,19 @@ done:
 }
 
 extern "C" int mxm_em_loop(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
-                           int64_t R, int32_t H, int32_t B, double *props_cur, double *props_new,
+                           int64_t R, int32_t H, int32_t B, double *props_cur, double *ln_cur, double *ln_new,
                            double *colsum, mxm_em_state *state, double tol, int32_t max_iter,
                            int32_t check_every, void *ws, size_t ws_bytes, void *stream,
                            mxm_em_state *state_host) {
-    return em_loop_impl(M, ldm, P, ldp, w, R, H, B, props_cur, props_new, colsum, state, tol, max_iter,
+    return em_loop_impl(M, ldm, P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, colsum, state, tol, max_iter,
                         check_every, ws, ws_bytes, stream, state_host, false);
 }
 
 extern "C" int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int64_t R, int32_t H, int32_t B,
-                               double *props_cur, double *props_new, double *colsum, mxm_em_state *state,
-                               double tol, int32_t max_iter, int32_t check_every, void *ws, size_t ws_bytes,
-                               void *stream, mxm_em_state *state_host) {
-    return em_loop_impl(nullptr, 0, reinterpret_cast<const double *>(P), ldp, w, R, H, B, props_cur, props_new,
+                               double *props_cur, double *ln_cur, double *ln_new, double *colsum,
+                               mxm_em_state *state, double tol, int32_t max_iter, int32_t check_every, void *ws,
+                               size_t ws_bytes, void *stream, mxm_em_state *state_host) {
+    return em_loop_impl(nullptr, 0, reinterpret_cast<const double *>(P), ldp, w, R, H, B, props_cur, ln_cur, ln_new,
                         colsum, state, tol, max_iter, check_every, ws, ws_bytes, stream, state_host, true);
 }
 

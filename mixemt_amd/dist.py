@@ -8,9 +8,9 @@ weighted column sum over rows (em.py:87-88).  So each rank keeps a contiguous
 row block of the matrix / weights / observations resident, and an EM
 iteration has exactly ONE exchange step:
 
-    colsum_local[b][h] = sum_{r in shard} w_r posterior_b[r][h]   (mxm_em_iter)
+    colsum_local[b][h] = sum_{r in shard} w_r P[r][h] / Z_b[r]     (mxm_em_iter)
     all-reduce(SUM, fp64, B*H values)                              (RCCL)
-    p' = colsum / sum colsum ; L1 test ; loop state                (mxm_m_finalize)
+    ln p' = ln p + ln colsum - ln sum_h p colsum ; L1 test ; state (mxm_m_finalize)
 
 The all-reduce hands every rank the same bytes, so every rank takes the same
 stop decision on the same iteration; kernels of a finished restart are no-ops,
@@ -71,25 +71,28 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8)
     The EM loop over a row-sharded matrix.  `plan` is the rank-local EmPlan (or
     any object with its em_iter / finalize / alloc / read_state surface -- the
     CPU tests pass a numpy-backed double).  Returns
-    (props_cur, props_new, [(done, iters, l1)]) -- identical on every rank.
+    (ln_cur = log theta_k, ln_new = log theta_{k+1}, [(done, iters, l1)]) --
+    identical on every rank.
     """
     rank, world = _world(group)
-    props_cur = plan.alloc_props(inits)
-    props_new = plan.alloc_props(inits)
-    colsum = plan.alloc_props(numpy.zeros_like(inits))
-    state = plan.alloc_state(inits.shape[0])
+    ln0, p0 = _em.log_inits(inits)
+    props_cur = plan.alloc_props(p0)
+    ln_cur = plan.alloc_props(ln0)
+    ln_new = plan.alloc_props(ln0)
+    colsum = plan.alloc_props(numpy.zeros_like(ln0))
+    state = plan.alloc_state(ln0.shape[0])
     issued = 0
     states = plan.read_state(state)
     while issued < max_iter and not all(s[0] != 0 for s in states):
         burst = min(check_every, max_iter - issued)
         for _ in range(burst):
-            plan.em_iter(props_cur, state, colsum)
+            plan.em_iter(props_cur, ln_cur, state, colsum)
             if world > 1:
                 dist.all_reduce(colsum, op=dist.ReduceOp.SUM, group=group)
-            plan.finalize(colsum, props_cur, props_new, state, tolerance, max_iter)
+            plan.finalize(colsum, ln_cur, ln_new, props_cur, state, tolerance, max_iter)
         issued += burst
         states = plan.read_state(state)
-    return props_cur, props_new, states
+    return ln_cur, ln_new, states
 
 
 def run_em_sharded(local_mat, local_weights, args, inits=None, group=None, want_read_mix=True,
@@ -104,9 +107,9 @@ def run_em_sharded(local_mat, local_weights, args, inits=None, group=None, want_
     if inits is None:
         inits = broadcast_inits(n_multi, plan.n_haps, args.init_alpha, plan.dev, group)
     inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
-    props_cur, props_new, states = sharded_em_loop(plan, inits, args.tolerance, args.max_iter,
-                                                   group=group, check_every=check_every)
-    return _em.collect_result(plan, inits, props_cur, props_new, states, want_read_mix)
+    ln_cur, ln_new, states = sharded_em_loop(plan, inits, args.tolerance, args.max_iter,
+                                             group=group, check_every=check_every)
+    return _em.collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix)
 
 
 def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_read_mix=True):
@@ -131,13 +134,12 @@ def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_rea
     run_props = torch.zeros((n_multi, n_haps), dtype=torch.float64, device=plan.dev)
     fold = None
     if mine:
-        props_cur, props_new, states = _em.em_loop(plan, inits[mine], args.tolerance, args.max_iter)
-        with numpy.errstate(divide="ignore"):
-            ln_k = numpy.log(props_cur.cpu().numpy())
-        ln_sum += torch.log(props_new).sum(dim=0)
+        ln_cur, ln_new, states = _em.em_loop(plan, inits[mine], args.tolerance, args.max_iter)
+        ln_k = ln_cur.cpu().numpy()
+        ln_sum += ln_new.sum(dim=0)
         for j, run in enumerate(mine):
             iters[run] = states[j][1]
-            run_props[run] = props_new[j]
+            run_props[run] = torch.exp(ln_new[j])
             if want_read_mix:
                 fold = _em.posterior(plan, ln_k[j], out=fold, fold=(j > 0))
     if world > 1:

@@ -12,10 +12,10 @@ or ROCm tensors (stay resident; `read_mix` comes back as a device tensor).
 
 How the loop runs on the device (DESIGN.md has the derivation):
   * once per run_em:  P = exp(M - rowmax)            (mxm_linearize)
-  * per iteration:    Z_r = sum_h p_h P_rh ; colsum_h = p_h sum_r w_r P_rh / Z_r
+  * per iteration:    Z_r = sum_h p_h P_rh ; T_h = sum_r w_r P_rh / Z_r
                       (mxm_em_iter, one read of P, no transcendental)
-                      p' = colsum / sum colsum ; L1 test ; loop state on device
-                      (mxm_m_finalize)
+                      ln p' = ln p + ln T - ln sum_h p T ; L1 test ; loop state on device,
+                      kept as LOG proportions like the reference's (mxm_m_finalize)
   * after the loop:   posterior under theta_k in log space from M itself
                       (mxm_em_step), folded over runs with logaddexp.
 All restarts of a multi-run advance in one device loop (mxm_em_loop); their
@@ -177,8 +177,9 @@ class EmPlan(object):
     def read_state(self, state):
         return read_state(state)
 
-    def em_iter(self, props, state, colsum):
-        """Enqueue one fused E+M step for every restart (mxm_em_iter)."""
+    def em_iter(self, props, ln_props, state, colsum):
+        """Enqueue one fused E+M step for every restart (mxm_em_iter): colsum <- the
+        unscaled column sums T (see include/mixemt_hip.h)."""
         m_ptr, ldm = self.mat_args()
         p_ptr, ldp = self.lin_args()
         if self.storage == "f32":
@@ -188,18 +189,17 @@ class EmPlan(object):
                                                 current_stream()), "mxm_em_iter_f32")
             return
         _lib.check(self.lib.mxm_em_iter(m_ptr, ldm, p_ptr, ldp, self.wts.data_ptr(),
-                                        props.data_ptr(), self.n_rows, self.n_haps,
-                                        props.shape[0], ptr(state), colsum.data_ptr(),
+                                        props.data_ptr(), ln_props.data_ptr(), self.n_rows,
+                                        self.n_haps, props.shape[0], ptr(state), colsum.data_ptr(),
                                         self.ws.data_ptr(), self.ws_bytes, current_stream()),
                    "mxm_em_iter")
 
-    def finalize(self, colsum, props_cur, props_new, state, tol, max_iter):
+    def finalize(self, colsum, ln_cur, ln_new, props_cur, state, tol, max_iter):
         """Enqueue the M-step normalisation + convergence test (mxm_m_finalize)."""
-        _lib.check(self.lib.mxm_m_finalize(colsum.data_ptr(), props_cur.data_ptr(),
-                                           props_new.data_ptr(), self.n_haps,
-                                           props_cur.shape[0], float(tol), int(max_iter),
-                                           state.data_ptr(), current_stream()),
-                   "mxm_m_finalize")
+        _lib.check(self.lib.mxm_m_finalize(colsum.data_ptr(), ln_cur.data_ptr(), ln_new.data_ptr(),
+                                           props_cur.data_ptr(), self.n_haps, props_cur.shape[0],
+                                           float(tol), int(max_iter), state.data_ptr(),
+                                           current_stream()), "mxm_m_finalize")
 
 
 def new_state(n_runs, dev):
@@ -215,38 +215,47 @@ def read_state(state):
     return [(s.done, s.iters, s.l1) for s in arr]
 
 
+def log_inits(inits):
+    """Initial LOG proportions exactly as the reference forms them (numpy.log on the host,
+    em.py:123-124) and the linear copy the streaming kernel multiplies with."""
+    with numpy.errstate(divide="ignore"):
+        ln0 = numpy.log(numpy.ascontiguousarray(inits, dtype=numpy.float64))
+    return ln0, numpy.exp(ln0)
+
+
 def em_loop(plan, inits, tolerance, max_iter, check_every=16):
     """
     The run_em inner loop (em.py:126-143) for all restarts at once on one GPU.
     inits: [B][H] linear initial proportions.  Returns
-    (props_cur = theta_k, props_new = theta_{k+1}, [(done, iters, l1)] per run).
+    (ln_cur = log theta_k, ln_new = log theta_{k+1}, [(done, iters, l1)] per run).
     """
     lib, dev = plan.lib, plan.dev
-    inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
-    n_runs, n_haps = inits.shape
-    props_cur = torch.from_numpy(inits).to(dev)
-    props_new = props_cur.clone()
+    ln0, p0 = log_inits(inits)
+    n_runs, n_haps = ln0.shape
+    props_cur = torch.from_numpy(p0).to(dev)
+    ln_cur = torch.from_numpy(ln0).to(dev)
+    ln_new = ln_cur.clone()
     colsum = torch.zeros_like(props_cur)
     state = new_state(n_runs, dev)
     host_state = (_lib.EmState * n_runs)()
     if max_iter > 0 and plan.storage == "f32":
         p_ptr, ldp = plan.lin_args()
         _lib.check(lib.mxm_em_loop_f32(p_ptr, ldp, plan.wts.data_ptr(), plan.n_rows, n_haps, n_runs,
-                                       props_cur.data_ptr(), props_new.data_ptr(), colsum.data_ptr(),
-                                       state.data_ptr(), float(tolerance), int(max_iter),
-                                       int(check_every), plan.ws.data_ptr(), plan.ws_bytes,
-                                       current_stream(), host_state), "mxm_em_loop_f32")
+                                       props_cur.data_ptr(), ln_cur.data_ptr(), ln_new.data_ptr(),
+                                       colsum.data_ptr(), state.data_ptr(), float(tolerance),
+                                       int(max_iter), int(check_every), plan.ws.data_ptr(),
+                                       plan.ws_bytes, current_stream(), host_state), "mxm_em_loop_f32")
     elif max_iter > 0:
         m_ptr, ldm = plan.mat_args()
         p_ptr, ldp = plan.lin_args()
         _lib.check(lib.mxm_em_loop(m_ptr, ldm, p_ptr, ldp, plan.wts.data_ptr(), plan.n_rows,
-                                   n_haps, n_runs, props_cur.data_ptr(), props_new.data_ptr(),
-                                   colsum.data_ptr(), state.data_ptr(), float(tolerance),
-                                   int(max_iter), int(check_every), plan.ws.data_ptr(),
-                                   plan.ws_bytes, current_stream(), host_state),
+                                   n_haps, n_runs, props_cur.data_ptr(), ln_cur.data_ptr(),
+                                   ln_new.data_ptr(), colsum.data_ptr(), state.data_ptr(),
+                                   float(tolerance), int(max_iter), int(check_every),
+                                   plan.ws.data_ptr(), plan.ws_bytes, current_stream(), host_state),
                    "mxm_em_loop")
     states = [(s.done, s.iters, s.l1) for s in host_state]
-    return props_cur, props_new, states
+    return ln_cur, ln_new, states
 
 
 def posterior(plan, ln_theta, out=None, fold=False):
@@ -266,16 +275,16 @@ def posterior(plan, ln_theta, out=None, fold=False):
     return out
 
 
-def collect_result(plan, inits, props_cur, props_new, states, want_read_mix=True,
-                   verbose=False):
+def collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix=True, verbose=False):
     """
     What run_em does after its loops (em.py:145-165): posterior under theta_k
     per run, folded with logaddexp, minus log n; proportions = exp(mean of the
     runs' LOG proportions) -- a geometric mean that is not renormalised.
+    ln_cur / ln_new are the loop's log theta_k / log theta_{k+1}.
     """
     n_multi, n_haps = inits.shape
-    theta_k = props_cur.cpu().numpy()
-    theta_next = props_new.cpu().numpy()
+    ln_k = ln_cur.cpu().numpy()
+    ln_next = ln_new.cpu().numpy()
     if verbose:
         for run, (done, iters, _) in enumerate(states):
             sys.stderr.write("Starting EM run %d...\n" % (run + 1))
@@ -283,9 +292,6 @@ def collect_result(plan, inits, props_cur, props_new, states, want_read_mix=True
             if done == 1:
                 sys.stderr.write("\nConverged! (%d)\n" % iters)
     read_mix = None
-    with numpy.errstate(divide="ignore"):
-        ln_k = numpy.log(theta_k)
-        ln_next = numpy.log(theta_next)
     if want_read_mix:
         for run in range(n_multi):
             read_mix = posterior(plan, ln_k[run], out=read_mix, fold=(run > 0))
@@ -293,16 +299,14 @@ def collect_result(plan, inits, props_cur, props_new, states, want_read_mix=True
             _lib.check(plan.lib.mxm_add_scalar(read_mix.data_ptr(), read_mix.stride(0),
                                                plan.n_rows, n_haps, -math.log(n_multi),
                                                current_stream()), "mxm_add_scalar")
+    res = ln_next[0].copy()
     if n_multi > 1:
-        res = ln_next[0].copy()
         for run in range(1, n_multi):
-            res += ln_next[run]
+            res += ln_next[run]                       # em.py:155, in log space
         res /= n_multi
-        props = numpy.exp(res)
-    else:
-        props = theta_next[0].copy()
+    props = numpy.exp(res)                            # em.py:163
     return {"props": props, "read_mix": read_mix, "iters": [s[1] for s in states],
-            "done": [s[0] for s in states], "run_props": theta_next, "inits": inits,
+            "done": [s[0] for s in states], "run_props": numpy.exp(ln_next), "inits": inits,
             "l1": [s[2] for s in states]}
 
 
@@ -324,8 +328,8 @@ def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, stora
         inits = numpy.stack([init_props(plan.n_haps, alpha=args.init_alpha)
                              for _ in range(n_multi)])
     inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
-    props_cur, props_new, states = em_loop(plan, inits, args.tolerance, args.max_iter)
-    return collect_result(plan, inits, props_cur, props_new, states, want_read_mix,
+    ln_cur, ln_new, states = em_loop(plan, inits, args.tolerance, args.max_iter)
+    return collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix,
                           getattr(args, "verbose", False))
 
 

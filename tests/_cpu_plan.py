@@ -27,23 +27,24 @@ class CpuPlan(object):
     def read_state(self, state):
         return [(int(s[0]), int(s[1]), float(s[2])) for s in state]
 
-    def em_iter(self, props, state, colsum):
+    def em_iter(self, props, ln_props, state, colsum):
         self.calls += 1
         for b in range(props.shape[0]):
             if state is not None and state[b, 0] != 0:
                 continue
-            with numpy.errstate(divide="ignore"):
-                lnp = numpy.log(props[b].numpy())
+            lnp = ln_props[b].numpy()
             mix, _ = em_oracle.em_step(self.mat, self.wts, lnp, numpy.empty_like(self.mat))
-            colsum[b] = torch.from_numpy((self.wts[:, None] * numpy.exp(mix)).sum(axis=0))
+            # unscaled sums T_h = sum_r w_r exp(posterior_rh) / p_h
+            colsum[b] = torch.from_numpy((self.wts[:, None] * numpy.exp(mix - lnp[None, :])).sum(axis=0))
 
-    def finalize(self, colsum, props_cur, props_new, state, tol, max_iter):
+    def finalize(self, colsum, ln_cur, ln_new, props_cur, state, tol, max_iter):
         for b in range(props_cur.shape[0]):
             if state[b, 0] != 0:
                 continue
-            new = colsum[b] / colsum[b].sum()
-            props_new[b] = new
-            l1 = float((new - props_cur[b]).abs().sum())
+            total = float((props_cur[b] * colsum[b]).sum())
+            new = ln_cur[b] + torch.log(colsum[b]) - numpy.log(total)
+            ln_new[b] = new
+            l1 = float((torch.exp(new) - props_cur[b]).abs().sum())
             state[b, 1] += 1
             state[b, 2] = l1
             if l1 < tol:
@@ -51,4 +52,5 @@ class CpuPlan(object):
             elif state[b, 1] >= max_iter:
                 state[b, 0] = 2
             else:
-                props_cur[b] = new
+                ln_cur[b] = new
+                props_cur[b] = torch.exp(new)

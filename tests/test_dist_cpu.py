@@ -39,7 +39,7 @@ def test_single_process_loop_matches_oracle_run():
     numpy.random.seed(3)
     props, _ = em_oracle.run_em(mat, wts, em_args(), trace=trace)
     assert states[0][0] == 1 and states[0][1] == trace[0]["iters"]
-    assert numpy.abs(new[0].numpy() - props).max() < 1e-12
+    assert numpy.abs(numpy.exp(new[0].numpy()) - props).max() < 1e-12
 
 
 def _free_port():
@@ -90,5 +90,5 @@ def test_two_rank_gloo_matches_single_process(tmp_path):
     cur, new, states = mdist.sharded_em_loop(CpuPlan(mat, wts), want_inits, 1e-4, 10000, check_every=7)
     assert [s[1] for s in states] == [int(s[1]) for s in res[0]["states"]]
     assert all(s[0] == 1 for s in states)
-    assert numpy.abs(new.numpy() - res[0]["new"]).max() < 1e-12
-    assert numpy.abs(cur.numpy() - res[0]["cur"]).max() < 1e-12
+    assert numpy.abs(numpy.exp(new.numpy()) - numpy.exp(res[0]["new"])).max() < 1e-12
+    assert numpy.abs(numpy.exp(cur.numpy()) - numpy.exp(res[0]["cur"])).max() < 1e-12

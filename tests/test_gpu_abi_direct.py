@@ -45,11 +45,12 @@ def test_padded_leading_dimensions_and_null_weights(lib):
     colsum = torch.zeros_like(p_d)
     nbytes = lib.mxm_workspace_bytes(n_rows, n_haps, 1)
     ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device="cuda")
-    rc = lib.mxm_em_iter(wide.data_ptr(), ldm, lin.data_ptr(), ldp, None, p_d.data_ptr(), n_rows, n_haps, 1,
-                         None, colsum.data_ptr(), ws.data_ptr(), nbytes, s)
+    lp_d = torch.log(p_d)
+    rc = lib.mxm_em_iter(wide.data_ptr(), ldm, lin.data_ptr(), ldp, None, p_d.data_ptr(), lp_d.data_ptr(),
+                         n_rows, n_haps, 1, None, colsum.data_ptr(), ws.data_ptr(), nbytes, s)
     assert rc == 0
     mix, new = em_oracle.em_step(host, numpy.ones(n_rows), numpy.log(props), numpy.empty_like(host))
-    got = colsum[0].cpu().numpy()
+    got = colsum[0].cpu().numpy() * props                     # the call returns the sums without p_h
     assert numpy.allclose(got / got.sum(), numpy.exp(new), rtol=0, atol=1e-13)
     out = torch.full((n_rows, ldo), 7.0, dtype=torch.float64, device="cuda")
     lnp = torch.from_numpy(numpy.log(props)).cuda()
@@ -64,15 +65,16 @@ def test_error_contract(lib):
     import torch
     x = torch.zeros(64, dtype=torch.float64, device="cuda")
     s = _stream()
-    assert lib.mxm_em_iter(x.data_ptr(), 8, None, 0, None, x.data_ptr(), 0, 8, 1, None, x.data_ptr(), None, 0, s) < 0
+    assert lib.mxm_em_iter(x.data_ptr(), 8, None, 0, None, x.data_ptr(), x.data_ptr(), 0, 8, 1, None,
+                           x.data_ptr(), None, 0, s) < 0
     assert b"mxm_em_iter" in lib.mxm_last_error()
     # odd ldp for the linear matrix
     assert lib.mxm_linearize(x.data_ptr(), 8, 8, 8, x.data_ptr(), 9, x.data_ptr(), s) < 0
     assert b"ldp" in lib.mxm_last_error()
     # workspace too small
     big = torch.zeros((4, 128), dtype=torch.float64, device="cuda")
-    assert lib.mxm_em_iter(big.data_ptr(), 128, big.data_ptr(), 128, None, big.data_ptr(), 4, 128, 1, None,
-                           big.data_ptr(), big.data_ptr(), 16, s) < 0
+    assert lib.mxm_em_iter(big.data_ptr(), 128, big.data_ptr(), 128, None, big.data_ptr(), big.data_ptr(), 4, 128,
+                           1, None, big.data_ptr(), big.data_ptr(), 16, s) < 0
     assert b"workspace" in lib.mxm_last_error()
     assert lib.mxm_set_batch_tile(7) < 0 and lib.mxm_set_batch_tile(3) == 0
     # build: lde not a multiple of 8

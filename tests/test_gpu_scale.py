@@ -30,12 +30,15 @@ def big(b17):
 
 
 def _one_iter(plan, props_host):
+    """M-step sums sum_r w_r posterior_rh of one fused iteration (= p_h times the kernel's
+    unscaled column sums)."""
     import torch
     props = torch.from_numpy(numpy.ascontiguousarray(props_host[None, :])).cuda()
+    ln_props = torch.log(props)
     colsum = torch.zeros_like(props)
-    plan.em_iter(props, None, colsum)
+    plan.em_iter(props, ln_props, None, colsum)
     torch.cuda.synchronize()
-    return colsum[0].cpu().numpy()
+    return (colsum[0] * props[0]).cpu().numpy()
 
 
 def test_matrix_rows_match_oracle_on_a_sample(big):
