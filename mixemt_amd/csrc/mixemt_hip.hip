@@ -372,6 +372,9 @@ extern "C" int mxm_em_iter(const double *M, int64_t ldm, const double *P, int64_
     for (int b = 0; b < B;) {
         int nb = B - b;
         if (nb > max_bt) nb = max_bt;
+        // never leave a single restart for a pass of its own when two passes of two do the
+        // same work (a pass costs about the same for 1, 2 or 3 restarts): 4 left -> 2 + 2
+        if (max_bt == 3 && B - b == 4) nb = 2;
         // a batch keeps nb proportion vectors in LDS: shrink the tile until they fit
         while (nb > 1 && batch_lds_bytes((int)H, nb) > MXM_LDS_BUDGET) --nb;
         const mxm_em_state *st = state ? state + b : nullptr;
