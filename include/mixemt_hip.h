@@ -236,6 +236,10 @@ int mxm_set_loop_graph(int32_t mode);
  */
 int mxm_set_batch_tile(int32_t bt);
 
+/* Tuning knob: shape of the single-restart streaming kernel (0: 256 threads, 2 workgroups per CU,
+ * register ring 2; 1: 512 threads, 1 workgroup per CU, ring 3).  Same results up to summation order. */
+int mxm_set_v1_shape(int32_t shape);
+
 /* Tuning knob: rows a workgroup of the streaming kernel handles at least (grid = min(cap, R / n)). */
 int mxm_set_min_rows_per_wg(int32_t n);
 

@@ -57,6 +57,7 @@ SIGNATURES = {
     "mxm_set_batch_tile": (ctypes.c_int, [c_i32]),
     "mxm_set_loop_graph": (ctypes.c_int, [c_i32]),
     "mxm_set_min_rows_per_wg": (ctypes.c_int, [c_i32]),
+    "mxm_set_v1_shape": (ctypes.c_int, [c_i32]),
     "mxm_row_argmax_votes": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                             c_ptr]),
 }

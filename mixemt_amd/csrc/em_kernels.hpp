@@ -134,13 +134,16 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
 #ifndef MXM_V1_P_LDS
 #define MXM_V1_P_LDS 0                // 1: the single-restart shape also keeps its proportions in LDS
 #endif
+#ifndef MXM_PIN_ACC
+#define MXM_PIN_ACC 0                 // 1 saves ~45 VGPRs (no third row copy) but measured equal or slower
+#endif
 #ifndef MXM_SCHED_FENCE
 #define MXM_SCHED_FENCE 0
 #endif
 // batched shapes run one workgroup per CU: min waves/SIMD = THREADS / 256
 
 template <int THREADS, int NCH, int BT, int NBUF>
-__global__ __launch_bounds__(THREADS, (BT == 1 ? MXM_V1_MINW : THREADS / 256)) void em_iter_wide_kernel(
+__global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW : THREADS / 256)) void em_iter_wide_kernel(
     const double *__restrict__ P, int64_t ldp, const double *__restrict__ w,
     const double *__restrict__ props, int64_t R, int H, int64_t rows_per_wg,
     double *__restrict__ partial, int64_t ldpart, const mxm_em_state *__restrict__ state) {
@@ -266,6 +269,17 @@ __global__ __launch_bounds__(THREADS, (BT == 1 ? MXM_V1_MINW : THREADS / 256)) v
             __builtin_amdgcn_sched_barrier(0);
 #endif
             process(x[j], r + j);
+#if MXM_PIN_ACC
+            // Pin the accumulator update HERE.  Left alone, the compiler sinks the post-barrier
+            // half of this row (1/Z, accumulate) below the next row's barrier and merges the two;
+            // this row's registers then stay live across the next loads, which costs a third
+            // copy of the row (+4 VGPRs per column chunk) and v_mov chains at the loop end.
+#pragma unroll
+            for (int b = 0; b < BT; ++b) {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) asm volatile("" : "+v"(acc[b][k].x), "+v"(acc[b][k].y)::"memory");
+            }
+#endif
 #if MXM_SCHED_FENCE
             __builtin_amdgcn_sched_barrier(0);
 #endif

@@ -157,6 +157,8 @@ extern "C" int mxm_linearize(const double *M, int64_t ldm, int64_t R, int32_t H,
 // ---- optional timing hook (bench.py): events recorded right around the dominant kernel --------
 static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static int g_min_rows_per_wg = 8;     // measured: 1000 x 5408 31 us/step (vs 39 at 2); no effect from 10^4 rows up
+static int g_v1_shape = 1;            // 0: 256 threads x 2 WG/CU, ring 2;  1: 512 threads x 1 WG/CU, ring 3
+                                      // (in-process A/B, profiles/r01/tune_sweep.txt: 6.43 vs 6.50 ms median)
 static int g_max_bt = 3;              // restarts per matrix pass (1..MXM_MAX_BT); see mxm_set_batch_tile
 extern "C" int mxm_set_timing_events(void *ev_start, void *ev_stop) {
     g_ev_start = (hipEvent_t)ev_start;
@@ -167,6 +169,12 @@ extern "C" int mxm_set_timing_events(void *ev_start, void *ev_stop) {
 extern "C" int mxm_set_min_rows_per_wg(int32_t n) {
     if (n < 1) return fail(-1, "mxm_set_min_rows_per_wg: n < 1%s", "");
     g_min_rows_per_wg = n;
+    return 0;
+}
+
+extern "C" int mxm_set_v1_shape(int32_t shape) {
+    if (shape < 0 || shape > 1) return fail(-1, "mxm_set_v1_shape: shape must be 0 or 1%s", "");
+    g_v1_shape = shape;
     return 0;
 }
 
@@ -200,6 +208,9 @@ extern "C" int mxm_set_batch_tile(int32_t bt) {
 #ifndef MXM_V3_NBUF
 #define MXM_V3_NBUF 2
 #endif
+// second single-restart shape, selectable at run time (mxm_set_v1_shape) for in-process A/B runs
+#define MXM_V1B_THREADS 512
+#define MXM_V1B_NBUF 3
 #define MXM_MAX_BT 3                  // restarts sharing one read of the matrix
 #define MXM_MAX_COL2 4096             // column pairs per row the register tiling covers (H <= 8192)
 #define MXM_LDS_BUDGET (156 * 1024)   // of the CU's 160 KiB, leaving room for the exchange buffers
@@ -257,9 +268,10 @@ static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, co
                                hipStream_t stream, bool timed) {
     const int64_t ldpart = part_ld(H);
     const int ncol2 = (H + 1) / 2;
-    const int threads = variant_threads(nb);
-    const int nbuf = variant_nbuf(nb);
-    const int wg_per_cu = (nb == 1) ? MXM_V1_WG_PER_CU : 1;
+    const bool alt = (nb == 1) && (g_v1_shape == 1);        // the second single-restart shape
+    const int threads = alt ? MXM_V1B_THREADS : variant_threads(nb);
+    const int nbuf = alt ? MXM_V1B_NBUF : variant_nbuf(nb);
+    const int wg_per_cu = alt ? 1 : ((nb == 1) ? MXM_V1_WG_PER_CU : 1);
     const int nch = (ncol2 + threads - 1) / threads;
     int cap = num_cu() * wg_per_cu;
     if (cap > MXM_MAX_WG) cap = MXM_MAX_WG;
@@ -275,7 +287,9 @@ static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, co
                     (long long)rows_per_wg, (long long)ldp);
     if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
     int rc;
-    if (nb == 1)
+    if (alt)
+        rc = dispatch_wide<MXM_V1B_THREADS, 1, MXM_V1B_NBUF>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
+    else if (nb == 1)
         rc = dispatch_wide<MXM_V1_THREADS, 1, MXM_V1_NBUF>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
     else if (nb == 2)
         rc = dispatch_wide<MXM_V2_THREADS, 2, MXM_V2_NBUF>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
