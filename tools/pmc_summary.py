@@ -19,7 +19,7 @@ import json
 import sys
 
 # kernels whose reads are 16 B/lane coalesced streams (FETCH_SIZE x2 applies)
-WIDE_READERS = ("em_iter_wide_kernel", "em_iter_wide_f32_kernel", "estep_wide_kernel")
+WIDE_READERS = ("em_iter_wide_kernel", "em_iter_wide_f32_kernel", "estep_wide_kernel", "linearize_wide_kernel")
 
 
 def per_kernel(path):
