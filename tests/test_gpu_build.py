@@ -195,3 +195,21 @@ def test_tables_that_do_not_qualify_fall_back(b17, toy):
     assert numpy.array_equal(got, g["mat"])
     with pytest.raises(ValueError):
         preprocess.build_em_matrix_device(tables, rp, si, ob, kernel="packed")
+
+
+def test_prob_for_vars_closed_forms(toy):
+    """preprocess_test.py:76-95: sums of logs against closed-form products, custom mutation weights."""
+    import math
+    import torch
+    from mixemt_amd import preprocess
+    ref, phy, haps = toy
+    obs_i = ",".join("%d:%s" % (p, b) for p, b in zip(range(9), "GAAAAAAAA"))
+    for mut_max, want in ((0.10, {"I": 0.9 ** 9, "C": (0.9 ** 7) * ((0.1 / 3) ** 2),
+                                  "D": (0.9 ** 5) * ((0.1 / 3) ** 4)}),
+                          (0.50, {"I": (0.9 ** 7) * (0.8 ** 2),
+                                  "C": (0.9 ** 5) * (0.8 ** 2) * ((0.1 / 3) ** 2)})):
+        tables = preprocess.HapVarTables.build(ref, phy, haps, mut_wt=0.10, mut_max=mut_max)
+        rp, si, ob = preprocess.encode_signatures([obs_i], tables)
+        row = preprocess.build_em_matrix_device(tables, rp, si, ob).cpu().numpy()[0]
+        for hap, prob in want.items():
+            assert abs(row[haps.index(hap)] - math.log(prob)) < 1e-7          # assertAlmostEqual (7 places)

@@ -118,3 +118,16 @@ def test_reduce_em_matrix_numpy():
     mat = numpy.arange(12.0).reshape(3, 4)
     sub, names = preprocess.reduce_em_matrix(mat, list("WXYZ"), [["hap1", "Y", 0.7], ["hap2", "W", 0.3]])
     assert names == ["W", "Y"] and numpy.array_equal(sub, mat[:, [0, 2]])
+
+
+def test_mutation_weight_scaling_reference_cases(toy):
+    """preprocess_test.py:52-74: hit = 1 - mu, miss = mu / 3 with mu = min(mut_max, mut_wt * count)."""
+    import math
+    ref, phy, haps = toy
+    flat = preprocess.HapVarTables.build(ref, phy, haps, mut_wt=0.10, mut_max=0.10)
+    assert numpy.array_equal(flat.lhit, numpy.array([math.log(1.0 - 0.1)] * 9))
+    assert numpy.array_equal(flat.lmiss, numpy.array([math.log(0.1 / 3.0)] * 9))
+    scaled = preprocess.HapVarTables.build(ref, phy, haps, mut_wt=0.10, mut_max=0.50)
+    # sites 3 and 4 (0-based) carry two mutation events in the toy tree
+    for pos, mu in ((0, 0.1), (3, 0.2), (4, 0.2), (2, 0.1)):
+        assert scaled.lhit[pos] == math.log(1.0 - mu) and scaled.lmiss[pos] == math.log(mu / 3.0)
