@@ -257,6 +257,21 @@ def load_build17(refseq=None, anon_haps=True, rm_unstable=False,
                          rm_unstable=rm_unstable, rm_backmut=rm_backmut)
 
 
+def load_rcrs():
+    """The revised Cambridge Reference Sequence shipped beside RSRS (reference: mixemt/ref/)."""
+    return read_fasta_first(os.path.join(_DATA_DIR, "rCRS.mtDNA.fa.gz"))
+
+
+def load_build16(refseq=None, anon_haps=True, rm_unstable=False, rm_backmut=False):
+    """Phylotree Build 16, the older tree the reference also ships (mixemt/phylotree/README.md)."""
+    if refseq is None:
+        refseq = load_rsrs()
+    path = os.path.join(_DATA_DIR, "mtDNA_tree_Build_16.csv.gz")
+    with gzip.open(path, "rt") as fin:
+        return Phylotree(fin, refseq=refseq, anon_haps=anon_haps, rm_unstable=rm_unstable,
+                         rm_backmut=rm_backmut)
+
+
 def example():
     """The 9-haplogroup toy tree used throughout the reference's tests
     (em_test.py:78-88); data, restated here for the parity tests."""

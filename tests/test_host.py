@@ -131,3 +131,25 @@ def test_mutation_weight_scaling_reference_cases(toy):
     # sites 3 and 4 (0-based) carry two mutation events in the toy tree
     for pos, mu in ((0, 0.1), (3, 0.2), (4, 0.2), (2, 0.1)):
         assert scaled.lhit[pos] == math.log(1.0 - mu) and scaled.lmiss[pos] == math.log(mu / 3.0)
+
+
+def test_other_trees_and_flags_match_reference_digests():
+    """Build 16, named-only, stable-only and strict variants of the tree parse to exactly what the
+    reference's parser produces (digests in g0b), and both shipped reference sequences are intact."""
+    import hashlib
+    g = golden("g0b_trees")
+    rsrs, rcrs = phylotree.load_rsrs(), phylotree.load_rcrs()
+    assert hashlib.sha256(rsrs.encode()).hexdigest() == str(g["rsrs_sha256"])
+    assert hashlib.sha256(rcrs.encode()).hexdigest() == str(g["rcrs_sha256"])
+    cases = (("b16", phylotree.load_build16(rsrs)),
+             ("b17_named", phylotree.load_build17(rsrs, anon_haps=False)),
+             ("b17_stable", phylotree.load_build17(rsrs, rm_unstable=True)),
+             ("b17_strict", phylotree.load_build17(rsrs, rm_unstable=True, rm_backmut=True)))
+    for tag, tree in cases:
+        names = sorted(tree.hap_var)
+        text = "\n".join("%s\t%s" % (n, ",".join(tree.hap_var[n])) for n in names)
+        counts = "\n".join("%d\t%s" % (p, ",".join("%s=%d" % kv for kv in sorted(tree.variants[p].items())))
+                           for p in sorted(tree.variants))
+        assert len(names) == int(g[tag + "_n_haps"]) and len(tree.variants) == int(g[tag + "_n_sites"])
+        assert hashlib.sha256(text.encode()).hexdigest() == str(g[tag + "_hap_var_sha256"]), tag
+        assert hashlib.sha256(counts.encode()).hexdigest() == str(g[tag + "_variants_sha256"]), tag

@@ -10,6 +10,7 @@ tests/golden/.  Only the fixtures travel; no reference code does.
 
 Fixtures (SURVEY.md section 8 c):
     g0  Build-17 + RSRS tables: haplogroup order, sites, mut_prob, sparse markers
+    g0b digests of the other shipped tree / flag combinations and of both reference sequences
     g1  9-haplogroup toy tree: signatures -> matrix, run_em for seeds x n_multi
     g2  Build 17: 32 synthetic rows -> full matrix; 1000 more rows -> row stats
     g3  em_step on 64 x 5408 (+ the two exact -inf cases of em_test.py:35-65)
@@ -126,6 +127,29 @@ def main():
              ref_codes=numpy.array([ord(refseq[p]) for p in sites], dtype=numpy.uint8),
              dense_sha256=numpy.array(sha(dense)),
              n_haps=numpy.array(len(haps)), n_sites=numpy.array(len(sites)))
+
+    if want("g0b"):
+        # the other shipped tree / flag combinations: digests of what the reference parses
+        out = {}
+        for tag, fn, kw in (("b16", "mtDNA_tree_Build_16.csv", dict(anon_haps=True)),
+                            ("b17_named", "mtDNA_tree_Build_17.csv", dict(anon_haps=False)),
+                            ("b17_stable", "mtDNA_tree_Build_17.csv", dict(anon_haps=True, rm_unstable=True)),
+                            ("b17_strict", "mtDNA_tree_Build_17.csv",
+                             dict(anon_haps=True, rm_unstable=True, rm_backmut=True))):
+            with open(os.path.join(REF, "mixemt/phylotree", fn)) as fin:
+                tree = ref.phylotree.Phylotree(fin, refseq=refseq, **kw)
+            names = sorted(tree.hap_var)
+            text = "\n".join("%s\t%s" % (n, ",".join(tree.hap_var[n])) for n in names)
+            counts = "\n".join("%d\t%s" % (p, ",".join("%s=%d" % kv for kv in sorted(tree.variants[p].items())))
+                               for p in sorted(tree.variants))
+            out[tag + "_n_haps"] = numpy.array(len(names))
+            out[tag + "_n_sites"] = numpy.array(len(tree.variants))
+            out[tag + "_hap_var_sha256"] = numpy.array(hashlib.sha256(text.encode()).hexdigest())
+            out[tag + "_variants_sha256"] = numpy.array(hashlib.sha256(counts.encode()).hexdigest())
+        rcrs = my_phy.read_fasta_first(os.path.join(REF, "mixemt/ref/rCRS.mtDNA.fa"))
+        out["rcrs_sha256"] = numpy.array(hashlib.sha256(rcrs.encode()).hexdigest())
+        out["rsrs_sha256"] = numpy.array(hashlib.sha256(refseq.encode()).hexdigest())
+        save("g0b_trees", **out)
 
     if want("g1"):
         toy = ref.phylotree.example()
