@@ -381,3 +381,27 @@ def test_f32_storage_iterations_vs_oracle(n_rows, n_haps, seed):
     for _ in range(4):
         buf, theta = em_oracle.em_step(mat, wts, theta, buf)
     assert numpy.abs(res["props"] - numpy.exp(theta)).max() < 2e-7      # float storage of P: ~6e-8 relative
+
+
+def test_other_tree_end_to_end_vs_oracle():
+    """Build 16 (different H and S than the goldens' Build 17): matrix bit-exact, run within 1e-9."""
+    from mixemt_amd import em, phylotree, preprocess, synth
+    from oracle import build_oracle
+    refseq = phylotree.load_rsrs()
+    phy = phylotree.load_build16(refseq)
+    haps = sorted(phy.hap_var)
+    tables = preprocess.HapVarTables.build(refseq, phy, haps)
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 300, seed=21, contrib=(5, 1500, 3000))
+    mat = preprocess.build_em_matrix_device(tables, row_ptr, site, obs)
+    flat = build_oracle.flat_tables(refseq, phy, haps)
+    want = c_oracle.build_em_matrix(flat[1], flat[2], flat[3], row_ptr, site, obs, len(haps))
+    assert numpy.array_equal(mat.cpu().numpy(), want)
+    wts = numpy.ones(300)
+    numpy.random.seed(3)
+    res = em.run_em_ex(mat, wts, em_args(max_iter=60))
+    trace = []
+    numpy.random.seed(3)
+    props, mix = em_oracle.run_em(want, wts, em_args(max_iter=60), trace=trace)
+    assert res["iters"] == [trace[0]["iters"]]
+    assert numpy.abs(res["props"] - props).max() < 1e-9
+    assert numpy.array_equal(res["read_mix"].argmax(dim=1).cpu().numpy(), mix.argmax(axis=1))
