@@ -88,8 +88,8 @@ def main():
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--rows", type=int, default=1000000, help="reads (matrix rows) per GPU")
-    ap.add_argument("--cpu-rows", type=int, default=16384)
-    ap.add_argument("--cpu-iters", type=int, default=2)
+    ap.add_argument("--cpu-rows", type=int, default=32768)
+    ap.add_argument("--cpu-iters", type=int, default=4)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--restarts", type=int, default=1,
