@@ -96,14 +96,15 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8)
 
 
 def run_em_sharded(local_mat, local_weights, args, inits=None, group=None, want_read_mix=True,
-                   check_every=8):
+                   check_every=8, storage=None):
     """
     run_em (em.py:94-165) over a matrix whose rows are spread over the ranks of
     `group`; each rank passes ITS row block and gets back the global proportions
     plus ITS block of the posterior matrix.  Same dict as em.run_em_ex.
     """
     n_multi = int(args.n_multi)
-    plan = _em.EmPlan(local_mat, local_weights, n_runs=n_multi)
+    plan = _em.EmPlan(local_mat, local_weights, n_runs=n_multi,
+                      storage=storage or getattr(args, "storage", "f64"))
     if inits is None:
         inits = broadcast_inits(n_multi, plan.n_haps, args.init_alpha, plan.dev, group)
     inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
