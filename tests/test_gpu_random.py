@@ -121,3 +121,21 @@ def test_random_consumers_vs_numpy(seed):
             continue                                           # -inf - -inf: NaN in the reference too
         name = contribs[order[0]][0] if ok else "unassigned"
         assert r in table[name], (r, vals, name)
+
+
+@pytest.mark.parametrize("n_rows,n_haps", [(1, 2), (1, 70), (2, 64), (3, 65), (1, 5408), (7, 8191)])
+def test_degenerate_shapes(n_rows, n_haps):
+    """Single rows, two columns, the switch-over width between the two loop kernels."""
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(n_rows * 10007 + n_haps)
+    mat = rng.normal(-20.0, 5.0, size=(n_rows, n_haps))
+    wts = rng.integers(1, 4, size=n_rows)
+    args = em_args(max_iter=25, n_multi=2)
+    numpy.random.seed(4)
+    res = em.run_em_ex(mat, wts, args)
+    trace = []
+    numpy.random.seed(4)
+    props, mix = em_oracle.run_em(mat, wts, args, trace=trace)
+    assert res["iters"] == [t["iters"] for t in trace]
+    assert numpy.abs(res["props"] - props).max() < 1e-10
+    assert numpy.allclose(res["read_mix"].cpu().numpy(), mix, rtol=0, atol=1e-8)
