@@ -42,3 +42,16 @@ def as_device(x, dtype, dev):
 
 def ptr(t):
     return 0 if t is None else t.data_ptr()
+
+
+def device_empty(shape, dtype, dev, what):
+    """torch.empty on the device; running out of HBM becomes the ValueError the reference's
+    CLI reports and exits on (bin/mixemt:325-327) instead of a torch-specific exception."""
+    try:
+        return torch.empty(shape, dtype=dtype, device=dev)
+    except torch.cuda.OutOfMemoryError as exc:
+        need = 1
+        for n in (shape if isinstance(shape, (tuple, list)) else (shape,)):
+            need *= int(n)
+        raise ValueError("not enough device memory for %s (%.1f GB): %s"
+                         % (what, need * torch.empty(0, dtype=dtype).element_size() / 1e9, exc))

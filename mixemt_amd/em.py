@@ -30,7 +30,7 @@ import sys
 import numpy
 
 from . import _lib
-from ._dev import as_device, current_stream, ptr, require_gpu, torch
+from ._dev import as_device, current_stream, device_empty, ptr, require_gpu, torch
 
 
 def init_props(nhaps, alpha=1.0):
@@ -139,14 +139,14 @@ class EmPlan(object):
             self.rowmax = torch.empty(self.n_rows, dtype=torch.float64, device=self.dev)
             if storage == "f32":
                 ldp = (self.n_haps + 3) // 4 * 4
-                self.lin = torch.empty((self.n_rows, ldp), dtype=torch.float32, device=self.dev)
+                self.lin = device_empty((self.n_rows, ldp), torch.float32, self.dev, "the linearised matrix")
                 _lib.check(self.lib.mxm_linearize_f32(self.mat.data_ptr(), self.mat.stride(0),
                                                       self.n_rows, self.n_haps, self.lin.data_ptr(),
                                                       self.lin.stride(0), self.rowmax.data_ptr(),
                                                       current_stream()), "mxm_linearize_f32")
             else:
                 ldp = (self.n_haps + 1) // 2 * 2
-                self.lin = torch.empty((self.n_rows, ldp), dtype=torch.float64, device=self.dev)
+                self.lin = device_empty((self.n_rows, ldp), torch.float64, self.dev, "the linearised matrix")
                 _lib.check(self.lib.mxm_linearize(self.mat.data_ptr(), self.mat.stride(0),
                                                   self.n_rows, self.n_haps, self.lin.data_ptr(),
                                                   self.lin.stride(0), self.rowmax.data_ptr(),
@@ -267,7 +267,7 @@ def posterior(plan, ln_theta, out=None, fold=False):
         raise ValueError("posterior pass needs the log matrix (keep_log_matrix=True)")
     lnp = as_device(ln_theta, torch.float64, plan.dev)
     if out is None:
-        out = torch.empty((plan.n_rows, plan.n_haps), dtype=torch.float64, device=plan.dev)
+        out = device_empty((plan.n_rows, plan.n_haps), torch.float64, plan.dev, "the posterior matrix")
     _lib.check(plan.lib.mxm_em_step(plan.mat.data_ptr(), plan.mat.stride(0), 0, lnp.data_ptr(),
                                     plan.n_rows, plan.n_haps, out.data_ptr(), out.stride(0),
                                     1 if fold else 0, 0, 0, 0, current_stream()),

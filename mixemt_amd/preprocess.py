@@ -24,7 +24,7 @@ import numpy
 
 from . import _lib
 from . import phylotree
-from ._dev import as_device, current_stream, require_gpu, torch
+from ._dev import as_device, current_stream, device_empty, require_gpu, torch
 
 MUT_WT = 0.01       # preprocess.py:39 defaults; not CLI flags (build_em_matrix :182)
 MUT_MAX = 0.5
@@ -197,7 +197,7 @@ def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto"):
         obs_d = as_device(obs, torch.uint8, dev)
         n_rows = row_ptr_d.numel() - 1
         if out is None:
-            out = torch.empty((n_rows, tables.n_haps), dtype=torch.float64, device=dev)
+            out = device_empty((n_rows, tables.n_haps), torch.float64, dev, "the EM input matrix")
         if n_rows == 0:
             return out
         _lib.check(lib.mxm_build_em_matrix_packed(
@@ -213,7 +213,7 @@ def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto"):
     n_rows = row_ptr_d.numel() - 1
     n_haps = tables.n_haps
     if out is None:
-        out = torch.empty((n_rows, n_haps), dtype=torch.float64, device=dev)
+        out = device_empty((n_rows, n_haps), torch.float64, dev, "the EM input matrix")
     if n_rows == 0:
         return out
     _lib.check(lib.mxm_build_em_matrix(

@@ -102,3 +102,11 @@ def test_em_loop_on_a_side_stream(lib):
         for _ in range(res["iters"][run]):
             buf, theta = em_oracle.em_step(mat, numpy.ones(200), theta, buf)
         assert numpy.abs(res["run_props"][run] - numpy.exp(theta)).max() < 1e-11
+
+
+def test_out_of_device_memory_is_a_value_error():
+    """A matrix that cannot fit reports ValueError (what bin/mixemt:325-327 catches), not a torch exception."""
+    import torch
+    from mixemt_amd._dev import device_empty
+    with pytest.raises(ValueError, match="not enough device memory"):
+        device_empty((60000000, 5408), torch.float64, torch.device("cuda"), "a 2.6 TB matrix")
