@@ -134,6 +134,9 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
 #ifndef MXM_V1_P_LDS
 #define MXM_V1_P_LDS 0                // 1: the single-restart shape also keeps its proportions in LDS
 #endif
+#ifndef MXM_LOAD_AUX
+#define MXM_LOAD_AUX 2                // cache policy of the row loads: 2 = non-temporal (streamed once per pass)
+#endif
 #ifndef MXM_PIN_ACC
 #define MXM_PIN_ACC 0                 // 1 saves ~45 VGPRs (no third row copy) but measured equal or slower
 #endif
@@ -206,9 +209,9 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW
 #pragma unroll
         for (int k = 0; k < NCH - 1; ++k)
             xr[k] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(
-                                               rsrc, voff, soff + k * THREADS * 16, 2 /* nt */));
+                                               rsrc, voff, soff + k * THREADS * 16, MXM_LOAD_AUX /* 2 = nt */));
         xr[NCH - 1] = __builtin_bit_cast(
-            d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, soff, 2 /* nt */));
+            d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, soff, MXM_LOAD_AUX /* 2 = nt */));
     };
 
     int buf = 0;
