@@ -600,9 +600,12 @@ extern "C" int mxm_em_step(const double *M, int64_t ldm, const double *w, const 
     const int nch = (H / 2 + 255) / 256;
     // register budget of estep_wide_kernel (spill-free instances only): 13 column chunks per
     // thread without the M-step sums, 10 with them
-    if (aligned && mxm_linear_supported(H) && nch <= (colsum != nullptr ? 10 : 13)) {
+    // the wide kernel addresses a workgroup's row block through one buffer descriptor (32-bit offsets)
+    const int wide_cap = num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG;
+    const bool range_ok = ((double)((R + wide_cap - 1) / wide_cap + 2) * (double)ldm * 8.0) < 2147483648.0;
+    if (aligned && range_ok && mxm_linear_supported(H) && nch <= (colsum != nullptr ? 10 : 13)) {
         // wide rows: one read + one write per cell, rows held in registers
-        int cap = num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG;
+        int cap = wide_cap;
         nwg = clamp_grid((R + 1) / 2, cap);
         int64_t rows_per_wg = (R + nwg - 1) / nwg;
         rows_per_wg = (rows_per_wg + 1) / 2 * 2;
