@@ -71,4 +71,25 @@ __device__ __forceinline__ double logaddexp_f64(double a, double b) {
     return d;                                                         // NaN
 }
 
+// ------------------------------------------------------------------------------------------
+// Row schedule of the streaming kernels: rows are DEALT round-robin over the workgroups --
+// step q of workgroup b is row b + q * grid -- so at any moment the whole grid reads one
+// contiguous window of grid * row_bytes (11 MB at 256 x 5408 fp64) that moves through the
+// matrix, evenly spread over the HBM channels whatever the physical placement of the buffer.
+// (Contiguous per-workgroup row blocks measured 0-10 % slower depending on the process /
+// allocation: 256 far-apart streams whose channel mix depends on the block stride;
+// profiles/r01/row_mapping.txt.)  A row is reached through its own buffer descriptor
+// (scalar work), so no workgroup ever needs a descriptor range beyond one row.
+// Requires gridDim.x <= R.
+// ------------------------------------------------------------------------------------------
+struct row_deal {
+    int64_t nq;                                     // steps (rows) of this workgroup
+    __device__ explicit row_deal(int64_t R) : nq((R - blockIdx.x + gridDim.x - 1) / gridDim.x) {}
+    __device__ bool live(int64_t q) const { return q < nq; }
+    // steps past the end re-read the workgroup's last row (their result is discarded)
+    __device__ int64_t row(int64_t q) const {
+        return (int64_t)blockIdx.x + (q < nq ? q : nq - 1) * (int64_t)gridDim.x;
+    }
+};
+
 #endif  // MIXEMT_COMMON_HPP

@@ -33,7 +33,7 @@ __global__ __launch_bounds__(ROW_THREADS) void linearize_kernel(const double *__
 // ------------------------------------------------------------------------------------------
 template <int NCH, typename ST>
 __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__restrict__ M, int64_t ldm,
-                                                                int64_t R, int H, int64_t rows_per_wg,
+                                                                int64_t R, int H,
                                                                 ST *__restrict__ P, int64_t ldp,
                                                                 double *__restrict__ rowmax) {
     constexpr int THREADS = 256, NW = THREADS / 64;
@@ -41,13 +41,9 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
     const int t = threadIdx.x;
     const int lane = t & 63, wv = t >> 6;
     const int ncol2 = H >> 1;
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
-    const int64_t r1 = (r0 + rows_per_wg < R) ? (r0 + rows_per_wg) : R;
-    if (r0 >= r1) return;
+    const row_deal deal(R);
 
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(M + r0 * ldm), 0,
-                                                        (int)((r1 - r0) * ldm * 8), 0x00020000);
     const int row_bytes = (int)(ldm * 8);
     const int voff = t * 16;
     int last_c2 = t + (NCH - 1) * THREADS;
@@ -56,17 +52,17 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
     const int voff_last = last_c2 * 16;
 
     d2 x[2][NCH];
-    auto load_row = [&](d2(&xr)[NCH], int64_t r) {
-        const int64_t rr = (r < r1) ? r : (r1 - 1);
-        const int soff = (int)(rr - r0) * row_bytes;
+    auto load_row = [&](d2(&xr)[NCH], int64_t q) {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(M + deal.row(q) * ldm), 0,
+                                                            row_bytes, 0x00020000);
 #pragma unroll
         for (int k = 0; k < NCH - 1; ++k)
             xr[k] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(
-                                               rsrc, voff, soff + k * THREADS * 16, 2));
-        xr[NCH - 1] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, soff, 2));
+                                               rsrc, voff, k * THREADS * 16, 2));
+        xr[NCH - 1] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, 0, 2));
     };
     int ring = 0;
-    auto process = [&](d2(&xr)[NCH], int64_t r) {
+    auto process = [&](d2(&xr)[NCH], int64_t q) {
         double m = -INFINITY;                   // a clamped lane repeats a real element: harmless for a max
 #pragma unroll
         for (int k = 0; k < NCH; ++k) m = fmax(m, fmax(xr[k].x, xr[k].y));
@@ -78,7 +74,8 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
 #pragma unroll
         for (int q = 1; q < NW; ++q) m = fmax(m, red[ring][q]);
         ring ^= 1;
-        if (r >= r1) return;
+        if (!deal.live(q)) return;
+        const int64_t r = deal.row(q);
         const double shift = isfinite(m) ? m : 0.0;
         if (t == 0) rowmax[r] = shift;
         ST *prow = P + r * ldp;
@@ -98,12 +95,12 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
         // pad columns [H, ldp) of P are zero by contract
         for (int c = H + t; c < (int)ldp; c += THREADS) prow[c] = (ST)0;
     };
-    load_row(x[0], r0);
-    for (int64_t r = r0; r < r1; r += 2) {
-        load_row(x[1], r + 1);
-        process(x[0], r);
-        load_row(x[0], r + 2);
-        process(x[1], r + 1);
+    load_row(x[0], 0);
+    for (int64_t q = 0; q < deal.nq; q += 2) {
+        load_row(x[1], q + 1);
+        process(x[0], q);
+        load_row(x[0], q + 2);
+        process(x[1], q + 1);
     }
 }
 
@@ -117,7 +114,7 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
 // which is em.py:80-88 with exp(M - rowmax) hoisted out of the loop:
 //   posterior_rh = p_h P_rh / Z_r,   colsum_h = sum_r w_r posterior_rh.
 //
-// A workgroup (256 threads) owns a contiguous block of rows.  Thread t owns the
+// Rows are dealt round-robin over the workgroups (row_deal, common.hpp).  Thread t owns the
 // double2 column pairs {t + 256 k}, k < NCH: one 16-byte load per pair per row
 // (a wave instruction covers 1 KiB contiguous), the row stays in VGPRs between
 // the dot product and the accumulation, so the matrix is read from HBM exactly
@@ -148,7 +145,7 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
 template <int THREADS, int NCH, int BT, int NBUF>
 __global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW : THREADS / 256)) void em_iter_wide_kernel(
     const double *__restrict__ P, int64_t ldp, const double *__restrict__ w,
-    const double *__restrict__ props, int64_t R, int H, int64_t rows_per_wg,
+    const double *__restrict__ props, int64_t R, int H,
     double *__restrict__ partial, int64_t ldpart, const mxm_em_state *__restrict__ state) {
     constexpr int NW = THREADS / 64;
     __shared__ double red[2][BT][NW];
@@ -183,18 +180,14 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW
         }
     }
 
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
-    const int64_t r1 = (r0 + rows_per_wg < R) ? (r0 + rows_per_wg) : R;
-    if (r0 >= r1) return;
+    const row_deal deal(R);                         // step q of this workgroup = row b + q * grid
 
-    // Row loads: buffer_load_dwordx4 through one descriptor over this workgroup's row block.
-    // Per-lane offset = one VGPR (t * 16), row and chunk offsets are scalar, so no 64-bit
-    // per-load addresses and no exec-masked branches: rows past the block and column pairs
-    // past the row are CLAMPED to a valid element instead of skipped -- a clamped row gets
-    // weight 0 below, a clamped column has p = 0 and its accumulator is never stored.
+    // Row loads: buffer_load_dwordx4 through a per-row descriptor (scalar registers only).
+    // Per-lane offset = one VGPR (t * 16), the chunk offset is an immediate, so no 64-bit
+    // per-load addresses and no exec-masked branches: steps past the workgroup's last row and
+    // column pairs past the row are CLAMPED to a valid element instead of skipped -- a clamped
+    // step gets weight 0 below, a clamped column has p = 0 and its accumulator is never stored.
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<double *>(P + r0 * ldp), 0, (int)((r1 - r0) * ldp * 8), 0x00020000);
     const int row_bytes = (int)(ldp * 8);
     const int voff = t * 16;
     int last_c2 = t + (NCH - 1) * THREADS;
@@ -203,19 +196,19 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW
 
     d2 x[NBUF][NCH];                                // register ring: NBUF - 1 rows in flight
 
-    auto load_row = [&](d2(&xr)[NCH], int64_t r) {
-        const int64_t rr = (r < r1) ? r : (r1 - 1);
-        const int soff = (int)(rr - r0) * row_bytes;
+    auto load_row = [&](d2(&xr)[NCH], int64_t q) {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(P + deal.row(q) * ldp), 0,
+                                                            row_bytes, 0x00020000);
 #pragma unroll
         for (int k = 0; k < NCH - 1; ++k)
             xr[k] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(
-                                               rsrc, voff, soff + k * THREADS * 16, MXM_LOAD_AUX /* 2 = nt */));
+                                               rsrc, voff, k * THREADS * 16, MXM_LOAD_AUX /* 2 = nt */));
         xr[NCH - 1] = __builtin_bit_cast(
-            d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, soff, MXM_LOAD_AUX /* 2 = nt */));
+            d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, 0, MXM_LOAD_AUX /* 2 = nt */));
     };
 
     int buf = 0;
-    auto process = [&](d2(&xr)[NCH], int64_t r) {
+    auto process = [&](d2(&xr)[NCH], int64_t q) {
         double d[BT];
         // keep the batch's proportions IN LDS: without this the loads are loop-invariant
         // and get hoisted back into (BT * NCH * 4) VGPRs
@@ -243,8 +236,7 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW
             for (int b = 0; b < BT; ++b) red[buf][b][wv] = d[b];
         }
         __syncthreads();
-        const bool live = r < r1;
-        const double wr = live ? (w != nullptr ? w[r] : 1.0) : 0.0;
+        const double wr = deal.live(q) ? (w != nullptr ? w[deal.row(q)] : 1.0) : 0.0;
 #pragma unroll
         for (int b = 0; b < BT; ++b) {
             double z = red[buf][b][0];
@@ -261,17 +253,17 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW
     };
 
 #pragma unroll
-    for (int j = 0; j < NBUF - 1; ++j) load_row(x[j], r0 + j);
-    for (int64_t r = r0; r < r1; r += NBUF) {
+    for (int j = 0; j < NBUF - 1; ++j) load_row(x[j], j);
+    for (int64_t q = 0; q < deal.nq; q += NBUF) {
 #pragma unroll
         for (int j = 0; j < NBUF; ++j) {
-            load_row(x[(j + NBUF - 1) % NBUF], r + j + NBUF - 1);
+            load_row(x[(j + NBUF - 1) % NBUF], q + j + NBUF - 1);
 #if MXM_SCHED_FENCE
             // keep the scheduler from hoisting these loads above the previous row's last
             // uses of the same ring slot (it would need a second register set for it)
             __builtin_amdgcn_sched_barrier(0);
 #endif
-            process(x[j], r + j);
+            process(x[j], q + j);
 #if MXM_PIN_ACC
             // Pin the accumulator update HERE.  Left alone, the compiler sinks the post-barrier
             // half of this row (1/Z, accumulate) below the next row's barrier and merges the two;
@@ -310,7 +302,7 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 template <int THREADS, int NCH, int NBUF>
 __global__ __launch_bounds__(THREADS, 2) void em_iter_wide_f32_kernel(
     const float *__restrict__ P, int64_t ldp, const double *__restrict__ w,
-    const double *__restrict__ props, int64_t R, int H, int64_t rows_per_wg,
+    const double *__restrict__ props, int64_t R, int H,
     double *__restrict__ partial, int64_t ldpart, const mxm_em_state *__restrict__ state) {
     constexpr int NW = THREADS / 64;
     __shared__ double red[2][NW];
@@ -329,13 +321,9 @@ __global__ __launch_bounds__(THREADS, 2) void em_iter_wide_f32_kernel(
             acc[k][e] = 0.0;
         }
     }
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
-    const int64_t r1 = (r0 + rows_per_wg < R) ? (r0 + rows_per_wg) : R;
-    if (r0 >= r1) return;
+    const row_deal deal(R);
 
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P + r0 * ldp), 0,
-                                                        (int)((r1 - r0) * ldp * 4), 0x00020000);
     const int row_bytes = (int)(ldp * 4);
     const int voff = t * 16;
     int last_c4 = t + (NCH - 1) * THREADS;
@@ -343,18 +331,18 @@ __global__ __launch_bounds__(THREADS, 2) void em_iter_wide_f32_kernel(
     const int voff_last = last_c4 * 16;
 
     f4 x[NBUF][NCH];
-    auto load_row = [&](f4(&xr)[NCH], int64_t r) {
-        const int64_t rr = (r < r1) ? r : (r1 - 1);
-        const int soff = (int)(rr - r0) * row_bytes;
+    auto load_row = [&](f4(&xr)[NCH], int64_t q) {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(P + deal.row(q) * ldp), 0,
+                                                            row_bytes, 0x00020000);
 #pragma unroll
         for (int k = 0; k < NCH - 1; ++k)
             xr[k] = __builtin_bit_cast(f4, (u4)__builtin_amdgcn_raw_buffer_load_b128(
-                                               rsrc, voff, soff + k * THREADS * 16, 2));
-        xr[NCH - 1] = __builtin_bit_cast(f4, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, soff, 2));
+                                               rsrc, voff, k * THREADS * 16, 2));
+        xr[NCH - 1] = __builtin_bit_cast(f4, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, 0, 2));
     };
 
     int buf = 0;
-    auto process = [&](f4(&xr)[NCH], int64_t r) {
+    auto process = [&](f4(&xr)[NCH], int64_t q) {
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
@@ -369,8 +357,7 @@ __global__ __launch_bounds__(THREADS, 2) void em_iter_wide_f32_kernel(
 #pragma unroll
         for (int q = 1; q < NW; ++q) z += red[buf][q];
         buf ^= 1;
-        const bool live = r < r1;
-        const double wr = live ? (w != nullptr ? w[r] : 1.0) : 0.0;
+        const double wr = deal.live(q) ? (w != nullptr ? w[deal.row(q)] : 1.0) : 0.0;
         const double c = (z > 0.0) ? wr / z : 0.0;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
@@ -386,12 +373,12 @@ __global__ __launch_bounds__(THREADS, 2) void em_iter_wide_f32_kernel(
     };
 
 #pragma unroll
-    for (int j = 0; j < NBUF - 1; ++j) load_row(x[j], r0 + j);
-    for (int64_t r = r0; r < r1; r += NBUF) {
+    for (int j = 0; j < NBUF - 1; ++j) load_row(x[j], j);
+    for (int64_t q = 0; q < deal.nq; q += NBUF) {
 #pragma unroll
         for (int j = 0; j < NBUF; ++j) {
-            load_row(x[(j + NBUF - 1) % NBUF], r + j + NBUF - 1);
-            process(x[j], r + j);
+            load_row(x[(j + NBUF - 1) % NBUF], q + j + NBUF - 1);
+            process(x[j], q + j);
         }
     }
     double *dst = partial + (int64_t)blockIdx.x * ldpart;

@@ -79,7 +79,7 @@ __global__ __launch_bounds__(ROW_THREADS) void estep_log_kernel(
 template <int NCH, bool COLSUM>
 __global__ __launch_bounds__(256, 2) void estep_wide_kernel(
     const double *__restrict__ M, int64_t ldm, const double *__restrict__ w,
-    const double *__restrict__ lnp_in, int64_t R, int H, int64_t rows_per_wg,
+    const double *__restrict__ lnp_in, int64_t R, int H,
     double *__restrict__ out, int64_t ldo, int mode, double *__restrict__ partial, int64_t ldpart) {
     constexpr int THREADS = 256, NW = THREADS / 64;
     __shared__ double red[2][2][NW];               // [ring][max|sum][wave]
@@ -87,9 +87,7 @@ __global__ __launch_bounds__(256, 2) void estep_wide_kernel(
     const int lane = t & 63, wv = t >> 6;
     const int ncol2 = H >> 1;
 
-    const int64_t r0 = (int64_t)blockIdx.x * rows_per_wg;
-    const int64_t r1 = (r0 + rows_per_wg < R) ? (r0 + rows_per_wg) : R;
-    if (r0 >= r1) return;
+    const row_deal deal(R);                         // step q of this workgroup = row b + q * grid
 
     // with the M-step sums the exponentials have to survive the second reduction: that variant
     // gives up the register double buffer (two workgroups per CU still overlap load and math)
@@ -107,8 +105,6 @@ __global__ __launch_bounds__(256, 2) void estep_wide_kernel(
     }
 
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
-    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(M + r0 * ldm), 0,
-                                                        (int)((r1 - r0) * ldm * 8), 0x00020000);
     const int row_bytes = (int)(ldm * 8);
     const int voff = t * 16;
     int last_c2 = t + (NCH - 1) * THREADS;
@@ -116,19 +112,20 @@ __global__ __launch_bounds__(256, 2) void estep_wide_kernel(
     const int voff_last = last_c2 * 16;
 
     d2 x[NBUF][NCH];
-    auto load_row = [&](d2(&xr)[NCH], int64_t r) {
-        const int64_t rr = (r < r1) ? r : (r1 - 1);
-        const int soff = (int)(rr - r0) * row_bytes;
+    auto load_row = [&](d2(&xr)[NCH], int64_t q) {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(M + deal.row(q) * ldm), 0,
+                                                            row_bytes, 0x00020000);
 #pragma unroll
         for (int k = 0; k < NCH - 1; ++k)
             xr[k] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(
-                                               rsrc, voff, soff + k * THREADS * 16, 2));
-        xr[NCH - 1] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, soff, 2));
+                                               rsrc, voff, k * THREADS * 16, 2));
+        xr[NCH - 1] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, 0, 2));
     };
 
     int ring = 0;
-    auto process = [&](d2(&xr)[NCH], int64_t r) {
-        const bool live = r < r1;
+    auto process = [&](d2(&xr)[NCH], int64_t q) {
+        const bool live = deal.live(q);
+        const int64_t r = deal.row(q);
         double m = -INFINITY;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
@@ -189,17 +186,17 @@ __global__ __launch_bounds__(256, 2) void estep_wide_kernel(
     };
 
     if constexpr (NBUF == 2) {
-        load_row(x[0], r0);
-        for (int64_t r = r0; r < r1; r += 2) {
-            load_row(x[1], r + 1);
-            process(x[0], r);
-            load_row(x[0], r + 2);
-            process(x[1], r + 1);
+        load_row(x[0], 0);
+        for (int64_t q = 0; q < deal.nq; q += 2) {
+            load_row(x[1], q + 1);
+            process(x[0], q);
+            load_row(x[0], q + 2);
+            process(x[1], q + 1);
         }
     } else {
-        for (int64_t r = r0; r < r1; ++r) {
-            load_row(x[0], r);
-            process(x[0], r);
+        for (int64_t q = 0; q < deal.nq; ++q) {
+            load_row(x[0], q);
+            process(x[0], q);
         }
     }
     if constexpr (COLSUM) {

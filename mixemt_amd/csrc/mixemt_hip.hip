@@ -118,13 +118,9 @@ static int linearize_wide(const double *M, int64_t ldm, int64_t R, int H, ST *P,
                           hipStream_t s) {
     const int nch = (H / 2 + 255) / 256;
     int cap = num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG;
-    int nwg = clamp_grid((R + 1) / 2, cap);
-    int64_t rows_per_wg = (R + nwg - 1) / nwg;
-    rows_per_wg = (rows_per_wg + 1) / 2 * 2;
-    nwg = (int)((R + rows_per_wg - 1) / rows_per_wg);
-    if ((double)rows_per_wg * (double)ldm * 8.0 >= 2147483648.0) return 1;      // caller falls back
+    const int nwg = clamp_grid((R + 1) / 2, cap);           // rows are dealt round-robin (row_deal)
     switch (nch) {
-#define LW_CASE(n) case n: hipLaunchKernelGGL((linearize_wide_kernel<n, ST>), dim3(nwg), dim3(256), 0, s, M, ldm, R, H, rows_per_wg, P, ldp, rowmax); break;
+#define LW_CASE(n) case n: hipLaunchKernelGGL((linearize_wide_kernel<n, ST>), dim3(nwg), dim3(256), 0, s, M, ldm, R, H, P, ldp, rowmax); break;
         LW_CASE(1) LW_CASE(2) LW_CASE(3) LW_CASE(4) LW_CASE(5) LW_CASE(6) LW_CASE(7) LW_CASE(8)
         LW_CASE(9) LW_CASE(10) LW_CASE(11) LW_CASE(12) LW_CASE(13) LW_CASE(14) LW_CASE(15) LW_CASE(16)
 #undef LW_CASE
@@ -200,7 +196,7 @@ extern "C" int mxm_set_batch_tile(int32_t bt) {
 #define MXM_V2_THREADS 512
 #endif
 #ifndef MXM_V2_NBUF
-#define MXM_V2_NBUF 3                 // measured: 6.22 ms vs 6.67 ms per pass at 1M x 5408 (profiles/r01/tune_sweep.txt)
+#define MXM_V2_NBUF 2                 // with dealt rows: 6.42 ms vs 6.85 ms (ring 3) per pass at 1M x 5408 (profiles/r01/row_mapping.txt)
 #endif
 #ifndef MXM_V3_THREADS
 #define MXM_V3_THREADS 512
@@ -216,7 +212,6 @@ extern "C" int mxm_set_batch_tile(int32_t bt) {
 #define MXM_LDS_BUDGET (156 * 1024)   // of the CU's 160 KiB, leaving room for the exchange buffers
 
 static inline int variant_threads(int nb) { return nb == 1 ? MXM_V1_THREADS : (nb == 2 ? MXM_V2_THREADS : MXM_V3_THREADS); }
-static inline int variant_nbuf(int nb) { return nb == 1 ? MXM_V1_NBUF : (nb == 2 ? MXM_V2_NBUF : MXM_V3_NBUF); }
 
 static size_t batch_lds_bytes(int H, int nb) {
     const int threads = variant_threads(nb);
@@ -226,7 +221,7 @@ static size_t batch_lds_bytes(int H, int nb) {
 
 template <int THREADS, int NCH, int BT, int NBUF>
 static int launch_wide(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
-                       int H, int grid, int64_t rows_per_wg, double *partial, int64_t ldpart,
+                       int H, int grid, double *partial, int64_t ldpart,
                        const mxm_em_state *state, hipStream_t stream) {
     if constexpr (NCH * THREADS > MXM_MAX_COL2) {
         return fail(-1, "mxm_em_iter: H=%s%lld outside the linear kernel's range", "", H);
@@ -243,17 +238,17 @@ static int launch_wide(const double *P, int64_t ldp, const double *w, const doub
             }
         }
         hipLaunchKernelGGL((em_iter_wide_kernel<THREADS, NCH, BT, NBUF>), dim3(grid), dim3(THREADS), lds,
-                           stream, P, ldp, w, props, R, H, rows_per_wg, partial, ldpart, state);
+                           stream, P, ldp, w, props, R, H, partial, ldpart, state);
         return 0;
     }
 }
 
 template <int THREADS, int BT, int NBUF>
 static int dispatch_wide(int nch, const double *P, int64_t ldp, const double *w, const double *props,
-                         int64_t R, int H, int grid, int64_t rows_per_wg, double *partial,
+                         int64_t R, int H, int grid, double *partial,
                          int64_t ldpart, const mxm_em_state *state, hipStream_t stream) {
     switch (nch) {
-#define WIDE_CASE(n) case n: return launch_wide<THREADS, n, BT, NBUF>(P, ldp, w, props, R, H, grid, rows_per_wg, partial, ldpart, state, stream);
+#define WIDE_CASE(n) case n: return launch_wide<THREADS, n, BT, NBUF>(P, ldp, w, props, R, H, grid, partial, ldpart, state, stream);
         WIDE_CASE(1) WIDE_CASE(2) WIDE_CASE(3) WIDE_CASE(4) WIDE_CASE(5) WIDE_CASE(6) WIDE_CASE(7) WIDE_CASE(8)
         WIDE_CASE(9) WIDE_CASE(10) WIDE_CASE(11) WIDE_CASE(12) WIDE_CASE(13) WIDE_CASE(14) WIDE_CASE(15) WIDE_CASE(16)
 #undef WIDE_CASE
@@ -270,31 +265,24 @@ static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, co
     const int ncol2 = (H + 1) / 2;
     const bool alt = (nb == 1) && (g_v1_shape == 1);        // the second single-restart shape
     const int threads = alt ? MXM_V1B_THREADS : variant_threads(nb);
-    const int nbuf = alt ? MXM_V1B_NBUF : variant_nbuf(nb);
     const int wg_per_cu = alt ? 1 : ((nb == 1) ? MXM_V1_WG_PER_CU : 1);
     const int nch = (ncol2 + threads - 1) / threads;
     int cap = num_cu() * wg_per_cu;
     if (cap > MXM_MAX_WG) cap = MXM_MAX_WG;
-    // small matrices: fewer, longer row blocks (every workgroup pays 2 x H x 8 bytes of
-    // proportion loads and partial stores, which colreduce then reads back)
-    int nwg = clamp_grid((R + g_min_rows_per_wg - 1) / g_min_rows_per_wg, cap);
-    int64_t rows_per_wg = (R + nwg - 1) / nwg;
-    rows_per_wg = (rows_per_wg + nbuf - 1) / nbuf * nbuf;
-    nwg = (int)((R + rows_per_wg - 1) / rows_per_wg);
-    // a workgroup addresses its row block through one buffer descriptor with 32-bit offsets
-    if ((double)rows_per_wg * (double)ldp * 8.0 >= 2147483648.0)
-        return fail(-1, "mxm_em_iter: %s%lld rows of %lld doubles per workgroup exceed the 2 GiB descriptor range", "",
-                    (long long)rows_per_wg, (long long)ldp);
+    // rows are dealt round-robin over the workgroups (row_deal, common.hpp).  Small matrices:
+    // fewer workgroups with more rows each (every workgroup pays 2 x H x 8 bytes of proportion
+    // loads and partial stores, which colreduce then reads back)
+    const int nwg = clamp_grid((R + g_min_rows_per_wg - 1) / g_min_rows_per_wg, cap);
     if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
     int rc;
     if (alt)
-        rc = dispatch_wide<MXM_V1B_THREADS, 1, MXM_V1B_NBUF>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V1B_THREADS, 1, MXM_V1B_NBUF>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
     else if (nb == 1)
-        rc = dispatch_wide<MXM_V1_THREADS, 1, MXM_V1_NBUF>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V1_THREADS, 1, MXM_V1_NBUF>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
     else if (nb == 2)
-        rc = dispatch_wide<MXM_V2_THREADS, 2, MXM_V2_NBUF>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V2_THREADS, 2, MXM_V2_NBUF>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
     else
-        rc = dispatch_wide<MXM_V3_THREADS, 3, MXM_V3_NBUF>(nch, P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V3_THREADS, 3, MXM_V3_NBUF>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
     if (rc != 0) return rc;
     HIP_TRY(hipGetLastError());
     if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
@@ -316,13 +304,13 @@ static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, co
 
 template <int NCH>
 static int launch_wide_f32(const float *P, int64_t ldp, const double *w, const double *props, int64_t R, int H,
-                           int grid, int64_t rows_per_wg, double *partial, int64_t ldpart,
+                           int grid, double *partial, int64_t ldpart,
                            const mxm_em_state *state, hipStream_t stream) {
     if constexpr (NCH * MXM_F32_THREADS > 2048) {
         return fail(-1, "mxm_em_iter_f32: H=%s%lld outside the kernel's range", "", H);
     } else {
         hipLaunchKernelGGL((em_iter_wide_f32_kernel<MXM_F32_THREADS, NCH, MXM_F32_NBUF>), dim3(grid),
-                           dim3(MXM_F32_THREADS), 0, stream, P, ldp, w, props, R, H, rows_per_wg, partial, ldpart,
+                           dim3(MXM_F32_THREADS), 0, stream, P, ldp, w, props, R, H, partial, ldpart,
                            state);
         return 0;
     }
@@ -336,13 +324,10 @@ static int em_iter_f32_one(const float *P, int64_t ldp, const double *w, const d
     const int nbuf = MXM_F32_NBUF;
     int cap = num_cu() * MXM_F32_WG_PER_CU;
     if (cap > MXM_MAX_WG) cap = MXM_MAX_WG;
-    int nwg = clamp_grid((R + nbuf - 1) / nbuf, cap);
-    int64_t rows_per_wg = (R + nwg - 1) / nwg;
-    rows_per_wg = (rows_per_wg + nbuf - 1) / nbuf * nbuf;
-    nwg = (int)((R + rows_per_wg - 1) / rows_per_wg);
+    const int nwg = clamp_grid((R + nbuf - 1) / nbuf, cap);
     if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
     switch (nch) {
-#define F32_CASE(n) case n: { const int lrc = launch_wide_f32<n>(P, ldp, w, props, R, H, nwg, rows_per_wg, partial, ldpart, state, stream); if (lrc != 0) return lrc; } break;
+#define F32_CASE(n) case n: { const int lrc = launch_wide_f32<n>(P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream); if (lrc != 0) return lrc; } break;
         F32_CASE(1) F32_CASE(2) F32_CASE(3) F32_CASE(4) F32_CASE(5) F32_CASE(6) F32_CASE(7) F32_CASE(8)
 #undef F32_CASE
         default: return fail(-1, "mxm_em_iter_f32: H=%s%lld outside the kernel's range", "", H);
@@ -574,14 +559,14 @@ extern "C" int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int
 
 template <int NCH>
 static void launch_estep_wide(const double *M, int64_t ldm, const double *w, const double *lnp, int64_t R, int H,
-                              int grid, int64_t rows_per_wg, double *out, int64_t ldo, int mode, double *partial,
+                              int grid, double *out, int64_t ldo, int mode, double *partial,
                               int64_t ldpart, hipStream_t s) {
     if (partial != nullptr)
         hipLaunchKernelGGL((estep_wide_kernel<NCH, true>), dim3(grid), dim3(256), 0, s, M, ldm, w, lnp, R, H,
-                           rows_per_wg, out, ldo, mode, partial, ldpart);
+                           out, ldo, mode, partial, ldpart);
     else
         hipLaunchKernelGGL((estep_wide_kernel<NCH, false>), dim3(grid), dim3(256), 0, s, M, ldm, w, lnp, R, H,
-                           rows_per_wg, out, ldo, mode, partial, ldpart);
+                           out, ldo, mode, partial, ldpart);
 }
 
 extern "C" int mxm_em_step(const double *M, int64_t ldm, const double *w, const double *ln_props, int64_t R,
@@ -600,18 +585,12 @@ extern "C" int mxm_em_step(const double *M, int64_t ldm, const double *w, const 
     const int nch = (H / 2 + 255) / 256;
     // register budget of estep_wide_kernel (spill-free instances only): 13 column chunks per
     // thread without the M-step sums, 10 with them
-    // the wide kernel addresses a workgroup's row block through one buffer descriptor (32-bit offsets)
     const int wide_cap = num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG;
-    const bool range_ok = ((double)((R + wide_cap - 1) / wide_cap + 2) * (double)ldm * 8.0) < 2147483648.0;
-    if (aligned && range_ok && mxm_linear_supported(H) && nch <= (colsum != nullptr ? 10 : 13)) {
+    if (aligned && mxm_linear_supported(H) && nch <= (colsum != nullptr ? 10 : 13)) {
         // wide rows: one read + one write per cell, rows held in registers
-        int cap = wide_cap;
-        nwg = clamp_grid((R + 1) / 2, cap);
-        int64_t rows_per_wg = (R + nwg - 1) / nwg;
-        rows_per_wg = (rows_per_wg + 1) / 2 * 2;
-        nwg = (int)((R + rows_per_wg - 1) / rows_per_wg);
+        nwg = clamp_grid((R + 1) / 2, wide_cap);            // rows are dealt round-robin (row_deal)
         switch (nch) {
-#define EW_CASE(n) case n: launch_estep_wide<n>(M, ldm, w, ln_props, R, (int)H, nwg, rows_per_wg, out, ldo, (int)mode, partial, ldpart, s); break;
+#define EW_CASE(n) case n: launch_estep_wide<n>(M, ldm, w, ln_props, R, (int)H, nwg, out, ldo, (int)mode, partial, ldpart, s); break;
             EW_CASE(1) EW_CASE(2) EW_CASE(3) EW_CASE(4) EW_CASE(5) EW_CASE(6) EW_CASE(7) EW_CASE(8)
             EW_CASE(9) EW_CASE(10) EW_CASE(11) EW_CASE(12) EW_CASE(13) EW_CASE(14) EW_CASE(15) EW_CASE(16)
 #undef EW_CASE
