@@ -95,7 +95,7 @@ def main():
     ap.add_argument("--restarts", type=int, default=1,
                     help="EM restarts advanced together (config 3 uses 10); a step then is one "
                          "iteration of EVERY restart and value counts cells x restarts")
-    ap.add_argument("--batch-tile", type=int, default=3,
+    ap.add_argument("--batch-tile", type=int, default=4,
                     help="restarts sharing one pass over the matrix (1 = unbatched schedule)")
     ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
                     help="element type of the streamed matrix; f32 is a labelled opt-in variant "

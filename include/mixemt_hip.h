@@ -230,8 +230,9 @@ int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_per_cu, int32
 int mxm_set_loop_graph(int32_t mode);
 
 /*
- * How many restarts share one pass over the matrix in mxm_em_iter (1..3,
- * default 3).  1 reproduces the unbatched schedule (B passes per iteration).
+ * How many restarts at most share one pass over the matrix in mxm_em_iter (1..4,
+ * default 4; B restarts take ceil(B / tile) passes with the restarts spread evenly:
+ * 10 -> 4 + 3 + 3).  1 reproduces the unbatched schedule (B passes per iteration).
  * Results do not depend on it beyond rounding of the reduction order.
  */
 int mxm_set_batch_tile(int32_t bt);

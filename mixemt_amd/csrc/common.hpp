@@ -62,6 +62,72 @@ __device__ __forceinline__ double block_reduce(double v, double *scratch) {
     return r;
 }
 
+// ------------------------------------------------------------------------------------------
+// Second stage of a workgroup-wide sum for the streaming kernel: `red` holds N groups of NW
+// per-wave partials (NW = 4 or 8, laid out [group][wave]).  Every wave fetches ONE partial per
+// lane (lanes >= N * NW re-read element 0), sums each group of NW lanes with three DPP steps and
+// hands the per-group results back in SGPRs (v_readlane) -- 2 VGPRs per wave instead of the
+// 2 * N * NW each thread needs when it reads all partials itself (48 at 3 restarts x 8 waves:
+// that was the peak of the kernel's register pressure, and what kept the batched shapes from a
+// third ring slot).  Fixed tree order -> deterministic.  Needs the full wave active.
+// ------------------------------------------------------------------------------------------
+template <int CTRL>
+__device__ __forceinline__ double dpp_mov_f64(double v) {
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xf, 0xf, true);
+    hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xf, 0xf, true);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double readlane_f64(double v, int src_lane) {
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), src_lane);
+    const int hi = __builtin_amdgcn_readlane(__double2hiint(v), src_lane);
+    return __hiloint2double(hi, lo);
+}
+// Wave-wide sum by DPP only (no LDS-crossbar permutes): four in-row steps leave every lane with
+// the sum of its row of 16, row_bcast:15 / row_bcast:31 then fold the four rows; the TOTAL is
+// valid in lane 63 only.  ~6 x (2 v_mov_dpp + v_add_f64) against 6 dependent ds_bpermute round
+// trips for the xor butterfly -- this sits on the per-row critical path of the streaming kernel.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_mov_old_f64(double old, double v) {   // masked-out rows get `old`
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(__double2loint(old), lo, CTRL, ROW_MASK, 0xf, false);
+    hi = __builtin_amdgcn_update_dpp(__double2hiint(old), hi, CTRL, ROW_MASK, 0xf, false);
+    return __hiloint2double(hi, lo);
+}
+__device__ __forceinline__ double wave_sum_lane63(double v) {
+    v += dpp_mov_f64<0xB1>(v);                      // lane ^ 1
+    v += dpp_mov_f64<0x4E>(v);                      // lane ^ 2
+    v += dpp_mov_f64<0x141>(v);                     // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);                     // row_mirror: every lane = its row's sum
+    v += dpp_mov_old_f64<0x142, 0xA>(0.0, v);       // row_bcast:15 into rows 1 and 3
+    v += dpp_mov_old_f64<0x143, 0xC>(0.0, v);       // row_bcast:31 into rows 2 and 3
+    return v;
+}
+__device__ __forceinline__ double wave_max_lane63(double v) {
+    v = fmax(v, dpp_mov_f64<0xB1>(v));
+    v = fmax(v, dpp_mov_f64<0x4E>(v));
+    v = fmax(v, dpp_mov_f64<0x141>(v));
+    v = fmax(v, dpp_mov_f64<0x140>(v));
+    v = fmax(v, dpp_mov_old_f64<0x142, 0xA>(v, v));
+    v = fmax(v, dpp_mov_old_f64<0x143, 0xC>(v, v));
+    return v;
+}
+
+// Returns c[g] = (sum_g > 0) ? num / sum_g : 0 -- the one fp64 division runs once per wave for
+// all groups (they sit in different lanes) instead of once per group.
+template <int NW, int N>
+__device__ __forceinline__ void group_ratio_to_sgpr(const double *red, int lane, double num, double (&c)[N]) {
+    static_assert(NW == 4 || NW == 8, "waves per workgroup");
+    static_assert(N * NW <= 64, "one partial per lane");
+    double v = red[lane < N * NW ? lane : 0];
+    v += dpp_mov_f64<0xB1>(v);                      // quad_perm [1,0,3,2]: lane ^ 1
+    v += dpp_mov_f64<0x4E>(v);                      // quad_perm [2,3,0,1]: lane ^ 2
+    if constexpr (NW == 8) v += dpp_mov_f64<0x141>(v);   // row_half_mirror: lane i <-> 7 - i
+    v = (v > 0.0) ? num / v : 0.0;
+#pragma unroll
+    for (int g = 0; g < N; ++g) c[g] = readlane_f64(v, g * NW);
+}
+
 __device__ __forceinline__ double logaddexp_f64(double a, double b) {
     // numpy.logaddexp semantics (em.py:156)
     if (a == b) return a + 0.693147180559945309417232121458176568;   // covers +-inf ties

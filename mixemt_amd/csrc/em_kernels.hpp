@@ -66,9 +66,8 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
         double m = -INFINITY;                   // a clamped lane repeats a real element: harmless for a max
 #pragma unroll
         for (int k = 0; k < NCH; ++k) m = fmax(m, fmax(xr[k].x, xr[k].y));
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
-        if (lane == 0) red[ring][wv] = m;
+        m = wave_max_lane63(m);
+        if (lane == 63) red[ring][wv] = m;
         __syncthreads();
         m = red[ring][0];
 #pragma unroll
@@ -128,8 +127,8 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
 #ifndef MXM_V1_MINW
 #define MXM_V1_MINW 2                 // min waves/SIMD the BT = 1 shape is compiled for (2 WGs of 256 per CU)
 #endif
-#ifndef MXM_V1_P_LDS
-#define MXM_V1_P_LDS 0                // 1: the single-restart shape also keeps its proportions in LDS
+#ifndef MXM_DPP_REDUCE
+#define MXM_DPP_REDUCE 1                // in-wave sum by DPP (1) or by the ds_bpermute xor butterfly (0)
 #endif
 #ifndef MXM_LOAD_AUX
 #define MXM_LOAD_AUX 2                // cache policy of the row loads: 2 = non-temporal (streamed once per pass)
@@ -142,7 +141,8 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
 #endif
 // batched shapes run one workgroup per CU: min waves/SIMD = THREADS / 256
 
-template <int THREADS, int NCH, int BT, int NBUF>
+// PREG of the BT restarts keep their proportions in VGPRs, the other BT - PREG in LDS.
+template <int THREADS, int NCH, int BT, int NBUF, int PREG>
 __global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW : THREADS / 256)) void em_iter_wide_kernel(
     const double *__restrict__ P, int64_t ldp, const double *__restrict__ w,
     const double *__restrict__ props, int64_t R, int H,
@@ -160,12 +160,13 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW
     const int lane = t & 63, wv = t >> 6;
     const int ncol2 = (H + 1) >> 1;                 // d2 pairs per row (pad column is 0 in P)
 
-    // proportions: registers for a single restart; for a batch they sit in LDS as
+    // proportions: registers for a single restart; a batch keeps (most of) them in LDS as
     // [b][k][thread] pairs (one conflict-free ds_read_b128 per use) so that the VGPR
-    // budget goes to the accumulators and the row double buffer
+    // budget goes to the accumulators and the row ring
+    static_assert(PREG >= 0 && PREG <= BT, "restarts with register-resident proportions");
     extern __shared__ d2 lds_p[];
-    constexpr bool P_IN_LDS = (BT > 1) || (MXM_V1_P_LDS != 0);
-    d2 p[P_IN_LDS ? 1 : NCH], acc[BT][NCH];
+    constexpr bool P_IN_LDS = PREG < BT;
+    d2 p[PREG > 0 ? PREG : 1][NCH], acc[BT][NCH];
 #pragma unroll
     for (int b = 0; b < BT; ++b) {
 #pragma unroll
@@ -174,8 +175,8 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW
             d2 v;
             v.x = (c < H) ? props[(int64_t)b * H + c] : 0.0;
             v.y = (c + 1 < H) ? props[(int64_t)b * H + c + 1] : 0.0;
-            if constexpr (!P_IN_LDS) p[k] = v;
-            else lds_p[(b * NCH + k) * THREADS + t] = v;
+            if (b < PREG) p[b < PREG ? b : 0][k] = v;
+            else lds_p[((b - PREG) * NCH + k) * THREADS + t] = v;
             acc[b][k] = d2{0.0, 0.0};
         }
     }
@@ -219,13 +220,21 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 d2 pk;
-                if constexpr (!P_IN_LDS) pk = p[k];
-                else pk = lds_p[(b * NCH + k) * THREADS + t];     // own slot: no barrier needed
+                if (b < PREG) pk = p[b < PREG ? b : 0][k];
+                else pk = lds_p[((b - PREG) * NCH + k) * THREADS + t];     // own slot: no barrier needed
                 s = fma(xr[k].x, pk.x, s);
                 s = fma(xr[k].y, pk.y, s);
             }
             d[b] = s;
         }
+#if MXM_DPP_REDUCE
+#pragma unroll
+        for (int b = 0; b < BT; ++b) d[b] = wave_sum_lane63(d[b]);
+        if (lane == 63) {
+#pragma unroll
+            for (int b = 0; b < BT; ++b) red[buf][b][wv] = d[b];
+        }
+#else
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) {
 #pragma unroll
@@ -235,14 +244,14 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW
 #pragma unroll
             for (int b = 0; b < BT; ++b) red[buf][b][wv] = d[b];
         }
+#endif
         __syncthreads();
         const double wr = deal.live(q) ? (w != nullptr ? w[deal.row(q)] : 1.0) : 0.0;
+        double cs[BT];                                  // w_r / Z_r per restart
+        group_ratio_to_sgpr<NW, BT>(&red[buf][0][0], lane, wr, cs);
 #pragma unroll
         for (int b = 0; b < BT; ++b) {
-            double z = red[buf][b][0];
-#pragma unroll
-            for (int q = 1; q < NW; ++q) z += red[buf][b][q];
-            const double c = (z > 0.0) ? wr / z : 0.0;
+            const double c = cs[b];
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 acc[b][k].x = fma(c, xr[k].x, acc[b][k].x);
@@ -349,16 +358,14 @@ __global__ __launch_bounds__(THREADS, 2) void em_iter_wide_f32_kernel(
 #pragma unroll
             for (int e = 0; e < 4; ++e) s = fma((double)xr[k][e], p[k][e], s);
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) s += __shfl_xor(s, off, 64);
-        if (lane == 0) red[buf][wv] = s;
+        s = wave_sum_lane63(s);
+        if (lane == 63) red[buf][wv] = s;
         __syncthreads();
-        double z = red[buf][0];
-#pragma unroll
-        for (int q = 1; q < NW; ++q) z += red[buf][q];
-        buf ^= 1;
         const double wr = deal.live(q) ? (w != nullptr ? w[deal.row(q)] : 1.0) : 0.0;
-        const double c = (z > 0.0) ? wr / z : 0.0;
+        double cs[1];
+        group_ratio_to_sgpr<NW, 1>(&red[buf][0], lane, wr, cs);
+        const double c = cs[0];
+        buf ^= 1;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
 #pragma unroll

@@ -133,9 +133,8 @@ __global__ __launch_bounds__(256, 2) void estep_wide_kernel(
             xr[k].y += lp[k].y;
             m = fmax(m, fmax(xr[k].x, xr[k].y));
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) m = fmax(m, __shfl_xor(m, off, 64));
-        if (lane == 0) red[ring][0][wv] = m;
+        m = wave_max_lane63(m);
+        if (lane == 63) red[ring][0][wv] = m;
         __syncthreads();
         m = red[ring][0][0];
 #pragma unroll
@@ -149,9 +148,8 @@ __global__ __launch_bounds__(256, 2) void estep_wide_kernel(
             if constexpr (COLSUM) e[k] = d2{ex, ey};
             ssum += ex + ey;
         }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) ssum += __shfl_xor(ssum, off, 64);
-        if (lane == 0) red[ring][1][wv] = ssum;
+        ssum = wave_sum_lane63(ssum);
+        if (lane == 63) red[ring][1][wv] = ssum;
         __syncthreads();
         ssum = red[ring][1][0];
 #pragma unroll

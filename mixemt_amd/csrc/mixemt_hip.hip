@@ -54,7 +54,7 @@ extern "C" int mxm_linear_supported(int32_t H) {
 extern "C" size_t mxm_workspace_bytes(int64_t R, int32_t H, int32_t B) {
     (void)R;
     (void)B;                      // restart tiles are processed one after another over the same scratch
-    return (size_t)MXM_MAX_WG * 3 * (size_t)part_ld(H) * sizeof(double);
+    return (size_t)MXM_MAX_WG * 4 /* MXM_MAX_BT */ * (size_t)part_ld(H) * sizeof(double);
 }
 
 extern "C" int mxm_build_em_matrix(const uint8_t *E, int64_t lde, const double *lhit,
@@ -155,7 +155,7 @@ static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static int g_min_rows_per_wg = 8;     // measured: 1000 x 5408 31 us/step (vs 39 at 2); no effect from 10^4 rows up
 static int g_v1_shape = 1;            // 0: 256 threads x 2 WG/CU, ring 2;  1: 512 threads x 1 WG/CU, ring 3
                                       // (in-process A/B, profiles/r01/tune_sweep.txt: 6.43 vs 6.50 ms median)
-static int g_max_bt = 3;              // restarts per matrix pass (1..MXM_MAX_BT); see mxm_set_batch_tile
+static int g_max_bt = 4;              // restarts per matrix pass (1..MXM_MAX_BT); see mxm_set_batch_tile
 extern "C" int mxm_set_timing_events(void *ev_start, void *ev_stop) {
     g_ev_start = (hipEvent_t)ev_start;
     g_ev_stop = (hipEvent_t)ev_stop;
@@ -175,7 +175,7 @@ extern "C" int mxm_set_v1_shape(int32_t shape) {
 }
 
 extern "C" int mxm_set_batch_tile(int32_t bt) {
-    if (bt < 1 || bt > 3) return fail(-1, "mxm_set_batch_tile: tile must be 1..3%s", "");
+    if (bt < 1 || bt > 4) return fail(-1, "mxm_set_batch_tile: tile must be 1..4%s", "");
     g_max_bt = bt;
     return 0;
 }
@@ -204,51 +204,87 @@ extern "C" int mxm_set_batch_tile(int32_t bt) {
 #ifndef MXM_V3_NBUF
 #define MXM_V3_NBUF 2
 #endif
+#ifndef MXM_V4_THREADS
+#define MXM_V4_THREADS 512
+#endif
+#ifndef MXM_V4_NBUF
+#define MXM_V4_NBUF 2
+#endif
+// restarts of a batch whose proportions stay in VGPRs (the rest sit in LDS: 160 KiB hold three
+// vectors of H = 5408, so four restarts per pass need one of them in registers)
+#ifndef MXM_V2_PREG
+#define MXM_V2_PREG 1
+#endif
+#ifndef MXM_V3_PREG
+#define MXM_V3_PREG 2
+#endif
+#ifndef MXM_V4_PREG
+#define MXM_V4_PREG 2
+#endif
 // second single-restart shape, selectable at run time (mxm_set_v1_shape) for in-process A/B runs
+#ifndef MXM_V1B_THREADS
 #define MXM_V1B_THREADS 512
+#endif
+#ifndef MXM_V1B_NBUF
 #define MXM_V1B_NBUF 3
-#define MXM_MAX_BT 3                  // restarts sharing one read of the matrix
+#endif
+#define MXM_MAX_BT 4                  // restarts sharing one read of the matrix
 #define MXM_MAX_COL2 4096             // column pairs per row the register tiling covers (H <= 8192)
 #define MXM_LDS_BUDGET (156 * 1024)   // of the CU's 160 KiB, leaving room for the exchange buffers
 
-static inline int variant_threads(int nb) { return nb == 1 ? MXM_V1_THREADS : (nb == 2 ? MXM_V2_THREADS : MXM_V3_THREADS); }
+static inline int variant_threads(int nb) {
+    return nb == 1 ? MXM_V1_THREADS : (nb == 2 ? MXM_V2_THREADS : (nb == 3 ? MXM_V3_THREADS : MXM_V4_THREADS));
+}
+static inline int variant_preg(int nb) {
+    return nb == 1 ? 1 : (nb == 2 ? MXM_V2_PREG : (nb == 3 ? MXM_V3_PREG : MXM_V4_PREG));
+}
 
 static size_t batch_lds_bytes(int H, int nb) {
     const int threads = variant_threads(nb);
     const int nch = ((H + 1) / 2 + threads - 1) / threads;
-    return (size_t)nb * nch * threads * 16;
+    return (size_t)(nb - variant_preg(nb)) * nch * threads * 16;
 }
 
-template <int THREADS, int NCH, int BT, int NBUF>
+// A tile of nb restarts needs its LDS-resident proportions to fit and a spill-free kernel
+// instance (scratch in the row loop costs 2-5x): column chunks per thread up to which the default
+// shapes compile without scratch (-Rpass-analysis=kernel-resource-usage), per tile size.
+static bool batch_fits(int H, int nb) {
+    if (nb <= 1) return true;
+    static const int max_nch[MXM_MAX_BT + 1] = {0, 16, 8, 7, 6};
+    const int threads = variant_threads(nb);
+    const int nch = ((H + 1) / 2 + threads - 1) / threads;
+    return nch <= max_nch[nb] && batch_lds_bytes(H, nb) <= MXM_LDS_BUDGET;
+}
+
+template <int THREADS, int NCH, int BT, int NBUF, int PREG>
 static int launch_wide(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
                        int H, int grid, double *partial, int64_t ldpart,
                        const mxm_em_state *state, hipStream_t stream) {
     if constexpr (NCH * THREADS > MXM_MAX_COL2) {
         return fail(-1, "mxm_em_iter: H=%s%lld outside the linear kernel's range", "", H);
     } else {
-        const bool p_in_lds = (BT > 1) || (MXM_V1_P_LDS != 0);
-        const size_t lds = p_in_lds ? (size_t)BT * NCH * THREADS * sizeof(d2) : 0;
-        if (p_in_lds) {
+        const size_t lds = (size_t)(BT - PREG) * NCH * THREADS * sizeof(d2);
+        if (lds > 0) {
             static bool raised = false;     // > 64 KiB of dynamic LDS must be opted into, once per kernel
             if (!raised) {
                 (void)hipFuncSetAttribute(
-                    reinterpret_cast<const void *>(&em_iter_wide_kernel<THREADS, NCH, BT, NBUF>),
+                    reinterpret_cast<const void *>(&em_iter_wide_kernel<THREADS, NCH, BT, NBUF, PREG>),
                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
                 raised = true;
             }
         }
-        hipLaunchKernelGGL((em_iter_wide_kernel<THREADS, NCH, BT, NBUF>), dim3(grid), dim3(THREADS), lds,
+        hipLaunchKernelGGL((em_iter_wide_kernel<THREADS, NCH, BT, NBUF, PREG>), dim3(grid), dim3(THREADS), lds,
                            stream, P, ldp, w, props, R, H, partial, ldpart, state);
         return 0;
     }
 }
 
-template <int THREADS, int BT, int NBUF>
+template <int THREADS, int BT, int NBUF, int PREG>
 static int dispatch_wide(int nch, const double *P, int64_t ldp, const double *w, const double *props,
                          int64_t R, int H, int grid, double *partial,
                          int64_t ldpart, const mxm_em_state *state, hipStream_t stream) {
     switch (nch) {
-#define WIDE_CASE(n) case n: return launch_wide<THREADS, n, BT, NBUF>(P, ldp, w, props, R, H, grid, partial, ldpart, state, stream);
+#define WIDE_CASE(n) case n: return launch_wide<THREADS, n, BT, NBUF, PREG>(P, ldp, w, props, R, H, grid, partial, ldpart, state, stream);
         WIDE_CASE(1) WIDE_CASE(2) WIDE_CASE(3) WIDE_CASE(4) WIDE_CASE(5) WIDE_CASE(6) WIDE_CASE(7) WIDE_CASE(8)
         WIDE_CASE(9) WIDE_CASE(10) WIDE_CASE(11) WIDE_CASE(12) WIDE_CASE(13) WIDE_CASE(14) WIDE_CASE(15) WIDE_CASE(16)
 #undef WIDE_CASE
@@ -276,13 +312,15 @@ static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, co
     if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
     int rc;
     if (alt)
-        rc = dispatch_wide<MXM_V1B_THREADS, 1, MXM_V1B_NBUF>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V1B_THREADS, 1, MXM_V1B_NBUF, 1>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
     else if (nb == 1)
-        rc = dispatch_wide<MXM_V1_THREADS, 1, MXM_V1_NBUF>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V1_THREADS, 1, MXM_V1_NBUF, 1>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
     else if (nb == 2)
-        rc = dispatch_wide<MXM_V2_THREADS, 2, MXM_V2_NBUF>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V2_THREADS, 2, MXM_V2_NBUF, MXM_V2_PREG>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
+    else if (nb == 3)
+        rc = dispatch_wide<MXM_V3_THREADS, 3, MXM_V3_NBUF, MXM_V3_PREG>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
     else
-        rc = dispatch_wide<MXM_V3_THREADS, 3, MXM_V3_NBUF>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V4_THREADS, 4, MXM_V4_NBUF, MXM_V4_PREG>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
     if (rc != 0) return rc;
     HIP_TRY(hipGetLastError());
     if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
@@ -367,15 +405,16 @@ extern "C" int mxm_em_iter(const double *M, int64_t ldm, const double *P, int64_
     const bool linear = (P != nullptr) && mxm_linear_supported(H);
     // restarts are taken in tiles of up to g_max_bt that share one pass over the matrix; the
     // scratch is reused tile after tile (same stream, so the passes are ordered)
-    const int max_bt = linear ? g_max_bt : 1;
+    // a batch keeps (most of) its proportion vectors in LDS: the largest tile that fits
+    int max_bt = linear ? g_max_bt : 1;
+    while (max_bt > 1 && !batch_fits((int)H, max_bt)) --max_bt;
     for (int b = 0; b < B;) {
-        int nb = B - b;
-        if (nb > max_bt) nb = max_bt;
-        // never leave a single restart for a pass of its own when two passes of two do the
-        // same work (a pass costs about the same for 1, 2 or 3 restarts): 4 left -> 2 + 2
-        if (max_bt == 3 && B - b == 4) nb = 2;
-        // a batch keeps nb proportion vectors in LDS: shrink the tile until they fit
-        while (nb > 1 && batch_lds_bytes((int)H, nb) > MXM_LDS_BUDGET) --nb;
+        // the fewest passes that cover what is left, restarts spread evenly over them (a pass
+        // costs nearly the same for 1..4 restarts, a little more the fuller it is):
+        // 10 -> 4 + 3 + 3, 5 -> 3 + 2, 8 -> 4 + 4
+        const int left = B - b;
+        const int passes = (left + max_bt - 1) / max_bt;
+        const int nb = (left + passes - 1) / passes;
         const mxm_em_state *st = state ? state + b : nullptr;
         int rc;
         if (linear)

@@ -76,7 +76,7 @@ def test_error_contract(lib):
     assert lib.mxm_em_iter(big.data_ptr(), 128, big.data_ptr(), 128, None, big.data_ptr(), big.data_ptr(), 4, 128,
                            1, None, big.data_ptr(), big.data_ptr(), 16, s) < 0
     assert b"workspace" in lib.mxm_last_error()
-    assert lib.mxm_set_batch_tile(7) < 0 and lib.mxm_set_batch_tile(3) == 0
+    assert lib.mxm_set_batch_tile(7) < 0 and lib.mxm_set_batch_tile(0) < 0 and lib.mxm_set_batch_tile(4) == 0
     # build: lde not a multiple of 8
     assert lib.mxm_build_em_matrix(x.data_ptr(), 7, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
                                    x.data_ptr(), 1, 5, 3, x.data_ptr(), 5, s) < 0

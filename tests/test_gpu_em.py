@@ -261,11 +261,12 @@ def test_row_argmax_votes_kernel(b17):
 
 
 @pytest.mark.parametrize("n_rows,n_haps,n_runs,seed", [(200, 5408, 3, 1), (150, 1000, 5, 2), (90, 8192, 3, 3),
-                                                      (64, 6200, 4, 4), (300, 66, 2, 5)])
+                                                      (64, 6200, 4, 4), (300, 66, 2, 5), (130, 5408, 4, 6),
+                                                      (77, 5408, 10, 7), (50, 4096, 7, 8)])
 def test_batched_restarts_share_matrix_reads(n_rows, n_haps, n_runs, seed):
     """
-    Restarts advance in tiles of up to 3 that share one pass over the matrix
-    (LDS-resident proportions).  Every restart must come out as if run alone:
+    Restarts advance in tiles of up to 4 that share one pass over the matrix
+    (proportions in LDS, the fourth restart's in registers).  Every restart must come out as if run alone:
     compared with the oracle and with the unbatched schedule (tile = 1).
     """
     from mixemt_amd import _lib, em
@@ -276,12 +277,14 @@ def test_batched_restarts_share_matrix_reads(n_rows, n_haps, n_runs, seed):
     inits = rng.dirichlet([1.0] * n_haps, size=n_runs)
     args = em_args(max_iter=4, tolerance=0.0, n_multi=n_runs)
     try:
-        lib.mxm_set_batch_tile(3)
+        lib.mxm_set_batch_tile(4)
         batched = em.run_em_ex(mat, wts, args, inits=inits, want_read_mix=False)
+        lib.mxm_set_batch_tile(3)
+        three = em.run_em_ex(mat, wts, args, inits=inits, want_read_mix=False)
         lib.mxm_set_batch_tile(1)
         single = em.run_em_ex(mat, wts, args, inits=inits, want_read_mix=False)
     finally:
-        lib.mxm_set_batch_tile(3)
+        lib.mxm_set_batch_tile(4)
     assert batched["iters"] == [4] * n_runs
     for run in range(n_runs):
         theta = numpy.log(inits[run])
@@ -290,6 +293,7 @@ def test_batched_restarts_share_matrix_reads(n_rows, n_haps, n_runs, seed):
             buf, theta = em_oracle.em_step(mat, wts, theta, buf)
         assert numpy.abs(batched["run_props"][run] - numpy.exp(theta)).max() < 1e-12
     assert numpy.abs(batched["run_props"] - single["run_props"]).max() < 1e-13
+    assert numpy.abs(three["run_props"] - single["run_props"]).max() < 1e-13
 
 
 def test_batched_restarts_stop_independently(b17):
@@ -306,7 +310,7 @@ def test_batched_restarts_stop_independently(b17):
             numpy.random.seed(11)
             out[tile] = em.run_em_ex(mat, g["wts"], em_args(n_multi=3), want_read_mix=False)
         finally:
-            lib.mxm_set_batch_tile(3)
+            lib.mxm_set_batch_tile(4)
         assert out[tile]["iters"] == list(g["iters"])
         assert numpy.abs(out[tile]["props"] - g["props"]).max() < PROPS_ATOL
 

@@ -36,9 +36,9 @@ libs = [bind(p) for p in paths]
 dev = torch.device("cuda")
 mat = torch.empty((rows, n_haps), dtype=torch.float64, device=dev).uniform_(-50.0, 0.0)
 wts = torch.ones(rows, dtype=torch.float64, device=dev)
-plan = em.EmPlan(mat, wts, n_runs=3)
+plan = em.EmPlan(mat, wts, n_runs=4)
 plan32 = em.EmPlan(mat, wts, n_runs=1, storage="f32") if "iter_f32" in ops else None
-init = numpy.random.default_rng(1).dirichlet([1.0] * n_haps, size=3)
+init = numpy.random.default_rng(1).dirichlet([1.0] * n_haps, size=4)
 ln0, p0 = em.log_inits(init)
 props, lnp = torch.from_numpy(p0).to(dev), torch.from_numpy(ln0).to(dev)
 colsum = torch.zeros_like(props)
