@@ -149,11 +149,12 @@ def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_rea
         dist.all_reduce(run_props, group=group)
     read_mix = None
     if want_read_mix:
-        lin = torch.exp(fold) if fold is not None else torch.zeros(
+        # in place: at 10^6 x 5408 every extra copy of the posterior is 43 GB
+        read_mix = fold.exp_() if fold is not None else torch.zeros(
             (plan.n_rows, n_haps), dtype=torch.float64, device=plan.dev)
         if world > 1:
-            dist.all_reduce(lin, group=group)
-        read_mix = torch.log(lin)
+            dist.all_reduce(read_mix, group=group)
+        read_mix.log_()
         if n_multi > 1:
             read_mix -= math.log(n_multi)
     props = torch.exp(ln_sum / n_multi).cpu().numpy() if n_multi > 1 else run_props[0].cpu().numpy()

@@ -409,3 +409,32 @@ def test_other_tree_end_to_end_vs_oracle():
     assert res["iters"] == [trace[0]["iters"]]
     assert numpy.abs(res["props"] - props).max() < 1e-9
     assert numpy.array_equal(res["read_mix"].argmax(dim=1).cpu().numpy(), mix.argmax(axis=1))
+
+
+@pytest.mark.parametrize("n_haps", [64, 1024, 1026, 2048, 3074, 4096, 5120, 5408, 6146, 7168, 7170, 8192])
+def test_streaming_kernel_shape_grid(n_haps):
+    """
+    One fused E+M step for every column-chunk count of the streaming kernel (H = 1024 k and
+    just past it) x row counts around the grid size (1, fewer rows than workgroups, one more
+    than a multiple) x 1..5 restarts per call (tiles of 1-4 + remainder), against the oracle's
+    em_step on the same inputs: colsum_b = exp(new_props_b) * sum(w).
+    """
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(n_haps)
+    for n_rows in (1, 2, 7, 255, 257, 1030):
+        mat = rng.normal(-20.0, 6.0, size=(n_rows, n_haps))
+        mat[rng.random(mat.shape) < 0.002] = -numpy.inf
+        wts = rng.integers(1, 4, size=n_rows).astype(numpy.float64)
+        n_runs = 1 + (n_rows % 5)
+        plan = em.EmPlan(mat, wts, n_runs=n_runs)
+        inits = rng.dirichlet([1.0] * n_haps, size=n_runs)
+        ln0, p0 = em.log_inits(inits)
+        props, lnp = plan.alloc_props(p0), plan.alloc_props(ln0)
+        colsum = plan.alloc_props(numpy.zeros_like(p0))
+        plan.em_iter(props, lnp, None, colsum)
+        got = (colsum * props).cpu().numpy()
+        for run in range(n_runs):
+            with numpy.errstate(divide="ignore"):
+                _, new = em_oracle.em_step(mat, wts, ln0[run], numpy.empty_like(mat))
+            want = numpy.exp(new) * wts.sum()
+            assert numpy.abs(got[run] - want).max() <= 1e-12 * wts.sum(), (n_rows, n_haps, run)
