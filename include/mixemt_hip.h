@@ -237,6 +237,14 @@ int mxm_set_loop_graph(int32_t mode);
  */
 int mxm_set_batch_tile(int32_t bt);
 
+/*
+ * mxm_em_loop keeps the restarts that are still running packed in the leading slots of the loop
+ * vectors (device-side slot exchanges, undone before it returns), so an iteration takes
+ * ceil(running / tile) passes over the matrix rather than ceil(B / tile).  1 (default) / 0.
+ * Results are the same either way: a stopped restart is frozen wherever it sits.
+ */
+int mxm_set_compact_restarts(int32_t on);
+
 /* Tuning knob: shape of the single-restart streaming kernel (0: 256 threads, 2 workgroups per CU,
  * register ring 2; 1: 512 threads, 1 workgroup per CU, ring 3).  Same results up to summation order. */
 int mxm_set_v1_shape(int32_t shape);

@@ -55,6 +55,7 @@ SIGNATURES = {
     "mxm_diag_stream_read": (ctypes.c_int, [c_ptr, c_size, c_i32, c_i32, c_ptr, c_ptr]),
     "mxm_set_timing_events": (ctypes.c_int, [c_ptr, c_ptr]),
     "mxm_set_batch_tile": (ctypes.c_int, [c_i32]),
+    "mxm_set_compact_restarts": (ctypes.c_int, [c_i32]),
     "mxm_set_loop_graph": (ctypes.c_int, [c_i32]),
     "mxm_set_min_rows_per_wg": (ctypes.c_int, [c_i32]),
     "mxm_set_v1_shape": (ctypes.c_int, [c_i32]),

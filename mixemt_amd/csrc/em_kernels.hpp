@@ -104,40 +104,32 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
 }
 
 // ------------------------------------------------------------------------------------------
-// K3  em_iter_wide: fused E+M step in linear space, one restart.
+// K3  em_iter_wide: fused E+M step in linear space, BT restarts per pass over the matrix.
 //
-//   Z_r      = sum_h p_h P_rh                     (row reduction)
-//   acc_h   += (w_r / Z_r) * P_rh                 (column accumulation, per workgroup)
-//   colsum_h = p_h * sum_wg acc_h                 (colreduce_kernel)
+//   Z_r[b]     = sum_h p_h[b] P_rh                  (row reduction, per restart)
+//   acc_h[b]  += (w_r / Z_r[b]) * P_rh              (column accumulation, per workgroup)
+//   T_h[b]     = sum_wg acc_h[b]                    (colreduce_kernel; finalize applies p_h)
 //
 // which is em.py:80-88 with exp(M - rowmax) hoisted out of the loop:
-//   posterior_rh = p_h P_rh / Z_r,   colsum_h = sum_r w_r posterior_rh.
+//   posterior_rh = p_h P_rh / Z_r,   colsum_h = sum_r w_r posterior_rh = p_h T_h.
 //
 // Rows are dealt round-robin over the workgroups (row_deal, common.hpp).  Thread t owns the
-// double2 column pairs {t + 256 k}, k < NCH: one 16-byte load per pair per row
-// (a wave instruction covers 1 KiB contiguous), the row stays in VGPRs between
-// the dot product and the accumulation, so the matrix is read from HBM exactly
-// once per iteration.  The next row's loads are issued before the current row's
-// reduction (register double buffer).  BT restarts can share each row: every
-// restart adds its own p / accumulator registers, the bytes read stay the same
-// (BT = 1: 256 threads, 2 workgroups per CU; BT = 2, 3: 512 threads, 1 per CU).
-// Column partials live in registers for the whole kernel and are written once:
-// partial[wg][h], summed in fixed order afterwards -> bitwise reproducible.
+// double2 column pairs {t + THREADS k}, k < NCH: one 16-byte buffer load per pair per row (a wave
+// instruction covers 1 KiB contiguous); the row stays in VGPRs between the dot products and the
+// accumulation, so the matrix is read from HBM exactly once per pass.  NBUF - 1 further rows are
+// in flight in a register ring.  Per row: dot products -> in-wave DPP sum -> one LDS exchange +
+// barrier -> w/Z through SGPRs (group_ratio_to_sgpr) -> accumulate.  BT restarts share each row:
+// every restart adds accumulator registers and a proportion vector (PREG of them in VGPRs, the
+// rest in LDS), the bytes read stay the same.  Column partials live in registers for the whole
+// kernel and are written once: partial[wg][b][h], summed in fixed order afterwards -> bitwise
+// reproducible.  Shapes in use (mixemt_hip.hip): BT = 1 <512 threads, ring 3>, BT = 2..4
+// <512, ring 2>, one workgroup per CU; <256, ring 2> x 2 per CU is the alternative BT = 1 shape.
 // ------------------------------------------------------------------------------------------
 #ifndef MXM_V1_MINW
 #define MXM_V1_MINW 2                 // min waves/SIMD the BT = 1 shape is compiled for (2 WGs of 256 per CU)
 #endif
-#ifndef MXM_DPP_REDUCE
-#define MXM_DPP_REDUCE 1                // in-wave sum by DPP (1) or by the ds_bpermute xor butterfly (0)
-#endif
 #ifndef MXM_LOAD_AUX
 #define MXM_LOAD_AUX 2                // cache policy of the row loads: 2 = non-temporal (streamed once per pass)
-#endif
-#ifndef MXM_PIN_ACC
-#define MXM_PIN_ACC 0                 // 1 saves ~45 VGPRs (no third row copy) but measured equal or slower
-#endif
-#ifndef MXM_SCHED_FENCE
-#define MXM_SCHED_FENCE 0
 #endif
 // batched shapes run one workgroup per CU: min waves/SIMD = THREADS / 256
 
@@ -227,24 +219,12 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW
             }
             d[b] = s;
         }
-#if MXM_DPP_REDUCE
 #pragma unroll
         for (int b = 0; b < BT; ++b) d[b] = wave_sum_lane63(d[b]);
         if (lane == 63) {
 #pragma unroll
             for (int b = 0; b < BT; ++b) red[buf][b][wv] = d[b];
         }
-#else
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-#pragma unroll
-            for (int b = 0; b < BT; ++b) d[b] += __shfl_xor(d[b], off, 64);
-        }
-        if (lane == 0) {
-#pragma unroll
-            for (int b = 0; b < BT; ++b) red[buf][b][wv] = d[b];
-        }
-#endif
         __syncthreads();
         const double wr = deal.live(q) ? (w != nullptr ? w[deal.row(q)] : 1.0) : 0.0;
         double cs[BT];                                  // w_r / Z_r per restart
@@ -267,26 +247,7 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW
 #pragma unroll
         for (int j = 0; j < NBUF; ++j) {
             load_row(x[(j + NBUF - 1) % NBUF], q + j + NBUF - 1);
-#if MXM_SCHED_FENCE
-            // keep the scheduler from hoisting these loads above the previous row's last
-            // uses of the same ring slot (it would need a second register set for it)
-            __builtin_amdgcn_sched_barrier(0);
-#endif
             process(x[j], q + j);
-#if MXM_PIN_ACC
-            // Pin the accumulator update HERE.  Left alone, the compiler sinks the post-barrier
-            // half of this row (1/Z, accumulate) below the next row's barrier and merges the two;
-            // this row's registers then stay live across the next loads, which costs a third
-            // copy of the row (+4 VGPRs per column chunk) and v_mov chains at the loop end.
-#pragma unroll
-            for (int b = 0; b < BT; ++b) {
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) asm volatile("" : "+v"(acc[b][k].x), "+v"(acc[b][k].y)::"memory");
-            }
-#endif
-#if MXM_SCHED_FENCE
-            __builtin_amdgcn_sched_barrier(0);
-#endif
         }
     }
 

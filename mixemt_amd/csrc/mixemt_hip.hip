@@ -25,6 +25,8 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <utility>
+#include <vector>
 
 #include "mixemt_hip.h"
 
@@ -155,6 +157,7 @@ static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static int g_min_rows_per_wg = 8;     // measured: 1000 x 5408 31 us/step (vs 39 at 2); no effect from 10^4 rows up
 static int g_v1_shape = 1;            // 0: 256 threads x 2 WG/CU, ring 2;  1: 512 threads x 1 WG/CU, ring 3
                                       // (in-process A/B, profiles/r01/tune_sweep.txt: 6.43 vs 6.50 ms median)
+static int g_compact_restarts = 1;    // mxm_em_loop packs the running restarts into the leading slots
 static int g_max_bt = 4;              // restarts per matrix pass (1..MXM_MAX_BT); see mxm_set_batch_tile
 extern "C" int mxm_set_timing_events(void *ev_start, void *ev_stop) {
     g_ev_start = (hipEvent_t)ev_start;
@@ -171,6 +174,11 @@ extern "C" int mxm_set_min_rows_per_wg(int32_t n) {
 extern "C" int mxm_set_v1_shape(int32_t shape) {
     if (shape < 0 || shape > 1) return fail(-1, "mxm_set_v1_shape: shape must be 0 or 1%s", "");
     g_v1_shape = shape;
+    return 0;
+}
+
+extern "C" int mxm_set_compact_restarts(int32_t on) {
+    g_compact_restarts = on ? 1 : 0;
     return 0;
 }
 
@@ -518,6 +526,17 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
     int64_t graph_iters = 0;
+    int graph_lead = 0;
+    // Restarts stop on different iterations.  The still-running ones are kept packed in the
+    // leading `lead` slots (slot exchanges on the device, undone before returning), so that an
+    // iteration takes ceil(running / tile) passes over the matrix instead of ceil(B / tile).
+    int lead = B;
+    std::vector<std::pair<int, int>> swaps;
+    auto swap_slots = [&](int i, int j) {
+        hipLaunchKernelGGL(swap_restart_slots_kernel, dim3((H + 255) / 256, 4), dim3(256), 0, s, props_cur, ln_cur,
+                           ln_new, colsum, state, i, j, (int)H);
+        std::swap(state_host[i], state_host[j]);
+    };
 #define LOOP_TRY(expr)                                                                        \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
@@ -530,23 +549,36 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     {
         int64_t issued = 0;
         for (;;) {
+            if (g_compact_restarts) {
+                // two-pointer partition of the leading slots: finished ones go behind the running ones
+                int lo = 0, hi = lead - 1;
+                for (;;) {
+                    while (lo < lead && state_host[lo].done == 0) ++lo;
+                    while (hi >= 0 && state_host[hi].done != 0) --hi;
+                    if (lo >= hi) break;
+                    swap_slots(lo, hi);
+                    swaps.emplace_back(lo, hi);
+                }
+                lead = lo;                             // = number of running restarts
+            }
             bool all_done = true;
-            for (int b = 0; b < B; ++b) all_done = all_done && (state_host[b].done != 0);
+            for (int b = 0; b < lead; ++b) all_done = all_done && (state_host[b].done != 0);
             if (all_done || issued >= (int64_t)max_iter) break;
             int64_t n = (int64_t)max_iter - issued;
             if (n > check_every) n = check_every;
             bool launched = false;
             if (want_graph) {
-                if (exec == nullptr || graph_iters != n) {
+                if (exec == nullptr || graph_iters != n || graph_lead != lead) {
                     if (exec != nullptr) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
                     if (graph != nullptr) { (void)hipGraphDestroy(graph); graph = nullptr; }
                     if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                        const int crc = enqueue_iterations(M, ldm, P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, colsum,
+                        const int crc = enqueue_iterations(M, ldm, P, ldp, w, R, H, lead, props_cur, ln_cur, ln_new, colsum,
                                                            state, tol, max_iter, n, ws, ws_bytes, s, p_is_f32);
                         const hipError_t ee = hipStreamEndCapture(s, &graph);
                         if (crc == 0 && ee == hipSuccess &&
                             hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
                             graph_iters = n;
+                            graph_lead = lead;
                         } else {
                             exec = nullptr;            // capture unavailable: plain launches below
                             (void)hipGetLastError();
@@ -559,7 +591,7 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
                 }
             }
             if (!launched) {
-                rc = enqueue_iterations(M, ldm, P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, colsum, state, tol,
+                rc = enqueue_iterations(M, ldm, P, ldp, w, R, H, lead, props_cur, ln_cur, ln_new, colsum, state, tol,
                                         max_iter, n, ws, ws_bytes, s, p_is_f32);
                 if (rc != 0) goto done;
             }
@@ -568,6 +600,8 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
             LOOP_TRY(hipStreamSynchronize(s));
         }
     }
+    for (size_t k = swaps.size(); k-- > 0;) swap_slots(swaps[k].first, swaps[k].second);   // original order again
+    LOOP_TRY(hipGetLastError());
     LOOP_TRY(hipEventRecord(ev, s));
     LOOP_TRY(hipStreamWaitEvent(caller, ev, 0));
 done:

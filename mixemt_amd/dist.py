@@ -66,32 +66,62 @@ def broadcast_inits(n_runs, n_haps, alpha, device, group=None, src=0):
     return buf.cpu().numpy()
 
 
-def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8):
+def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8, compact=True):
     """
     The EM loop over a row-sharded matrix.  `plan` is the rank-local EmPlan (or
     any object with its em_iter / finalize / alloc / read_state surface -- the
     CPU tests pass a numpy-backed double).  Returns
     (ln_cur = log theta_k, ln_new = log theta_{k+1}, [(done, iters, l1)]) --
     identical on every rank.
+
+    compact: restarts stop on different iterations; the ones still running are
+    kept packed in the leading slots of the loop vectors (as mxm_em_loop does on
+    one GPU), so an iteration takes ceil(running / tile) passes over the shard
+    and all-reduces only the running restarts' sums.  Every rank sees the same
+    state, hence takes the same packing decisions.
     """
     rank, world = _world(group)
     ln0, p0 = _em.log_inits(inits)
+    n_runs = ln0.shape[0]
     props_cur = plan.alloc_props(p0)
     ln_cur = plan.alloc_props(ln0)
     ln_new = plan.alloc_props(ln0)
     colsum = plan.alloc_props(numpy.zeros_like(ln0))
-    state = plan.alloc_state(ln0.shape[0])
+    state = plan.alloc_state(n_runs).view(n_runs, -1)          # one row per restart
+    vectors = (props_cur, ln_cur, ln_new, colsum, state)
+    slot_run = list(range(n_runs))                             # slot -> caller's run index
+    lead = n_runs
     issued = 0
     states = plan.read_state(state)
-    while issued < max_iter and not all(s[0] != 0 for s in states):
+    while issued < max_iter:
+        running = [s for s in range(lead) if states[s][0] == 0]
+        if not running:
+            break
+        if compact and len(running) < lead:
+            order = running + [s for s in range(n_runs) if s not in set(running)]
+            idx = torch.as_tensor(order, device=props_cur.device)
+            for vec in vectors:
+                vec.copy_(vec[idx])
+            slot_run = [slot_run[s] for s in order]
+            states = [states[s] for s in order]
+            lead = len(running)
         burst = min(check_every, max_iter - issued)
         for _ in range(burst):
-            plan.em_iter(props_cur, ln_cur, state, colsum)
+            plan.em_iter(props_cur[:lead], ln_cur[:lead], state[:lead], colsum[:lead])
             if world > 1:
-                dist.all_reduce(colsum, op=dist.ReduceOp.SUM, group=group)
-            plan.finalize(colsum, ln_cur, ln_new, props_cur, state, tolerance, max_iter)
+                dist.all_reduce(colsum[:lead], op=dist.ReduceOp.SUM, group=group)
+            plan.finalize(colsum[:lead], ln_cur[:lead], ln_new[:lead], props_cur[:lead], state[:lead],
+                          tolerance, max_iter)
         issued += burst
         states = plan.read_state(state)
+    if slot_run != list(range(n_runs)):                        # back to the caller's run order
+        back = [0] * n_runs
+        for slot, run in enumerate(slot_run):
+            back[run] = slot
+        idx = torch.as_tensor(back, device=props_cur.device)
+        for vec in vectors:
+            vec.copy_(vec[idx])
+        states = [states[s] for s in back]
     return ln_cur, ln_new, states
 
 

@@ -438,3 +438,44 @@ def test_streaming_kernel_shape_grid(n_haps):
                 _, new = em_oracle.em_step(mat, wts, ln0[run], numpy.empty_like(mat))
             want = numpy.exp(new) * wts.sum()
             assert numpy.abs(got[run] - want).max() <= 1e-12 * wts.sum(), (n_rows, n_haps, run)
+
+
+@pytest.mark.parametrize("n_rows,n_haps,n_runs,seed", [(240, 1000, 9, 1), (90, 5408, 6, 2), (300, 66, 5, 3)])
+def test_running_restarts_are_packed_without_changing_results(n_rows, n_haps, n_runs, seed):
+    """
+    mxm_em_loop packs the restarts that still run into the leading slots (fewer passes per
+    iteration once some have stopped) and restores the order before returning: per-run
+    iteration counts, proportions and the folded posterior must equal the unpacked schedule's,
+    in the caller's run order.
+    """
+    from mixemt_amd import _lib, em
+    lib = _lib.load()
+    rng = numpy.random.default_rng(seed)
+    mat = rng.normal(-30.0, 10.0, size=(n_rows, n_haps))
+    truth = rng.choice(n_haps, size=3, replace=False)
+    for r in range(n_rows):
+        mat[r, truth[r % 3]] += 22.0
+    wts = rng.integers(1, 4, size=n_rows)
+    inits = rng.dirichlet([0.3] * n_haps, size=n_runs)
+    args = em_args(n_multi=n_runs, max_iter=300, tolerance=1e-5)
+    out = {}
+    try:
+        for on in (1, 0):
+            lib.mxm_set_compact_restarts(on)
+            out[on] = em.run_em_ex(mat, wts, args, inits=inits, want_read_mix=True)
+    finally:
+        lib.mxm_set_compact_restarts(1)
+    assert len(set(out[0]["iters"])) > 1, "the case must have restarts stopping on different iterations"
+    assert out[1]["iters"] == out[0]["iters"]
+    assert numpy.abs(out[1]["run_props"] - out[0]["run_props"]).max() < 1e-13
+    assert numpy.abs(out[1]["props"] - out[0]["props"]).max() < 1e-13
+    a, b = out[1]["read_mix"].cpu().numpy(), out[0]["read_mix"].cpu().numpy()
+    fin = numpy.isfinite(a) & numpy.isfinite(b)
+    assert numpy.array_equal(numpy.isfinite(a), numpy.isfinite(b))
+    assert numpy.abs(a[fin] - b[fin]).max() < 1e-9
+    for run in range(n_runs):        # and each run is the oracle's run from the same init
+        with numpy.errstate(divide="ignore"):
+            theta, _, n_iter = em_oracle._one_run(mat, wts, numpy.log(inits[run]), numpy.empty_like(mat),
+                                                  300, 1e-5, False)
+        assert out[1]["iters"][run] == n_iter
+        assert numpy.abs(out[1]["run_props"][run] - numpy.exp(theta)).max() < 1e-9
