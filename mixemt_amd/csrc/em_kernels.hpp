@@ -126,7 +126,7 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
 // <512, ring 2>, one workgroup per CU; <256, ring 2> x 2 per CU is the alternative BT = 1 shape.
 // ------------------------------------------------------------------------------------------
 #ifndef MXM_V1_MINW
-#define MXM_V1_MINW 2                 // min waves/SIMD the BT = 1 shape is compiled for (2 WGs of 256 per CU)
+#define MXM_V1_MINW 2                 // min waves/SIMD the ring-2 BT = 1 shape is compiled for (2 WGs of 256 per CU)
 #endif
 #ifndef MXM_LOAD_AUX
 #define MXM_LOAD_AUX 2                // cache policy of the row loads: 2 = non-temporal (streamed once per pass)
@@ -135,7 +135,7 @@ __global__ __launch_bounds__(256, 2) void linearize_wide_kernel(const double *__
 
 // PREG of the BT restarts keep their proportions in VGPRs, the other BT - PREG in LDS.
 template <int THREADS, int NCH, int BT, int NBUF, int PREG>
-__global__ __launch_bounds__(THREADS, ((BT == 1 && THREADS == 256) ? MXM_V1_MINW : THREADS / 256)) void em_iter_wide_kernel(
+__global__ __launch_bounds__(THREADS, ((BT == 1 && NBUF == 2) ? MXM_V1_MINW : THREADS / 256)) void em_iter_wide_kernel(
     const double *__restrict__ P, int64_t ldp, const double *__restrict__ w,
     const double *__restrict__ props, int64_t R, int H,
     double *__restrict__ partial, int64_t ldpart, const mxm_em_state *__restrict__ state) {
