@@ -15,7 +15,7 @@
 //   common.hpp          error plumbing, reductions
 //   build_kernels.hpp   build_em_matrix_kernel (byte table, L2/MALL), build_tile_kernel (LDS-staged 4-bit table)
 //   em_kernels.hpp      linearize, em_iter_wide_kernel (THE hot kernel: R*H*8 B read per EM iteration,
-//                       1-3 restarts per pass), em_iter_wide_f32_kernel (opt-in storage variant),
+//                       1-4 restarts per pass), em_iter_wide_f32_kernel (opt-in storage variant),
 //                       colreduce_kernel, finalize_kernel
 //   estep_kernels.hpp   estep_log_kernel (any H), estep_wide_kernel (register-resident posterior pass)
 //   aux_kernels.hpp     log_normalize, l1_exp_diff, add_scalar, row_argmax_votes, assign_reads, diag_stream_read
