@@ -3,7 +3,10 @@
 Summarise rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, collected in
 separate runs as MI355X_MICROARCH.md prescribes) into per-kernel HBM traffic.
 
-    python tools/pmc_summary.py FETCH.csv WRITE.csv > profiles/rNN/pmc_traffic.json
+    python tools/pmc_summary.py FETCH.csv WRITE.csv [ROWS HAPS] > profiles/rNN/pmc_traffic_<shape>.json
+
+ROWS / HAPS (default 1000000 / 5408, bench.py's default workload) are recorded as "_workload";
+bench.py only quotes a traffic figure whose workload matches the one it runs.
 
 Units and corrections (MI355X_MICROARCH.md, section HBM):
   * both counters count units of 1024 B;
@@ -44,6 +47,11 @@ def main():
                      "hbm_read_bytes_per_launch": f * 1024.0 * corr,
                      "hbm_write_bytes_per_launch": w * 1024.0,
                      "hbm_bytes_per_launch": f * 1024.0 * corr + w * 1024.0}
+    rows = int(sys.argv[3]) if len(sys.argv) > 3 else 1000000
+    haps = int(sys.argv[4]) if len(sys.argv) > 4 else 5408
+    out["_workload"] = {"rows_per_gpu": rows, "haps": haps,
+                        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py "
+                                   "--steps 4 --warmup 1 --no-cpu-baseline (tools/profile_round.sh)"}
     json.dump(out, sys.stdout, indent=1)
     sys.stdout.write("\n")
 

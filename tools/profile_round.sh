@@ -17,4 +17,5 @@ python3 $repo/bench.py --restarts 10 --no-cpu-baseline > $out/bench_1m_10restart
 rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt10 -o kt -- python3 $repo/bench.py --restarts 10 --no-cpu-baseline > /dev/null 2> $out/kt10.log
 python3 $repo/bench.py --storage f32 --no-cpu-baseline > $out/bench_1m_f32_storage_variant.json 2> /dev/null
 python3 $repo/bench.py --rows 100000 --no-cpu-baseline > $out/bench_100k.json 2> /dev/null
+python3 $repo/tools/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv > $out/pmc_traffic_1m.json
 find $out -name "*.csv" | head -40
