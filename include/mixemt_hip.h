@@ -205,6 +205,25 @@ int mxm_assign_reads(const double *X, int64_t ldx, const double *log_props,
                      double log_min_fold, int32_t *assigned, void *stream);
 
 /*
+ * HOST function (no device work): the read signatures 'pos:base,pos:base,...' that
+ * preprocess.build_em_matrix receives (reference: preprocess.py:142-160, parsed per cell at
+ * :151-160) -> the CSR observations mxm_build_em_matrix takes.
+ *   text     all signatures back to back; signature r is text[off[r] .. off[r+1] - 1)
+ *            (one separator byte follows each signature; its value is not looked at)
+ *   site_of_pos[ref_len]  0-based position -> index into the sorted variant sites, -1 if none
+ *   row_ptr[R+1], site[cap], obs[cap]  outputs; obs is the ASCII base, 0 for an observation that
+ *            is not exactly one character (it can never equal a base)
+ * Returns the number of observations written (>= 0), or -(r + 1) when signature r needs the
+ * caller's slow path: empty signature, a position that is not plain decimal digits, not a
+ * variant site or out of range, a stray ':' or more than `cap` observations.  The Python host
+ * then re-parses with the reference's own expressions so that the exception raised
+ * (ValueError / KeyError) is the reference's.
+ */
+int64_t mxm_encode_signatures(const char *text, const int64_t *off, int64_t R,
+                              const int32_t *site_of_pos, int64_t ref_len, int64_t *row_ptr,
+                              uint16_t *site, uint8_t *obs, int64_t cap);
+
+/*
  * Measurement hook (bench.py): when both handles are non-NULL, mxm_em_iter
  * records hipEvent_t `ev_start` / `ev_stop` on its stream immediately before /
  * after the streaming kernel (the dominant one), so its device time can be read

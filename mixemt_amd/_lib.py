@@ -55,6 +55,8 @@ SIGNATURES = {
     "mxm_diag_stream_read": (ctypes.c_int, [c_ptr, c_size, c_i32, c_i32, c_ptr, c_ptr]),
     "mxm_set_timing_events": (ctypes.c_int, [c_ptr, c_ptr]),
     "mxm_set_batch_tile": (ctypes.c_int, [c_i32]),
+    "mxm_encode_signatures": (ctypes.c_int64, [ctypes.c_char_p, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
+                                               c_i64]),
     "mxm_set_compact_restarts": (ctypes.c_int, [c_i32]),
     "mxm_set_loop_graph": (ctypes.c_int, [c_i32]),
     "mxm_set_min_rows_per_wg": (ctypes.c_int, [c_i32]),

@@ -59,6 +59,44 @@ extern "C" size_t mxm_workspace_bytes(int64_t R, int32_t H, int32_t B) {
     return (size_t)MXM_MAX_WG * 4 /* MXM_MAX_BT */ * (size_t)part_ld(H) * sizeof(double);
 }
 
+extern "C" int64_t mxm_encode_signatures(const char *text, const int64_t *off, int64_t R,
+                                         const int32_t *site_of_pos, int64_t ref_len, int64_t *row_ptr,
+                                         uint16_t *site, uint8_t *obs, int64_t cap) {
+    int64_t n = 0;
+    row_ptr[0] = 0;
+    for (int64_t r = 0; r < R; ++r) {
+        const char *p = text + off[r];
+        const char *end = text + off[r + 1] - 1;           // the separator byte is not part of it
+        if (p >= end) return -(r + 1);                     // '' -> int('') in the reference
+        while (p < end) {
+            int64_t pos = 0;
+            int digits = 0;
+            while (p < end && *p >= '0' && *p <= '9' && digits < 10) {
+                pos = pos * 10 + (*p - '0');
+                ++p;
+                ++digits;
+            }
+            if (digits == 0 || digits >= 10 || p >= end || *p != ':') return -(r + 1);
+            ++p;
+            const char *b = p;
+            while (p < end && *p != ',') {
+                if (*p == ':') return -(r + 1);
+                ++p;
+            }
+            if (pos >= ref_len || site_of_pos[pos] < 0 || n >= cap) return -(r + 1);
+            site[n] = (uint16_t)site_of_pos[pos];
+            obs[n] = (p - b == 1) ? (uint8_t)*b : (uint8_t)0;
+            ++n;
+            if (p < end) {
+                ++p;                                       // ','
+                if (p >= end) return -(r + 1);             // trailing ',': an empty item
+            }
+        }
+        row_ptr[r + 1] = n;
+    }
+    return n;
+}
+
 extern "C" int mxm_build_em_matrix(const uint8_t *E, int64_t lde, const double *lhit,
                                    const double *lmiss, const int64_t *row_ptr, const uint16_t *site,
                                    const uint8_t *obs, int64_t R, int32_t H, int32_t S, double *M,

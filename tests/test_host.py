@@ -101,6 +101,43 @@ def test_encode_signatures_roundtrip_and_errors(b17):
     assert list(ob) == [ord("N"), 0]
 
 
+def test_native_and_itemwise_signature_parsers_agree(b17):
+    """
+    encode_signatures goes through the library's host parser (mxm_encode_signatures) and keeps
+    the item-by-item Python expressions of the reference for anything unusual: both must give the
+    same CSR, and the unusual inputs must raise what the reference raises.
+    """
+    from mixemt_amd import build
+    build.build()                                     # host function of the in-tree library
+    refseq, phy, haps, tables = b17
+    rng = numpy.random.default_rng(4)
+    sites = numpy.asarray(tables.sites)
+    sigs = []
+    for _ in range(400):
+        picked = numpy.sort(rng.choice(sites, size=int(rng.integers(1, 60)), replace=False))
+        sigs.append(",".join("%0*d:%s" % (int(rng.integers(1, 7)), p, rng.choice(["A", "C", "G", "T", "N", "a", "-", "AC", ""]))
+                             for p in picked))
+    fast = preprocess._encode_signatures_native(sigs, tables)
+    slow = preprocess._encode_signatures_py(sigs, tables)
+    assert fast is not None
+    for a, b in zip(fast, slow):
+        assert a.dtype == b.dtype and numpy.array_equal(a, b)
+    s0 = int(sites[0])
+    # inputs the C parser hands back; the Python expressions then decide, like the reference
+    for sig, exc in (("", ValueError), ("%d:A," % s0, ValueError), (",%d:A" % s0, ValueError),
+                     ("%d:A:C" % s0, ValueError), ("x:A", ValueError), ("%d" % s0, ValueError),
+                     ("0:A", KeyError), ("-5:A", KeyError), ("99999999999:A", KeyError)):
+        assert preprocess._encode_signatures_native(["%d:A" % s0, sig], tables) is None
+        with pytest.raises(exc):
+            preprocess.encode_signatures(["%d:A" % s0, sig], tables)
+    # int() accepts more than digits: same answer through the slow path
+    rp, si, ob = preprocess.encode_signatures([" %d :G" % s0, "%d_0:A" % (int(sites[1]) // 10)] if int(sites[1]) % 10 == 0
+                                              else [" %d :G" % s0], tables)
+    assert si[0] == 0 and ob[0] == ord("G")
+    assert preprocess._encode_signatures_native([], tables) is None
+    assert preprocess.encode_signatures([], tables)[0].tolist() == [0]
+
+
 def test_synth_v1_is_pinned(b17):
     """The generator's stream is part of the bench definition: same seed, same bytes."""
     refseq, phy, haps, tables = b17
