@@ -140,7 +140,7 @@ def run_em_sharded(local_mat, local_weights, args, inits=None, group=None, want_
     inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
     ln_cur, ln_new, states = sharded_em_loop(plan, inits, args.tolerance, args.max_iter,
                                              group=group, check_every=check_every)
-    return _em.collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix)
+    return _em.collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix, reuse_linear=True)
 
 
 def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_read_mix=True):
@@ -168,6 +168,8 @@ def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_rea
         ln_cur, ln_new, states = _em.em_loop(plan, inits[mine], args.tolerance, args.max_iter)
         ln_k = ln_cur.cpu().numpy()
         ln_sum += ln_new.sum(dim=0)
+        if want_read_mix:
+            fold = plan.release_linear()              # the loop is over: reuse its 43 GB
         for j, run in enumerate(mine):
             iters[run] = states[j][1]
             run_props[run] = torch.exp(ln_new[j])

@@ -167,6 +167,20 @@ class EmPlan(object):
             return 0, 0
         return self.lin.data_ptr(), self.lin.stride(0)
 
+    def release_linear(self):
+        """
+        Hand the linearised matrix's storage over for reuse as an [R][H] fp64 buffer (the
+        posterior matrix run_em returns has exactly that shape): the plan cannot iterate
+        afterwards.  None if there is no such buffer (narrow matrix, fp32 storage, padded rows).
+        A 43 GB hipMalloc costs ~1.2 s -- half the EM loop's time at 10^6 x 5408.
+        """
+        lin = self.lin
+        if lin is None or lin.dtype != torch.float64 or lin.stride(0) != self.n_haps:
+            return None
+        self.lin = None
+        self.spent = True
+        return lin
+
     # buffers (the surface dist.sharded_em_loop drives) ----------------------
     def alloc_props(self, host):
         return torch.from_numpy(numpy.ascontiguousarray(host, dtype=numpy.float64)).to(self.dev)
@@ -180,6 +194,8 @@ class EmPlan(object):
     def em_iter(self, props, ln_props, state, colsum):
         """Enqueue one fused E+M step for every restart (mxm_em_iter): colsum <- the
         unscaled column sums T (see include/mixemt_hip.h)."""
+        if getattr(self, "spent", False):
+            raise ValueError("this plan's linearised matrix has been released (release_linear)")
         m_ptr, ldm = self.mat_args()
         p_ptr, ldp = self.lin_args()
         if self.storage == "f32":
@@ -230,6 +246,8 @@ def em_loop(plan, inits, tolerance, max_iter, check_every=16):
     (ln_cur = log theta_k, ln_new = log theta_{k+1}, [(done, iters, l1)] per run).
     """
     lib, dev = plan.lib, plan.dev
+    if getattr(plan, "spent", False):
+        raise ValueError("this plan's linearised matrix has been released (release_linear)")
     ln0, p0 = log_inits(inits)
     n_runs, n_haps = ln0.shape
     props_cur = torch.from_numpy(p0).to(dev)
@@ -275,12 +293,15 @@ def posterior(plan, ln_theta, out=None, fold=False):
     return out
 
 
-def collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix=True, verbose=False):
+def collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix=True, verbose=False,
+                   reuse_linear=False):
     """
     What run_em does after its loops (em.py:145-165): posterior under theta_k
     per run, folded with logaddexp, minus log n; proportions = exp(mean of the
     runs' LOG proportions) -- a geometric mean that is not renormalised.
     ln_cur / ln_new are the loop's log theta_k / log theta_{k+1}.
+    reuse_linear: the loops are over, write the posterior into the linearised
+    matrix's storage instead of a new allocation (the plan is spent afterwards).
     """
     n_multi, n_haps = inits.shape
     ln_k = ln_cur.cpu().numpy()
@@ -293,6 +314,8 @@ def collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix=True, verb
                 sys.stderr.write("\nConverged! (%d)\n" % iters)
     read_mix = None
     if want_read_mix:
+        if reuse_linear and plan.mat is not None:
+            read_mix = plan.release_linear()          # overwritten by run 0's store below
         for run in range(n_multi):
             read_mix = posterior(plan, ln_k[run], out=read_mix, fold=(run > 0))
         if n_multi > 1:
@@ -330,7 +353,7 @@ def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, stora
     inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
     ln_cur, ln_new, states = em_loop(plan, inits, args.tolerance, args.max_iter)
     return collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix,
-                          getattr(args, "verbose", False))
+                          getattr(args, "verbose", False), reuse_linear=True)
 
 
 def run_em(read_hap_mat, weights, args):

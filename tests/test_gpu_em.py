@@ -479,3 +479,26 @@ def test_running_restarts_are_packed_without_changing_results(n_rows, n_haps, n_
                                                   300, 1e-5, False)
         assert out[1]["iters"][run] == n_iter
         assert numpy.abs(out[1]["run_props"][run] - numpy.exp(theta)).max() < 1e-9
+
+
+def test_posterior_reuses_the_linearised_matrix_storage():
+    """run_em's posterior lands in the buffer the loop streamed from (no second R x H allocation);
+    the caller's matrix is untouched and the values equal a freshly allocated posterior's."""
+    import torch
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(12)
+    mat = torch.from_numpy(rng.normal(-25.0, 8.0, size=(300, 1000))).cuda()
+    keep = mat.clone()
+    wts = torch.ones(300, dtype=torch.float64, device="cuda")
+    inits = rng.dirichlet([1.0] * 1000, size=2)
+    args = em_args(n_multi=2, max_iter=6, tolerance=0.0)
+    plan = em.EmPlan(mat, wts, n_runs=2)
+    lin_ptr = plan.lin.data_ptr()
+    ln_cur, ln_new, states = em.em_loop(plan, inits, args.tolerance, args.max_iter)
+    fresh = em.collect_result(plan, inits, ln_cur, ln_new, states)["read_mix"]
+    assert fresh.data_ptr() != lin_ptr and plan.lin is not None
+    reused = em.collect_result(plan, inits, ln_cur, ln_new, states, reuse_linear=True)["read_mix"]
+    assert reused.data_ptr() == lin_ptr and plan.lin is None
+    assert torch.equal(reused, fresh) and torch.equal(mat, keep)
+    with pytest.raises(ValueError):
+        plan.em_iter(ln_cur, ln_cur, None, ln_cur.clone())      # a spent plan fails loudly
