@@ -79,6 +79,113 @@ __global__ __launch_bounds__(ROW_THREADS) void row_argmax_votes_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Wide rows (H even, 16-byte aligned): the same answer as row_argmax_votes_kernel with the
+// streaming kernels' machinery -- rows dealt over the workgroups, 16-byte non-temporal buffer
+// loads, the next row in flight while this one is reduced, DPP reductions, one barrier per row.
+// Votes are collected per workgroup in LDS (ds_add_f64) and flushed once, instead of 10^6
+// global atomics onto the handful of winning columns.
+// ------------------------------------------------------------------------------------------
+struct argmax_cand {
+    double v;
+    int i, n;                                       // value, column, is-NaN
+};
+__device__ __forceinline__ argmax_cand cand_pick(const argmax_cand &a, const argmax_cand &b) {
+    return cand_better(b.n, b.v, b.i, a.n, a.v, a.i) ? b : a;
+}
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ argmax_cand cand_dpp(const argmax_cand &c) {   // masked-out rows keep their own
+    argmax_cand o;
+    o.v = dpp_mov_old_f64<CTRL, ROW_MASK>(c.v, c.v);
+    o.i = __builtin_amdgcn_update_dpp(c.i, c.i, CTRL, ROW_MASK, 0xf, false);
+    o.n = __builtin_amdgcn_update_dpp(c.n, c.n, CTRL, ROW_MASK, 0xf, false);
+    return o;
+}
+__device__ __forceinline__ argmax_cand wave_best_lane63(argmax_cand c) {
+    c = cand_pick(c, cand_dpp<0xB1, 0xF>(c));
+    c = cand_pick(c, cand_dpp<0x4E, 0xF>(c));
+    c = cand_pick(c, cand_dpp<0x141, 0xF>(c));
+    c = cand_pick(c, cand_dpp<0x140, 0xF>(c));
+    c = cand_pick(c, cand_dpp<0x142, 0xA>(c));
+    c = cand_pick(c, cand_dpp<0x143, 0xC>(c));
+    return c;
+}
+
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void row_argmax_wide_kernel(
+    const double *__restrict__ X, int64_t ldx, const double *__restrict__ w, int64_t R, int H,
+    int32_t *__restrict__ best, double *__restrict__ votes) {
+    constexpr int THREADS = 256, NW = THREADS / 64;
+    extern __shared__ double lds_votes[];           // [H] when votes are wanted
+    __shared__ double s_val[2][NW];
+    __shared__ int s_idx[2][NW], s_nan[2][NW];
+    const int t = threadIdx.x;
+    const int lane = t & 63, wv = t >> 6;
+    const int ncol2 = H >> 1;
+    const row_deal deal(R);
+    if (votes != nullptr) {
+        for (int h = t; h < H; h += THREADS) lds_votes[h] = 0.0;
+        __syncthreads();
+    }
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const int row_bytes = (int)(ldx * 8);
+    const int voff = t * 16;
+    int last_c2 = t + (NCH - 1) * THREADS;
+    const bool last_own = last_c2 < ncol2;
+    if (!last_own) last_c2 = ncol2 - 1;             // a clamped lane re-reads a real element: harmless
+    const int voff_last = last_c2 * 16;
+
+    d2 x[2][NCH];
+    auto load_row = [&](d2(&xr)[NCH], int64_t q) {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(X + deal.row(q) * ldx), 0,
+                                                            row_bytes, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NCH - 1; ++k)
+            xr[k] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, k * THREADS * 16, 2));
+        xr[NCH - 1] = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, 0, 2));
+    };
+    int ring = 0;
+    auto process = [&](d2(&xr)[NCH], int64_t q) {
+        argmax_cand c{-INFINITY, 0x7fffffff, 0};
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {             // ascending columns: the first maximum wins
+            const int col = 2 * ((k < NCH - 1) ? (t + k * THREADS) : last_c2);
+            const argmax_cand a{xr[k].x, col, (xr[k].x != xr[k].x) ? 1 : 0};
+            const argmax_cand b{xr[k].y, col + 1, (xr[k].y != xr[k].y) ? 1 : 0};
+            c = cand_pick(c, a);
+            c = cand_pick(c, b);
+        }
+        c = wave_best_lane63(c);
+        if (lane == 63) { s_val[ring][wv] = c.v; s_idx[ring][wv] = c.i; s_nan[ring][wv] = c.n; }
+        __syncthreads();
+        if (t == 0 && deal.live(q)) {
+            argmax_cand g{s_val[ring][0], s_idx[ring][0], s_nan[ring][0]};
+#pragma unroll
+            for (int j = 1; j < NW; ++j) g = cand_pick(g, argmax_cand{s_val[ring][j], s_idx[ring][j], s_nan[ring][j]});
+            const int64_t r = deal.row(q);
+            int ci = g.i;
+            if (ci >= H) ci = 0;
+            best[r] = ci;
+            if (votes != nullptr) atomicAdd(&lds_votes[ci], (w != nullptr) ? w[r] : 1.0);
+        }
+        ring ^= 1;
+    };
+    load_row(x[0], 0);
+    for (int64_t q = 0; q < deal.nq; q += 2) {
+        load_row(x[1], q + 1);
+        process(x[0], q);
+        load_row(x[0], q + 2);
+        process(x[1], q + 1);
+    }
+    if (votes != nullptr) {
+        __syncthreads();
+        for (int h = t; h < H; h += THREADS) {
+            const double v = lds_votes[h];
+            if (v != 0.0) atomicAdd(votes + h, v);
+        }
+    }
+}
+
 // Read -> contributor assignment (assemble.py:284-334): per row, among the contributor columns
 // only, the two largest  X[r][c] - log p_c ; assigned to the best one if the gap reaches
 // log(min_fold), else unassigned (-1).  One thread per row; the row touches nC scattered cells.

@@ -71,6 +71,89 @@ __global__ __launch_bounds__(ROW_THREADS) void estep_log_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// K6n estep_narrow: the same two computations for matrices with a handful of columns -- the
+// refinement EM on the contributors' columns (bin/mixemt:311-320, H = 2..10) and its posterior.
+// One THREAD per row (grid-stride): the row, the proportions and the column sums sit in
+// registers, nothing is exchanged per row (estep_log_kernel spends a workgroup, two barriers and
+// two block reductions on every 24-byte row: 2.75 ms per pass over 10^6 x 3, this kernel is
+// bandwidth-bound on the same 24 MB).  Column sums: per-thread registers -> wave sum -> LDS ->
+// partial[wg][h], reduced in fixed order by colreduce_kernel like everywhere else.
+// ------------------------------------------------------------------------------------------
+template <int HMAX, bool ITER>
+__global__ __launch_bounds__(256) void estep_narrow_kernel(
+    const double *__restrict__ M, int64_t ldm, const double *__restrict__ w,
+    const double *__restrict__ ln_props, int64_t R, int H, double *__restrict__ out, int64_t ldo,
+    int mode, double *__restrict__ partial, int64_t ldpart,
+    const mxm_em_state *__restrict__ state) {
+    __shared__ double red[4][HMAX];
+    if (state != nullptr && state->done != 0) return;
+    const int t = threadIdx.x;
+    double lp[HMAX], acc[HMAX];                     // ITER: lp holds the LINEAR proportions
+#pragma unroll
+    for (int h = 0; h < HMAX; ++h) {
+        const double l = (h < H) ? ln_props[h] : -INFINITY;
+        lp[h] = ITER ? exp(l) : l;
+        acc[h] = 0.0;
+    }
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + t; r < R; r += stride) {
+        const double *src = M + r * ldm;
+        const double wr = (w != nullptr) ? w[r] : 1.0;
+        double x[HMAX];
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h) x[h] = (h < H) ? src[h] : -INFINITY;
+        if constexpr (ITER) {
+            // T_h += (w_r / Z_r) e_h,  e_h = exp(M_rh - rowmax_r),  Z_r = sum_h p_h e_h
+            double m = x[0];
+#pragma unroll
+            for (int h = 1; h < HMAX; ++h) m = fmax(m, x[h]);
+            const double shift = isfinite(m) ? m : 0.0;
+            double z = 0.0;
+#pragma unroll
+            for (int h = 0; h < HMAX; ++h) {
+                x[h] = exp(x[h] - shift);           // pad columns: exp(-inf) = 0
+                z = fma(lp[h], x[h], z);
+            }
+            const double c = (z > 0.0) ? wr / z : 0.0;
+#pragma unroll
+            for (int h = 0; h < HMAX; ++h) acc[h] = fma(c, x[h], acc[h]);
+        } else {
+            // em.py:80-83 verbatim: z = ln p + M;  z -= logsumexp(z)
+#pragma unroll
+            for (int h = 0; h < HMAX; ++h) x[h] += lp[h];
+            double m = x[0];
+#pragma unroll
+            for (int h = 1; h < HMAX; ++h) m = fmax(m, x[h]);
+            const double shift = isfinite(m) ? m : 0.0;
+            double ssum = 0.0;
+#pragma unroll
+            for (int h = 0; h < HMAX; ++h) ssum += exp(x[h] - shift);
+            const double lse = log(ssum) + m;       // m (not shift): -inf rows stay -inf, as scipy does
+#pragma unroll
+            for (int h = 0; h < HMAX; ++h) {
+                if (h < H) {
+                    const double v = x[h] - lse;
+                    if (out != nullptr) {
+                        double *o = out + r * ldo + h;
+                        *o = (mode == 1) ? logaddexp_f64(*o, v) : v;
+                    }
+                    if (partial != nullptr) acc[h] += wr * exp(v);
+                }
+            }
+        }
+    }
+    if (partial != nullptr) {
+#pragma unroll
+        for (int h = 0; h < HMAX; ++h) {
+            const double a = wave_sum(acc[h]);
+            if ((t & 63) == 0) red[t >> 6][h] = a;
+        }
+        __syncthreads();
+        if (t < H) partial[(int64_t)blockIdx.x * ldpart + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K6b estep_wide: the same E-step (em.py:80-83, fold :156, M-step sums :87-88) for wide rows,
 // one HBM read + one write per cell: the row is held in VGPRs across the two row reductions
 // (max, then sum of exp), exactly like the streaming kernel holds it across its dot product.

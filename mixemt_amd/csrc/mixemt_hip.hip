@@ -424,6 +424,27 @@ static int em_iter_f32_one(const float *P, int64_t ldp, const double *w, const d
     return 0;
 }
 
+// Narrow matrices (H <= 32: the refinement EM's contributor columns): one thread per row.
+#define MXM_NARROW_MAX_H 32
+template <bool ITER>
+static int launch_narrow(const double *M, int64_t ldm, const double *w, const double *ln_props, int64_t R, int H,
+                         double *out, int64_t ldo, int mode, double *partial, int64_t ldpart,
+                         const mxm_em_state *state, hipStream_t stream, int *nwg_out) {
+    const int cap = num_cu() * 4 < MXM_MAX_WG ? num_cu() * 4 : MXM_MAX_WG;
+    const int nwg = clamp_grid((R + 255) / 256, cap);
+    *nwg_out = nwg;
+#define NARROW_LAUNCH(hmax)                                                                                  \
+    hipLaunchKernelGGL((estep_narrow_kernel<hmax, ITER>), dim3(nwg), dim3(256), 0, stream, M, ldm, w, ln_props, R, H, \
+                       out, ldo, mode, partial, ldpart, state)
+    if (H <= 4) NARROW_LAUNCH(4);
+    else if (H <= 8) NARROW_LAUNCH(8);
+    else if (H <= 16) NARROW_LAUNCH(16);
+    else NARROW_LAUNCH(32);
+#undef NARROW_LAUNCH
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static int em_iter_log_one(const double *M, int64_t ldm, const double *w, const double *ln_props, int64_t R, int H,
                            const mxm_em_state *state, double *colsum, double *partial, hipStream_t stream) {
     if (M == nullptr) return fail(-1, "mxm_em_iter: M is NULL and the linear path does not apply%s", "");
@@ -431,10 +452,17 @@ static int em_iter_log_one(const double *M, int64_t ldm, const double *w, const 
     const size_t lds = 2 * (size_t)H * sizeof(double);
     if (lds > 150 * 1024) return fail(-1, "mxm_em_iter: H=%s%lld too large for the log-space kernel", "", H);
     const int64_t ldpart = part_ld(H);
-    const int nwg = clamp_grid(R, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
-    hipLaunchKernelGGL((estep_log_kernel<true>), dim3(nwg), dim3(ROW_THREADS), lds, stream, M, ldm, w, ln_props,
-                       R, H, (double *)nullptr, (int64_t)0, 0, partial, ldpart, state);
-    HIP_TRY(hipGetLastError());
+    int nwg;
+    if (H <= MXM_NARROW_MAX_H) {
+        const int rc = launch_narrow<true>(M, ldm, w, ln_props, R, H, (double *)nullptr, (int64_t)0, 0, partial, ldpart,
+                                           state, stream, &nwg);
+        if (rc != 0) return rc;
+    } else {
+        nwg = clamp_grid(R, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
+        hipLaunchKernelGGL((estep_log_kernel<true>), dim3(nwg), dim3(ROW_THREADS), lds, stream, M, ldm, w, ln_props,
+                           R, H, (double *)nullptr, (int64_t)0, 0, partial, ldpart, state);
+        HIP_TRY(hipGetLastError());
+    }
     hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg, 1,
                        H, (const double *)nullptr, colsum, state);
     HIP_TRY(hipGetLastError());
@@ -707,6 +735,10 @@ extern "C" int mxm_em_step(const double *M, int64_t ldm, const double *w, const 
 #undef EW_CASE
             default: return fail(-1, "mxm_em_step: H=%s%lld outside the wide kernel's range", "", H);
         }
+    } else if (H <= MXM_NARROW_MAX_H) {
+        const int rc = launch_narrow<false>(M, ldm, w, ln_props, R, (int)H, out, ldo, (int)mode, partial, ldpart,
+                                            (const mxm_em_state *)nullptr, s, &nwg);
+        if (rc != 0) return rc;
     } else {
         const size_t lds = 2 * (size_t)H * sizeof(double);
         if (lds > 150 * 1024) return fail(-1, "mxm_em_step: H=%s%lld too large", "", H);
@@ -770,6 +802,27 @@ extern "C" int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_pe
 extern "C" int mxm_row_argmax_votes(const double *X, int64_t ldx, const double *w, int64_t R, int32_t H,
                                     int32_t *best, double *votes, void *stream) {
     if (R <= 0 || H <= 0 || ldx < H) return fail(-1, "mxm_row_argmax_votes: bad shape%s", "");
+    if (wide_rows_ok(X, ldx, H)) {
+        const int nch = (H / 2 + 255) / 256;
+        const int cap = num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG;
+        const int nwg = clamp_grid((R + 1) / 2, cap);
+        const size_t lds = votes != nullptr ? (size_t)H * sizeof(double) : 0;
+        switch (nch) {
+#define AW_CASE(n) case n:                                                                                   \
+        if (lds > 60 * 1024)   /* with the static exchange buffers this passes the 64 KiB default */          \
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&row_argmax_wide_kernel<n>),                \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+        hipLaunchKernelGGL((row_argmax_wide_kernel<n>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, X, ldx, \
+                           w, R, (int)H, best, votes);                                                         \
+        break;
+            AW_CASE(1) AW_CASE(2) AW_CASE(3) AW_CASE(4) AW_CASE(5) AW_CASE(6) AW_CASE(7) AW_CASE(8)
+            AW_CASE(9) AW_CASE(10) AW_CASE(11) AW_CASE(12) AW_CASE(13) AW_CASE(14) AW_CASE(15) AW_CASE(16)
+#undef AW_CASE
+            default: return fail(-1, "mxm_row_argmax_votes: H=%s%lld outside the wide kernel's range", "", H);
+        }
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(row_argmax_votes_kernel, dim3(clamp_grid(R, num_cu() * 8)), dim3(ROW_THREADS), 0,
                        (hipStream_t)stream, X, ldx, w, R, (int)H, best, votes);
     HIP_TRY(hipGetLastError());

@@ -145,3 +145,32 @@ def test_save_files_stream_from_device(tmp_path, run600):
     assert numpy.array_equal(init, run600["mat"].cpu().numpy())
     assert numpy.array_equal(mix, run600["read_mix"].cpu().numpy())
     assert numpy.array_equal(props, run600["props"])
+
+
+@pytest.mark.parametrize("n_rows,n_haps,seed", [(1, 64, 1), (300, 66, 2), (257, 1024, 3), (130, 5408, 4), (65, 8192, 5),
+                                                (90, 4098, 6), (40, 1001, 7)])
+def test_row_argmax_votes_shapes_ties_and_nans(n_rows, n_haps, seed):
+    """
+    Wide streaming kernel (even H, 64..8192) and the generic one (odd H) against numpy.argmax:
+    first maximum wins, a NaN counts as the maximum (first NaN wins), rows of -inf give column 0;
+    votes are the weights summed per winning column.
+    """
+    import torch
+    from mixemt_amd import assign
+    rng = numpy.random.default_rng(seed)
+    mat = rng.normal(-20.0, 5.0, size=(n_rows, n_haps))
+    for r in range(0, n_rows, 3):                      # ties: the maximum repeated at a later column
+        a, b = sorted(rng.choice(n_haps, size=2, replace=False))
+        mat[r, a] = mat[r, b] = mat[r].max() + 1.0
+    for r in range(1, n_rows, 7):
+        mat[r, rng.choice(n_haps, size=2, replace=False)] = numpy.nan
+    if n_rows > 5:
+        mat[5, :] = -numpy.inf
+    mat[0, n_haps - 1] = 1e9                           # the very last column can win
+    wts = rng.integers(1, 5, size=n_rows).astype(numpy.float64)
+    best, votes = assign.row_argmax_votes(torch.from_numpy(mat).cuda(), torch.from_numpy(wts).cuda())
+    want = numpy.argmax(mat, axis=1)
+    assert numpy.array_equal(best, want)
+    want_votes = numpy.zeros(n_haps)
+    numpy.add.at(want_votes, want, wts)
+    assert numpy.array_equal(votes, want_votes)

@@ -58,7 +58,10 @@ def main():
         sys.stderr.write("%d\t%0.6f\t%s\n" % (i + 1, props[order[i]], haps[order[i]]))
     assign.report_read_votes(haps, read_mix, 10)
 
+    t0 = time.perf_counter()
     cons = assign.find_contribs_from_reads(read_mix, wts, args)
+    torch.cuda.synchronize()
+    sys.stderr.write("contributors from read votes: %.1f ms\n" % ((time.perf_counter() - t0) * 1e3))
     contribs = sorted(([haps[c], props[c]] for c in cons), key=lambda c: c[1], reverse=True)
     fmt = "hap%%0%dd" % len(str(len(contribs) + 1))
     contribs = [[fmt % (i + 1)] + c for i, c in enumerate(contribs)]
@@ -67,11 +70,17 @@ def main():
         return 1
 
     sys.stderr.write("Refining contribution estimates...\n")
+    t0 = time.perf_counter()
     sub, sub_haps = preprocess.reduce_em_matrix(em_mat, haps, contribs)
     results = em.run_em(sub, wts, args)
+    torch.cuda.synchronize()
+    sys.stderr.write("refinement run_em on %d x %d: %.1f ms\n" % (sub.shape[0], sub.shape[1], (time.perf_counter() - t0) * 1e3))
     contribs = assign.update_contribs(contribs, results, sub_haps)
     reads = [[str(i)] for i in range(opts.reads)]
+    t0 = time.perf_counter()
     table = assign.assign_read_indexes(contribs, results, sub_haps, reads, args.min_fold)
+    sys.stderr.write("read assignment (device kernel + host table of %d ids): %.1f ms\n"
+                     % (opts.reads, (time.perf_counter() - t0) * 1e3))
 
     print("hap#   Haplogroup      Contribution   Reads")
     print("-------------------------------------------")
