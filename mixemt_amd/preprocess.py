@@ -19,7 +19,6 @@ exactly the reference's string comparison, for any alphabet ('N' included).
 
 import collections
 import math
-import os
 import sys
 
 import numpy
@@ -182,12 +181,13 @@ def _encode_signatures_native(reads, tables):
     """
     The same CSR through the library's host parser (mxm_encode_signatures): one pass over the
     joined text, ~0.5 s per 10^6 reads.  Returns None whenever anything is out of the ordinary
-    (non-ASCII text, a signature the C parser hands back, library not built): the caller then
-    takes the item-by-item path, which also produces the reference's exceptions.
+    (non-ASCII text, a signature the C parser hands back): the caller then takes the
+    item-by-item path, which also produces the reference's exceptions.
     """
     n_reads = len(reads)
-    if n_reads == 0 or not os.path.exists(_lib.LIB_PATH):
+    if n_reads == 0:
         return None
+    lib = _lib.load()                                 # raises if the library is not built
     try:
         text = ("\n".join(reads) + "\n").encode("ascii")
     except (UnicodeEncodeError, TypeError):
@@ -201,7 +201,7 @@ def _encode_signatures_native(reads, tables):
     site = numpy.empty(cap, dtype=numpy.uint16)
     obs = numpy.empty(cap, dtype=numpy.uint8)
     lut = tables.site_of_pos
-    got = _lib.load().mxm_encode_signatures(text, off.ctypes.data, n_reads, lut.ctypes.data, len(lut),
+    got = lib.mxm_encode_signatures(text, off.ctypes.data, n_reads, lut.ctypes.data, len(lut),
                                             row_ptr.ctypes.data, site.ctypes.data, obs.ctypes.data, cap)
     if got < 0:
         return None

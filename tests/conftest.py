@@ -43,6 +43,14 @@ def em_args(**kw):
     return args
 
 
+@pytest.fixture(scope="session", autouse=True)
+def built_library():
+    """The in-tree library (hipcc cross-compiles without a GPU; a no-op when it is up to date):
+    host-side entry points such as the signature parser live in it, so CPU tests need it too."""
+    from mixemt_amd import build
+    return build.build()
+
+
 @pytest.fixture(scope="session")
 def b17():
     """(refseq, phylo, sorted haplogroups, HapVarTables) for Build 17 + RSRS."""
