@@ -235,7 +235,9 @@ int mxm_set_timing_events(void *ev_start, void *ev_stop);
 /*
  * Diagnostic, not part of the reference boundary: a bare streaming read of `bytes` bytes
  * (16 B per lane, 8 loads in flight per lane, `wg_per_cu` workgroups of 256 per CU; blocked = 0:
- * grid-stride plain loads, 1: one contiguous block per workgroup, non-temporal loads) to measure
+ * grid-stride plain loads, 1: one contiguous block per workgroup, non-temporal loads, 2: the
+ * streaming EM kernel's own pattern without its arithmetic -- 43 264-byte rows dealt over
+ * workgroups of 512, per-row buffer descriptors, non-temporal loads, a ring of 3 rows) to measure
  * the practical HBM read ceiling on the device at hand (tools/stream_ceiling.py).
  */
 int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_per_cu, int32_t blocked,

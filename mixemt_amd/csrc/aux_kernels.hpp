@@ -257,6 +257,44 @@ __global__ __launch_bounds__(256) void diag_stream_read_kernel(const uint4 *__re
     if (acc == 0x9e3779b9u) sink[0] = acc;          // practically never: keeps the loads alive
 }
 
+// Diagnostic only: the streaming EM kernel's access pattern with the arithmetic taken out --
+// 512 threads, rows of `row16` 16-byte units dealt over the workgroups, per-row buffer
+// descriptor, non-temporal loads, register ring of 3 rows; the loaded words are xor-folded.
+template <int NCH>
+__global__ __launch_bounds__(512, 2) void diag_stream_dealt_kernel(const double *__restrict__ src, int64_t R,
+                                                                   int row16, unsigned int *__restrict__ sink) {
+    constexpr int THREADS = 512, NBUF = 3;
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    const int t = threadIdx.x;
+    const row_deal deal(R);
+    const int row_bytes = row16 * 16;
+    const int voff = t * 16;
+    int last = t + (NCH - 1) * THREADS;
+    if (last > row16 - 1) last = row16 - 1;
+    const int voff_last = last * 16;
+    u4 x[NBUF][NCH];
+    unsigned int acc = 0;
+    auto load_row = [&](u4(&xr)[NCH], int64_t q) {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(
+            const_cast<double *>(src + deal.row(q) * (int64_t)row16 * 2), 0, row_bytes, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NCH - 1; ++k)
+            xr[k] = (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff, k * THREADS * 16, 2);
+        xr[NCH - 1] = (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, voff_last, 0, 2);
+    };
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j) load_row(x[j], j);
+    for (int64_t q = 0; q < deal.nq; q += NBUF) {
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) {
+            load_row(x[(j + NBUF - 1) % NBUF], q + j + NBUF - 1);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) acc ^= x[j][k].x ^ x[j][k].y ^ x[j][k].z ^ x[j][k].w;
+        }
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;
+}
+
 // ------------------------------------------------------------------------------------------
 // Loop bookkeeping: exchange restart slots i and j of the four [B][H] loop vectors and of the
 // state array (em_loop_impl packs the still-running restarts into the leading slots so that

@@ -789,7 +789,14 @@ extern "C" int mxm_assign_reads(const double *X, int64_t ldx, const double *log_
 extern "C" int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_per_cu, int32_t blocked, void *sink,
                                     void *stream) {
     if (src == nullptr || sink == nullptr || bytes < 16 || wg_per_cu < 1) return fail(-1, "mxm_diag_stream_read: bad arguments%s", "");
-    if (blocked)
+    if (blocked == 2) {
+        // the EM kernel's pattern: rows of 5408 doubles (2704 x 16 B) dealt over one workgroup per CU
+        const int row16 = 2704;
+        const int64_t rows = (int64_t)(bytes / 16) / row16;
+        if (rows < 1) return fail(-1, "mxm_diag_stream_read: buffer smaller than one row%s", "");
+        hipLaunchKernelGGL(diag_stream_dealt_kernel<6>, dim3(clamp_grid(rows, num_cu() * wg_per_cu)), dim3(512), 0,
+                           (hipStream_t)stream, (const double *)src, rows, row16, (unsigned int *)sink);
+    } else if (blocked)
         hipLaunchKernelGGL(diag_stream_read_kernel<true>, dim3(num_cu() * wg_per_cu), dim3(256), 0, (hipStream_t)stream,
                            (const uint4 *)src, (int64_t)(bytes / 16), (unsigned int *)sink);
     else

@@ -17,8 +17,9 @@ lib = _lib.load()
 nbytes = int(float(sys.argv[1])) if len(sys.argv) > 1 else 43264000000
 buf = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda").uniform_()
 sink = torch.zeros(4, dtype=torch.int32, device="cuda")
-for blocked in (0, 1):
-    for wg in (1, 2, 4, 8, 16):
+NAMES = {0: "grid-stride", 1: "blocked, nt", 2: "dealt 43 KB rows, nt, ring 3, 512 thr"}
+for blocked in (0, 1, 2):
+    for wg in ((1, 2) if blocked == 2 else (1, 2, 4, 8, 16)):
         times = []
         for rep in range(6):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,5 +31,5 @@ for blocked in (0, 1):
             times.append(a.elapsed_time(b))
         best, med = min(times[1:]), sorted(times[1:])[len(times[1:]) // 2]
         print("bare read (%s), %2d WG/CU: median %.3f ms = %.2f TB/s (best %.3f ms = %.2f TB/s)"
-              % ("blocked, nt" if blocked else "grid-stride", wg, med, nbytes / med / 1e9, best,
+              % (NAMES[blocked], wg, med, nbytes / med / 1e9, best,
                  nbytes / best / 1e9))
