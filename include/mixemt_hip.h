@@ -19,7 +19,10 @@
  *   - matrices are row-major with an explicit leading dimension (in elements);
  *   - return value: 0 = ok, negative = error (text via mxm_last_error());
  *   - no allocation inside: the caller owns every buffer including `ws`
- *     (size from mxm_workspace_bytes), so calls are hipGraph-capturable.
+ *     (size from mxm_workspace_bytes), so calls are hipGraph-capturable;
+ *   - work goes to the calling thread's current device; one process (or thread) per GPU.
+ *     mxm_last_error() is per thread.  The mxm_set_* tuning / measurement knobs are
+ *     process-wide and not synchronised: set them before the work starts.
  */
 #ifndef MIXEMT_HIP_H
 #define MIXEMT_HIP_H

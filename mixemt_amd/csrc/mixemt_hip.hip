@@ -44,6 +44,13 @@ static inline int clamp_grid(int64_t want, int cap) {
     return (int)(want < cap ? want : cap);
 }
 
+// one bit per device of the node (the current device of the calling thread)
+static inline unsigned device_bit() {
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    return 1u << (dev & 31);
+}
+
 static inline int64_t part_ld(int H) { return ((int64_t)H + 1) & ~(int64_t)1; }
 
 extern "C" int mxm_version(void) { return MXM_VERSION; }
@@ -130,11 +137,11 @@ extern "C" int mxm_build_em_matrix_packed(const uint32_t *Epk, const uint8_t *mu
     const size_t lds = mxm_build_packed_lds_bytes(S, n_mu);
     if (lds > 158 * 1024) return fail(-1, "mxm_build_em_matrix_packed: tables need %s%lld B of LDS (> 158 KiB); use mxm_build_em_matrix", "", (long long)lds);
     if (R == 0) return 0;
-    static bool raised = false;
-    if (!raised) {
+    static unsigned raised = 0;                 // bit per device: the attribute is per device
+    if (!(raised & device_bit())) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&build_tile_kernel),
                                   hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised = true;
+        raised |= device_bit();
     }
     const int ntiles = (H + TILE_COLS - 1) / TILE_COLS;
     // one workgroup per CU (the table slice fills the LDS): aim at ~2 waves of workgroups
@@ -311,12 +318,12 @@ static int launch_wide(const double *P, int64_t ldp, const double *w, const doub
     } else {
         const size_t lds = (size_t)(BT - PREG) * NCH * THREADS * sizeof(d2);
         if (lds > 0) {
-            static bool raised = false;     // > 64 KiB of dynamic LDS must be opted into, once per kernel
-            if (!raised) {
+            static unsigned raised = 0;     // > 64 KiB of dynamic LDS must be opted into, once per kernel and device
+            if (!(raised & device_bit())) {
                 (void)hipFuncSetAttribute(
                     reinterpret_cast<const void *>(&em_iter_wide_kernel<THREADS, NCH, BT, NBUF, PREG>),
                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                raised = true;
+                raised |= device_bit();
             }
         }
         hipLaunchKernelGGL((em_iter_wide_kernel<THREADS, NCH, BT, NBUF, PREG>), dim3(grid), dim3(THREADS), lds,
