@@ -113,7 +113,16 @@ __device__ __forceinline__ double wave_max_lane63(double v) {
     return v;
 }
 
-// Returns c[g] = (sum_g > 0) ? num / sum_g : 0 -- the one fp64 division runs once per wave for
+// w_r / Z_r of a row.  Z_r == 0 means the row is -inf everywhere (no haplogroup can have produced
+// the read): the reference's E-step forms -inf - (-inf) = NaN there (em.py:81-83) and its weighted
+// column logsumexp (em.py:87) carries the NaN into every proportion -- unless the row's weight is 0,
+// which scipy drops.  Same here: the NaN coefficient times the row's zeros poisons every column sum.
+__device__ __forceinline__ double weight_over_norm(double wr, double z) {
+    if (z > 0.0) return wr / z;
+    return (wr != 0.0) ? __builtin_nan("") : 0.0;
+}
+
+// Returns c[g] = weight_over_norm(num, sum_g) -- the one fp64 division runs once per wave for
 // all groups (they sit in different lanes) instead of once per group.
 template <int NW, int N>
 __device__ __forceinline__ void group_ratio_to_sgpr(const double *red, int lane, double num, double (&c)[N]) {
@@ -123,7 +132,7 @@ __device__ __forceinline__ void group_ratio_to_sgpr(const double *red, int lane,
     v += dpp_mov_f64<0xB1>(v);                      // quad_perm [1,0,3,2]: lane ^ 1
     v += dpp_mov_f64<0x4E>(v);                      // quad_perm [2,3,0,1]: lane ^ 2
     if constexpr (NW == 8) v += dpp_mov_f64<0x141>(v);   // row_half_mirror: lane i <-> 7 - i
-    v = (v > 0.0) ? num / v : 0.0;
+    v = weight_over_norm(num, v);
 #pragma unroll
     for (int g = 0; g < N; ++g) c[g] = readlane_f64(v, g * NW);
 }

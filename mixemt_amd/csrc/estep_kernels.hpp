@@ -43,7 +43,7 @@ __global__ __launch_bounds__(ROW_THREADS) void estep_log_kernel(
             double z = 0.0;
             for (int h = t; h < H; h += ROW_THREADS) z += exp(lnp[h] + (src[h] - shift));
             z = block_reduce<ROW_THREADS, false>(z, scratch);
-            const double c = (z > 0.0) ? wr / z : 0.0;
+            const double c = weight_over_norm(wr, z);
             for (int h = t; h < H; h += ROW_THREADS) acc[h] += c * exp(src[h] - shift);
         } else {
             double m = -INFINITY;
@@ -60,7 +60,7 @@ __global__ __launch_bounds__(ROW_THREADS) void estep_log_kernel(
                     double *o = out + r * ldo + h;
                     *o = (mode == 1) ? logaddexp_f64(*o, v) : v;
                 }
-                if (partial != nullptr) acc[h] += wr * exp(v);
+                if (partial != nullptr && wr != 0.0) acc[h] += wr * exp(v);   // scipy drops zero-weight rows, NaN or not
             }
         }
     }
@@ -114,7 +114,7 @@ __global__ __launch_bounds__(256) void estep_narrow_kernel(
                 x[h] = exp(x[h] - shift);           // pad columns: exp(-inf) = 0
                 z = fma(lp[h], x[h], z);
             }
-            const double c = (z > 0.0) ? wr / z : 0.0;
+            const double c = weight_over_norm(wr, z);
 #pragma unroll
             for (int h = 0; h < HMAX; ++h) acc[h] = fma(c, x[h], acc[h]);
         } else {
@@ -137,7 +137,7 @@ __global__ __launch_bounds__(256) void estep_narrow_kernel(
                         double *o = out + r * ldo + h;
                         *o = (mode == 1) ? logaddexp_f64(*o, v) : v;
                     }
-                    if (partial != nullptr) acc[h] += wr * exp(v);
+                    if (partial != nullptr && wr != 0.0) acc[h] += wr * exp(v);   // scipy drops zero-weight rows, NaN or not
                 }
             }
         }
@@ -257,7 +257,7 @@ __global__ __launch_bounds__(256, 2) void estep_wide_kernel(
         }
         if constexpr (COLSUM) {
             const double wr = live ? (w != nullptr ? w[r] : 1.0) : 0.0;
-            const double c = (ssum > 0.0) ? wr / ssum : 0.0;     // w * exp(z - lse) = w * e / sum
+            const double c = weight_over_norm(wr, ssum);         // w * exp(z - lse) = w * e / sum
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
                 acc[k].x = fma(c, e[k].x, acc[k].x);

@@ -182,13 +182,17 @@ def test_run_em_refinement_shape_golden(b17):
 
 
 @pytest.mark.parametrize("n_rows,n_haps,seed", [(37, 66, 1), (500, 513, 2), (300, 1000, 3), (64, 2049, 4),
-                                                (33, 8192, 5), (129, 5408, 6)])
+                                                (33, 8192, 5), (129, 5408, 6), (20, 1, 7), (300, 2, 8),
+                                                (70, 16, 9), (70, 17, 10), (50, 32, 11), (50, 33, 12),
+                                                (50, 64, 13), (50, 65, 14)])
 def test_em_iterations_vs_oracle_random_shapes(n_rows, n_haps, seed):
-    """A few EM steps on random matrices across the streaming kernel's NCH range, odd H included."""
+    """A few EM steps on random matrices across the streaming kernel's NCH range, odd H included,
+    and across the narrow kernels' widths (thread per row up to 32 columns, workgroup per row to 64)."""
     from mixemt_amd import em
     rng = numpy.random.default_rng(seed)
     mat = rng.normal(-25.0, 8.0, size=(n_rows, n_haps))
-    mat[rng.random(mat.shape) < 0.01] = -numpy.inf
+    if n_haps > 1:                                  # (a row that is -inf everywhere is its own test below)
+        mat[rng.random(mat.shape) < 0.01] = -numpy.inf
     wts = rng.integers(1, 5, size=n_rows)
     init = rng.dirichlet([1.0] * n_haps)
     res = em.run_em_ex(mat, wts, em_args(max_iter=5, tolerance=0.0), inits=init[None, :],
@@ -502,3 +506,38 @@ def test_posterior_reuses_the_linearised_matrix_storage():
     assert torch.equal(reused, fresh) and torch.equal(mat, keep)
     with pytest.raises(ValueError):
         plan.em_iter(ln_cur, ln_cur, None, ln_cur.clone())      # a spent plan fails loudly
+
+
+@pytest.mark.parametrize("n_rows,n_haps", [(40, 3), (60, 20), (50, 48), (50, 66), (30, 1001), (70, 5408)])
+def test_row_without_any_possible_haplogroup_poisons_like_the_reference(n_rows, n_haps):
+    """
+    A row that is -inf in every column: the reference's E-step forms -inf - (-inf) = NaN
+    (em.py:81-83) and the weighted column logsumexp (em.py:87) spreads it to every proportion;
+    the loop then never converges and stops at max_iter with NaN proportions.  With weight 0 on
+    that row scipy's logsumexp drops it and everything stays finite.  Same here, on every kernel
+    family (thread per row, workgroup per row, linear-space streaming, em_step's wide kernel).
+    """
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(n_haps)
+    mat = rng.normal(-25.0, 8.0, size=(n_rows, n_haps))
+    mat[7, :] = -numpy.inf
+    init = rng.dirichlet([1.0] * n_haps)
+    for w7 in (2.0, 0.0):
+        wts = rng.integers(1, 4, size=n_rows).astype(numpy.float64)
+        wts[7] = w7
+        with numpy.errstate(invalid="ignore", divide="ignore"):
+            want_mix, want_new = em_oracle.em_step(mat, wts, numpy.log(init), numpy.empty_like(mat))
+            theta = numpy.log(init)
+            for _ in range(3):
+                _, theta = em_oracle.em_step(mat, wts, theta, numpy.empty_like(mat))
+        assert numpy.isnan(want_new).all() == (w7 != 0.0)          # what the reference does
+        mix, new = em.em_step(mat, wts, numpy.log(init), numpy.empty_like(mat))
+        assert numpy.array_equal(numpy.isnan(new), numpy.isnan(want_new))
+        assert numpy.array_equal(numpy.isnan(mix), numpy.isnan(want_mix))
+        res = em.run_em_ex(mat, wts, em_args(max_iter=3, tolerance=1e-4), inits=init[None, :], want_read_mix=False)
+        assert numpy.array_equal(numpy.isnan(res["props"]), numpy.isnan(theta))
+        if w7 != 0.0:
+            assert res["iters"] == [3] and res["done"] == [2]      # NaN never passes the convergence test
+        else:
+            assert numpy.abs(res["props"] - numpy.exp(theta)).max() < 1e-12
+            assert numpy.abs(new - want_new).max() < 1e-12
