@@ -146,14 +146,34 @@ __global__ __launch_bounds__(256, 2) void row_argmax_wide_kernel(
     };
     int ring = 0;
     auto process = [&](d2(&xr)[NCH], int64_t q) {
-        argmax_cand c{-INFINITY, 0x7fffffff, 0};
+        // this lane's candidate in two cheap sweeps over its registers: the maximum (v_max ignores
+        // NaNs) and whether there is a NaN at all; then the first column holding it (descending,
+        // so the smallest column is written last).  NaN rows are rare: the wave branches only then.
+        double m = -INFINITY;
+        bool any_nan = false;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {             // ascending columns: the first maximum wins
+        for (int k = 0; k < NCH; ++k) {
+            m = fmax(m, fmax(xr[k].x, xr[k].y));
+            any_nan = any_nan || (xr[k].x != xr[k].x) || (xr[k].y != xr[k].y);
+        }
+        argmax_cand c{m, 0x7fffffff, 0};
+#pragma unroll
+        for (int k = NCH - 1; k >= 0; --k) {
             const int col = 2 * ((k < NCH - 1) ? (t + k * THREADS) : last_c2);
-            const argmax_cand a{xr[k].x, col, (xr[k].x != xr[k].x) ? 1 : 0};
-            const argmax_cand b{xr[k].y, col + 1, (xr[k].y != xr[k].y) ? 1 : 0};
-            c = cand_pick(c, a);
-            c = cand_pick(c, b);
+            c.i = (xr[k].y == m) ? col + 1 : c.i;
+            c.i = (xr[k].x == m) ? col : c.i;
+        }
+        if (__builtin_amdgcn_ballot_w64(any_nan) != 0) {
+            if (any_nan) {
+                c.n = 1;
+                c.i = 0x7fffffff;
+#pragma unroll
+                for (int k = NCH - 1; k >= 0; --k) {
+                    const int col = 2 * ((k < NCH - 1) ? (t + k * THREADS) : last_c2);
+                    c.i = (xr[k].y != xr[k].y) ? col + 1 : c.i;
+                    c.i = (xr[k].x != xr[k].x) ? col : c.i;
+                }
+            }
         }
         c = wave_best_lane63(c);
         if (lane == 63) { s_val[ring][wv] = c.v; s_idx[ring][wv] = c.i; s_nan[ring][wv] = c.n; }
