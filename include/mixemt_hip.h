@@ -110,6 +110,8 @@ int mxm_linearize(const double *M, int64_t ldm, int64_t R, int32_t H,
  * P != NULL and mxm_linear_supported(H): streams P (no transcendental), reads `props`;
  * otherwise streams M in log space and reads `ln_props` (must then be non-NULL).
  * Restarts with state[b].done != 0 are skipped (their colsum is left untouched).
+ * A row with Z_b[r] == 0 (-inf in every column) and w[r] != 0 makes every T_bh NaN, as the
+ * reference's -inf - (-inf) does (em.py:81-83, :87); with w[r] == 0 it is dropped like scipy drops it.
  * props[B][H] = exp(ln_props[B][H]) (theta_k), w[R] fp64 weights (NULL = all 1).
  * With several ranks the caller all-reduces (SUM) colsum before mxm_m_finalize.
  */
