@@ -102,6 +102,9 @@ def main():
                          "(fp64 math on float-stored P), never the default")
     ap.add_argument("--min-rows-per-wg", type=int, default=0, help="tuning knob (0 = library default)")
     ap.add_argument("--build-kernel", default="auto", choices=["auto", "packed", "bytes"])
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and issue the per-iteration all-reduce even with "
+                         "one rank (exercises the RCCL path on a single-GPU box)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to test the "
                          "multi-process path on a single GPU)")
@@ -121,7 +124,8 @@ def main():
         raise SystemExit("bench: %d ranks but %d GPU(s) visible" % (world, n_dev))
     dev = torch.device("cuda", local_rank % max(n_dev, 1))
     torch.cuda.set_device(dev)
-    if world > 1:
+    use_dist = world > 1 or opts.force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         if opts.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
@@ -177,7 +181,7 @@ def main():
     ln0, p0 = em.log_inits(init)
     props_cur = torch.from_numpy(p0).to(dev)
     ln_cur = torch.from_numpy(ln0).to(dev)
-    if world > 1:
+    if use_dist:
         dist.broadcast(ln_cur, src=0)
         props_cur = torch.exp(ln_cur)
     ln_new = ln_cur.clone()
@@ -196,12 +200,12 @@ def main():
         plan.em_iter(props_cur, ln_cur, state, colsum)
         if pair is not None:
             lib.mxm_set_timing_events(None, None)
-        if world > 1:
+        if use_dist:
             dist.all_reduce(colsum, op=dist.ReduceOp.SUM)
         plan.finalize(colsum, ln_cur, ln_new, props_cur, state, 0.0, total + 1)
 
     def fence():
-        if world > 1:
+        if use_dist:
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -213,7 +217,7 @@ def main():
         step(evs[i])
     fence()
     elapsed = time.perf_counter() - t0
-    if world > 1:
+    if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
@@ -223,7 +227,7 @@ def main():
     # sanity (untimed): one more E+M pass; the M-step sums  sum_h p_h T_h  must add up to the
     # total weight of all ranks' rows, once per restart
     plan.em_iter(props_cur, ln_cur, state, colsum)
-    if world > 1:
+    if use_dist:
         dist.all_reduce(colsum, op=dist.ReduceOp.SUM)
     mass = float((props_cur * colsum).sum().item())
     sane = (st[1] == total) and abs(mass - n_rows * world * n_runs) < 1e-6 * n_rows * world * n_runs
@@ -297,7 +301,7 @@ def main():
         }
         print(json.dumps(line))
         sys.stdout.flush()
-    if world > 1:
+    if use_dist:
         dist.barrier()
         dist.destroy_process_group()
 

@@ -50,6 +50,12 @@ def _world(group):
     return dist.get_rank(group), dist.get_world_size(group)
 
 
+def _collective(group):
+    """True when a process group exists: the collectives are then issued even for a world of one
+    (a no-op exchange), so that a single-GPU box drives the same calls as an 8-GPU node."""
+    return dist is not None and dist.is_available() and dist.is_initialized()
+
+
 def broadcast_inits(n_runs, n_haps, alpha, device, group=None, src=0):
     """
     The restarts' initial proportions are sequential draws from numpy's global
@@ -61,7 +67,7 @@ def broadcast_inits(n_runs, n_haps, alpha, device, group=None, src=0):
     else:
         host = numpy.empty((n_runs, n_haps))
     buf = torch.from_numpy(numpy.ascontiguousarray(host)).to(device)
-    if world > 1:
+    if _collective(group):
         dist.broadcast(buf, src=src, group=group)
     return buf.cpu().numpy()
 
@@ -80,7 +86,7 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     and all-reduces only the running restarts' sums.  Every rank sees the same
     state, hence takes the same packing decisions.
     """
-    rank, world = _world(group)
+    exchange = _collective(group)
     ln0, p0 = _em.log_inits(inits)
     n_runs = ln0.shape[0]
     props_cur = plan.alloc_props(p0)
@@ -108,7 +114,7 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
         burst = min(check_every, max_iter - issued)
         for _ in range(burst):
             plan.em_iter(props_cur[:lead], ln_cur[:lead], state[:lead], colsum[:lead])
-            if world > 1:
+            if exchange:
                 dist.all_reduce(colsum[:lead], op=dist.ReduceOp.SUM, group=group)
             plan.finalize(colsum[:lead], ln_cur[:lead], ln_new[:lead], props_cur[:lead], state[:lead],
                           tolerance, max_iter)
@@ -175,7 +181,7 @@ def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_rea
             run_props[run] = torch.exp(ln_new[j])
             if want_read_mix:
                 fold = _em.posterior(plan, ln_k[j], out=fold, fold=(j > 0))
-    if world > 1:
+    if _collective(group):
         dist.all_reduce(ln_sum, group=group)
         dist.all_reduce(iters, group=group)
         dist.all_reduce(run_props, group=group)
@@ -184,7 +190,7 @@ def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_rea
         # in place: at 10^6 x 5408 every extra copy of the posterior is 43 GB
         read_mix = fold.exp_() if fold is not None else torch.zeros(
             (plan.n_rows, n_haps), dtype=torch.float64, device=plan.dev)
-        if world > 1:
+        if _collective(group):
             dist.all_reduce(read_mix, group=group)
         read_mix.log_()
         if n_multi > 1:

@@ -1,7 +1,7 @@
 """
 The row-sharded multi-process EM loop on real kernels.  The GPU box has ONE
 GPU, so two ranks share cuda:0 and the collective runs over gloo (RCCL refuses
-two ranks on one device); everything else -- shard bounds, mxm_em_iter on the
+two ranks on one device; a one-rank RCCL group covers the nccl-backend calls); everything else -- shard bounds, mxm_em_iter on the
 local rows, the all-reduce between it and mxm_m_finalize, the frozen-state stop
 logic, rank-0 init broadcast, per-rank posterior blocks -- is the production
 path of mixemt_amd.dist.  Checked against the reference-derived golden g4/g5.
@@ -23,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, name, seed, n_multi, mode):
+def _worker(rank, world, port, out_dir, name, seed, n_multi, mode, backend="gloo"):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
@@ -35,7 +35,10 @@ def _worker(rank, world, port, out_dir, name, seed, n_multi, mode):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
-    dist.init_process_group("gloo", rank=rank, world_size=world)
+    if backend == "nccl":
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
+    else:
+        dist.init_process_group(backend, rank=rank, world_size=world)
     try:
         g = numpy.load(os.path.join(here, "golden", name + ".npz"))
         refseq = phylotree.load_rsrs()
@@ -89,6 +92,24 @@ def test_two_ranks_restart_parallel_match_reference(tmp_path):
         assert numpy.abs(r["props"] - g["props"]).max() < 1e-9
         assert numpy.array_equal(r["best"], g["mix_argmax"])
         assert numpy.allclose(r["rowmax"], g["mix_rowmax"], rtol=0, atol=1e-8)
+
+
+@pytest.mark.parametrize("mode", ["rows", "restarts"])
+def test_one_rank_over_rccl_matches_reference(tmp_path, mode):
+    """
+    The collectives of both modes issued through the nccl (= RCCL) backend -- group creation with
+    a device id, init broadcast, fp64 all-reduce between mxm_em_iter and mxm_m_finalize, the final
+    combines -- with the one rank a single-GPU box allows: same results as the reference.
+    """
+    import torch.multiprocessing as mp
+    g = golden("g5_run_em_multi")
+    mp.spawn(_worker, args=(1, _free_port(), str(tmp_path), "g5_run_em_multi", 11, 3, mode, "nccl"),
+             nprocs=1, join=True)
+    r = numpy.load(str(tmp_path / "rank0.npz"))
+    assert list(r["iters"]) == list(g["iters"])
+    assert numpy.abs(r["props"] - g["props"]).max() < 1e-9
+    assert numpy.array_equal(r["best"], g["mix_argmax"])
+    assert numpy.allclose(r["rowmax"], g["mix_rowmax"], rtol=0, atol=1e-8)
 
 
 def test_world_of_one_needs_no_process_group(b17):
