@@ -7,7 +7,8 @@
 // K6  estep_log: the reference's E-step verbatim in log space (em.py:80-83), optional posterior
 // write / logaddexp fold (em.py:156) and optional M-step sums (em.py:87-88, linear space).
 // One workgroup per row (grid-stride), column sums in LDS (each thread owns its columns).
-// Used for em_step(), the final posterior pass, and EM iterations when H is tiny.
+// Used for em_step() and the posterior pass when the rows are not 16-byte aligned / H is odd, and
+// for anything wider than the register-resident kernels cover; narrow matrices take K6n.
 // ------------------------------------------------------------------------------------------
 template <bool ITER>
 __global__ __launch_bounds__(ROW_THREADS) void estep_log_kernel(
@@ -79,34 +80,39 @@ __global__ __launch_bounds__(ROW_THREADS) void estep_log_kernel(
 // bandwidth-bound on the same 24 MB).  Column sums: per-thread registers -> wave sum -> LDS ->
 // partial[wg][h], reduced in fixed order by colreduce_kernel like everywhere else.
 // ------------------------------------------------------------------------------------------
-template <int HMAX, bool ITER>
+// LPR = lanes per row: 1 (H <= 32), or 2 adjacent lanes that own the columns [0, HMAX) and
+// [HMAX, 2 HMAX) of one row and combine their row maximum / row sum through a DPP lane swap.
+template <int HMAX, bool ITER, int LPR>
 __global__ __launch_bounds__(256) void estep_narrow_kernel(
     const double *__restrict__ M, int64_t ldm, const double *__restrict__ w,
     const double *__restrict__ ln_props, int64_t R, int H, double *__restrict__ out, int64_t ldo,
     int mode, double *__restrict__ partial, int64_t ldpart,
     const mxm_em_state *__restrict__ state) {
-    __shared__ double red[4][HMAX];
+    static_assert(LPR == 1 || LPR == 2, "lanes per row");
+    __shared__ double red[4][HMAX * LPR];
     if (state != nullptr && state->done != 0) return;
     const int t = threadIdx.x;
+    const int c0 = (LPR == 2) ? (t & 1) * HMAX : 0; // first column of this lane
     double lp[HMAX], acc[HMAX];                     // ITER: lp holds the LINEAR proportions
 #pragma unroll
     for (int h = 0; h < HMAX; ++h) {
-        const double l = (h < H) ? ln_props[h] : -INFINITY;
+        const double l = (c0 + h < H) ? ln_props[c0 + h] : -INFINITY;
         lp[h] = ITER ? exp(l) : l;
         acc[h] = 0.0;
     }
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t r = (int64_t)blockIdx.x * 256 + t; r < R; r += stride) {
-        const double *src = M + r * ldm;
+    const int64_t stride = (int64_t)gridDim.x * (256 / LPR);
+    for (int64_t r = (int64_t)blockIdx.x * (256 / LPR) + t / LPR; r < R; r += stride) {
+        const double *src = M + r * ldm + c0;
         const double wr = (w != nullptr) ? w[r] : 1.0;
         double x[HMAX];
 #pragma unroll
-        for (int h = 0; h < HMAX; ++h) x[h] = (h < H) ? src[h] : -INFINITY;
+        for (int h = 0; h < HMAX; ++h) x[h] = (c0 + h < H) ? src[h] : -INFINITY;
         if constexpr (ITER) {
             // T_h += (w_r / Z_r) e_h,  e_h = exp(M_rh - rowmax_r),  Z_r = sum_h p_h e_h
             double m = x[0];
 #pragma unroll
             for (int h = 1; h < HMAX; ++h) m = fmax(m, x[h]);
+            if constexpr (LPR == 2) m = fmax(m, dpp_mov_f64<0xB1>(m));      // the row's other half
             const double shift = isfinite(m) ? m : 0.0;
             double z = 0.0;
 #pragma unroll
@@ -114,6 +120,7 @@ __global__ __launch_bounds__(256) void estep_narrow_kernel(
                 x[h] = exp(x[h] - shift);           // pad columns: exp(-inf) = 0
                 z = fma(lp[h], x[h], z);
             }
+            if constexpr (LPR == 2) z += dpp_mov_f64<0xB1>(z);
             const double c = weight_over_norm(wr, z);
 #pragma unroll
             for (int h = 0; h < HMAX; ++h) acc[h] = fma(c, x[h], acc[h]);
@@ -124,17 +131,19 @@ __global__ __launch_bounds__(256) void estep_narrow_kernel(
             double m = x[0];
 #pragma unroll
             for (int h = 1; h < HMAX; ++h) m = fmax(m, x[h]);
+            if constexpr (LPR == 2) m = fmax(m, dpp_mov_f64<0xB1>(m));
             const double shift = isfinite(m) ? m : 0.0;
             double ssum = 0.0;
 #pragma unroll
             for (int h = 0; h < HMAX; ++h) ssum += exp(x[h] - shift);
+            if constexpr (LPR == 2) ssum += dpp_mov_f64<0xB1>(ssum);
             const double lse = log(ssum) + m;       // m (not shift): -inf rows stay -inf, as scipy does
 #pragma unroll
             for (int h = 0; h < HMAX; ++h) {
-                if (h < H) {
+                if (c0 + h < H) {
                     const double v = x[h] - lse;
                     if (out != nullptr) {
-                        double *o = out + r * ldo + h;
+                        double *o = out + r * ldo + c0 + h;
                         *o = (mode == 1) ? logaddexp_f64(*o, v) : v;
                     }
                     if (partial != nullptr && wr != 0.0) acc[h] += wr * exp(v);   // scipy drops zero-weight rows, NaN or not
@@ -145,8 +154,14 @@ __global__ __launch_bounds__(256) void estep_narrow_kernel(
     if (partial != nullptr) {
 #pragma unroll
         for (int h = 0; h < HMAX; ++h) {
-            const double a = wave_sum(acc[h]);
-            if ((t & 63) == 0) red[t >> 6][h] = a;
+            double a = acc[h];
+            if constexpr (LPR == 2) {               // sum the lanes of equal parity: every xor step but the last
+#pragma unroll
+                for (int off = 32; off > 1; off >>= 1) a += __shfl_xor(a, off, 64);
+            } else {
+                a = wave_sum(a);
+            }
+            if ((t & 63) < LPR) red[t >> 6][c0 + h] = a;
         }
         __syncthreads();
         if (t < H) partial[(int64_t)blockIdx.x * ldpart + t] = ((red[0][t] + red[1][t]) + red[2][t]) + red[3][t];

@@ -431,22 +431,25 @@ static int em_iter_f32_one(const float *P, int64_t ldp, const double *w, const d
     return 0;
 }
 
-// Narrow matrices (H <= 32: the refinement EM's contributor columns): one thread per row.
-#define MXM_NARROW_MAX_H 32
+// Narrow matrices (the refinement EM's contributor columns): one thread per row up to 32 columns,
+// a lane pair per row up to 64.
+#define MXM_NARROW_MAX_H 64
 template <bool ITER>
 static int launch_narrow(const double *M, int64_t ldm, const double *w, const double *ln_props, int64_t R, int H,
                          double *out, int64_t ldo, int mode, double *partial, int64_t ldpart,
                          const mxm_em_state *state, hipStream_t stream, int *nwg_out) {
     const int cap = num_cu() * 4 < MXM_MAX_WG ? num_cu() * 4 : MXM_MAX_WG;
-    const int nwg = clamp_grid((R + 255) / 256, cap);
+    const int rows_per_wg = (H <= 32) ? 256 : 128;
+    const int nwg = clamp_grid((R + rows_per_wg - 1) / rows_per_wg, cap);
     *nwg_out = nwg;
-#define NARROW_LAUNCH(hmax)                                                                                  \
-    hipLaunchKernelGGL((estep_narrow_kernel<hmax, ITER>), dim3(nwg), dim3(256), 0, stream, M, ldm, w, ln_props, R, H, \
+#define NARROW_LAUNCH(hmax, lpr)                                                                             \
+    hipLaunchKernelGGL((estep_narrow_kernel<hmax, ITER, lpr>), dim3(nwg), dim3(256), 0, stream, M, ldm, w, ln_props, R, H, \
                        out, ldo, mode, partial, ldpart, state)
-    if (H <= 4) NARROW_LAUNCH(4);
-    else if (H <= 8) NARROW_LAUNCH(8);
-    else if (H <= 16) NARROW_LAUNCH(16);
-    else NARROW_LAUNCH(32);
+    if (H <= 4) NARROW_LAUNCH(4, 1);
+    else if (H <= 8) NARROW_LAUNCH(8, 1);
+    else if (H <= 16) NARROW_LAUNCH(16, 1);
+    else if (H <= 32) NARROW_LAUNCH(32, 1);
+    else NARROW_LAUNCH(32, 2);
 #undef NARROW_LAUNCH
     HIP_TRY(hipGetLastError());
     return 0;
