@@ -3,7 +3,9 @@
 bench.py -- EM hot-path throughput on MI355X (BASELINE.json metric:
 "EM iters/sec + read x hap cells/sec, 1M reads x 5.4k haps, 1/2/4/8 GPUs").
 
-    python bench.py [--gpus N] [--steps K] [--warmup W] [--rows R_PER_GPU]
+    python bench.py [--gpus N] [--steps K] [--warmup W]
+                    [--scaling strong|weak] [--total-rows R] [--rows R_PER_GPU]
+                    [--mode rows|restarts] [--restarts B]
 
 A "step" is one full EM iteration (em.py:57-91 + the convergence bookkeeping
 of em.py:126-143) over this rank's resident rows of the synthetic (synth-v1)
@@ -11,10 +13,26 @@ reads x haplogroups matrix: mxm_em_iter -> [RCCL all-reduce of the H column
 sums when N > 1] -> mxm_m_finalize.  The tolerance is 0 inside the timed
 region so that exactly K iterations run; nothing is skipped or cached.
 
+Scaling (SURVEY.md section 8 e): rows shard over the ranks.
+  strong (default)  the metric's own problem: --total-rows (1 000 000) rows IN TOTAL,
+                    rank r holds rows shard_bounds(total, r, N) of the same global read
+                    set at every N; --total-rows 10000000 --gpus 8 is BASELINE config 4
+  weak              --rows rows PER GPU (per-GPU work fixed as N grows)
+At N = 1 both are the same 1 000 000 x 5408 workload.
+
+--gpus N > 1 without a launcher (no RANK in the environment): this process starts N
+rank processes itself (python -m torch.distributed.run, 127.0.0.1) BEFORE touching
+torch or the GPU, relays their output and exits with their status.  Under the
+driver's own torch.distributed.run it is a plain rank.
+
+--mode restarts (BASELINE config 5): the matrix is replicated, --restarts EM
+restarts are dealt over the ranks and run to convergence with no per-iteration
+traffic; reports restart-iterations/s, each rank's loop time (idle tail) and the
+end-of-run combine.  --steps / --warmup do not apply there (a run is a run).
+
 Inputs are resident in HBM before the clock starts (the matrix is BUILT on the
-device from CSR observations by mxm_build_em_matrix; build and posterior pass
-are timed separately and reported as extra fields).  Rows are sharded over
-ranks with per-GPU work fixed ("weak"); value = cells of all ranks / time.
+device from CSR observations by mxm_build_em_matrix; build, linearize and
+posterior pass are timed separately and reported as extra fields).
 
 One JSON line on stdout (rank 0); progress on stderr.
 """
@@ -22,15 +40,16 @@ One JSON line on stdout (rank 0); progress on stderr.
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
-
-import numpy
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_BYTES_PER_S = 8.0e12        # MI355X HBM3E spec (MI355X_MICROARCH.md)
+PARITY_PROPS_BAR = 1e-9              # in-run parity bar on proportions (north-star bar: 1e-6)
 
 
 def log(msg):
@@ -38,23 +57,112 @@ def log(msg):
     sys.stderr.flush()
 
 
-def cpu_baseline(mat_rows, n_iters):
+def parse_args(argv=None):
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--mode", default="rows", choices=["rows", "restarts"],
+                    help="rows: row-sharded EM iteration (configs 2-4); restarts: replicated matrix, "
+                         "restarts dealt over the ranks, run to convergence (config 5)")
+    ap.add_argument("--scaling", default=None, choices=["strong", "weak"],
+                    help="default strong (the metric's 1M-row problem at every N); weak if --rows is given")
+    ap.add_argument("--total-rows", type=int, default=1000000, help="reads in total (strong scaling)")
+    ap.add_argument("--rows", type=int, default=None, help="reads per GPU (selects weak scaling)")
+    ap.add_argument("--cpu-rows", type=int, default=32768)
+    ap.add_argument("--cpu-iters", type=int, default=4)
+    ap.add_argument("--no-cpu-baseline", action="store_true",
+                    help="skip the oracle leg (cpu_baseline and parity_in_run become null)")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--restarts", type=int, default=1,
+                    help="mode rows: EM restarts advanced together (config 3 uses 10); a step then is one "
+                         "iteration of EVERY restart and value counts cells x restarts.  mode restarts: "
+                         "restarts in total (config 5 uses 64)")
+    ap.add_argument("--batch-tile", type=int, default=4,
+                    help="restarts sharing one pass over the matrix (1 = unbatched schedule)")
+    ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
+                    help="element type of the streamed matrix; f32 is a labelled opt-in variant "
+                         "(fp64 math on float-stored P), never the default")
+    ap.add_argument("--min-rows-per-wg", type=int, default=0, help="tuning knob (0 = library default)")
+    ap.add_argument("--build-kernel", default="auto", choices=["auto", "packed", "bytes", "lut"])
+    ap.add_argument("--force-dist", action="store_true",
+                    help="initialise the process group and issue the per-iteration all-reduce even with "
+                         "one rank (exercises the RCCL path on a single-GPU box)")
+    ap.add_argument("--backend", default="nccl",
+                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to test the "
+                         "multi-process path on a single GPU)")
+    return ap.parse_args(argv)
+
+
+def spawn_ranks(opts, argv):
     """
-    The oracle's em_step (numpy restatement of em.py:57-91, single thread like
-    the reference) on a bounded sample of the same matrix.  CHECKER/baseline
-    only -- never part of the measured GPU path.
+    `python bench.py --gpus N` with no launcher: start the N rank processes here.  This
+    process has not imported torch and never touches the GPU; the ranks are fresh
+    interpreters (no exec of a GPU-initialised process anywhere).
     """
+    with socket.socket() as sock:
+        sock.bind(("127.0.0.1", 0))
+        port = sock.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")      # dmabuf IPC: what RCCL needs on this driver
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(opts.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + list(argv)
+    log("starting %d ranks: %s" % (opts.gpus, " ".join(cmd[1:])))
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_reference_leg(mat_rows, n_iters, tol=1e-4):
+    """
+    The oracle's em_step (numpy restatement of em.py:57-91, single thread like the
+    reference) on a bounded sample of the same matrix, iterated the way run_em does
+    (em.py:126-143: stop when converged(), result = theta_{k+1} with the posterior under
+    theta_k).  CHECKER / baseline only -- never part of the measured GPU path.
+    -> dict(rate cells/s, seconds, iters, done, l1, init, ln_new, best (row argmax of the posterior))
+    """
+    import numpy
     from oracle import em_oracle
     n_rows, n_haps = mat_rows.shape
     wts = numpy.ones(n_rows, dtype=numpy.int64)
     numpy.random.seed(7)
-    ln_props = numpy.log(numpy.random.dirichlet([1.0] * n_haps))
+    init = numpy.random.dirichlet([1.0] * n_haps)
+    ln_props = numpy.log(init)
     buf = numpy.empty_like(mat_rows)
+    iters, done, l1 = 0, 2, float("nan")
     t0 = time.perf_counter()
     for _ in range(n_iters):
-        buf, ln_props = em_oracle.em_step(mat_rows, wts, ln_props, buf)
+        buf, ln_next = em_oracle.em_step(mat_rows, wts, ln_props, buf)
+        iters += 1
+        l1 = float(numpy.sum(numpy.abs(numpy.exp(ln_props) - numpy.exp(ln_next))))    # em.py:53-54
+        if l1 < tol:
+            done = 1
+            ln_props = ln_next
+            break
+        ln_props = ln_next
     dt = time.perf_counter() - t0
-    return n_rows * n_haps * n_iters / dt, dt
+    return {"rate": n_rows * n_haps * iters / dt, "seconds": dt, "iters": iters, "done": done, "l1": l1,
+            "init": init, "ln_new": ln_props, "best": buf.argmax(axis=1)}
+
+
+def parity_in_run(em, torch, slab, cpu, n_iters, tol=1e-4):
+    """
+    The HIP path on the same slab, same init, same loop bounds as the oracle leg above
+    (outside the timed region): proportions, stopping iteration and haplogroup calls.
+    """
+    import numpy
+    n_rows = slab.shape[0]
+    wts = torch.ones(n_rows, dtype=torch.float64, device=slab.device)
+    plan = em.EmPlan(slab, wts, n_runs=1)
+    ln_cur, ln_new, states = em.em_loop(plan, cpu["init"][None, :], tol, n_iters)
+    done, iters, l1 = states[0]
+    post = em.posterior(plan, ln_cur[0])
+    best = post.argmax(dim=1).cpu().numpy()
+    d_props = float(numpy.abs(numpy.exp(ln_new[0].cpu().numpy()) - numpy.exp(cpu["ln_new"])).max())
+    return {"rows": int(n_rows), "iters": int(iters), "max_abs_dprops": d_props,
+            "iters_equal": bool(iters == cpu["iters"] and done == cpu["done"]),
+            "argmax_equal": bool(numpy.array_equal(best, cpu["best"])),
+            "l1_gpu": float(l1), "l1_cpu": cpu["l1"],
+            "against": "oracle em_step x%d (em.py:57-91, :126-143) on the first %d rows of the same "
+                       "matrix, same Dirichlet init" % (cpu["iters"], n_rows)}
 
 
 def pmc_traffic(n_rows, n_haps):
@@ -82,56 +190,59 @@ def pmc_traffic(n_rows, n_haps):
     return best
 
 
-def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=20)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--rows", type=int, default=1000000, help="reads (matrix rows) per GPU")
-    ap.add_argument("--cpu-rows", type=int, default=32768)
-    ap.add_argument("--cpu-iters", type=int, default=4)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--seed", type=int, default=1)
-    ap.add_argument("--restarts", type=int, default=1,
-                    help="EM restarts advanced together (config 3 uses 10); a step then is one "
-                         "iteration of EVERY restart and value counts cells x restarts")
-    ap.add_argument("--batch-tile", type=int, default=4,
-                    help="restarts sharing one pass over the matrix (1 = unbatched schedule)")
-    ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
-                    help="element type of the streamed matrix; f32 is a labelled opt-in variant "
-                         "(fp64 math on float-stored P), never the default")
-    ap.add_argument("--min-rows-per-wg", type=int, default=0, help="tuning knob (0 = library default)")
-    ap.add_argument("--build-kernel", default="auto", choices=["auto", "packed", "bytes"])
-    ap.add_argument("--force-dist", action="store_true",
-                    help="initialise the process group and issue the per-iteration all-reduce even with "
-                         "one rank (exercises the RCCL path on a single-GPU box)")
-    ap.add_argument("--backend", default="nccl",
-                    help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to test the "
-                         "multi-process path on a single GPU)")
-    opts = ap.parse_args()
+def main(argv=None):
+    argv = list(sys.argv[1:] if argv is None else argv)
+    opts = parse_args(argv)
+    if opts.gpus < 1:
+        raise SystemExit("bench: --gpus must be >= 1")
+    if opts.gpus > 1 and "RANK" not in os.environ:
+        raise SystemExit(spawn_ranks(opts, argv))          # before torch / the GPU are touched
 
+    import numpy
     import torch
     import torch.distributed as dist
     from mixemt_amd import _lib, em, phylotree, preprocess, synth
+    from mixemt_amd import dist as mdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != opts.gpus:
-        log("warning: --gpus %d but WORLD_SIZE=%d; using WORLD_SIZE" % (opts.gpus, world))
+        raise SystemExit("bench: --gpus %d but the launcher started WORLD_SIZE=%d ranks; they must agree "
+                         "(plain `python bench.py --gpus N` starts its own ranks)" % (opts.gpus, world))
     n_dev = torch.cuda.device_count()
+    if n_dev < 1:
+        raise SystemExit("bench: no ROCm GPU visible (the EM hot path has no CPU fallback)")
     if opts.backend == "nccl" and world > n_dev:
         raise SystemExit("bench: %d ranks but %d GPU(s) visible" % (world, n_dev))
-    dev = torch.device("cuda", local_rank % max(n_dev, 1))
+    dev = torch.device("cuda", local_rank % n_dev)
     torch.cuda.set_device(dev)
     use_dist = world > 1 or opts.force_dist
     if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29533")
         if opts.backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
         else:
             dist.init_process_group(opts.backend, rank=rank, world_size=world)
     lib = _lib.load()
+
+    # ---- which rows live here ---------------------------------------------------------------
+    scaling = opts.scaling or ("weak" if opts.rows is not None else "strong")
+    if opts.mode == "restarts":
+        scaling = "strong"                      # total work (restarts) fixed, matrix replicated
+        total_rows = opts.rows if opts.rows is not None else opts.total_rows
+        lo, hi = 0, total_rows
+    elif scaling == "weak":
+        per_gpu = opts.rows if opts.rows is not None else opts.total_rows
+        total_rows = per_gpu * world
+        lo, hi = rank * per_gpu, (rank + 1) * per_gpu
+    else:
+        total_rows = opts.total_rows if opts.rows is None else opts.rows * world
+        lo, hi = mdist.shard_bounds(total_rows, rank, world)
+    n_rows = hi - lo
+    if n_rows < 1:
+        raise SystemExit("bench: rank %d of %d has no rows (%d in total)" % (rank, world, total_rows))
 
     # ---- inputs: Build 17 + RSRS tables, synth-v1 reads, matrix built on the device -------------
     t0 = time.perf_counter()
@@ -139,11 +250,16 @@ def main():
     phy = phylotree.load_build17(refseq)
     haps = sorted(phy.hap_var)
     tables = preprocess.HapVarTables.build(refseq, phy, haps)
-    n_rows, n_haps = opts.rows, len(haps)
-    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=opts.seed + rank)
+    n_haps = len(haps)
+    need_gb = (2.0 + (1.0 if opts.mode == "rows" else 0.0)) * n_rows * n_haps * 8 / 1e9
+    free_gb = torch.cuda.mem_get_info(dev)[0] / 1e9
+    if need_gb > free_gb:
+        raise SystemExit("bench: %d rows x %d haplogroups per GPU need about %.0f GB (matrix, linearised copy, "
+                         "posterior), %.0f GB free: use more GPUs or fewer rows" % (n_rows, n_haps, need_gb, free_gb))
+    row_ptr, site, obs, _ = synth.synth_rows(tables, len(refseq), lo, hi, seed=opts.seed)
     if rank == 0:
-        log("tables + %d synthetic reads (%.1f sites/read) on host: %.1f s"
-            % (n_rows, row_ptr[-1] / float(n_rows), time.perf_counter() - t0))
+        log("tables + rows [%d, %d) of %d synthetic reads (%.1f sites/read) on host: %.1f s"
+            % (lo, hi, total_rows, row_ptr[-1] / float(n_rows), time.perf_counter() - t0))
     row_ptr_d = torch.from_numpy(row_ptr).to(dev)
     site_d = torch.from_numpy(site.view(numpy.int16)).to(dev)
     obs_d = torch.from_numpy(obs).to(dev)
@@ -157,7 +273,35 @@ def main():
     torch.cuda.synchronize()
     build_s = time.perf_counter() - t0
     wts = torch.ones(n_rows, dtype=torch.float64, device=dev)
-    plan = em.EmPlan(mat, wts, n_runs=opts.restarts, storage=opts.storage)          # allocates P and linearises once (untimed: hipMalloc)
+    lib.mxm_set_batch_tile(opts.batch_tile)
+    if opts.min_rows_per_wg > 0:
+        lib.mxm_set_min_rows_per_wg(opts.min_rows_per_wg)
+
+    if opts.mode == "restarts":
+        line = bench_restarts(opts, locals())
+    else:
+        line = bench_rows(opts, locals())
+    if rank == 0:
+        print(json.dumps(line))
+        sys.stdout.flush()
+    if use_dist:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0 and not line.get("sanity_ok", False):
+        raise SystemExit(3)
+
+
+def bench_rows(opts, env):
+    """Row-sharded EM iteration: the BASELINE metric (configs 2, 3, 4)."""
+    import numpy
+    import torch
+    import torch.distributed as dist
+    from mixemt_amd import _lib, em
+    (lib, dev, rank, world, use_dist, mat, wts, n_rows, n_haps, total_rows, scaling, build_s) = (
+        env[k] for k in ("lib", "dev", "rank", "world", "use_dist", "mat", "wts", "n_rows", "n_haps",
+                         "total_rows", "scaling", "build_s"))
+    n_runs = opts.restarts
+    plan = em.EmPlan(mat, wts, n_runs=n_runs, storage=opts.storage)     # allocates P and linearises once (untimed: hipMalloc)
     torch.cuda.synchronize()
     t0 = time.perf_counter()                      # timed again on the now-resident buffers
     lin_fn = lib.mxm_linearize_f32 if opts.storage == "f32" else lib.mxm_linearize
@@ -168,14 +312,9 @@ def main():
     linearize_s = time.perf_counter() - t0
     if rank == 0:
         log("matrix build %.3f s (%.3g cells/s), linearize %.3f s, HBM in use %.1f GB"
-            % (build_s, n_rows * n_haps / build_s, linearize_s,
-               torch.cuda.memory_allocated() / 1e9))
+            % (build_s, n_rows * n_haps / build_s, linearize_s, torch.cuda.memory_allocated() / 1e9))
 
-    # ---- loop state: one restart, init = first Dirichlet draw after numpy.random.seed(7) --------
-    n_runs = opts.restarts
-    lib.mxm_set_batch_tile(opts.batch_tile)
-    if opts.min_rows_per_wg > 0:
-        lib.mxm_set_min_rows_per_wg(opts.min_rows_per_wg)
+    # ---- loop state: init = sequential Dirichlet draws after numpy.random.seed(7) on rank 0 ------
     numpy.random.seed(7)
     init = numpy.stack([em.init_props(n_haps, 1.0) for _ in range(n_runs)])   # sequential draws
     ln0, p0 = em.log_inits(init)
@@ -188,20 +327,23 @@ def main():
     colsum = torch.zeros_like(props_cur)
     state = em.new_state(n_runs, dev)
     total = opts.warmup + opts.steps
-    evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-           for _ in range(opts.steps)]
-    for a, b in evs:                       # materialise the hipEvent_t handles
-        a.record()
-        b.record()
+    evs = [tuple(torch.cuda.Event(enable_timing=True) for _ in range(4)) for _ in range(opts.steps)]
+    for quad in evs:                       # materialise the hipEvent_t handles
+        for ev in quad:
+            ev.record()
 
-    def step(pair=None):
-        if pair is not None:
-            lib.mxm_set_timing_events(pair[0].cuda_event, pair[1].cuda_event)
+    def step(quad=None):
+        if quad is not None:
+            lib.mxm_set_timing_events(quad[0].cuda_event, quad[1].cuda_event)
         plan.em_iter(props_cur, ln_cur, state, colsum)
-        if pair is not None:
+        if quad is not None:
             lib.mxm_set_timing_events(None, None)
         if use_dist:
+            if quad is not None:
+                quad[2].record()
             dist.all_reduce(colsum, op=dist.ReduceOp.SUM)
+            if quad is not None:
+                quad[3].record()
         plan.finalize(colsum, ln_cur, ln_new, props_cur, state, 0.0, total + 1)
 
     def fence():
@@ -222,7 +364,9 @@ def main():
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    kernel_ms = numpy.array([a.elapsed_time(b) for a, b in evs])
+    kernel_ms = numpy.array([q[0].elapsed_time(q[1]) for q in evs])
+    # colreduce done -> all-reduced sums visible to this rank's stream (includes waiting for the slowest rank)
+    all_reduce_us = float(numpy.mean([q[2].elapsed_time(q[3]) for q in evs]) * 1e3) if use_dist else None
     st = em.read_state(state)[0]
     # sanity (untimed): one more E+M pass; the M-step sums  sum_h p_h T_h  must add up to the
     # total weight of all ranks' rows, once per restart
@@ -230,18 +374,18 @@ def main():
     if use_dist:
         dist.all_reduce(colsum, op=dist.ReduceOp.SUM)
     mass = float((props_cur * colsum).sum().item())
-    sane = (st[1] == total) and abs(mass - n_rows * world * n_runs) < 1e-6 * n_rows * world * n_runs
+    sane = (st[1] == total) and abs(mass - total_rows * n_runs) < 1e-6 * total_rows * n_runs
     if rank == 0:
         log("%d steps in %.4f s; streaming kernel avg %.4f ms (min %.4f, max %.4f); "
-            "sum(colsum)=%.6f iters=%d" % (opts.steps, elapsed, kernel_ms.mean(), kernel_ms.min(),
-                                            kernel_ms.max(), mass, st[1]))
+            "sum(colsum)=%.6f iters=%d%s" % (opts.steps, elapsed, kernel_ms.mean(), kernel_ms.min(),
+                                             kernel_ms.max(), mass, st[1],
+                                             "" if all_reduce_us is None else "; all-reduce %.1f us" % all_reduce_us))
 
     # ---- posterior pass (reported, not part of the step) ----------------------------------------
     posterior_ms = None
     try:
         out = torch.empty((n_rows, n_haps), dtype=torch.float64, device=dev)
-        with numpy.errstate(divide="ignore"):
-            ln_theta = ln_cur[0].clone()
+        ln_theta = ln_cur[0].clone()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
         em.posterior(plan, ln_theta, out=out)
@@ -251,59 +395,137 @@ def main():
     except Exception as exc:       # out of memory at very large --rows: report and go on
         log("posterior pass skipped: %s" % exc)
 
-    # ---- CPU baseline: oracle em_step on a bounded sample of the same matrix (rank 0, N = 1) ----
+    # ---- CPU leg (rank 0, N = 1): oracle em_step on a bounded sample of the same matrix, timed as the
+    # cpu_baseline, and its result compared with the HIP path on the same slab (parity_in_run) -----
     cpu = None
+    parity = None
     if rank == 0 and world == 1 and not opts.no_cpu_baseline:
         n_cpu = min(n_rows, opts.cpu_rows)
         sample = mat[:n_cpu].cpu().numpy()
-        rate, dt = cpu_baseline(sample, opts.cpu_iters)
-        cpu = {"value": rate, "unit": "cells/s", "cores": 1, "kind": "port",
+        leg = cpu_reference_leg(sample, opts.cpu_iters)
+        cpu = {"value": leg["rate"], "unit": "cells/s", "cores": 1, "kind": "port",
                "sample": "oracle em_step (numpy restatement of em.py:57-91) x%d on the first %d rows "
                          "x %d haps of the same matrix, %.1f s; host has %d cores, 1 used like the "
-                         "reference" % (opts.cpu_iters, n_cpu, n_haps, dt, os.cpu_count())}
-        log("cpu baseline: %.3g cells/s (%.1f s)" % (rate, dt))
+                         "reference" % (leg["iters"], n_cpu, n_haps, leg["seconds"], os.cpu_count())}
+        log("cpu baseline: %.3g cells/s (%.1f s)" % (leg["rate"], leg["seconds"]))
+        parity = parity_in_run(em, torch, mat[:n_cpu], leg, opts.cpu_iters)
+        log("parity in run: max |dprops| %.2e, iterations equal %s, haplogroup calls equal %s"
+            % (parity["max_abs_dprops"], parity["iters_equal"], parity["argmax_equal"]))
+        sane = sane and parity["max_abs_dprops"] < PARITY_PROPS_BAR and parity["iters_equal"] \
+            and parity["argmax_equal"]
 
-    if rank == 0:
-        cells = float(n_rows) * n_haps
-        elem = 4.0 if opts.storage == "f32" else 8.0
-        algo_bytes = cells * elem                     # the stored matrix is read once per iteration
-        achieved = algo_bytes / (kernel_ms.mean() * 1e-3)
-        traffic = pmc_traffic(n_rows, n_haps) if (opts.storage == "f64" and n_runs == 1) else None
-        line = {
-            "metric": "read x hap cells/sec through the EM iteration (EM iters/sec reported beside it as "
-                      "em_iters_per_s), 1M reads x 5.4k haps per GPU, whole job",
-            "value": cells * world * n_runs * opts.steps / elapsed,
-            "unit": "cells/s",
-            "em_iters_per_s": n_runs * opts.steps / elapsed,
-            "n_gpus": world, "steps": opts.steps, "warmup": opts.warmup,
-            "ms_per_step": elapsed / opts.steps * 1e3,
-            "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-            "dtype": "f64" if opts.storage == "f64" else "f64 arithmetic on f32-stored matrix (opt-in variant)",
-            "data": "synthetic (synth-v1 reads, matrix built on device)",
-            "config": {"workload": "%d reads x %d haplogroups per GPU (Phylotree B17 + RSRS), "
-                                   "%d EM restart(s) advanced together (tile %d), %s matrix"
-                                   % (n_rows, n_haps, n_runs, opts.batch_tile,
-                                      "fp64" if opts.storage == "f64" else "fp32-stored"),
-                       "rows_per_gpu": n_rows, "haps": n_haps, "restarts": n_runs,
-                       "sharding": "rows over %d rank(s), 1 all-reduce of %d fp64 per iteration"
-                                   % (world, n_haps)},
-            "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
-                         "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S,
-                         "traffic": traffic[0] if traffic else None,
-                         "traffic_source": traffic[1] if traffic else None,
-                         "kernel": "em_iter_wide_kernel" if opts.storage == "f64" else "em_iter_wide_f32_kernel", "kernel_ms": float(kernel_ms.mean()),
-                         "algorithmic_bytes_per_launch": algo_bytes},
-            "cpu_baseline": cpu,
-            "matrix_build_cells_per_s": cells / build_s,
-            "linearize_ms": linearize_s * 1e3,
-            "posterior_pass_ms": posterior_ms,
-            "sanity_ok": bool(sane),
-        }
-        print(json.dumps(line))
-        sys.stdout.flush()
+    if rank != 0:
+        return None
+    cells = float(total_rows) * n_haps
+    elem = 4.0 if opts.storage == "f32" else 8.0
+    algo_bytes = float(n_rows) * n_haps * elem        # this rank's stored matrix is read once per iteration
+    achieved = algo_bytes / (kernel_ms.mean() * 1e-3)
+    traffic = pmc_traffic(n_rows, n_haps) if (opts.storage == "f64" and n_runs == 1) else None
+    return {
+        "metric": "read x hap cells/sec through the EM iteration (EM iters/sec reported beside it as "
+                  "em_iters_per_s), %d reads x %d haps in total, whole job" % (total_rows, n_haps),
+        "value": cells * n_runs * opts.steps / elapsed,
+        "unit": "cells/s",
+        "em_iters_per_s": n_runs * opts.steps / elapsed,
+        "n_gpus": world, "steps": opts.steps, "warmup": opts.warmup,
+        "ms_per_step": elapsed / opts.steps * 1e3,
+        "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
+        "dtype": "f64" if opts.storage == "f64" else "f64 arithmetic on f32-stored matrix (opt-in variant)",
+        "data": "synthetic (synth-v1 reads in blocks of %d, matrix built on device)" % 125000,
+        "config": {"workload": "%d reads x %d haplogroups in total (Phylotree B17 + RSRS), %d per rank, "
+                               "%d EM restart(s) advanced together (tile %d), %s matrix"
+                               % (total_rows, n_haps, n_rows, n_runs, opts.batch_tile,
+                                  "fp64" if opts.storage == "f64" else "fp32-stored"),
+                   "total_rows": total_rows, "rows_per_gpu": n_rows, "haps": n_haps, "restarts": n_runs,
+                   "scaling": scaling,
+                   "sharding": "rows over %d rank(s), 1 all-reduce of %d fp64 per iteration"
+                               % (world, n_haps * n_runs)},
+        "roofline": {"bound": "hbm", "achieved": achieved / 1e9, "peak": HBM_PEAK_BYTES_PER_S / 1e9,
+                     "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S,
+                     "traffic": traffic[0] if traffic else None,
+                     "traffic_source": traffic[1] if traffic else None,
+                     "kernel": "em_iter_wide_kernel" if opts.storage == "f64" else "em_iter_wide_f32_kernel",
+                     "kernel_ms": float(kernel_ms.mean()),
+                     "algorithmic_bytes_per_launch": algo_bytes},
+        "cpu_baseline": cpu,
+        "parity_in_run": parity,
+        "all_reduce_us": all_reduce_us,
+        "matrix_build_cells_per_s": float(n_rows) * n_haps / build_s,
+        "linearize_ms": linearize_s * 1e3,
+        "posterior_pass_ms": posterior_ms,
+        "sanity_ok": bool(sane),
+    }
+
+
+def bench_restarts(opts, env):
+    """
+    BASELINE config 5: the matrix replicated on every rank, --restarts EM restarts dealt over the
+    ranks (run i -> rank i % N), each rank keeps one full tile of restarts in flight and refills a
+    slot when its restart converges; no per-iteration traffic; at the end one all-reduce of the
+    summed log-proportions and the row-block exchange of the folded posterior.
+    """
+    import argparse as _ap
+    import numpy
+    import torch
+    import torch.distributed as dist
+    from mixemt_amd import dist as mdist
+    (dev, rank, world, use_dist, mat, wts, n_rows, n_haps, build_s) = (
+        env[k] for k in ("dev", "rank", "world", "use_dist", "mat", "wts", "n_rows", "n_haps", "build_s"))
+    args = _ap.Namespace(init_alpha=1.0, tolerance=1e-4, max_iter=10000, n_multi=opts.restarts, verbose=False)
+    numpy.random.seed(7)
+    timing = {}
     if use_dist:
         dist.barrier()
-        dist.destroy_process_group()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    res = mdist.run_em_restart_parallel(mat, wts, args, timing=timing)
+    torch.cuda.synchronize()
+    wall = time.perf_counter() - t0
+    stats = torch.tensor([timing["loop_s"], timing["fold_s"], timing["combine_s"], wall],
+                         dtype=torch.float64, device=dev)
+    if use_dist:
+        every = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(every, stats)
+    else:
+        every = [stats]
+    every = torch.stack(every).cpu().numpy()
+    loop_s = every[:, 0]
+    iters = res["iters"]
+    total_iters = int(sum(iters))
+    # sanity: every restart stopped by convergence, the proportions are a geometric mean of unit-sum vectors
+    sane = all(d == 1 for d in res["done"]) and float(res["run_props"].sum(axis=1).min()) > 0.999999
+    lo, hi = res["rows"]
+    if res["read_mix"] is not None:
+        lse = torch.logsumexp(res["read_mix"][: min(hi - lo, 4096)], dim=1)
+        # a log-mean-exp of row-normalised posteriors is itself row-normalised
+        sane = sane and float(lse.abs().max().item()) < 1e-9
+    if rank != 0:
+        return None
+    cells = float(n_rows) * n_haps
+    return {
+        "metric": "EM restart-iterations/sec over %d restarts run to convergence (cells/sec = x R x H), "
+                  "%d reads x %d haps replicated on every GPU, whole job" % (opts.restarts, n_rows, n_haps),
+        "value": cells * total_iters / float(loop_s.max()),
+        "unit": "cells/s",
+        "restart_iters_per_s": total_iters / float(loop_s.max()),
+        "n_gpus": world, "steps": total_iters, "warmup": 0,
+        "ms_per_step": float(loop_s.max()) / max(total_iters, 1) * 1e3,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic (synth-v1 reads in blocks of %d, matrix built on device)" % 125000,
+        "config": {"workload": "%d EM restarts (sequential Dirichlet inits after seed 7) on %d reads x %d "
+                               "haplogroups replicated per GPU, dealt over %d rank(s), tile %d with slot refill"
+                               % (opts.restarts, n_rows, n_haps, world, opts.batch_tile),
+                   "rows_per_gpu": n_rows, "haps": n_haps, "restarts": opts.restarts, "mode": "restarts"},
+        "iters_per_restart": [int(x) for x in iters],
+        "loop_s_per_rank": [float(x) for x in loop_s],
+        "idle_tail_s_per_rank": [float(loop_s.max() - x) for x in loop_s],
+        "posterior_fold_s_per_rank": [float(x) for x in every[:, 1]],
+        "combine_s_per_rank": [float(x) for x in every[:, 2]],
+        "wall_s": float(every[:, 3].max()),
+        "matrix_build_cells_per_s": cells / build_s,
+        "roofline": None, "cpu_baseline": None,
+        "sanity_ok": bool(sane),
+    }
 
 
 if __name__ == "__main__":

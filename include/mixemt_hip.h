@@ -21,8 +21,8 @@
  *   - no allocation inside: the caller owns every buffer including `ws`
  *     (size from mxm_workspace_bytes), so calls are hipGraph-capturable;
  *   - work goes to the calling thread's current device; one process (or thread) per GPU.
- *     mxm_last_error() is per thread.  The mxm_set_* tuning / measurement knobs are
- *     process-wide and not synchronised: set them before the work starts.
+ *     mxm_last_error() is per thread.  Tuning / measurement knobs are NOT part of this
+ *     boundary: they live in mixemt_hip_tuning.h.
  */
 #ifndef MIXEMT_HIP_H
 #define MIXEMT_HIP_H
@@ -49,6 +49,11 @@ const char *mxm_last_error(void);
 /* Largest haplogroup count the linear-space streaming kernel accepts; above it
  * (and below MXM_LINEAR_MIN_H) mxm_em_iter runs the generic log-space kernel. */
 int         mxm_linear_supported(int32_t H);
+
+/* How many restarts share one pass over the matrix in mxm_em_iter at this width (1..4: the
+ * per-restart on-chip state -- accumulators, proportions -- must fit a CU beside the row buffers);
+ * B restarts take ceil(B / tile) passes.  mxm_em_loop keeps one full tile iterating. */
+int         mxm_restart_tile(int32_t H);
 
 /* Bytes of scratch mxm_em_iter / mxm_em_step / mxm_em_loop need. */
 size_t      mxm_workspace_bytes(int64_t R, int32_t H, int32_t B);
@@ -193,11 +198,14 @@ int mxm_add_scalar(double *x, int64_t ld, int64_t R, int32_t H, double delta,
 /*
  * Row argmax + weighted votes -- assemble.py:115-123 / stats.py:39-40:
  *   best[r] = first index of max_h X[r][h] ;  votes[h] = sum_{r: best[r]==h} w[r]
- * votes[H] must be zeroed by the caller; w NULL = 1.
+ * votes[H] is overwritten (NULL = not wanted); w NULL = 1.  The votes are summed without float
+ * atomics (per-workgroup rows of `ws`, reduced in fixed order), so fractional weights give the
+ * same bits on every run; ws / ws_bytes as for mxm_em_iter (mxm_workspace_bytes(R, H, 1)),
+ * only needed when votes != NULL.
  */
 int mxm_row_argmax_votes(const double *X, int64_t ldx, const double *w,
                          int64_t R, int32_t H, int32_t *best, double *votes,
-                         void *stream);
+                         void *ws, size_t ws_bytes, void *stream);
 
 /*
  * Read -> contributor assignment -- assemble.py:284-334 (_find_best_n_for_read :267-281 inlined):
@@ -208,6 +216,25 @@ int mxm_row_argmax_votes(const double *X, int64_t ldx, const double *w,
 int mxm_assign_reads(const double *X, int64_t ldx, const double *log_props,
                      const int32_t *cols, int32_t nC, int64_t R, int32_t H,
                      double log_min_fold, int32_t *assigned, void *stream);
+
+/*
+ * Column subset for the refinement EM -- preprocess.py:247-251 (em_mat[:, indexes]):
+ *   out[r][i] = M[r][cols[i]],  i < nC;  cols[] device int32, each in [0, H).
+ */
+int mxm_gather_columns(const double *M, int64_t ldm, int64_t R, int32_t H,
+                       const int32_t *cols, int32_t nC, double *out, int64_t ldo,
+                       void *stream);
+
+/*
+ * Fold of log-posterior blocks across runs / ranks -- em.py:156 and :161:
+ *   acc[r][h] = logaddexp(... logaddexp(logaddexp(acc, in[0]), in[1]) ..., in[n_in-1]) + delta
+ * in that fixed order, in log space (entries below exp(-745) keep their finite logs).
+ * in_host[n_in] / ld_in_host[n_in] are HOST arrays of device pointers / leading dimensions,
+ * n_in <= 8 per call; delta = -log(n_multi) on the last call, 0 otherwise.
+ */
+int mxm_fold_logaddexp(double *acc, int64_t lda, const double *const *in_host,
+                       const int64_t *ld_in_host, int32_t n_in, int64_t R, int32_t H,
+                       double delta, void *stream);
 
 /*
  * HOST function (no device work): the read signatures 'pos:base,pos:base,...' that
@@ -227,56 +254,6 @@ int mxm_assign_reads(const double *X, int64_t ldx, const double *log_props,
 int64_t mxm_encode_signatures(const char *text, const int64_t *off, int64_t R,
                               const int32_t *site_of_pos, int64_t ref_len, int64_t *row_ptr,
                               uint16_t *site, uint8_t *obs, int64_t cap);
-
-/*
- * Measurement hook (bench.py): when both handles are non-NULL, mxm_em_iter
- * records hipEvent_t `ev_start` / `ev_stop` on its stream immediately before /
- * after the streaming kernel (the dominant one), so its device time can be read
- * without a profiler.  Pass NULLs to switch it off.  Not part of the reference
- * boundary.
- */
-int mxm_set_timing_events(void *ev_start, void *ev_stop);
-
-/*
- * Diagnostic, not part of the reference boundary: a bare streaming read of `bytes` bytes
- * (16 B per lane, 8 loads in flight per lane, `wg_per_cu` workgroups of 256 per CU; blocked = 0:
- * grid-stride plain loads, 1: one contiguous block per workgroup, non-temporal loads, 2: the
- * streaming EM kernel's own pattern without its arithmetic -- 43 264-byte rows dealt over
- * workgroups of 512, per-row buffer descriptors, non-temporal loads, a ring of 3 rows) to measure
- * the practical HBM read ceiling on the device at hand (tools/stream_ceiling.py).
- */
-int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_per_cu, int32_t blocked,
-                         void *sink, void *stream);
-
-/*
- * mxm_em_loop replays its chunk of iterations from a hipGraph when that pays
- * (launch-bound sizes): mode -1 = automatic (R*H*B < 6.4e7 cells), 0 = never,
- * 1 = always.  Results are identical either way.
- */
-int mxm_set_loop_graph(int32_t mode);
-
-/*
- * How many restarts at most share one pass over the matrix in mxm_em_iter (1..4,
- * default 4; B restarts take ceil(B / tile) passes with the restarts spread evenly:
- * 10 -> 4 + 3 + 3).  1 reproduces the unbatched schedule (B passes per iteration).
- * Results do not depend on it beyond rounding of the reduction order.
- */
-int mxm_set_batch_tile(int32_t bt);
-
-/*
- * mxm_em_loop keeps the restarts that are still running packed in the leading slots of the loop
- * vectors (device-side slot exchanges, undone before it returns), so an iteration takes
- * ceil(running / tile) passes over the matrix rather than ceil(B / tile).  1 (default) / 0.
- * Results are the same either way: a stopped restart is frozen wherever it sits.
- */
-int mxm_set_compact_restarts(int32_t on);
-
-/* Tuning knob: shape of the single-restart streaming kernel (0: 256 threads, 2 workgroups per CU,
- * register ring 2; 1: 512 threads, 1 workgroup per CU, ring 3).  Same results up to summation order. */
-int mxm_set_v1_shape(int32_t shape);
-
-/* Tuning knob: rows a workgroup of the streaming kernel handles at least (grid = min(cap, R / n)). */
-int mxm_set_min_rows_per_wg(int32_t n);
 
 #ifdef __cplusplus
 }

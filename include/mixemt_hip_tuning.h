@@ -1,0 +1,75 @@
+/*
+ * mixemt_hip_tuning.h -- measurement hooks and kernel-shape knobs of libmixemt_hip.so.
+ *
+ * NOT part of the drop-in boundary (include/mixemt_hip.h): nothing here replaces a line of
+ * the reference.  bench.py, tools/ and the parity tests use these to time the dominant kernel
+ * without a profiler and to A/B kernel shapes inside one process.  All of them set
+ * PROCESS-WIDE, unsynchronised state: call them before the work starts, from one thread.
+ * Results never depend on them beyond the rounding of a different summation order.
+ */
+#ifndef MIXEMT_HIP_TUNING_H
+#define MIXEMT_HIP_TUNING_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/*
+ * Measurement hook (bench.py): when both handles are non-NULL, mxm_em_iter
+ * records hipEvent_t `ev_start` / `ev_stop` on its stream immediately before /
+ * after the streaming kernel (the dominant one), so its device time can be read
+ * without a profiler.  Pass NULLs to switch it off.
+ */
+int mxm_set_timing_events(void *ev_start, void *ev_stop);
+
+/*
+ * Diagnostic, not part of the reference boundary: a bare streaming read of `bytes` bytes
+ * (16 B per lane, 8 loads in flight per lane, `wg_per_cu` workgroups of 256 per CU; blocked = 0:
+ * grid-stride plain loads, 1: one contiguous block per workgroup, non-temporal loads, 2: the
+ * streaming EM kernel's own pattern without its arithmetic -- 43 264-byte rows dealt over
+ * workgroups of 512, per-row buffer descriptors, non-temporal loads, a ring of 3 rows) to measure
+ * the practical HBM read ceiling on the device at hand (tools/stream_ceiling.py).
+ */
+int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_per_cu, int32_t blocked,
+                         void *sink, void *stream);
+
+/*
+ * mxm_em_loop replays its chunk of iterations from a hipGraph when that pays
+ * (launch-bound sizes): mode -1 = automatic (R*H*B < 6.4e7 cells), 0 = never,
+ * 1 = always.  Results are identical either way.
+ */
+int mxm_set_loop_graph(int32_t mode);
+
+/*
+ * How many restarts at most share one pass over the matrix in mxm_em_iter (1..4,
+ * default 4; B restarts take ceil(B / tile) passes with the restarts spread evenly:
+ * 10 -> 4 + 3 + 3).  1 reproduces the unbatched schedule (B passes per iteration).
+ * Results do not depend on it beyond rounding of the reduction order.
+ */
+int mxm_set_batch_tile(int32_t bt);
+
+/*
+ * Restart schedule of mxm_em_loop.  0: all B restarts advance together, ceil(B / tile) passes per
+ * iteration until each tile's last member stops.  1: the restarts still running are kept packed in
+ * the leading slots of the loop vectors (device-side slot exchanges, undone before it returns), so
+ * an iteration takes ceil(running / tile) passes.  2 (default): packed, and only ONE full tile of
+ * them iterates at a time -- a slot whose restart has stopped is refilled with a waiting one -- so
+ * every pass over the matrix carries a full tile.  Results are the same in all modes: each restart
+ * counts its own iterations and is frozen wherever it sits once it has stopped.
+ */
+int mxm_set_compact_restarts(int32_t mode);
+
+/* Tuning knob: shape of the single-restart streaming kernel (0: 256 threads, 2 workgroups per CU,
+ * register ring 2; 1: 512 threads, 1 workgroup per CU, ring 3).  Same results up to summation order. */
+int mxm_set_v1_shape(int32_t shape);
+
+/* Tuning knob: rows a workgroup of the streaming kernel handles at least (grid = min(cap, R / n)). */
+int mxm_set_min_rows_per_wg(int32_t n);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* MIXEMT_HIP_TUNING_H */

@@ -21,12 +21,14 @@ class EmState(ctypes.Structure):
     _fields_ = [("done", c_i32), ("iters", c_i32), ("l1", c_f64)]
 
 
-# name -> (restype, argtypes); must list every symbol the header declares
+# name -> (restype, argtypes); must list every symbol the two headers declare
+# (include/mixemt_hip.h: the boundary; include/mixemt_hip_tuning.h: measurement / shape knobs)
 SIGNATURES = {
     "mxm_version": (ctypes.c_int, []),
     "mxm_last_error": (ctypes.c_char_p, []),
     "mxm_linear_supported": (ctypes.c_int, [c_i32]),
     "mxm_workspace_bytes": (c_size, [c_i64, c_i32, c_i32]),
+    "mxm_restart_tile": (ctypes.c_int, [c_i32]),
     "mxm_build_em_matrix": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                            c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     "mxm_build_packed_lds_bytes": (c_size, [c_i32, c_i32]),
@@ -62,7 +64,10 @@ SIGNATURES = {
     "mxm_set_min_rows_per_wg": (ctypes.c_int, [c_i32]),
     "mxm_set_v1_shape": (ctypes.c_int, [c_i32]),
     "mxm_row_argmax_votes": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
-                                            c_ptr]),
+                                            c_ptr, c_size, c_ptr]),
+    "mxm_gather_columns": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),
+    "mxm_fold_logaddexp": (ctypes.c_int, [c_ptr, c_i64, ctypes.POINTER(c_ptr), ctypes.POINTER(c_i64), c_i32,
+                                          c_i64, c_i32, c_f64, c_ptr]),
 }
 
 _lib = None

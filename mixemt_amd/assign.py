@@ -37,9 +37,11 @@ def row_argmax_votes(read_hap_mat, wts=None):
     best = torch.empty(n_rows, dtype=torch.int32, device=dev)
     votes = torch.zeros(n_haps, dtype=torch.float64, device=dev)
     if n_rows:
+        nbytes = lib.mxm_workspace_bytes(n_rows, n_haps, 1)       # per-workgroup vote rows (no float atomics)
+        ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=dev)
         _lib.check(lib.mxm_row_argmax_votes(mat.data_ptr(), mat.stride(0), ptr(w_d), n_rows, n_haps,
-                                            best.data_ptr(), votes.data_ptr(), current_stream()),
-                   "mxm_row_argmax_votes")
+                                            best.data_ptr(), votes.data_ptr(), ws.data_ptr(), nbytes,
+                                            current_stream()), "mxm_row_argmax_votes")
     return best.cpu().numpy(), votes.cpu().numpy()
 
 

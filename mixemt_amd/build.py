@@ -17,7 +17,7 @@ import sys
 _PKG = os.path.dirname(os.path.abspath(__file__))
 _ROOT = os.path.dirname(_PKG)
 SRC = os.path.join(_PKG, "csrc", "mixemt_hip.hip")
-HDR = os.path.join(_ROOT, "include", "mixemt_hip.h")
+HDRS = [os.path.join(_ROOT, "include", "mixemt_hip.h"), os.path.join(_ROOT, "include", "mixemt_hip_tuning.h")]
 LIB_DIR = os.path.join(_PKG, "lib")
 LIB = os.path.join(LIB_DIR, "libmixemt_hip.so")
 ARCH = "gfx950"
@@ -32,7 +32,7 @@ def _hipcc():
 
 def _sources():
     csrc = os.path.dirname(SRC)
-    return sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))) + [HDR]
+    return sorted(os.path.join(csrc, f) for f in os.listdir(csrc) if f.endswith((".hip", ".hpp"))) + HDRS
 
 
 def _digest(flags):

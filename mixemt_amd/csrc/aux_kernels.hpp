@@ -44,12 +44,20 @@ __device__ __forceinline__ bool cand_better(int an, double av, int ai, int bn, d
 
 __global__ __launch_bounds__(ROW_THREADS) void row_argmax_votes_kernel(
     const double *__restrict__ X, int64_t ldx, const double *__restrict__ w, int64_t R, int H,
-    int32_t *__restrict__ best, double *__restrict__ votes) {
+    int32_t *__restrict__ best, double *__restrict__ vote_part, int64_t ldpart) {
+    // vote_part[wg][h]: this workgroup's votes, added up by ONE thread in row order (no atomics:
+    // fractional weights give the same bits on every run); colreduce_kernel sums the workgroups.
     constexpr int NW = ROW_THREADS / 64;
     __shared__ double s_val[NW];
     __shared__ int s_idx[NW];
     __shared__ int s_nan[NW];
     const int t = threadIdx.x;
+    double *my_votes = vote_part != nullptr ? vote_part + (int64_t)blockIdx.x * ldpart : nullptr;
+    if (my_votes != nullptr) {
+        for (int h = t; h < H; h += ROW_THREADS) my_votes[h] = 0.0;
+        __threadfence_block();
+        __syncthreads();
+    }
     for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
         const double *row = X + r * ldx;
         int cn = 0, ci = 0x7fffffff;
@@ -74,7 +82,10 @@ __global__ __launch_bounds__(ROW_THREADS) void row_argmax_votes_kernel(
                 if (cand_better(s_nan[q], s_val[q], s_idx[q], cn, cv, ci)) { cn = s_nan[q]; cv = s_val[q]; ci = s_idx[q]; }
             if (ci >= H) ci = 0;
             best[r] = ci;
-            if (votes != nullptr) atomicAdd(votes + ci, (w != nullptr) ? w[r] : 1.0);
+            if (my_votes != nullptr) {
+                volatile double *slot = my_votes + ci;          // same thread wrote the zero / the last sum
+                *slot = *slot + ((w != nullptr) ? w[r] : 1.0);
+            }
         }
     }
 }
@@ -114,7 +125,8 @@ __device__ __forceinline__ argmax_cand wave_best_lane63(argmax_cand c) {
 template <int NCH>
 __global__ __launch_bounds__(256, 2) void row_argmax_wide_kernel(
     const double *__restrict__ X, int64_t ldx, const double *__restrict__ w, int64_t R, int H,
-    int32_t *__restrict__ best, double *__restrict__ votes) {
+    int32_t *__restrict__ best, double *__restrict__ votes, int64_t ldpart) {
+    // votes = vote_part[wg][h] (this workgroup's row is written whole; colreduce_kernel sums them)
     constexpr int THREADS = 256, NW = THREADS / 64;
     extern __shared__ double lds_votes[];           // [H] when votes are wanted
     __shared__ double s_val[2][NW];
@@ -186,7 +198,7 @@ __global__ __launch_bounds__(256, 2) void row_argmax_wide_kernel(
             int ci = g.i;
             if (ci >= H) ci = 0;
             best[r] = ci;
-            if (votes != nullptr) atomicAdd(&lds_votes[ci], (w != nullptr) ? w[r] : 1.0);
+            if (votes != nullptr) lds_votes[ci] += (w != nullptr) ? w[r] : 1.0;   // one thread, row order
         }
         ring ^= 1;
     };
@@ -199,10 +211,8 @@ __global__ __launch_bounds__(256, 2) void row_argmax_wide_kernel(
     }
     if (votes != nullptr) {
         __syncthreads();
-        for (int h = t; h < H; h += THREADS) {
-            const double v = lds_votes[h];
-            if (v != 0.0) atomicAdd(votes + h, v);
-        }
+        double *dst = votes + (int64_t)blockIdx.x * ldpart;
+        for (int h = t; h < H; h += THREADS) dst[h] = lds_votes[h];
     }
 }
 
@@ -230,6 +240,54 @@ __global__ __launch_bounds__(256) void assign_reads_kernel(const double *__restr
         }
     }
     assigned[r] = (nC >= 2 && (v1 - v2) >= log_min_fold) ? i1 : -1;
+}
+
+// Column subset for the refinement EM (preprocess.py:247-251: em_mat[:, indexes]):
+// out[r][i] = M[r][cols[i]].  A wave covers 64 / nC' rows (nC' = nC rounded up to a power of two,
+// capped at 64), so the writes of a wave are contiguous; the reads touch nC sectors per row.
+__global__ __launch_bounds__(256) void gather_columns_kernel(const double *__restrict__ M, int64_t ldm, int64_t R,
+                                                             const int32_t *__restrict__ cols, int nC,
+                                                             double *__restrict__ out, int64_t ldo) {
+    const int64_t n = R * (int64_t)nC;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int64_t r = i / nC;
+        const int c = (int)(i - r * nC);
+        out[r * ldo + c] = M[r * ldm + cols[c]];
+    }
+}
+
+// Log-space fold of posterior blocks (em.py:156, :161 across ranks / runs):
+//   acc[r][h] = logaddexp(...logaddexp(logaddexp(acc, in[0]), in[1])..., in[n_in - 1]) + delta
+// in fixed order (deterministic).  Entries far below exp(-745) keep their finite logs, unlike a
+// sum in linear space.  16-byte vectors when H, the leading dimensions and the pointers allow.
+#define FOLD_MAX_IN 8
+struct fold_inputs {
+    const double *ptr[FOLD_MAX_IN];
+    int64_t ld[FOLD_MAX_IN];
+};
+template <bool VEC>
+__global__ __launch_bounds__(256) void fold_logaddexp_kernel(double *__restrict__ acc, int64_t lda, fold_inputs in,
+                                                             int n_in, int64_t R, int H, double delta) {
+    const int hw = VEC ? (H >> 1) : H;                  // work items per row
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        for (int c = threadIdx.x; c < hw; c += 256) {
+            if constexpr (VEC) {
+                d2 *dst = reinterpret_cast<d2 *>(acc + r * lda) + c;
+                d2 v = *dst;
+                for (int k = 0; k < n_in; ++k) {
+                    const d2 x = __builtin_nontemporal_load(reinterpret_cast<const d2 *>(in.ptr[k] + r * in.ld[k]) + c);
+                    v.x = logaddexp_f64(v.x, x.x);
+                    v.y = logaddexp_f64(v.y, x.y);
+                }
+                *dst = d2{v.x + delta, v.y + delta};
+            } else {
+                double *dst = acc + r * lda + c;
+                double v = *dst;
+                for (int k = 0; k < n_in; ++k) v = logaddexp_f64(v, in.ptr[k][r * in.ld[k] + c]);
+                *dst = v + delta;
+            }
+        }
+    }
 }
 
 // Diagnostic only: bare streaming reads (16 B/lane, 8 loads in flight per lane, xor-folded so

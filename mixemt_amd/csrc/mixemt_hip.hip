@@ -29,6 +29,7 @@
 #include <vector>
 
 #include "mixemt_hip.h"
+#include "mixemt_hip_tuning.h"
 
 #include "common.hpp"
 #include "build_kernels.hpp"
@@ -44,14 +45,18 @@ static inline int clamp_grid(int64_t want, int cap) {
     return (int)(want < cap ? want : cap);
 }
 
-// one bit per device of the node (the current device of the calling thread)
-static inline unsigned device_bit() {
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    return 1u << (dev & 31);
-}
-
 static inline int64_t part_ld(int H) { return ((int64_t)H + 1) & ~(int64_t)1; }
+
+// More than 64 KiB of dynamic LDS must be opted into per kernel (and device).  Re-issued on every
+// call: the attribute is idempotent and costs a table write, and nothing is cached that two host
+// threads (one per GPU) could race on.  A refusal is reported with the kernel's name and the size.
+static hipError_t raise_dynamic_lds(const void *kernel, size_t bytes, const char *name) {
+    const hipError_t e = hipFuncSetAttribute(kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess)
+        snprintf(g_err, sizeof(g_err), "%s: cannot opt into %zu bytes of dynamic LDS: %s", name, bytes,
+                 hipGetErrorString(e));
+    return e;
+}
 
 extern "C" int mxm_version(void) { return MXM_VERSION; }
 extern "C" const char *mxm_last_error(void) { return g_err; }
@@ -137,12 +142,8 @@ extern "C" int mxm_build_em_matrix_packed(const uint32_t *Epk, const uint8_t *mu
     const size_t lds = mxm_build_packed_lds_bytes(S, n_mu);
     if (lds > 158 * 1024) return fail(-1, "mxm_build_em_matrix_packed: tables need %s%lld B of LDS (> 158 KiB); use mxm_build_em_matrix", "", (long long)lds);
     if (R == 0) return 0;
-    static unsigned raised = 0;                 // bit per device: the attribute is per device
-    if (!(raised & device_bit())) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&build_tile_kernel),
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-        raised |= device_bit();
-    }
+    if (raise_dynamic_lds(reinterpret_cast<const void *>(&build_tile_kernel), 160 * 1024, "build_tile_kernel") != hipSuccess)
+        return -2;
     const int ntiles = (H + TILE_COLS - 1) / TILE_COLS;
     // one workgroup per CU (the table slice fills the LDS): aim at ~2 waves of workgroups
     int nchunks = (2 * num_cu() + ntiles - 1) / ntiles;
@@ -202,7 +203,8 @@ static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
 static int g_min_rows_per_wg = 8;     // measured: 1000 x 5408 31 us/step (vs 39 at 2); no effect from 10^4 rows up
 static int g_v1_shape = 1;            // 0: 256 threads x 2 WG/CU, ring 2;  1: 512 threads x 1 WG/CU, ring 3
                                       // (in-process A/B, profiles/r01/tune_sweep.txt: 6.43 vs 6.50 ms median)
-static int g_compact_restarts = 1;    // mxm_em_loop packs the running restarts into the leading slots
+static int g_compact_restarts = 2;    // mxm_em_loop: 1 packs the running restarts into the leading slots, 2 also
+                                      // keeps only one full tile of them iterating (slot refill)
 static int g_max_bt = 4;              // restarts per matrix pass (1..MXM_MAX_BT); see mxm_set_batch_tile
 extern "C" int mxm_set_timing_events(void *ev_start, void *ev_stop) {
     g_ev_start = (hipEvent_t)ev_start;
@@ -222,8 +224,8 @@ extern "C" int mxm_set_v1_shape(int32_t shape) {
     return 0;
 }
 
-extern "C" int mxm_set_compact_restarts(int32_t on) {
-    g_compact_restarts = on ? 1 : 0;
+extern "C" int mxm_set_compact_restarts(int32_t mode) {
+    g_compact_restarts = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
     return 0;
 }
 
@@ -317,15 +319,10 @@ static int launch_wide(const double *P, int64_t ldp, const double *w, const doub
         return fail(-1, "mxm_em_iter: H=%s%lld outside the linear kernel's range", "", H);
     } else {
         const size_t lds = (size_t)(BT - PREG) * NCH * THREADS * sizeof(d2);
-        if (lds > 0) {
-            static unsigned raised = 0;     // > 64 KiB of dynamic LDS must be opted into, once per kernel and device
-            if (!(raised & device_bit())) {
-                (void)hipFuncSetAttribute(
-                    reinterpret_cast<const void *>(&em_iter_wide_kernel<THREADS, NCH, BT, NBUF, PREG>),
-                    hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-                raised |= device_bit();
-            }
-        }
+        if (lds > 60 * 1024 &&
+            raise_dynamic_lds(reinterpret_cast<const void *>(&em_iter_wide_kernel<THREADS, NCH, BT, NBUF, PREG>), lds,
+                              "em_iter_wide_kernel") != hipSuccess)
+            return -2;
         hipLaunchKernelGGL((em_iter_wide_kernel<THREADS, NCH, BT, NBUF, PREG>), dim3(grid), dim3(THREADS), lds,
                            stream, P, ldp, w, props, R, H, partial, ldpart, state);
         return 0;
@@ -545,6 +542,13 @@ extern "C" int mxm_em_iter_f32(const float *P, int64_t ldp, const double *w, con
     return 0;
 }
 
+extern "C" int mxm_restart_tile(int32_t H) {
+    if (!mxm_linear_supported(H)) return 1;
+    int bt = g_max_bt;
+    while (bt > 1 && !batch_fits((int)H, bt)) --bt;
+    return bt;
+}
+
 extern "C" int mxm_m_finalize(const double *colsum, double *ln_cur, double *ln_new, double *props_cur, int32_t H,
                               int32_t B, double tol, int32_t max_iter, mxm_em_state *state, void *stream) {
     if (H <= 0 || B <= 0 || state == nullptr) return fail(-1, "mxm_m_finalize: bad arguments%s", "");
@@ -606,7 +610,10 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     // Restarts stop on different iterations.  The still-running ones are kept packed in the
     // leading `lead` slots (slot exchanges on the device, undone before returning), so that an
     // iteration takes ceil(running / tile) passes over the matrix instead of ceil(B / tile).
-    int lead = B;
+    int lead = B, unfinished = B;
+    int window = g_max_bt;                             // the largest restart tile that fits (mxm_em_iter)
+    if (p_is_f32 || P == nullptr || !mxm_linear_supported(H)) window = 1;
+    while (window > 1 && !batch_fits((int)H, window)) --window;
     std::vector<std::pair<int, int>> swaps;
     auto swap_slots = [&](int i, int j) {
         hipLaunchKernelGGL(swap_restart_slots_kernel, dim3((H + 255) / 256, 4), dim3(256), 0, s, props_cur, ln_cur,
@@ -626,22 +633,31 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
         int64_t issued = 0;
         for (;;) {
             if (g_compact_restarts) {
-                // two-pointer partition of the leading slots: finished ones go behind the running ones
-                int lo = 0, hi = lead - 1;
+                // two-pointer partition of the unfinished slots: finished ones go behind them
+                int lo = 0, hi = unfinished - 1;
                 for (;;) {
-                    while (lo < lead && state_host[lo].done == 0) ++lo;
+                    while (lo < unfinished && state_host[lo].done == 0) ++lo;
                     while (hi >= 0 && state_host[hi].done != 0) --hi;
                     if (lo >= hi) break;
                     swap_slots(lo, hi);
                     swaps.emplace_back(lo, hi);
                 }
-                lead = lo;                             // = number of running restarts
+                unfinished = lo;                       // running + not yet started
             }
+            // Window (mode 2): only the first `tile` unfinished slots iterate -- ONE full pass over the
+            // matrix per iteration (1.70 ms per restart-iteration at 10^6 x 5408 against 1.95 for the
+            // 4 + 3 + 3 tiles of ten restarts advancing together); a slot whose restart has stopped is
+            // refilled from behind the window by the partition above.  Each restart counts its own
+            // iterations (finalize_kernel), so waiting outside the window changes nothing in its result.
+            lead = (g_compact_restarts == 2 && unfinished > window) ? window : unfinished;
             bool all_done = true;
             for (int b = 0; b < lead; ++b) all_done = all_done && (state_host[b].done != 0);
-            if (all_done || issued >= (int64_t)max_iter) break;
-            int64_t n = (int64_t)max_iter - issued;
-            if (n > check_every) n = check_every;
+            if (all_done) break;
+            // every restart stops after at most max_iter iterations of its own (finalize_kernel); a full
+            // chunk may overshoot a restart's end: the kernels of a finished restart are no-ops
+            int64_t n = check_every;
+            if (lead == B && (int64_t)max_iter - issued < n) n = (int64_t)max_iter - issued;
+            if (n < 1) break;                          // max_iter reached by all of them: states say done = 2
             bool launched = false;
             if (want_graph) {
                 if (exec == nullptr || graph_iters != n || graph_lead != lead) {
@@ -817,31 +833,82 @@ extern "C" int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_pe
 }
 
 extern "C" int mxm_row_argmax_votes(const double *X, int64_t ldx, const double *w, int64_t R, int32_t H,
-                                    int32_t *best, double *votes, void *stream) {
+                                    int32_t *best, double *votes, void *ws, size_t ws_bytes, void *stream) {
     if (R <= 0 || H <= 0 || ldx < H) return fail(-1, "mxm_row_argmax_votes: bad shape%s", "");
+    if (votes != nullptr && (ws == nullptr || ws_bytes < mxm_workspace_bytes(R, H, 1)))
+        return fail(-1, "mxm_row_argmax_votes: workspace too small%s", "");
+    // votes: every workgroup fills its own row of the scratch (one thread adds in row order), the
+    // rows are summed in fixed order -- no float atomics, so fractional weights reproduce bit for bit
+    double *part = votes != nullptr ? (double *)ws : (double *)nullptr;
+    const int64_t ldpart = part_ld(H);
+    int nwg;
     if (wide_rows_ok(X, ldx, H)) {
         const int nch = (H / 2 + 255) / 256;
         const int cap = num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG;
-        const int nwg = clamp_grid((R + 1) / 2, cap);
+        nwg = clamp_grid((R + 1) / 2, cap);
         const size_t lds = votes != nullptr ? (size_t)H * sizeof(double) : 0;
         switch (nch) {
 #define AW_CASE(n) case n:                                                                                   \
-        if (lds > 60 * 1024)   /* with the static exchange buffers this passes the 64 KiB default */          \
-            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(&row_argmax_wide_kernel<n>),                \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);                    \
+        if (lds > 60 * 1024 && /* with the static exchange buffers this passes the 64 KiB default */          \
+            raise_dynamic_lds(reinterpret_cast<const void *>(&row_argmax_wide_kernel<n>), lds,                \
+                              "row_argmax_wide_kernel") != hipSuccess)                                        \
+            return -2;                                                                                        \
         hipLaunchKernelGGL((row_argmax_wide_kernel<n>), dim3(nwg), dim3(256), lds, (hipStream_t)stream, X, ldx, \
-                           w, R, (int)H, best, votes);                                                         \
+                           w, R, (int)H, best, part, ldpart);                                                  \
         break;
             AW_CASE(1) AW_CASE(2) AW_CASE(3) AW_CASE(4) AW_CASE(5) AW_CASE(6) AW_CASE(7) AW_CASE(8)
             AW_CASE(9) AW_CASE(10) AW_CASE(11) AW_CASE(12) AW_CASE(13) AW_CASE(14) AW_CASE(15) AW_CASE(16)
 #undef AW_CASE
             default: return fail(-1, "mxm_row_argmax_votes: H=%s%lld outside the wide kernel's range", "", H);
         }
-        HIP_TRY(hipGetLastError());
-        return 0;
+    } else {
+        nwg = clamp_grid(R, num_cu() * 4 < MXM_MAX_WG ? num_cu() * 4 : MXM_MAX_WG);
+        hipLaunchKernelGGL(row_argmax_votes_kernel, dim3(nwg), dim3(ROW_THREADS), 0, (hipStream_t)stream, X, ldx, w, R,
+                           (int)H, best, part, ldpart);
     }
-    hipLaunchKernelGGL(row_argmax_votes_kernel, dim3(clamp_grid(R, num_cu() * 8)), dim3(ROW_THREADS), 0,
-                       (hipStream_t)stream, X, ldx, w, R, (int)H, best, votes);
+    HIP_TRY(hipGetLastError());
+    if (votes != nullptr) {
+        hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, (hipStream_t)stream,
+                           (const double *)part, ldpart, nwg, 1, (int)H, (const double *)nullptr, votes,
+                           (const mxm_em_state *)nullptr);
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+extern "C" int mxm_gather_columns(const double *M, int64_t ldm, int64_t R, int32_t H, const int32_t *cols, int32_t nC,
+                                  double *out, int64_t ldo, void *stream) {
+    if (R < 0 || H <= 0 || nC <= 0 || ldm < H || ldo < nC) return fail(-1, "mxm_gather_columns: bad shape%s", "");
+    if (R == 0) return 0;
+    const int64_t want = (R * (int64_t)nC + 255) / 256;
+    hipLaunchKernelGGL(gather_columns_kernel, dim3(clamp_grid(want, num_cu() * 16)), dim3(256), 0, (hipStream_t)stream,
+                       M, ldm, R, cols, (int)nC, out, ldo);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_fold_logaddexp(double *acc, int64_t lda, const double *const *in_host, const int64_t *ld_in_host,
+                                  int32_t n_in, int64_t R, int32_t H, double delta, void *stream) {
+    if (R < 0 || H <= 0 || lda < H || n_in < 0 || n_in > FOLD_MAX_IN)
+        return fail(-1, "mxm_fold_logaddexp: bad shape (at most %s%lld inputs per call)", "", (long long)FOLD_MAX_IN);
+    if (R == 0) return 0;
+    fold_inputs in;
+    bool vec = ((H & 1) == 0) && ((lda & 1) == 0) && ((reinterpret_cast<uintptr_t>(acc) & 15) == 0);
+    for (int k = 0; k < FOLD_MAX_IN; ++k) {
+        in.ptr[k] = k < n_in ? in_host[k] : nullptr;
+        in.ld[k] = k < n_in ? ld_in_host[k] : 0;
+        if (k < n_in) {
+            if (in.ptr[k] == nullptr || in.ld[k] < H) return fail(-1, "mxm_fold_logaddexp: bad input %s%lld", "", k);
+            vec = vec && ((in.ld[k] & 1) == 0) && ((reinterpret_cast<uintptr_t>(in.ptr[k]) & 15) == 0);
+        }
+    }
+    const int grid = clamp_grid(R, num_cu() * 8);
+    if (vec)
+        hipLaunchKernelGGL(fold_logaddexp_kernel<true>, dim3(grid), dim3(256), 0, (hipStream_t)stream, acc, lda, in,
+                           (int)n_in, R, (int)H, delta);
+    else
+        hipLaunchKernelGGL(fold_logaddexp_kernel<false>, dim3(grid), dim3(256), 0, (hipStream_t)stream, acc, lda, in,
+                           (int)n_in, R, (int)H, delta);
     HIP_TRY(hipGetLastError());
     return 0;
 }

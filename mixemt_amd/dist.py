@@ -20,14 +20,21 @@ iterations without overshooting the reference's stopping iteration.
 Two modes:
     run_em_sharded            rows sharded, every restart on every rank (configs 2-4)
     run_em_restart_parallel   matrix replicated, restarts dealt round-robin
-                              over ranks, no per-iteration traffic (config 5)
+                              over ranks, no per-iteration traffic (config 5); at the
+                              end the folded posteriors are combined by a direct
+                              row-block exchange (every rank sends block j straight to
+                              rank j -- xGMI is point to point, all links carry one
+                              block each) and a log-space fold kernel, so that each
+                              rank ends up with ITS row block of the result
 """
 
 import math
 
 import numpy
 
+from . import _lib
 from . import em as _em
+from ._dev import require_gpu
 
 try:
     import torch
@@ -72,7 +79,8 @@ def broadcast_inits(n_runs, n_haps, alpha, device, group=None, src=0):
     return buf.cpu().numpy()
 
 
-def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8, compact=True):
+def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8, compact=True,
+                    window=None, verify=True):
     """
     The EM loop over a row-sharded matrix.  `plan` is the rank-local EmPlan (or
     any object with its em_iter / finalize / alloc / read_state surface -- the
@@ -80,15 +88,24 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     (ln_cur = log theta_k, ln_new = log theta_{k+1}, [(done, iters, l1)]) --
     identical on every rank.
 
-    compact: restarts stop on different iterations; the ones still running are
+    compact: restarts stop on different iterations; the unfinished ones are
     kept packed in the leading slots of the loop vectors (as mxm_em_loop does on
-    one GPU), so an iteration takes ceil(running / tile) passes over the shard
-    and all-reduces only the running restarts' sums.  Every rank sees the same
-    state, hence takes the same packing decisions.
+    one GPU).  window: at most that many of them iterate at a time (default: the
+    plan's restart tile, i.e. one full pass over the shard per iteration; a slot
+    whose restart has stopped is refilled with a waiting one); each restart
+    counts its own iterations (mxm_m_finalize), so waiting changes nothing in its
+    result.  Only the iterating restarts' sums are all-reduced.  Every rank sees
+    the same state, hence takes the same packing decisions.
+    verify: at every state check the ranks compare (done, iters) of all restarts
+    (two tiny all-reduces, MIN and MAX) and fail loudly if they ever disagree --
+    the loop's correctness rests on bit-identical all-reduce results on all ranks.
     """
     exchange = _collective(group)
     ln0, p0 = _em.log_inits(inits)
     n_runs = ln0.shape[0]
+    if window is None:
+        window = plan.restart_tile() if (compact and hasattr(plan, "restart_tile")) else n_runs
+    window = max(1, int(window))
     props_cur = plan.alloc_props(p0)
     ln_cur = plan.alloc_props(ln0)
     ln_new = plan.alloc_props(ln0)
@@ -96,30 +113,30 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     state = plan.alloc_state(n_runs).view(n_runs, -1)          # one row per restart
     vectors = (props_cur, ln_cur, ln_new, colsum, state)
     slot_run = list(range(n_runs))                             # slot -> caller's run index
-    lead = n_runs
-    issued = 0
     states = plan.read_state(state)
-    while issued < max_iter:
-        running = [s for s in range(lead) if states[s][0] == 0]
+    if max_iter <= 0:
+        return ln_cur, ln_new, states
+    while True:
+        running = [s for s in range(n_runs) if states[s][0] == 0]        # slot order: started ones first
         if not running:
             break
-        if compact and len(running) < lead:
-            order = running + [s for s in range(n_runs) if s not in set(running)]
+        if compact and running != list(range(len(running))):
+            order = running + [s for s in range(n_runs) if states[s][0] != 0]
             idx = torch.as_tensor(order, device=props_cur.device)
             for vec in vectors:
                 vec.copy_(vec[idx])
             slot_run = [slot_run[s] for s in order]
             states = [states[s] for s in order]
-            lead = len(running)
-        burst = min(check_every, max_iter - issued)
-        for _ in range(burst):
+        lead = min(len(running), window) if compact else n_runs
+        for _ in range(check_every):
             plan.em_iter(props_cur[:lead], ln_cur[:lead], state[:lead], colsum[:lead])
             if exchange:
                 dist.all_reduce(colsum[:lead], op=dist.ReduceOp.SUM, group=group)
             plan.finalize(colsum[:lead], ln_cur[:lead], ln_new[:lead], props_cur[:lead], state[:lead],
                           tolerance, max_iter)
-        issued += burst
         states = plan.read_state(state)
+        if exchange and verify:
+            _assert_ranks_agree(states, props_cur.device, group)
     if slot_run != list(range(n_runs)):                        # back to the caller's run order
         back = [0] * n_runs
         for slot, run in enumerate(slot_run):
@@ -129,6 +146,18 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
             vec.copy_(vec[idx])
         states = [states[s] for s in back]
     return ln_cur, ln_new, states
+
+
+def _assert_ranks_agree(states, device, group):
+    """Every rank must hold the same (done, iters) for every restart: they all received the same
+    all-reduced bytes.  A mismatch means the collective did not deliver identical results."""
+    mine = torch.tensor([[s[0], s[1]] for s in states], dtype=torch.int64, device=device)
+    low, high = mine.clone(), mine.clone()
+    dist.all_reduce(low, op=dist.ReduceOp.MIN, group=group)
+    dist.all_reduce(high, op=dist.ReduceOp.MAX, group=group)
+    if not bool(torch.equal(low, high)):
+        raise RuntimeError("sharded EM loop: ranks disagree on the loop state (done, iters): min %s max %s"
+                           % (low.tolist(), high.tolist()))
 
 
 def run_em_sharded(local_mat, local_weights, args, inits=None, group=None, want_read_mix=True,
@@ -149,52 +178,181 @@ def run_em_sharded(local_mat, local_weights, args, inits=None, group=None, want_
     return _em.collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix, reuse_linear=True)
 
 
-def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_read_mix=True):
+EXCHANGE_CHUNK_BYTES = 2 << 30          # receive staging per chunk of the row-block exchange (x2: double buffer)
+
+
+def _global_rank(group, r):
+    return dist.get_global_rank(group, r) if group is not None else r
+
+
+def exchange_fold_blocks(fold, has_fold, n_rows, n_haps, delta, lib, dev, group=None,
+                         chunk_bytes=EXCHANGE_CHUNK_BYTES):
+    """
+    End-of-run combine of config 5 (SURVEY.md section 8 e; em.py:156-161 across ranks).
+    Every rank r that ran restarts holds `fold` = logaddexp over ITS runs of the full
+    [R][H] log posterior.  Rank j must end up with rows shard_bounds(R, j, world) of
+    logaddexp over ALL ranks' folds, plus `delta` (= -log n_multi).
+
+    Transport: a direct exchange, not a ring -- xGMI links are point to point, so rank r
+    sends its copy of block j straight to rank j for every j at once (grouped RCCL
+    send/recv) and all 7 links of a GPU carry one block each: (world - 1) / world of the
+    matrix leaves each GPU once, 1/world of it per link.  The blocks move in row chunks,
+    double buffered: chunk c + 1 is in flight while mxm_fold_logaddexp folds chunk c
+    (own rows first, then the peers' in rank order -> deterministic) in log space, so
+    entries below exp(-745) keep the finite values numpy.logaddexp gives them.
+
+    fold: [R][H] device tensor, or None on a rank without restarts (has_fold[rank] False).
+    Returns this rank's [hi - lo][H] block (a view of `fold` where there is one).
+    """
+    import ctypes
+    rank, world = _world(group)
+    bounds = [shard_bounds(n_rows, r, world) for r in range(world)]
+    lo, hi = bounds[rank]
+    stream = torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else 0
+
+    def fold_into(acc, pieces, dlt):
+        """acc = logaddexp(acc, *pieces) + dlt, at most 8 inputs per launch"""
+        pieces = list(pieces)
+        first = True
+        while pieces or first:
+            now, pieces = pieces[:8], pieces[8:]
+            ptrs = (ctypes.c_void_p * max(len(now), 1))(*[t.data_ptr() for t in now])
+            lds = (ctypes.c_int64 * max(len(now), 1))(*[t.stride(0) for t in now])
+            _lib.check(lib.mxm_fold_logaddexp(acc.data_ptr(), acc.stride(0), ptrs, lds, len(now),
+                                                  acc.shape[0], n_haps, dlt if not pieces else 0.0, stream),
+                           "mxm_fold_logaddexp")
+            first = False
+
+    if has_fold[rank]:
+        mine = fold[lo:hi]
+    else:
+        mine = torch.full((hi - lo, n_haps), float("-inf"), dtype=torch.float64, device=dev)
+    senders = [r for r in range(world) if r != rank and has_fold[r]]      # who sends me pieces of my block
+    if world == 1 or (not senders and not has_fold[rank]):
+        if hi > lo and delta != 0.0:
+            fold_into(mine, [], delta)
+        return mine
+    direct = dist.get_backend(group) == "nccl"          # RCCL moves device memory; gloo (tests) is staged on the host
+    blocks = [b[1] - b[0] for b in bounds]
+    chunk_rows = max(1, min(max(blocks), int(chunk_bytes // (n_haps * 8 * max(1, len(senders))))))
+    n_chunks = (max(blocks) + chunk_rows - 1) // chunk_rows
+    stage_dev = dev if direct else torch.device("cpu")
+    tmp = [torch.empty((max(1, len(senders)), chunk_rows, n_haps), dtype=torch.float64, device=stage_dev)
+           for _ in range(2 if n_chunks > 1 else 1)]
+
+    def post(c, slot):
+        ops, keep = [], []
+        if has_fold[rank]:
+            for p in range(world):
+                if p == rank:
+                    continue
+                a = bounds[p][0] + c * chunk_rows
+                b = min(a + chunk_rows, bounds[p][1])
+                if b > a:
+                    src = fold[a:b] if direct else fold[a:b].cpu()
+                    keep.append(src)
+                    ops.append(dist.P2POp(dist.isend, src, _global_rank(group, p), group))
+        a = lo + c * chunk_rows
+        b = min(a + chunk_rows, hi)
+        if b > a:
+            for k, p in enumerate(senders):
+                ops.append(dist.P2POp(dist.irecv, tmp[slot][k, :b - a], _global_rank(group, p), group))
+        return (dist.batch_isend_irecv(ops) if ops else []), keep, (a, b)
+
+    pending = post(0, 0)
+    for c in range(n_chunks):
+        nxt = post(c + 1, (c + 1) % len(tmp)) if c + 1 < n_chunks else None
+        reqs, keep, (a, b) = pending
+        for req in reqs:
+            req.wait()
+        if b > a:
+            slot = c % len(tmp)
+            pieces = [tmp[slot][k, :b - a] for k in range(len(senders))]
+            if not direct:
+                pieces = [t.to(dev) for t in pieces]
+            fold_into(mine[a - lo:b - lo], pieces, delta)
+        del keep
+        pending = nxt
+    return mine
+
+
+def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_read_mix=True, timing=None):
     """
     Config 5: the matrix is replicated, the n_multi restarts are dealt
     round-robin over the ranks (run i -> rank i % world) and run with no
-    per-iteration communication.  At the end the per-run log-proportions are
-    summed with one all-reduce; the posterior fold (em.py:156, log-mean-exp over
-    runs) is completed in linear space with one all-reduce of the local folds.
-    Every rank returns the full result.
+    per-iteration communication; on each rank mxm_em_loop keeps one full tile of
+    its restarts iterating and refills a slot when its restart stops.  The deal is
+    static: restarts of one matrix take about the same number of iterations
+    (396-563 at 10^6 x 5408), a rank runs its 8 of 64 in two generations of one
+    tile either way, and the job ends with the slowest restart wherever it runs
+    (bench.py --mode restarts reports each rank's idle tail).
+
+    At the end: the per-run log-proportions are summed with one all-reduce [H]
+    (em.py:155, geometric mean); the posterior fold (em.py:156, log-mean-exp over
+    runs) is completed by exchange_fold_blocks -- each rank returns ITS row block
+    `rows` = shard_bounds(R, rank, world) of read_mix, like run_em_sharded does.
+    A rank without restarts (world > n_multi) builds no plan at all.
+    `timing` (dict) receives loop_s / fold_s / combine_s of this rank.
     """
+    import math
+    import time
     rank, world = _world(group)
     n_multi = int(args.n_multi)
-    plan = _em.EmPlan(mat, weights, n_runs=max(1, (n_multi + world - 1) // world))
+    lib = _lib.load()
+    dev = require_gpu() if not isinstance(mat, torch.Tensor) else mat.device
+    n_rows, n_haps = mat.shape
     if inits is None:
-        inits = broadcast_inits(n_multi, plan.n_haps, args.init_alpha, plan.dev, group)
+        inits = broadcast_inits(n_multi, n_haps, args.init_alpha, dev, group)
     inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
     mine = list(range(rank, n_multi, world))
-    n_haps = plan.n_haps
-    ln_sum = torch.zeros(n_haps, dtype=torch.float64, device=plan.dev)
-    iters = torch.zeros(n_multi, dtype=torch.int64, device=plan.dev)
-    run_props = torch.zeros((n_multi, n_haps), dtype=torch.float64, device=plan.dev)
+    has_fold = [r < n_multi for r in range(world)]             # rank r got run r at least
+    ln_sum = torch.zeros(n_haps, dtype=torch.float64, device=dev)
+    counts = torch.zeros((n_multi, 2), dtype=torch.int64, device=dev)       # iters, done
+    run_props = torch.zeros((n_multi, n_haps), dtype=torch.float64, device=dev)
     fold = None
+
+    def sync():
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+
+    sync()
+    t0 = time.perf_counter()
+    ln_k = None
+    plan = None
     if mine:
+        plan = _em.EmPlan(mat, weights, n_runs=len(mine))
         ln_cur, ln_new, states = _em.em_loop(plan, inits[mine], args.tolerance, args.max_iter)
         ln_k = ln_cur.cpu().numpy()
         ln_sum += ln_new.sum(dim=0)
-        if want_read_mix:
-            fold = plan.release_linear()              # the loop is over: reuse its 43 GB
         for j, run in enumerate(mine):
-            iters[run] = states[j][1]
+            counts[run, 0] = states[j][1]
+            counts[run, 1] = states[j][0]
             run_props[run] = torch.exp(ln_new[j])
-            if want_read_mix:
-                fold = _em.posterior(plan, ln_k[j], out=fold, fold=(j > 0))
+    sync()
+    t1 = time.perf_counter()
+    if mine and want_read_mix:
+        fold = plan.release_linear()                  # the loop is over: reuse its R x H storage
+        for j in range(len(mine)):
+            fold = _em.posterior(plan, ln_k[j], out=fold, fold=(j > 0))
+    sync()
+    t2 = time.perf_counter()
     if _collective(group):
         dist.all_reduce(ln_sum, group=group)
-        dist.all_reduce(iters, group=group)
+        dist.all_reduce(counts, group=group)
         dist.all_reduce(run_props, group=group)
     read_mix = None
+    lo, hi = shard_bounds(n_rows, rank, world)
     if want_read_mix:
-        # in place: at 10^6 x 5408 every extra copy of the posterior is 43 GB
-        read_mix = fold.exp_() if fold is not None else torch.zeros(
-            (plan.n_rows, n_haps), dtype=torch.float64, device=plan.dev)
+        delta = -math.log(n_multi) if n_multi > 1 else 0.0
         if _collective(group):
-            dist.all_reduce(read_mix, group=group)
-        read_mix.log_()
-        if n_multi > 1:
-            read_mix -= math.log(n_multi)
+            read_mix = exchange_fold_blocks(fold, has_fold, n_rows, n_haps, delta, lib, dev, group)
+        else:
+            read_mix = exchange_fold_blocks(fold, [True], n_rows, n_haps, delta, lib, dev, None)
+    sync()
+    t3 = time.perf_counter()
+    if timing is not None:
+        timing.update(loop_s=t1 - t0, fold_s=t2 - t1, combine_s=t3 - t2)
     props = torch.exp(ln_sum / n_multi).cpu().numpy() if n_multi > 1 else run_props[0].cpu().numpy()
-    return {"props": props, "read_mix": read_mix, "iters": [int(x) for x in iters.cpu()],
-            "run_props": run_props.cpu().numpy(), "inits": inits}
+    counts = counts.cpu().numpy()
+    return {"props": props, "read_mix": read_mix, "rows": (lo, hi), "iters": [int(x) for x in counts[:, 0]],
+            "done": [int(x) for x in counts[:, 1]], "run_props": run_props.cpu().numpy(), "inits": inits}

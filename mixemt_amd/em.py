@@ -181,6 +181,13 @@ class EmPlan(object):
         self.spent = True
         return lin
 
+    def restart_tile(self):
+        """Restarts that share one pass over this plan's matrix (mxm_restart_tile; 1 for the
+        fp32-storage variant and for narrow matrices, which iterate one restart per pass)."""
+        if self.lin is None or self.storage == "f32":
+            return 1
+        return int(self.lib.mxm_restart_tile(self.n_haps))
+
     # buffers (the surface dist.sharded_em_loop drives) ----------------------
     def alloc_props(self, host):
         return torch.from_numpy(numpy.ascontiguousarray(host, dtype=numpy.float64)).to(self.dev)

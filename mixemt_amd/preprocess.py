@@ -357,11 +357,19 @@ def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False):
     read_obs = process_reads(bamfile.fetch(), var_pos, args.min_mq, args.min_bq)
     read_sigs = reduce_reads(read_obs)
     dropped = read_sigs.pop("", None)
+    if dropped:
+        # never silent: weights and read ids below no longer cover these fragments (the reference
+        # would have died on them), so the accounting must show it whatever the verbosity
+        sys.stderr.write("Warning: skipped %d fragment(s) whose every site was conflicted away "
+                         "(empty signature; the reference stops at int('') there): %s%s\n"
+                         % (len(dropped), ", ".join(str(x) for x in dropped[:5]),
+                            ", ..." if len(dropped) > 5 else ""))
+        build_em_input.last_dropped = list(dropped)
+    else:
+        build_em_input.last_dropped = []
     if getattr(args, "verbose", False):
         sys.stderr.write("Using %d aligned fragments (MQ>=%d) (%d distinct sub-haplotypes)\n\n"
-                         % (len(read_obs), args.min_mq, len(read_sigs)))
-        if dropped:
-            sys.stderr.write("Skipped %d fragment(s) without a usable site.\n" % len(dropped))
+                         % (len(read_obs) - len(dropped or ()), args.min_mq, len(read_sigs)))
     haplogroups = sorted(phylo.hap_var)
     reads = sorted(read_sigs)
     weights = numpy.array([len(read_sigs[r]) for r in reads])
@@ -380,5 +388,23 @@ def reduce_em_matrix(em_mat, haplogroups, contrib_props):
     idx = [i for i, hap in enumerate(haplogroups) if hap in keep]
     names = [haplogroups[i] for i in idx]
     if torch is not None and isinstance(em_mat, torch.Tensor):
-        return em_mat[:, torch.tensor(idx, device=em_mat.device)].contiguous(), names
+        return gather_columns_device(em_mat, idx), names
     return em_mat[:, idx], names
+
+
+def gather_columns_device(em_mat, idx):
+    """em_mat[:, idx] on the device (mxm_gather_columns): [R][len(idx)] float64, contiguous."""
+    lib = _lib.load()
+    n_rows, n_haps = em_mat.shape
+    if em_mat.dtype != torch.float64 or em_mat.stride(1) != 1:
+        raise ValueError("reduce_em_matrix: the device matrix must be float64 with unit column stride")
+    cols = numpy.asarray(idx, dtype=numpy.int32)
+    if cols.size and (cols.min() < 0 or cols.max() >= n_haps):
+        raise ValueError("reduce_em_matrix: column index out of range")
+    out = device_empty((n_rows, len(cols)), torch.float64, em_mat.device, "the reduced EM matrix")
+    if n_rows and len(cols):
+        cols_d = torch.from_numpy(cols).to(em_mat.device)
+        _lib.check(lib.mxm_gather_columns(em_mat.data_ptr(), em_mat.stride(0), n_rows, n_haps,
+                                          cols_d.data_ptr(), len(cols), out.data_ptr(), out.stride(0),
+                                          current_stream()), "mxm_gather_columns")
+    return out

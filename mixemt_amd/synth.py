@@ -66,6 +66,37 @@ def synth_reads(tables, ref_len, n_reads, seed=1, contrib=DEFAULT_CONTRIB,
     return row_ptr, site.astype(numpy.uint16), obs, who
 
 
+GEN_BLOCK = 125000          # rows per independently seeded block of synth_rows
+
+
+def synth_rows(tables, ref_len, lo, hi, seed=1, block=GEN_BLOCK, **kw):
+    """
+    Rows [lo, hi) of a synth-v1 read set of any size, without generating the rest:
+    the set is defined block by block -- block k (rows k*block ... (k+1)*block - 1) is
+    synth_reads(..., n_reads=block, seed=[seed, k]) -- so that every rank of a row-sharded
+    run builds its own shard of ONE global problem, whatever the number of ranks
+    (bench.py strong scaling; SURVEY.md section 8 d/e).
+    -> (row_ptr[hi-lo+1], site, obs, who) like synth_reads.
+    """
+    lo, hi = int(lo), int(hi)
+    if hi <= lo:
+        return (numpy.zeros(1, dtype=numpy.int64), numpy.zeros(0, dtype=numpy.uint16),
+                numpy.zeros(0, dtype=numpy.uint8), numpy.zeros(0, dtype=numpy.int64))
+    ptrs, sites, obss, whos = [], [], [], []
+    base = 0
+    for k in range(lo // block, (hi - 1) // block + 1):
+        rp, st, ob, who = synth_reads(tables, ref_len, block, seed=[int(seed), k], **kw)
+        a = max(lo - k * block, 0)
+        b = min(hi - k * block, block)
+        ptrs.append(rp[a:b] - rp[a] + base)
+        base += int(rp[b] - rp[a])
+        sites.append(st[rp[a]:rp[b]])
+        obss.append(ob[rp[a]:rp[b]])
+        whos.append(who[a:b])
+    row_ptr = numpy.concatenate(ptrs + [numpy.array([base], dtype=numpy.int64)])
+    return row_ptr, numpy.concatenate(sites), numpy.concatenate(obss), numpy.concatenate(whos)
+
+
 def signatures(tables, row_ptr, site, obs):
     """CSR observations -> the reference's signature strings (preprocess.py:142-148)."""
     out = []

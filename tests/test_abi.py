@@ -17,10 +17,13 @@ def lib_path():
     return build.build()
 
 
-def _declared():
-    text = open(os.path.join(ROOT, "include", "mixemt_hip.h")).read()
-    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
-    return sorted(set(re.findall(r"\b(mxm_[a-z0-9_]+)\s*\(", text)))
+def _declared(headers=("mixemt_hip.h", "mixemt_hip_tuning.h")):
+    names = set()
+    for header in headers:
+        text = open(os.path.join(ROOT, "include", header)).read()
+        text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+        names.update(re.findall(r"\b(mxm_[a-z0-9_]+)\s*\(", text))
+    return sorted(names)
 
 
 def test_header_declares_the_boundary():
@@ -28,6 +31,13 @@ def test_header_declares_the_boundary():
     for must in ("mxm_build_em_matrix", "mxm_em_iter", "mxm_m_finalize", "mxm_em_loop",
                  "mxm_em_step", "mxm_workspace_bytes", "mxm_last_error", "mxm_version"):
         assert must in names
+
+
+def test_boundary_header_holds_no_tuning_knobs():
+    """Process-wide knobs and measurement hooks live in mixemt_hip_tuning.h, not in the boundary."""
+    boundary = _declared(("mixemt_hip.h",))
+    assert not [n for n in boundary if n.startswith("mxm_set_") or n.startswith("mxm_diag_")]
+    assert "mxm_set_timing_events" in _declared(("mixemt_hip_tuning.h",))
 
 
 def test_library_exports_every_declared_symbol(lib_path):

@@ -255,8 +255,11 @@ def test_row_argmax_votes_kernel(b17):
     best = torch.empty(300, dtype=torch.int32, device="cuda")
     votes = torch.zeros(777, dtype=torch.float64, device="cuda")
     lib = _lib.load()
+    nbytes = lib.mxm_workspace_bytes(300, 777, 1)
+    ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device="cuda")
     _lib.check(lib.mxm_row_argmax_votes(x.data_ptr(), x.stride(0), w.data_ptr(), 300, 777,
-                                        best.data_ptr(), votes.data_ptr(), current_stream()), "argmax")
+                                        best.data_ptr(), votes.data_ptr(), ws.data_ptr(), nbytes,
+                                        current_stream()), "argmax")
     want = mat.argmax(axis=1)
     assert numpy.array_equal(best.cpu().numpy(), want)
     want_votes = numpy.zeros(777)

@@ -19,6 +19,7 @@ Fixtures (SURVEY.md section 8 c):
     g6  refinement shape: 600 x 5 contributor columns
     g7  config 1: 1000 x 100
     g8  consumers of the result on the g4 run: contributor votes, read assignment, refinement
+    g9  run_em on 2400 x 5408 with de-duplication-style weights (repeats up to 400), n_multi = 1
 """
 
 import argparse
@@ -296,6 +297,28 @@ def main():
              refined_props=numpy.array([c[2] for c in refined]), refined_iters=riters,
              refined_inits=rinits, refined_assigned=rassigned,
              props=props, iters=iters)
+
+    if want("g9"):
+        # 4x the g4 size, weights as reduce_reads leaves them (preprocess.py:218-220: fragments per
+        # distinct signature -- mostly 1, a heavy tail of repeats up to a few hundred)
+        row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), 2400, seed=9)
+        sigs = synth.signatures(tables, row_ptr, site, obs)
+        t0 = time.time()
+        mat = ref.preprocess.build_em_matrix(refseq, phy, sigs, haps, quiet)
+        print("g9: reference built 2400 x %d in %.0f s" % (len(haps), time.time() - t0))
+        rng = numpy.random.default_rng(99)
+        wts = numpy.minimum(rng.zipf(1.6, size=2400), 400).astype(numpy.int64)
+        t0 = time.time()
+        props, mix, iters, inits = ref_run_em(ref, mat, wts, 17)
+        print("g9: reference run_em %d iterations in %.0f s" % (iters[0], time.time() - t0))
+        best, votes = votes_of(mix, wts, len(haps))
+        save("g9_run_em_2400", row_ptr=row_ptr, site=site, obs=obs, who=who, wts=wts,
+             mat_sha256=numpy.array(sha(mat)), mat_row_sum=mat.sum(axis=1),
+             props=props, iters=iters, inits=inits, mix_rows=mix[:4].copy(),
+             mix_argmax=best, mix_argmax_sha256=numpy.array(sha(best)), votes=votes,
+             mix_rowmax=mix.max(axis=1), mix_row_lse_abs_max=numpy.array(
+                 numpy.abs(numpy.log(numpy.exp(mix).sum(axis=1))).max()),
+             contributors=numpy.flatnonzero(votes >= 10).astype(numpy.int32))
 
     if want("g7"):
         cols = list(range(0, 5400, 54))
