@@ -44,6 +44,17 @@ int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_per_cu, int32
 int mxm_set_loop_graph(int32_t mode);
 
 /*
+ * mxm_em_loop runs the whole loop of a cache-resident matrix (R * H <= 2.5e7 cells = 200 MB of
+ * fp64) in ONE persistent launch (em_fused_loop_kernel: grid barriers instead of kernel
+ * boundaries): mode -1 = automatic by size, 0 = never (per-iteration kernels), 1 = whenever the
+ * shape allows.  chunk > 0 splits the loop into launches of that many iterations per restart
+ * (same bits: a resumed restart continues from its saved proportions); 0 = one launch.
+ * Against the per-iteration kernels the results differ by rounding only (another summation
+ * order; the linear proportions are carried as p T / tot instead of exp(ln p')).
+ */
+int mxm_set_loop_fused(int32_t mode, int32_t chunk);
+
+/*
  * How many restarts at most share one pass over the matrix in mxm_em_iter (1..4,
  * default 4; B restarts take ceil(B / tile) passes with the restarts spread evenly:
  * 10 -> 4 + 3 + 3).  1 reproduces the unbatched schedule (B passes per iteration).

@@ -18,7 +18,8 @@
 //                       1-4 restarts per pass), em_iter_wide_f32_kernel (opt-in storage variant),
 //                       colreduce_kernel, finalize_kernel
 //   estep_kernels.hpp   estep_log_kernel (any H), estep_wide_kernel (register-resident posterior pass)
-//   aux_kernels.hpp     log_normalize, l1_exp_diff, add_scalar, row_argmax_votes, assign_reads, diag_stream_read
+//   aux_kernels.hpp     log_normalize, l1_exp_diff, add_scalar, row_argmax_votes, assign_reads, gather, fold, diag_stream_read
+//   fused_kernels.hpp   em_fused_loop_kernel (the whole EM loop of a cache-resident matrix in one persistent launch)
 // This file: the host side of the C ABI (shape checks, grid sizing, dispatch, the loop driver).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -36,6 +37,7 @@
 #include "em_kernels.hpp"
 #include "estep_kernels.hpp"
 #include "aux_kernels.hpp"
+#include "fused_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------
 // host side of the C ABI
@@ -584,6 +586,74 @@ static int enqueue_iterations(const double *M, int64_t ldm, const double *P, int
     return 0;
 }
 
+// ---- one-launch loop for cache-resident matrices (fused_kernels.hpp) ---------------------------
+static int g_loop_fused = -1;          // -1 auto (R * H below g_fused_cells), 0 never, 1 whenever the shape allows
+static int g_fused_chunk = 0;          // iterations per launch (0 = run to the end in one launch)
+static double g_fused_cells = 2.5e7;   // 200 MB of fp64: the matrix stays in L2 / Infinity Cache between iterations
+extern "C" int mxm_set_loop_fused(int32_t mode, int32_t chunk) {
+    g_loop_fused = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+    g_fused_chunk = chunk > 0 ? chunk : 0;
+    return 0;
+}
+
+static size_t fused_sync_bytes() { return (sizeof(fused_sync) + 255) & ~(size_t)255; }
+
+static bool fused_eligible(const double *P, int64_t ldp, int64_t R, int H, size_t ws_bytes, bool p_is_f32) {
+    if (g_loop_fused == 0 || p_is_f32 || P == nullptr || !mxm_linear_supported(H)) return false;
+    if ((ldp & 1) || (reinterpret_cast<uintptr_t>(P) & 15)) return false;
+    int nwg = num_cu() < MXM_MAX_WG ? num_cu() : MXM_MAX_WG;
+    const int ncol2 = (H + 1) / 2;
+    if ((ncol2 + nwg - 1) / nwg > 16 * FUSED_MAX_M) return false;           // slice wider than the column reduce covers
+    if ((ncol2 + FUSED_THREADS - 1) / FUSED_THREADS > FUSED_MAX_NCH) return false;   // spill-free instances only (H <= 6144)
+    if ((int64_t)nwg * part_ld(H) * 8 >= ((int64_t)1 << 31)) return false;  // one buffer descriptor over the partials
+    if (ws_bytes < fused_sync_bytes() + (size_t)(nwg + 2) * part_ld(H) * sizeof(double)) return false;
+    if (g_loop_fused == 1) return true;
+    return (double)R * (double)H <= g_fused_cells;
+}
+
+template <int NCH>
+static void launch_fused(int nwg, hipStream_t s, const double *P, int64_t ldp, const double *w, int64_t R, int H, int B,
+                         double *ln_cur, double *ln_new, double *props_cur, mxm_em_state *state, double tol,
+                         int max_iter, int chunk, double *partial, int64_t ldpart, double *tbuf, fused_sync *sync) {
+    hipLaunchKernelGGL((em_fused_loop_kernel<NCH, 2>), dim3(nwg), dim3(FUSED_THREADS), 0, s, P, ldp, w, R, H, B, ln_cur,
+                       ln_new, props_cur, state, tol, max_iter, chunk, partial, ldpart, tbuf, sync);
+}
+
+// The loop of every restart in [0, B) that is not done yet, in launches of at most `chunk` iterations
+// per restart (one launch unless the caller wants to look at the state in between).
+static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t R, int32_t H, int32_t B,
+                         double *props_cur, double *ln_cur, double *ln_new, mxm_em_state *state, double tol,
+                         int32_t max_iter, int32_t chunk, void *ws, hipStream_t s, mxm_em_state *state_host) {
+    const int nwg = num_cu() < MXM_MAX_WG ? num_cu() : MXM_MAX_WG;
+    const int64_t ldpart = part_ld(H);
+    char *base = static_cast<char *>(ws);
+    fused_sync *sync = reinterpret_cast<fused_sync *>(base);
+    double *tbuf = reinterpret_cast<double *>(base + fused_sync_bytes());
+    double *partial = tbuf + 2 * ldpart;
+    const int nch = ((H + 1) / 2 + FUSED_THREADS - 1) / FUSED_THREADS;
+    if (chunk < 1) chunk = 1;
+    for (;;) {
+        HIP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        bool all_done = true;
+        for (int b = 0; b < B; ++b) {
+            if (state_host[b].done < 0)
+                return fail(-3, "mxm_em_loop: the one-launch loop's grid barrier timed out (restart %s%lld): are all %lld "
+                                "workgroups resident?  mxm_set_loop_fused(0) selects the per-iteration kernels", "", b, nwg);
+            all_done = all_done && state_host[b].done != 0;
+        }
+        if (all_done) return 0;
+        HIP_TRY(hipMemsetAsync(sync, 0, fused_sync_bytes(), s));       // every polled word, before EVERY launch
+        switch (nch) {
+#define FU_CASE(n) case n: launch_fused<n>(nwg, s, P, ldp, w, R, (int)H, (int)B, ln_cur, ln_new, props_cur, state, tol, (int)max_iter, (int)chunk, partial, ldpart, tbuf, sync); break;
+            FU_CASE(1) FU_CASE(2) FU_CASE(3) FU_CASE(4) FU_CASE(5) FU_CASE(6)
+#undef FU_CASE
+            default: return fail(-1, "mxm_em_loop: H=%s%lld outside the one-launch loop's range", "", H);
+        }
+        HIP_TRY(hipGetLastError());
+    }
+}
+
 static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
                         int64_t R, int32_t H, int32_t B, double *props_cur, double *ln_cur, double *ln_new,
                         double *colsum, mxm_em_state *state, double tol, int32_t max_iter,
@@ -593,6 +663,13 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     if (check_every < 1) check_every = 1;
     hipStream_t caller = (hipStream_t)stream;
     (void)num_cu();                                    // device query outside any capture
+    if (fused_eligible(P, ldp, R, (int)H, ws_bytes, p_is_f32)) {
+        // cache-resident matrix: the whole loop in one persistent launch on the caller's stream
+        // (the host only waits for it; nothing is decided between iterations)
+        if (R <= 0 || H <= 0 || B <= 0 || ws == nullptr) return fail(-1, "mxm_em_loop: bad shape R=%s%lld H=%lld", "", R, H);
+        return em_loop_fused(P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, state, tol, max_iter,
+                             g_fused_chunk > 0 ? g_fused_chunk : max_iter, ws, caller, state_host);
+    }
     const bool want_graph = g_loop_graph == 1 ||
                             (g_loop_graph == -1 && (double)R * (double)H * (double)B < 6.4e7);
 

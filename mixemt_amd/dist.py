@@ -185,8 +185,8 @@ def _global_rank(group, r):
     return dist.get_global_rank(group, r) if group is not None else r
 
 
-def exchange_fold_blocks(fold, has_fold, n_rows, n_haps, delta, lib, dev, group=None,
-                         chunk_bytes=EXCHANGE_CHUNK_BYTES):
+def exchange_fold_blocks(fold, has_fold, n_rows, n_haps, delta, dev, group=None,
+                         chunk_bytes=EXCHANGE_CHUNK_BYTES, fold_fn=None):
     """
     End-of-run combine of config 5 (SURVEY.md section 8 e; em.py:156-161 across ranks).
     Every rank r that ran restarts holds `fold` = logaddexp over ITS runs of the full
@@ -202,16 +202,21 @@ def exchange_fold_blocks(fold, has_fold, n_rows, n_haps, delta, lib, dev, group=
     entries below exp(-745) keep the finite values numpy.logaddexp gives them.
 
     fold: [R][H] device tensor, or None on a rank without restarts (has_fold[rank] False).
+    fold_fn(acc, pieces, delta): stand-in for the device kernel (the gloo CPU tests drive the
+    transport with a numpy logaddexp); None = mxm_fold_logaddexp.
     Returns this rank's [hi - lo][H] block (a view of `fold` where there is one).
     """
     import ctypes
     rank, world = _world(group)
     bounds = [shard_bounds(n_rows, r, world) for r in range(world)]
     lo, hi = bounds[rank]
-    stream = torch.cuda.current_stream().cuda_stream if dev.type == "cuda" else 0
 
     def fold_into(acc, pieces, dlt):
         """acc = logaddexp(acc, *pieces) + dlt, at most 8 inputs per launch"""
+        if fold_fn is not None:
+            return fold_fn(acc, list(pieces), dlt)
+        lib = _lib.load()
+        stream = torch.cuda.current_stream().cuda_stream
         pieces = list(pieces)
         first = True
         while pieces or first:
@@ -234,7 +239,10 @@ def exchange_fold_blocks(fold, has_fold, n_rows, n_haps, delta, lib, dev, group=
         return mine
     direct = dist.get_backend(group) == "nccl"          # RCCL moves device memory; gloo (tests) is staged on the host
     blocks = [b[1] - b[0] for b in bounds]
-    chunk_rows = max(1, min(max(blocks), int(chunk_bytes // (n_haps * 8 * max(1, len(senders))))))
+    # the chunking must be the same on every rank (a send's size has to match its receive):
+    # size it by the most pieces any rank can receive, not by this rank's own senders
+    most = max(1, sum(1 for f in has_fold if f))
+    chunk_rows = max(1, min(max(blocks), int(chunk_bytes // (n_haps * 8 * most))))
     n_chunks = (max(blocks) + chunk_rows - 1) // chunk_rows
     stage_dev = dev if direct else torch.device("cpu")
     tmp = [torch.empty((max(1, len(senders)), chunk_rows, n_haps), dtype=torch.float64, device=stage_dev)
@@ -298,7 +306,6 @@ def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_rea
     import time
     rank, world = _world(group)
     n_multi = int(args.n_multi)
-    lib = _lib.load()
     dev = require_gpu() if not isinstance(mat, torch.Tensor) else mat.device
     n_rows, n_haps = mat.shape
     if inits is None:
@@ -345,9 +352,9 @@ def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_rea
     if want_read_mix:
         delta = -math.log(n_multi) if n_multi > 1 else 0.0
         if _collective(group):
-            read_mix = exchange_fold_blocks(fold, has_fold, n_rows, n_haps, delta, lib, dev, group)
+            read_mix = exchange_fold_blocks(fold, has_fold, n_rows, n_haps, delta, dev, group)
         else:
-            read_mix = exchange_fold_blocks(fold, [True], n_rows, n_haps, delta, lib, dev, None)
+            read_mix = exchange_fold_blocks(fold, [True], n_rows, n_haps, delta, dev, None)
     sync()
     t3 = time.perf_counter()
     if timing is not None:

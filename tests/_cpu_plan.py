@@ -18,6 +18,7 @@ class CpuPlan(object):
         self.n_rows, self.n_haps = self.mat.shape
         self.calls = 0
         self.restart_steps = 0          # restarts handed to em_iter, summed over calls
+        self.widest = 0                 # most restarts one em_iter call carried
 
     def alloc_props(self, host):
         return torch.from_numpy(numpy.array(host, dtype=numpy.float64))
@@ -31,6 +32,7 @@ class CpuPlan(object):
     def em_iter(self, props, ln_props, state, colsum):
         self.calls += 1
         self.restart_steps += props.shape[0]
+        self.widest = max(self.widest, props.shape[0])
         for b in range(props.shape[0]):
             if state is not None and state[b, 0] != 0:
                 continue

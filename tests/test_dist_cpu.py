@@ -115,3 +115,83 @@ def test_running_restarts_are_packed_in_the_sharded_loop():
     assert numpy.array_equal(new_a.numpy(), new_b.numpy()) and numpy.array_equal(cur_a.numpy(), cur_b.numpy())
     assert packed_plan.calls == plain_plan.calls
     assert packed_plan.restart_steps < plain_plan.restart_steps
+
+
+def test_window_runs_one_tile_at_a_time_with_identical_results():
+    """
+    window = 2 of 5 restarts: only two iterate at a time, a stopped one is replaced by a waiting
+    one; every restart counts its own iterations, so states and vectors equal the all-together
+    schedule bit for bit while no em_iter call ever carries more than the window.
+    """
+    from _cpu_plan import CpuPlan
+    g = golden("g7_config1")
+    mat = g["mat"][:120]
+    wts = (numpy.arange(120) % 3 + 1).astype(numpy.float64)
+    numpy.random.seed(6)
+    inits = numpy.stack([numpy.random.dirichlet([0.5] * mat.shape[1]) for _ in range(5)])
+    win_plan, all_plan = CpuPlan(mat, wts), CpuPlan(mat, wts)
+    cur_a, new_a, st_a = mdist.sharded_em_loop(win_plan, inits, 1e-4, 10000, check_every=4, window=2)
+    cur_b, new_b, st_b = mdist.sharded_em_loop(all_plan, inits, 1e-4, 10000, check_every=4, compact=False)
+    assert st_a == st_b and all(s[0] == 1 for s in st_a)
+    assert numpy.array_equal(new_a.numpy(), new_b.numpy()) and numpy.array_equal(cur_a.numpy(), cur_b.numpy())
+    assert win_plan.widest == 2 and all_plan.widest == 5
+
+
+def test_max_iter_is_per_restart_under_the_window():
+    from _cpu_plan import CpuPlan
+    g = golden("g7_config1")
+    mat = g["mat"][:60]
+    numpy.random.seed(8)
+    inits = numpy.stack([numpy.random.dirichlet([1.0] * mat.shape[1]) for _ in range(3)])
+    cur, new, states = mdist.sharded_em_loop(CpuPlan(mat, numpy.ones(60)), inits, 0.0, 7, check_every=3, window=1)
+    assert [s[:2] for s in states] == [(2, 7)] * 3           # each one ran its own 7 iterations
+
+
+def _numpy_fold(acc, pieces, delta):
+    out = acc.numpy()
+    for piece in pieces:
+        numpy.logaddexp(out, piece.numpy(), out=out)
+    out += delta
+
+
+def _exchange_worker(rank, world, port, out_dir, n_rows, n_haps, n_with_fold, chunk_bytes):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = numpy.random.default_rng(500 + rank)
+        has_fold = [r < n_with_fold for r in range(world)]
+        fold = None
+        if has_fold[rank]:
+            host = rng.normal(size=(n_rows, n_haps)) * 30.0 - 800.0      # far below exp(-745): log space matters
+            fold = torch.from_numpy(host.copy())
+            numpy.save(os.path.join(out_dir, "fold%d.npy" % rank), host)
+        block = mdist.exchange_fold_blocks(fold, has_fold, n_rows, n_haps, -0.25, torch.device("cpu"),
+                                           chunk_bytes=chunk_bytes, fold_fn=_numpy_fold)
+        numpy.save(os.path.join(out_dir, "block%d.npy" % rank), block.numpy())
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_with_fold,n_rows,chunk_bytes", [(2, 2, 37, 1 << 30), (3, 3, 50, 7 * 11 * 8 * 2),
+                                                                  (3, 2, 20, 5 * 11 * 8), (2, 1, 9, 1 << 30)])
+def test_row_block_exchange_is_a_log_space_reduce_scatter(tmp_path, world, n_with_fold, n_rows, chunk_bytes):
+    """
+    Config 5's end-of-run combine: every rank ends with its row block of logaddexp over all
+    ranks' folds (+ delta), also when the blocks move in several chunks, when a rank has no
+    fold of its own, and for values whose exp() underflows.
+    """
+    n_haps = 11
+    mp.spawn(_exchange_worker, args=(world, _free_port(), str(tmp_path), n_rows, n_haps, n_with_fold, chunk_bytes),
+             nprocs=world, join=True)
+    folds = [numpy.load(str(tmp_path / ("fold%d.npy" % r))) for r in range(n_with_fold)]
+    want = folds[0].copy()
+    for other in folds[1:]:
+        want = numpy.logaddexp(want, other)
+    want -= 0.25
+    assert numpy.isfinite(want).all() and (numpy.exp(want) == 0).any()
+    for r in range(world):
+        lo, hi = mdist.shard_bounds(n_rows, r, world)
+        got = numpy.load(str(tmp_path / ("block%d.npy" % r)))
+        assert got.shape == (hi - lo, n_haps)
+        assert numpy.allclose(got, want[lo:hi], rtol=0, atol=1e-12)

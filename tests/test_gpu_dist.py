@@ -52,12 +52,14 @@ def _worker(rank, world, port, out_dir, name, seed, n_multi, mode, backend="gloo
             lo, hi = mdist.shard_bounds(full.shape[0], rank, world)
             res = mdist.run_em_sharded(full[lo:hi], wts[lo:hi], mk(n_multi=n_multi), check_every=5)
         else:
-            lo, hi = 0, full.shape[0]
             res = mdist.run_em_restart_parallel(full, wts, mk(n_multi=n_multi))
+            lo, hi = res["rows"]                               # each rank returns ITS row block
+            assert (lo, hi) == mdist.shard_bounds(full.shape[0], rank, world)
         mix = res["read_mix"].cpu().numpy()
+        assert mix.shape == (hi - lo, full.shape[1])
         numpy.savez(os.path.join(out_dir, "rank%d.npz" % rank), props=res["props"],
                     iters=numpy.array(res["iters"]), best=mix.argmax(axis=1), lo=lo, hi=hi,
-                    rowmax=mix.max(axis=1), inits=res["inits"])
+                    rowmax=mix.max(axis=1), inits=res["inits"], head=mix[:16], rowmin=mix.min(axis=1))
     finally:
         dist.destroy_process_group()
 
@@ -88,10 +90,16 @@ def test_two_ranks_restart_parallel_match_reference(tmp_path):
              nprocs=2, join=True)
     res = [numpy.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(2)]
     for r in res:
+        lo, hi = int(r["lo"]), int(r["hi"])
         assert list(r["iters"]) == list(g["iters"])
         assert numpy.abs(r["props"] - g["props"]).max() < 1e-9
-        assert numpy.array_equal(r["best"], g["mix_argmax"])
-        assert numpy.allclose(r["rowmax"], g["mix_rowmax"], rtol=0, atol=1e-8)
+        assert numpy.array_equal(r["best"], g["mix_argmax"][lo:hi])
+        assert numpy.allclose(r["rowmax"], g["mix_rowmax"][lo:hi], rtol=0, atol=1e-8)
+        # the combine runs in log space (mxm_fold_logaddexp): nothing underflows to -inf on the way
+        # (tests/test_dist_cpu.py drives the same exchange on values below exp(-745))
+        assert numpy.isfinite(r["rowmin"]).all()
+    assert int(res[0]["lo"]) == 0 and int(res[0]["hi"]) == int(res[1]["lo"]) and int(res[1]["hi"]) == 600
+    assert numpy.allclose(res[0]["head"], g["mix_rows"], rtol=0, atol=1e-8)     # the reference's first 16 rows
 
 
 @pytest.mark.parametrize("mode", ["rows", "restarts"])

@@ -147,6 +147,36 @@ def test_run_em_b17_golden(b17):
     assert numpy.allclose(mix.max(axis=1), g["mix_rowmax"], rtol=0, atol=1e-8)
 
 
+def test_run_em_b17_golden_2400_rows_with_repeat_weights(b17):
+    """
+    g9: the reference's run_em on 2400 x 5408 with the weights reduce_reads leaves
+    (preprocess.py:218-220: fragments per distinct signature, repeats up to 400) -- 4x the rows of
+    g4.  Bit-exact matrix, identical init / iteration count / haplogroup calls / votes /
+    contributor set, proportions within 1e-9, posterior within 1e-8.
+    """
+    import hashlib
+    from mixemt_amd import assign, em, preprocess
+    refseq, phy, haps, tables = b17
+    g = golden("g9_run_em_2400")
+    mat = preprocess.build_em_matrix_device(tables, g["row_ptr"], g["site"], g["obs"])      # built on the device
+    assert hashlib.sha256(mat.cpu().numpy().tobytes()).hexdigest() == str(g["mat_sha256"])  # the reference's bits
+    assert int(g["wts"].max()) >= 100
+    numpy.random.seed(17)
+    res = em.run_em_ex(mat, g["wts"], em_args())
+    assert numpy.array_equal(res["inits"], g["inits"])
+    assert res["iters"] == list(g["iters"])
+    assert numpy.abs(res["props"] - g["props"]).max() < PROPS_ATOL
+    best, votes = assign.row_argmax_votes(res["read_mix"], g["wts"])
+    assert numpy.array_equal(best, g["mix_argmax"])                 # identical haplogroup calls, all 2400 rows
+    assert hashlib.sha256(numpy.ascontiguousarray(best.astype(g["mix_argmax"].dtype)).tobytes()).hexdigest() \
+        == str(g["mix_argmax_sha256"])
+    assert numpy.array_equal(votes, g["votes"])
+    assert numpy.array_equal(numpy.flatnonzero(votes >= 10), g["contributors"])
+    mix = res["read_mix"].cpu().numpy()
+    assert numpy.allclose(mix[:4], g["mix_rows"], rtol=0, atol=1e-8)
+    assert numpy.allclose(mix.max(axis=1), g["mix_rowmax"], rtol=0, atol=1e-8)
+
+
 def test_run_em_b17_multi_golden(b17):
     """n_multi = 3: sequential init draws, geometric-mean proportions (sum != 1), folded posterior."""
     from mixemt_amd import em

@@ -193,3 +193,32 @@ def test_run_em_b17_bitwise_slow(b17, name, seed, n_multi):
     assert [t["iters"] for t in trace] == list(g["iters"])
     assert numpy.array_equal(props, g["props"])
     assert numpy.array_equal(mix.argmax(axis=1), g["mix_argmax"])
+
+
+@pytest.mark.slow
+def test_run_em_b17_2400_rows_bitwise_slow(b17):
+    """g9 (2400 x 5408, repeat weights up to 400): the oracle reproduces the reference bit for bit."""
+    refseq, phy, haps, tables = b17
+    g = golden("g9_run_em_2400")
+    flat = build_oracle.flat_tables(refseq, phy, haps)
+    mat = c_oracle.build_em_matrix(flat[1], flat[2], flat[3], g["row_ptr"], g["site"], g["obs"],
+                                   len(haps))
+    assert _sha(mat) == str(g["mat_sha256"])
+    trace = []
+    numpy.random.seed(17)
+    props, mix = em_oracle.run_em(mat, g["wts"], em_args(), trace=trace)
+    assert [t["iters"] for t in trace] == list(g["iters"])
+    assert numpy.array_equal(props, g["props"])
+    assert numpy.array_equal(mix.argmax(axis=1), g["mix_argmax"])
+
+
+def test_g9_matrix_bits_from_the_c_oracle(b17):
+    """The build half of g9 is cheap enough for every CPU run: the C oracle's matrix has the
+    reference's sha256 (2400 x 5408)."""
+    refseq, phy, haps, tables = b17
+    g = golden("g9_run_em_2400")
+    flat = build_oracle.flat_tables(refseq, phy, haps)
+    mat = c_oracle.build_em_matrix(flat[1], flat[2], flat[3], g["row_ptr"], g["site"], g["obs"],
+                                   len(haps))
+    assert _sha(mat) == str(g["mat_sha256"])
+    assert numpy.array_equal(mat.sum(axis=1), g["mat_row_sum"])

@@ -2,7 +2,8 @@
 """
 Wall time of a full multi-restart run_em (BASELINE config 3 shape: synth-v1 reads x 5408
 haplogroups, n_multi sequential Dirichlet inits, defaults tol 1e-4 / max_iter 10000) with the
-running-restart packing of mxm_em_loop on and off.
+restart schedules of mxm_em_loop (mxm_set_compact_restarts: 0 all together,
+1 running ones packed, 2 one full tile at a time with slot refill).
 
     python tools/time_restarts.py [--reads N] [--multi M]
 """
@@ -33,7 +34,7 @@ numpy.random.seed(7)
 inits = numpy.stack([em.init_props(len(haps), 1.0) for _ in range(opts.multi)])
 plan = em.EmPlan(mat, wts, n_runs=opts.multi)
 res = {}
-for on in (1, 0, 1, 0):
+for on in (2, 1, 0, 2, 1):
     lib.mxm_set_compact_restarts(on)
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -42,9 +43,10 @@ for on in (1, 0, 1, 0):
     dt = time.perf_counter() - t0
     iters = [s[1] for s in states]
     res[on] = (ln_new.cpu().numpy(), iters)
-    print("packing %d: EM loop %.3f s, iterations per restart %s (sum %d) -> %.1f restart-iterations/s"
+    print("schedule %d: EM loop %.3f s, iterations per restart %s (sum %d) -> %.1f restart-iterations/s"
           % (on, dt, iters, sum(iters), sum(iters) / dt))
-lib.mxm_set_compact_restarts(1)
-print("same iteration counts: %s; max |delta ln p| over finite entries: %.3e"
-      % (res[0][1] == res[1][1],
-         float(numpy.nanmax(numpy.abs(numpy.where(numpy.isfinite(res[0][0]), res[0][0] - res[1][0], 0.0))))))
+lib.mxm_set_compact_restarts(2)
+for a in (1, 2):
+    print("schedule %d vs 0: same iteration counts: %s; max |delta ln p| over finite entries: %.3e"
+          % (a, res[0][1] == res[a][1],
+             float(numpy.nanmax(numpy.abs(numpy.where(numpy.isfinite(res[0][0]), res[0][0] - res[a][0], 0.0))))))
