@@ -98,6 +98,27 @@ int mxm_build_em_matrix_packed(const uint32_t *Epk, const uint8_t *muidx, const 
                                double *M, int64_t ldm, void *stream);
 
 /*
+ * build_em_matrix, lookup-table fast path -- same arithmetic, same order, same bits as
+ * mxm_build_em_matrix (preprocess.py:177-198 with :69-96 inlined); the hit / miss choice of _prob
+ * (:75-84) is a 16-entry LDS lookup instead of two selects.  The host pre-encodes
+ *   Ecode[S][lde]  uint8: 4-bit code of the expected base, SHIFTED LEFT BY 3 (code 1..14 names the
+ *                  alphabet of the table, at most 14 letters; pad bytes 0); lde a multiple of 4
+ *   obsmap[256]    uint8: observation byte -> its code << 3; 15 << 3 for a byte that equals no expected base
+ * order[R] (nullable): a permutation of the rows -- the order in which the grid takes them (rows that
+ *   start at nearby positions share table rows; dealing them out together keeps those in L2).
+ *   Results do not depend on it.
+ * P / ldp / rowmax (all or none; NULL = matrix only): the kernel also emits mxm_linearize's output
+ *   for the same rows -- rowmax[r] = max_h M[r][h], P[r][h] = exp(M[r][h] - rowmax[r]), pad columns
+ *   [H, ldp) zero -- from the sums it still holds in registers, so the loop's one-time change of
+ *   variables costs no second pass over M.  ldp even and >= H.
+ * H <= 8192, S * lde < 2^31; otherwise call mxm_build_em_matrix.
+ */
+int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const double *lhit, const double *lmiss,
+                            const uint8_t *obsmap, const int64_t *row_ptr, const uint16_t *site,
+                            const uint8_t *obs, const int64_t *order, int64_t R, int32_t H, int32_t S,
+                            double *M, int64_t ldm, double *P, int64_t ldp, double *rowmax, void *stream);
+
+/*
  * One-time change of variables for the streaming loop:
  *   rowmax[r] = max_h M[r][h]   (0 if not finite),  P[r][h] = exp(M[r][h] - rowmax[r])
  * ldp must be even and >= H; pad columns [H, ldp) are written as 0.
@@ -117,6 +138,12 @@ int mxm_linearize(const double *M, int64_t ldm, int64_t R, int32_t H,
  * Restarts with state[b].done != 0 are skipped (their colsum is left untouched).
  * A row with Z_b[r] == 0 (-inf in every column) and w[r] != 0 makes every T_bh NaN, as the
  * reference's -inf - (-inf) does (em.py:81-83, :87); with w[r] == 0 it is dropped like scipy drops it.
+ * LIMIT of the linear form: Z_b[r] is also 0 when every haplogroup that supports row r (P > 0) has a
+ * proportion whose exp() underflowed (ln p < -745) although the row is not empty; the reference's
+ * log-space E-step stays finite there, this kernel poisons the restart with NaN (it then runs to
+ * max_iter and reports NaN proportions -- loud, not silent).  Matrices from build_em_matrix cannot
+ * get there: every cell is finite and >= k * log(0.0033), so the best-supported haplogroup of a row
+ * keeps P = 1 and would need ln p < -745 while the row's weight pulls it up every iteration.
  * props[B][H] = exp(ln_props[B][H]) (theta_k), w[R] fp64 weights (NULL = all 1).
  * With several ranks the caller all-reduces (SUM) colsum before mxm_m_finalize.
  */

@@ -44,8 +44,8 @@ int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_per_cu, int32
 int mxm_set_loop_graph(int32_t mode);
 
 /*
- * mxm_em_loop runs the whole loop of a cache-resident matrix (R * H <= 2.5e7 cells = 200 MB of
- * fp64) in ONE persistent launch (em_fused_loop_kernel: grid barriers instead of kernel
+ * mxm_em_loop runs the whole loop of a small matrix (R * H <= 1e8 cells = 800 MB of fp64; the
+ * kernels' own break-even is ~1.6e8) in ONE persistent launch (em_fused_loop_kernel: grid barriers instead of kernel
  * boundaries): mode -1 = automatic by size, 0 = never (per-iteration kernels), 1 = whenever the
  * shape allows.  chunk > 0 splits the loop into launches of that many iterations per restart
  * (same bits: a resumed restart continues from its saved proportions); 0 = one launch.
@@ -63,13 +63,13 @@ int mxm_set_loop_fused(int32_t mode, int32_t chunk);
 int mxm_set_batch_tile(int32_t bt);
 
 /*
- * Restart schedule of mxm_em_loop.  0: all B restarts advance together, ceil(B / tile) passes per
- * iteration until each tile's last member stops.  1: the restarts still running are kept packed in
- * the leading slots of the loop vectors (device-side slot exchanges, undone before it returns), so
- * an iteration takes ceil(running / tile) passes.  2 (default): packed, and only ONE full tile of
- * them iterates at a time -- a slot whose restart has stopped is refilled with a waiting one -- so
- * every pass over the matrix carries a full tile.  Results are the same in all modes: each restart
- * counts its own iterations and is frozen wherever it sits once it has stopped.
+ * Restart schedule of mxm_em_loop.  0: every restart in every iteration, static tiles over all B
+ * (ceil(B / tile) passes until each tile's last member stops).  1: tiles over the restarts still
+ * running, ceil(running / tile) passes per iteration.  2 (default): ONE full tile per iteration,
+ * dealt round-robin over the running restarts chunk by chunk, so every pass over the matrix carries a
+ * full tile and all restarts advance at the same rate.  Tiles name their restarts by index; nothing
+ * moves in memory.  Results are the same in all modes: each restart counts its own iterations and is
+ * frozen once it has stopped.
  */
 int mxm_set_compact_restarts(int32_t mode);
 

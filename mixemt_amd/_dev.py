@@ -35,9 +35,47 @@ def as_device(x, dtype, dev):
     arr = numpy.ascontiguousarray(x)
     if dtype == torch.uint16:
         # torch has no first-class uint16 arithmetic; only the bytes matter here
-        arr = numpy.ascontiguousarray(arr.astype(numpy.uint16, copy=False))
-        return torch.from_numpy(arr.view(numpy.int16)).to(dev)
-    return torch.from_numpy(arr).to(device=dev).to(dtype).contiguous()
+        arr = numpy.ascontiguousarray(arr.astype(numpy.uint16, copy=False)).view(numpy.int16)
+        return _upload(torch.from_numpy(arr), dev)
+    return _upload(torch.from_numpy(arr), dev).to(dtype).contiguous()
+
+
+def _upload(host, dev):
+    """Host tensor -> device; large ones through a page-locked staging buffer (see to_host)."""
+    if host.numel() * host.element_size() < PINNED_FROM_BYTES:
+        return host.to(dev)
+    try:
+        staged = torch.empty(host.shape, dtype=host.dtype, pin_memory=True)
+    except RuntimeError:
+        return host.to(dev)
+    staged.copy_(host)
+    out = staged.to(dev, non_blocking=True)
+    torch.cuda.current_stream(dev).synchronize()      # the staging buffer may go away after this
+    return out
+
+
+PINNED_FROM_BYTES = 1 << 20      # host <-> device copies of at least this size go through page-locked staging
+
+
+def to_host(t):
+    """
+    Device tensor -> numpy array.  Large results (the drop-in path returns whole R x H matrices to
+    numpy callers) are copied into a page-locked buffer first: a pageable destination makes the
+    runtime bounce through its own small pinned chunks at ~10 GB/s, a pinned one runs at the PCIe
+    rate.  The pinned buffer backs the returned array (no second host copy).
+    """
+    if not isinstance(t, torch.Tensor):
+        return numpy.asarray(t)
+    if t.device.type != "cuda" or t.numel() * t.element_size() < PINNED_FROM_BYTES:
+        return t.detach().cpu().numpy()
+    src = t.detach().contiguous()
+    try:
+        host = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
+    except RuntimeError:                     # no page-locked memory left: the plain copy still works
+        return src.cpu().numpy()
+    host.copy_(src, non_blocking=True)
+    torch.cuda.current_stream(src.device).synchronize()
+    return host.numpy()
 
 
 def ptr(t):

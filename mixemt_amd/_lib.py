@@ -31,6 +31,8 @@ SIGNATURES = {
     "mxm_restart_tile": (ctypes.c_int, [c_i32]),
     "mxm_build_em_matrix": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                            c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
+    "mxm_build_em_matrix_lut": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                               c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
     "mxm_build_packed_lds_bytes": (c_size, [c_i32, c_i32]),
     "mxm_build_em_matrix_packed": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
                                                   c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),

@@ -373,25 +373,4 @@ __global__ __launch_bounds__(512, 2) void diag_stream_dealt_kernel(const double 
     if (acc == 0x9e3779b9u) sink[0] = acc;
 }
 
-// ------------------------------------------------------------------------------------------
-// Loop bookkeeping: exchange restart slots i and j of the four [B][H] loop vectors and of the
-// state array (em_loop_impl packs the still-running restarts into the leading slots so that
-// they need fewer passes over the matrix).  grid (ceil(H / 256), 4).
-// ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void swap_restart_slots_kernel(double *a0, double *a1, double *a2, double *a3,
-                                                                  mxm_em_state *state, int i, int j, int H) {
-    double *a = blockIdx.y == 0 ? a0 : (blockIdx.y == 1 ? a1 : (blockIdx.y == 2 ? a2 : a3));
-    const int h = blockIdx.x * 256 + threadIdx.x;
-    if (h < H) {
-        const double t = a[(int64_t)i * H + h];
-        a[(int64_t)i * H + h] = a[(int64_t)j * H + h];
-        a[(int64_t)j * H + h] = t;
-    }
-    if (blockIdx.x == 0 && blockIdx.y == 0 && threadIdx.x == 0) {
-        const mxm_em_state t = state[i];
-        state[i] = state[j];
-        state[j] = t;
-    }
-}
-
 #endif  // MIXEMT_AUX_KERNELS_HPP

@@ -1,0 +1,182 @@
+// build_lut_kernels.hpp -- part of libmixemt_hip.so (gfx950); included by mixemt_hip.hip only.
+// build_em_matrix (preprocess.py:177-198) with the hit/miss choice served by an LDS lookup, and the
+// loop's change of variables (mxm_linearize) fused into the same pass.
+#ifndef MIXEMT_BUILD_LUT_KERNELS_HPP
+#define MIXEMT_BUILD_LUT_KERNELS_HPP
+
+// ------------------------------------------------------------------------------------------
+// K1c build_lut: same sums, same order, same bits as build_em_matrix_kernel (K1).
+//
+// K1 spends 4 VALU operations per (cell, site): byte compare, two 32-bit selects for the fp64
+// hit / miss term, the fp64 add -- and it is VALU-bound (72 % pipe busy at 37 ms for 2e11 terms).
+// Here the select is a table lookup on the LDS pipe, which K1 leaves idle:
+//   * the expected-base table holds 4-bit codes PRE-SHIFTED by 3 (code << 3, one byte per cell),
+//     the observation likewise; x = e ^ o is then 0 for a hit and a multiple of 8 below 128 otherwise
+//     -- directly the byte offset into a 16-entry table of doubles;
+//   * per observation of the row a 128-byte LUT {log hit, log miss x 15} is staged in LDS
+//     (double buffered with the row's record list, filled while the previous row is added up);
+//   * per (cell, site): one address add (x's byte + the site's LUT base), one ds_read_b64, one
+//     fp64 add: 2 VALU + 1 LDS instead of 4 VALU.  Per 4 cells and site: one 4-byte table load through
+//     a buffer descriptor (32-bit offset arithmetic), one xor, one 8-byte record read.
+// The 16 entries of a site sit in 16 different 8-byte bank pairs, equal addresses broadcast:
+// the reads are conflict free whatever the mix of hits and misses.
+//
+// FUSE_P: the row's 5408 sums stay in registers until the row is complete; the workgroup takes
+// the row maximum and stores, beside M, rowmax and P = exp(M - rowmax) -- mxm_linearize's output,
+// without reading the 43 GB of M back (em.py:80-83's shift, hoisted out of the loop).
+// All stores are non-temporal: the matrix streams past the L2 instead of evicting the table.
+//
+// `order` (nullable): row processing order.  Rows that start at nearby positions touch the same
+// table rows; handing them to the grid together keeps those rows in L2.  Results do not depend on it.
+// ------------------------------------------------------------------------------------------
+#define LUT_THREADS 256
+#define LUT_CAP 128                // observations staged per pass (longer rows take several passes)
+#define LUT_NOMATCH (15u << 3)     // observation code that equals no expected code
+
+template <bool FUSE_P, int NT>
+__global__ __launch_bounds__(LUT_THREADS) void build_lut_kernel(
+    const uint8_t *__restrict__ E, int64_t lde, int64_t e_bytes, const double *__restrict__ lhit,
+    const double *__restrict__ lmiss, const uint8_t *__restrict__ obsmap, const int64_t *__restrict__ row_ptr,
+    const uint16_t *__restrict__ site, const uint8_t *__restrict__ obs, const int64_t *__restrict__ order,
+    int64_t R, int H, double *__restrict__ M, int64_t ldm, double *__restrict__ P, int64_t ldp,
+    double *__restrict__ rowmax, int vec_ok) {
+    constexpr int CPL = 4;                              // columns per lane and tile: one 4-byte table load per site
+    __shared__ double s_lut[2][LUT_CAP][16];            // per observation: [0] = log hit, [1..15] = log miss
+    __shared__ uint2 s_rec[2][LUT_CAP];                 // per observation: {table row byte offset, obs code << 3 in 4 bytes}
+    __shared__ double s_red[LUT_THREADS / 64];
+    const int t = threadIdx.x;
+    const auto e_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(E), 0, (int)e_bytes, 0x00020000);
+
+    auto stage = [&](int buf, int slot, int64_t at) {   // observation `at` of the CSR -> slot of buffer buf
+        const uint32_t s0 = site[at];
+        const uint32_t oc = obsmap[obs[at]];
+        const double hv = lhit[s0], mv = lmiss[s0];
+        s_rec[buf][slot] = make_uint2((uint32_t)(s0 * (uint32_t)lde), oc * 0x01010101u);
+        d2 *dst = reinterpret_cast<d2 *>(&s_lut[buf][slot][0]);
+        dst[0] = d2{hv, mv};
+#pragma unroll
+        for (int q = 1; q < 8; ++q) dst[q] = d2{mv, mv};
+    };
+
+    int cur = 0;
+    bool have = false;                                  // buffer[cur] already holds this row's list
+    for (int64_t i = blockIdx.x; i < R; i += gridDim.x, cur ^= 1) {
+        const int64_t r = order != nullptr ? order[i] : i;
+        const int64_t beg = row_ptr[r], end = row_ptr[r + 1];
+        const int64_t n_all = end - beg;
+        const bool fast = n_all <= LUT_CAP;
+        const int64_t in = i + gridDim.x;
+        const int64_t rn = (in < R) ? (order != nullptr ? order[in] : in) : 0;
+        const int64_t begn = (in < R) ? row_ptr[rn] : 0;
+        const int nn = (in < R) ? (int)((row_ptr[rn + 1] - begn) <= LUT_CAP ? (row_ptr[rn + 1] - begn) : 0) : 0;
+        if (fast && !have && t < (int)n_all) stage(cur, t, beg + t);
+        __syncthreads();
+        // next row's list in three steps spread over this row's tiles, so neither of its two dependent
+        // global loads (site -> lhit[site]) is ever waited for: here the first hop
+        uint32_t nsite = 0, nobs = 0, ncode = 0;
+        double nhit = 0.0, nmiss = 0.0;
+        if (t < nn) {
+            nsite = site[begn + t];
+            nobs = obs[begn + t];
+        }
+
+        double vals[FUSE_P ? NT : 1][CPL];
+#pragma unroll
+        for (int tile = 0; tile < NT; ++tile) {
+            const int h = tile * (LUT_THREADS * CPL) + CPL * t;
+            double a[CPL];
+#pragma unroll
+            for (int c = 0; c < CPL; ++c) a[c] = 0.0;
+            auto add_sites = [&](int n) {
+                const char *lut = reinterpret_cast<const char *>(&s_lut[cur][0][0]);
+#pragma unroll 8
+                for (int j = 0; j < n; ++j) {
+                    const uint2 rc = s_rec[cur][j];
+                    const uint32_t e = __builtin_amdgcn_raw_buffer_load_b32(e_rsrc, (int)(rc.x + (uint32_t)h), 0, 0);
+                    const uint32_t x = e ^ rc.y;
+                    const char *row = lut + j * 128;
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c)
+                        a[c] += *reinterpret_cast<const double *>(row + ((x >> (8 * c)) & 0xffu));
+                }
+            };
+            if (fast) {
+                if (h < H) add_sites((int)n_all);
+            } else {
+                for (int64_t j0 = beg; j0 < end; j0 += LUT_CAP) {
+                    const int n = (int)((end - j0) < LUT_CAP ? (end - j0) : LUT_CAP);
+                    __syncthreads();
+                    if (t < n) stage(cur, t, j0 + t);
+                    __syncthreads();
+                    if (h < H) add_sites(n);
+                }
+            }
+            if (tile == 0 && t < nn) {                  // second hop of the next row's list
+                nhit = lhit[nsite];
+                nmiss = lmiss[nsite];
+                ncode = obsmap[nobs];
+            }
+            if (h < H) {
+                double *dst = M + r * ldm + h;
+                if (vec_ok && h + CPL <= H) {
+#pragma unroll
+                    for (int c = 0; c < CPL; c += 2)
+                        __builtin_nontemporal_store(d2{a[c], a[c + 1]}, reinterpret_cast<d2 *>(dst) + c / 2);
+                } else {
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c)
+                        if (h + c < H) dst[c] = a[c];
+                }
+            }
+            if constexpr (FUSE_P) {
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) vals[tile][c] = (h + c < H) ? a[c] : -INFINITY;
+            }
+        }
+        if (t < nn) {                                   // third step: park it in the other buffer
+            s_rec[cur ^ 1][t] = make_uint2((uint32_t)(nsite * (uint32_t)lde), ncode * 0x01010101u);
+            d2 *dst = reinterpret_cast<d2 *>(&s_lut[cur ^ 1][t][0]);
+            dst[0] = d2{nhit, nmiss};
+#pragma unroll
+            for (int q = 1; q < 8; ++q) dst[q] = d2{nmiss, nmiss};
+        }
+        have = nn > 0;
+
+        if constexpr (FUSE_P) {
+            // rowmax[r] = max_h M[r][h] (0 if not finite), P[r][h] = exp(M[r][h] - rowmax[r]); pad columns 0
+            double m = -INFINITY;
+#pragma unroll
+            for (int tile = 0; tile < NT; ++tile)
+#pragma unroll
+                for (int c = 0; c < CPL; ++c) m = fmax(m, vals[tile][c]);
+            m = wave_max(m);
+            __syncthreads();                               // s_red free (previous row's readers are done)
+            if ((t & 63) == 0) s_red[t >> 6] = m;
+            __syncthreads();
+            m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+            const double shift = isfinite(m) ? m : 0.0;
+            if (t == 0) rowmax[r] = shift;
+            double *prow = P + r * ldp;
+#pragma unroll
+            for (int tile = 0; tile < NT; ++tile) {
+                const int h = tile * (LUT_THREADS * CPL) + CPL * t;
+                if (h < (int)ldp) {
+                    double e[CPL];
+#pragma unroll
+                    for (int c = 0; c < CPL; ++c) e[c] = exp(vals[tile][c] - shift);    // columns past H hold -inf: exp gives the pad's 0
+                    if (vec_ok && h + CPL <= (int)ldp) {
+#pragma unroll
+                        for (int c = 0; c < CPL; c += 2)
+                            __builtin_nontemporal_store(d2{e[c], e[c + 1]}, reinterpret_cast<d2 *>(prow + h) + c / 2);
+                    } else {
+#pragma unroll
+                        for (int c = 0; c < CPL; ++c)
+                            if (h + c < (int)ldp) prow[h + c] = e[c];
+                    }
+                }
+            }
+        }
+    }
+}
+
+#endif  // MIXEMT_BUILD_LUT_KERNELS_HPP

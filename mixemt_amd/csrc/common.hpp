@@ -6,6 +6,14 @@
 typedef double d2 __attribute__((ext_vector_type(2)));
 
 #define MXM_MAX_WG 1024            // upper bound on the persistent grid (workspace sizing)
+#define MXM_MAX_BT 4               // restarts sharing one read of the matrix
+
+// Which restarts a launch works on: slot b of the tile is restart s[b] of the [B][H] loop vectors
+// and of the state array.  Passed by value, so a tile may name ANY restarts -- the loop driver deals
+// full tiles round-robin over the restarts still running without moving their vectors.
+struct mxm_slots {
+    int s[MXM_MAX_BT];
+};
 #define MXM_LINEAR_MIN_H 65        // below this the log-space kernel is used
 
 // ------------------------------------------------------------------------------------------

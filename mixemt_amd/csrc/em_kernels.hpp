@@ -138,13 +138,14 @@ template <int THREADS, int NCH, int BT, int NBUF, int PREG>
 __global__ __launch_bounds__(THREADS, ((BT == 1 && NBUF == 2) ? MXM_V1_MINW : THREADS / 256)) void em_iter_wide_kernel(
     const double *__restrict__ P, int64_t ldp, const double *__restrict__ w,
     const double *__restrict__ props, int64_t R, int H,
-    double *__restrict__ partial, int64_t ldpart, const mxm_em_state *__restrict__ state) {
+    double *__restrict__ partial, int64_t ldpart, const mxm_em_state *__restrict__ state, mxm_slots slots) {
+    // props / state are the bases of the loop vectors; restart b of this tile is slots.s[b]
     constexpr int NW = THREADS / 64;
     __shared__ double red[2][BT][NW];
     if (state != nullptr) {
         bool any = false;
 #pragma unroll
-        for (int b = 0; b < BT; ++b) any = any || (state[b].done == 0);
+        for (int b = 0; b < BT; ++b) any = any || (state[slots.s[b]].done == 0);
         if (!any) return;                           // every restart of this tile has stopped
     }
 
@@ -165,8 +166,8 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && NBUF == 2) ? MXM_V1_MINW : TH
         for (int k = 0; k < NCH; ++k) {
             const int c = 2 * (t + k * THREADS);
             d2 v;
-            v.x = (c < H) ? props[(int64_t)b * H + c] : 0.0;
-            v.y = (c + 1 < H) ? props[(int64_t)b * H + c + 1] : 0.0;
+            v.x = (c < H) ? props[(int64_t)slots.s[b] * H + c] : 0.0;
+            v.y = (c + 1 < H) ? props[(int64_t)slots.s[b] * H + c + 1] : 0.0;
             if (b < PREG) p[b < PREG ? b : 0][k] = v;
             else lds_p[((b - PREG) * NCH + k) * THREADS + t] = v;
             acc[b][k] = d2{0.0, 0.0};
@@ -387,14 +388,17 @@ __global__ __launch_bounds__(COLRED_THREADS) void colreduce_kernel(const double 
                                                                    int64_t ldpart, int nwg, int nb, int H,
                                                                    const double *__restrict__ props,
                                                                    double *__restrict__ colsum,
-                                                                   const mxm_em_state *__restrict__ state) {
-    // grid = (ceil(H/64), nb); partial is [nwg][nb][ldpart]; props / colsum are [nb][H].
+                                                                   const mxm_em_state *__restrict__ state,
+                                                                   mxm_slots slots) {
+    // grid = (ceil(H/64), nb); partial is [nwg][nb][ldpart] (tile-local b); props / colsum / state are
+    // the loop vectors' bases, indexed by the restart slots.s[b].
     // 16 waves take interleaved sixteenths of the partial rows, four independent chains each
     // (the loads are what this kernel waits for); every order below is fixed -> deterministic.
     constexpr int NW = COLRED_THREADS / 64;
     __shared__ double part[NW][64];
     const int b = blockIdx.y;
-    if (state != nullptr && state[b].done != 0) return;
+    const int run = slots.s[b];
+    if (state != nullptr && state[run].done != 0) return;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int h = blockIdx.x * 64 + lane;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(COLRED_THREADS) void colreduce_kernel(const double 
         double tot = part[0][lane];
 #pragma unroll
         for (int q = 1; q < NW; ++q) tot += part[q][lane];
-        colsum[(int64_t)b * H + h] = (props != nullptr) ? props[(int64_t)b * H + h] * tot : tot;
+        colsum[(int64_t)run * H + h] = (props != nullptr) ? props[(int64_t)run * H + h] * tot : tot;
     }
 }
 
@@ -430,7 +434,8 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(const double *__r
                                                                double *__restrict__ ln_new,
                                                                double *__restrict__ props_cur, int H,
                                                                double tol, int max_iter,
-                                                               mxm_em_state *__restrict__ state) {
+                                                               mxm_em_state *__restrict__ state, int base,
+                                                               int use_slots, mxm_slots slots) {
     // The state of the loop is the LOG proportions, as in the reference (em.py:123-124, :140):
     //   colsum_h = T_h = sum_r (w_r / Z_r) P_rh      (no p_h factor: representable however small p_h is)
     //   ln p'_h  = ln p_h + ln T_h - ln sum_h p_h T_h        == em.py:87-89
@@ -438,7 +443,7 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(const double *__r
     // so a proportion that underflows in linear space keeps a finite log, exactly like the
     // reference's; props_cur = exp(ln_cur) is what the streaming kernel multiplies with.
     __shared__ double scratch[FIN_THREADS / 64];
-    const int b = blockIdx.x;
+    const int b = use_slots ? slots.s[blockIdx.x] : base + (int)blockIdx.x;       // which restart
     mxm_em_state *st = state + b;
     if (st->done != 0) return;
     const double *cs = colsum + (int64_t)b * H;

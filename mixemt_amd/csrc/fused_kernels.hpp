@@ -38,33 +38,77 @@
 // their spin at once, and the launch returns with state.done = -1 (the host reports it).
 // ------------------------------------------------------------------------------------------
 #define FUSED_THREADS 512
-#define FUSED_GROUP 16                     // workgroups per first-level counter
-#define FUSED_MAX_GROUPS 64                // grid <= 1024
-#define FUSED_SPIN_LIMIT (1u << 22)        // polls (>= ~1 us each) before a workgroup gives up: seconds
+#define FUSED_SPIN_LIMIT (1u << 22)        // poll rounds (>= ~1 us each) before a workgroup gives up: seconds
 #define FUSED_MAX_M 4                      // column pairs per slice <= 16 * FUSED_MAX_M
 #define FUSED_MAX_NCH 6                    // column chunks per thread the kernel is instantiated for (H <= 6144)
 
-struct fused_sync {                        // every word on a 128-byte line of its own
+#ifndef FUSED_BARRIER
+#define FUSED_BARRIER 0                    // 0: two-level counter tree; 1: one flat counter; 2: flag word per workgroup
+#endif
+#define FUSED_GROUP 16                     // workgroups per first-level counter
+#define FUSED_MAX_GROUPS (MXM_MAX_WG / FUSED_GROUP)
+
+struct fused_sync {                        // every polled word on a 128-byte line of its own
     unsigned grp[FUSED_MAX_GROUPS][32];
     unsigned top[32];
     unsigned gen[32];
     unsigned abort_[32];
+    unsigned flag[MXM_MAX_WG];             // FUSED_BARRIER == 2 only
 };
 
-// All waves of the workgroup have drained their write-through stores (s_waitcnt vmcnt(0)) before
-// calling.  Returns false if the grid has given up (every workgroup then leaves the kernel).
-__device__ __forceinline__ bool fused_grid_barrier(fused_sync *s, unsigned epoch, int ngroups, int *lds_flag) {
+// Grid barrier.  Contract (MI355X_MICROARCH.md, "Valid forms", row 1): all waves of the workgroup have
+// drained their write-through payload stores (s_waitcnt vmcnt(0)) before calling; the other waves load
+// handed-off bytes only after the __syncthreads() the polling lane joins at the end.  Returns false if
+// the grid has given up (every workgroup then leaves the kernel).
+// Measured per EM iteration at 600 x 5408 (two barriers each; profiles/r02/small_runs*.txt):
+//   counter tree 17.0 us -- one agent-scope atomic per workgroup on its group's counter, the group's last
+//     arriver adds to the top counter, the last of those publishes the epoch in `gen`, everybody polls
+//     that ONE word;
+//   a flag word per workgroup polled by a wave of every workgroup 22.6 us -- 256 pollers sweeping 1 KB
+//     of write-through lines each cost more than the three dependent round trips of the tree.
+// Counters and the generation word only grow with the epoch, so nothing is reset inside a launch.
+__device__ __forceinline__ bool fused_grid_barrier(fused_sync *s, unsigned epoch, int nwg, int *lds_flag) {
     __syncthreads();
+#if FUSED_BARRIER == 2
+    if (threadIdx.x < 64) {
+        const int lane = threadIdx.x;
+        if (lane == 0) __hip_atomic_store(&s->flag[blockIdx.x], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        bool ok = true;
+        unsigned spins = 0;
+        for (;;) {
+            bool here = true;
+            for (int i = lane; i < nwg; i += 64)
+                here = here && (__hip_atomic_load(&s->flag[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= epoch);
+            const unsigned gave_up = __hip_atomic_load(&s->abort_[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            if (gave_up != 0u) { ok = false; break; }                        // wave-uniform (one address)
+            if (__builtin_amdgcn_ballot_w64(!here) == 0ull) break;           // every flag has arrived
+            if (++spins > FUSED_SPIN_LIMIT) {
+                if (lane == 0) __hip_atomic_store(&s->abort_[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                ok = false;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(1);
+        }
+        if (lane == 0) *lds_flag = ok ? 1 : 0;
+    }
+#else
     if (threadIdx.x == 0) {
+#if FUSED_BARRIER == 1
+        const unsigned old = __hip_atomic_fetch_add(&s->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (old + 1u == (unsigned)nwg * epoch)
+            __hip_atomic_store(&s->gen[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#else
         const int g = blockIdx.x / FUSED_GROUP;
         const int first = g * FUSED_GROUP;
-        const unsigned gsize = (unsigned)(((int)gridDim.x - first) < FUSED_GROUP ? ((int)gridDim.x - first) : FUSED_GROUP);
+        const int ngroups = (nwg + FUSED_GROUP - 1) / FUSED_GROUP;
+        const unsigned gsize = (unsigned)((nwg - first) < FUSED_GROUP ? (nwg - first) : FUSED_GROUP);
         const unsigned old = __hip_atomic_fetch_add(&s->grp[g][0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if (old + 1u == gsize * epoch) {
             const unsigned o2 = __hip_atomic_fetch_add(&s->top[0], 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
             if (o2 + 1u == (unsigned)ngroups * epoch)
                 __hip_atomic_store(&s->gen[0], epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         }
+#endif
         unsigned spins = 0;
         for (;;) {
             const unsigned seen = __hip_atomic_load(&s->gen[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -78,6 +122,7 @@ __device__ __forceinline__ bool fused_grid_barrier(fused_sync *s, unsigned epoch
         }
         *lds_flag = (__hip_atomic_load(&s->abort_[0], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) == 0u) ? 1 : 0;
     }
+#endif
     __syncthreads();
     return *lds_flag != 0;
 }
@@ -100,7 +145,6 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void em_fused_loop_kernel(
     const int lane = t & 63, wv = t >> 6;
     const int ncol2 = (H + 1) >> 1;
     const int nwg = (int)gridDim.x;
-    const int ngroups = (nwg + FUSED_GROUP - 1) / FUSED_GROUP;
     const int cp2 = (ncol2 + nwg - 1) / nwg;               // column pairs per workgroup slice (<= 16 * FUSED_MAX_M)
     const int64_t nq = (R > (int64_t)blockIdx.x) ? (R - blockIdx.x + nwg - 1) / nwg : 0;   // rows dealt to this workgroup
 
@@ -195,7 +239,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void em_fused_loop_kernel(
                                                            FUSED_SC1);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-            if (!fused_grid_barrier(sync, ++epoch, ngroups, &ok_flag)) { done = -1; break; }
+            if (!fused_grid_barrier(sync, ++epoch, nwg, &ok_flag)) { done = -1; break; }
 
             // ================= phase B: this workgroup's slice of the column sums =================
             {
@@ -209,15 +253,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void em_fused_loop_kernel(
                         if (!valid) c2 = 0;
                         d2 s = d2{0.0, 0.0};
                         int g = gsub;
-                        for (; g + 96 < nwg; g += 128) {    // four loads in flight per lane
-                            d2 v[4];
+                        for (; g + 224 < nwg; g += 256) {   // eight loads in flight per lane: one round trip at 256 workgroups
+                            d2 v[8];
 #pragma unroll
-                            for (int u = 0; u < 4; ++u)
+                            for (int u = 0; u < 8; ++u)
                                 v[u] = __builtin_bit_cast(d2, (fu4)__builtin_amdgcn_raw_buffer_load_b128(
                                                                   part_rsrc, (int)((int64_t)(g + 32 * u) * ldpart * 8) + c2 * 16,
                                                                   0, FUSED_SC1));
 #pragma unroll
-                            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; }
+                            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; }
                         }
                         for (; g < nwg; g += 32) {
                             const d2 v = __builtin_bit_cast(d2, (fu4)__builtin_amdgcn_raw_buffer_load_b128(
@@ -247,7 +291,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void em_fused_loop_kernel(
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
-            if (!fused_grid_barrier(sync, ++epoch, ngroups, &ok_flag)) { done = -1; break; }
+            if (!fused_grid_barrier(sync, ++epoch, nwg, &ok_flag)) { done = -1; break; }
 
             // ================= phase C: normalise, convergence test (every workgroup alike) =================
             d2 T[NCH], LT[NCH];

@@ -14,6 +14,7 @@
 // (DESIGN.md section 4 has the roofline of each):
 //   common.hpp          error plumbing, reductions
 //   build_kernels.hpp   build_em_matrix_kernel (byte table, L2/MALL), build_tile_kernel (LDS-staged 4-bit table)
+//   build_lut_kernels.hpp  build_lut_kernel (hit/miss by LDS lookup; optionally emits the linearised matrix too)
 //   em_kernels.hpp      linearize, em_iter_wide_kernel (THE hot kernel: R*H*8 B read per EM iteration,
 //                       1-4 restarts per pass), em_iter_wide_f32_kernel (opt-in storage variant),
 //                       colreduce_kernel, finalize_kernel
@@ -26,6 +27,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <math.h>
+#include <algorithm>
 #include <utility>
 #include <vector>
 
@@ -34,6 +36,7 @@
 
 #include "common.hpp"
 #include "build_kernels.hpp"
+#include "build_lut_kernels.hpp"
 #include "em_kernels.hpp"
 #include "estep_kernels.hpp"
 #include "aux_kernels.hpp"
@@ -70,7 +73,7 @@ extern "C" int mxm_linear_supported(int32_t H) {
 extern "C" size_t mxm_workspace_bytes(int64_t R, int32_t H, int32_t B) {
     (void)R;
     (void)B;                      // restart tiles are processed one after another over the same scratch
-    return (size_t)MXM_MAX_WG * 4 /* MXM_MAX_BT */ * (size_t)part_ld(H) * sizeof(double);
+    return (size_t)MXM_MAX_WG * MXM_MAX_BT * (size_t)part_ld(H) * sizeof(double);
 }
 
 extern "C" int64_t mxm_encode_signatures(const char *text, const int64_t *off, int64_t R,
@@ -125,6 +128,48 @@ extern "C" int mxm_build_em_matrix(const uint8_t *E, int64_t lde, const double *
     const int vec_ok = ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
     hipLaunchKernelGGL(build_em_matrix_kernel, dim3(grid), dim3(BUILD_THREADS), 0, (hipStream_t)stream, E,
                        lde, lhit, lmiss, row_ptr, site, obs, R, (int)H, M, ldm, vec_ok);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+template <bool FUSE_P>
+static int launch_build_lut(int nt, int grid, hipStream_t s, const uint8_t *E, int64_t lde, int64_t e_bytes,
+                            const double *lhit, const double *lmiss, const uint8_t *obsmap, const int64_t *row_ptr,
+                            const uint16_t *site, const uint8_t *obs, const int64_t *order, int64_t R, int H, double *M,
+                            int64_t ldm, double *P, int64_t ldp, double *rowmax, int vec_ok) {
+    switch (nt) {
+#define BL_CASE(n) case n: hipLaunchKernelGGL((build_lut_kernel<FUSE_P, n>), dim3(grid), dim3(LUT_THREADS), 0, s, E, lde, e_bytes, lhit, lmiss, obsmap, row_ptr, site, obs, order, R, H, M, ldm, P, ldp, rowmax, vec_ok); break;
+        BL_CASE(1) BL_CASE(2) BL_CASE(3) BL_CASE(4) BL_CASE(5) BL_CASE(6) BL_CASE(7) BL_CASE(8)
+#undef BL_CASE
+        default: return 1;
+    }
+    return 0;
+}
+
+extern "C" int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const double *lhit, const double *lmiss,
+                                       const uint8_t *obsmap, const int64_t *row_ptr, const uint16_t *site,
+                                       const uint8_t *obs, const int64_t *order, int64_t R, int32_t H, int32_t S,
+                                       double *M, int64_t ldm, double *P, int64_t ldp, double *rowmax, void *stream) {
+    if (R < 0 || H <= 0 || S <= 0) return fail(-1, "mxm_build_em_matrix_lut: bad shape R=%s%lld H=%lld", "", R, H);
+    if (H > 8192) return fail(-1, "mxm_build_em_matrix_lut: more than 8192 haplogroups%s (H=%lld): use mxm_build_em_matrix", "", H);
+    if (lde < (((int64_t)H + 3) & ~(int64_t)3) || (lde & 3) != 0 || (reinterpret_cast<uintptr_t>(Ecode) & 3) != 0)
+        return fail(-1, "mxm_build_em_matrix_lut: Ecode must be 4-byte aligned with lde a multiple of 4 and >= H rounded up to 4%s (lde=%lld)", "", lde);
+    if (ldm < H) return fail(-1, "mxm_build_em_matrix_lut: ldm < H%s", "");
+    if (S > 65536 || (int64_t)S * lde >= ((int64_t)1 << 31))
+        return fail(-1, "mxm_build_em_matrix_lut: table of %s%lld x %lld bytes exceeds one buffer descriptor", "", S, lde);
+    if (P != nullptr && (ldp < H || (ldp & 1) || rowmax == nullptr))
+        return fail(-1, "mxm_build_em_matrix_lut: P needs an even ldp >= H and rowmax%s", "");
+    if (R == 0) return 0;
+    const int grid = clamp_grid(R, num_cu() * 8);
+    const int nt = (H + LUT_THREADS * 4 - 1) / (LUT_THREADS * 4);
+    int vec_ok = ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
+    if (P != nullptr) vec_ok = vec_ok && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
+    const int rc = (P != nullptr)
+                       ? launch_build_lut<true>(nt, grid, (hipStream_t)stream, Ecode, lde, (int64_t)S * lde, lhit, lmiss, obsmap,
+                                                row_ptr, site, obs, order, R, (int)H, M, ldm, P, ldp, rowmax, vec_ok)
+                       : launch_build_lut<false>(nt, grid, (hipStream_t)stream, Ecode, lde, (int64_t)S * lde, lhit, lmiss, obsmap,
+                                                 row_ptr, site, obs, order, R, (int)H, M, ldm, P, ldp, rowmax, vec_ok);
+    if (rc != 0) return fail(-1, "mxm_build_em_matrix_lut: H=%s%lld outside the kernel's range", "", H);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -285,7 +330,6 @@ extern "C" int mxm_set_batch_tile(int32_t bt) {
 #ifndef MXM_V1B_NBUF
 #define MXM_V1B_NBUF 3
 #endif
-#define MXM_MAX_BT 4                  // restarts sharing one read of the matrix
 #define MXM_MAX_COL2 4096             // column pairs per row the register tiling covers (H <= 8192)
 #define MXM_LDS_BUDGET (156 * 1024)   // of the CU's 160 KiB, leaving room for the exchange buffers
 
@@ -316,7 +360,7 @@ static bool batch_fits(int H, int nb) {
 template <int THREADS, int NCH, int BT, int NBUF, int PREG>
 static int launch_wide(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
                        int H, int grid, double *partial, int64_t ldpart,
-                       const mxm_em_state *state, hipStream_t stream) {
+                       const mxm_em_state *state, mxm_slots slots, hipStream_t stream) {
     if constexpr (NCH * THREADS > MXM_MAX_COL2) {
         return fail(-1, "mxm_em_iter: H=%s%lld outside the linear kernel's range", "", H);
     } else {
@@ -326,7 +370,7 @@ static int launch_wide(const double *P, int64_t ldp, const double *w, const doub
                               "em_iter_wide_kernel") != hipSuccess)
             return -2;
         hipLaunchKernelGGL((em_iter_wide_kernel<THREADS, NCH, BT, NBUF, PREG>), dim3(grid), dim3(THREADS), lds,
-                           stream, P, ldp, w, props, R, H, partial, ldpart, state);
+                           stream, P, ldp, w, props, R, H, partial, ldpart, state, slots);
         return 0;
     }
 }
@@ -334,9 +378,9 @@ static int launch_wide(const double *P, int64_t ldp, const double *w, const doub
 template <int THREADS, int BT, int NBUF, int PREG>
 static int dispatch_wide(int nch, const double *P, int64_t ldp, const double *w, const double *props,
                          int64_t R, int H, int grid, double *partial,
-                         int64_t ldpart, const mxm_em_state *state, hipStream_t stream) {
+                         int64_t ldpart, const mxm_em_state *state, mxm_slots slots, hipStream_t stream) {
     switch (nch) {
-#define WIDE_CASE(n) case n: return launch_wide<THREADS, n, BT, NBUF, PREG>(P, ldp, w, props, R, H, grid, partial, ldpart, state, stream);
+#define WIDE_CASE(n) case n: return launch_wide<THREADS, n, BT, NBUF, PREG>(P, ldp, w, props, R, H, grid, partial, ldpart, state, slots, stream);
         WIDE_CASE(1) WIDE_CASE(2) WIDE_CASE(3) WIDE_CASE(4) WIDE_CASE(5) WIDE_CASE(6) WIDE_CASE(7) WIDE_CASE(8)
         WIDE_CASE(9) WIDE_CASE(10) WIDE_CASE(11) WIDE_CASE(12) WIDE_CASE(13) WIDE_CASE(14) WIDE_CASE(15) WIDE_CASE(16)
 #undef WIDE_CASE
@@ -345,10 +389,17 @@ static int dispatch_wide(int nch, const double *P, int64_t ldp, const double *w,
     return fail(-1, "mxm_em_iter: H=%s%lld outside the linear kernel's range", "", H);
 }
 
+static inline mxm_slots slots_from(int first) {
+    mxm_slots sl;
+    for (int i = 0; i < MXM_MAX_BT; ++i) sl.s[i] = first + i;
+    return sl;
+}
+
 // One tile of nb (<= MXM_MAX_BT) restarts over the linear matrix: streaming kernel + column reduce.
+// props / state / colsum are the BASES of the loop vectors; the tile's members are slots.s[0 .. nb).
 static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
-                               int H, int nb, const mxm_em_state *state, double *colsum, double *partial,
-                               hipStream_t stream, bool timed) {
+                               int H, int nb, mxm_slots slots, const mxm_em_state *state, double *colsum,
+                               double *partial, hipStream_t stream, bool timed) {
     const int64_t ldpart = part_ld(H);
     const int ncol2 = (H + 1) / 2;
     const bool alt = (nb == 1) && (g_v1_shape == 1);        // the second single-restart shape
@@ -361,23 +412,24 @@ static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, co
     // fewer workgroups with more rows each (every workgroup pays 2 x H x 8 bytes of proportion
     // loads and partial stores, which colreduce then reads back)
     const int nwg = clamp_grid((R + g_min_rows_per_wg - 1) / g_min_rows_per_wg, cap);
+    for (int i = nb; i < MXM_MAX_BT; ++i) slots.s[i] = slots.s[0];          // unused entries stay in range
     if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
     int rc;
     if (alt)
-        rc = dispatch_wide<MXM_V1B_THREADS, 1, MXM_V1B_NBUF, 1>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V1B_THREADS, 1, MXM_V1B_NBUF, 1>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, slots, stream);
     else if (nb == 1)
-        rc = dispatch_wide<MXM_V1_THREADS, 1, MXM_V1_NBUF, 1>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V1_THREADS, 1, MXM_V1_NBUF, 1>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, slots, stream);
     else if (nb == 2)
-        rc = dispatch_wide<MXM_V2_THREADS, 2, MXM_V2_NBUF, MXM_V2_PREG>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V2_THREADS, 2, MXM_V2_NBUF, MXM_V2_PREG>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, slots, stream);
     else if (nb == 3)
-        rc = dispatch_wide<MXM_V3_THREADS, 3, MXM_V3_NBUF, MXM_V3_PREG>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V3_THREADS, 3, MXM_V3_NBUF, MXM_V3_PREG>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, slots, stream);
     else
-        rc = dispatch_wide<MXM_V4_THREADS, 4, MXM_V4_NBUF, MXM_V4_PREG>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream);
+        rc = dispatch_wide<MXM_V4_THREADS, 4, MXM_V4_NBUF, MXM_V4_PREG>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, slots, stream);
     if (rc != 0) return rc;
     HIP_TRY(hipGetLastError());
     if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
     hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, nb), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg, nb,
-                       H, (const double *)nullptr, colsum, state);
+                       H, (const double *)nullptr, colsum, state, slots);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -425,7 +477,7 @@ static int em_iter_f32_one(const float *P, int64_t ldp, const double *w, const d
     HIP_TRY(hipGetLastError());
     if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
     hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg,
-                       1, H, (const double *)nullptr, colsum, state);
+                       1, H, (const double *)nullptr, colsum, state, slots_from(0));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -473,7 +525,7 @@ static int em_iter_log_one(const double *M, int64_t ldm, const double *w, const 
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg, 1,
-                       H, (const double *)nullptr, colsum, state);
+                       H, (const double *)nullptr, colsum, state, slots_from(0));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -501,8 +553,8 @@ extern "C" int mxm_em_iter(const double *M, int64_t ldm, const double *P, int64_
         const mxm_em_state *st = state ? state + b : nullptr;
         int rc;
         if (linear)
-            rc = em_iter_linear_tile(P, ldp, w, props + (int64_t)b * H, R, (int)H, nb, st,
-                                     colsum + (int64_t)b * H, (double *)ws, (hipStream_t)stream, b == 0);
+            rc = em_iter_linear_tile(P, ldp, w, props, R, (int)H, nb, slots_from(b), state, colsum, (double *)ws,
+                                     (hipStream_t)stream, b == 0);
         else
             rc = em_iter_log_one(M, ldm, w, ln_props ? ln_props + (int64_t)b * H : nullptr, R, (int)H, st,
                                  colsum + (int64_t)b * H, (double *)ws, (hipStream_t)stream);
@@ -555,7 +607,7 @@ extern "C" int mxm_m_finalize(const double *colsum, double *ln_cur, double *ln_n
                               int32_t B, double tol, int32_t max_iter, mxm_em_state *state, void *stream) {
     if (H <= 0 || B <= 0 || state == nullptr) return fail(-1, "mxm_m_finalize: bad arguments%s", "");
     hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), 0, (hipStream_t)stream, colsum, ln_cur, ln_new,
-                       props_cur, (int)H, tol, (int)max_iter, state);
+                       props_cur, (int)H, tol, (int)max_iter, state, 0, 0, slots_from(0));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -571,25 +623,11 @@ extern "C" int mxm_set_loop_graph(int32_t mode) {
     return 0;
 }
 
-static int enqueue_iterations(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
-                              int64_t R, int32_t H, int32_t B, double *props_cur, double *ln_cur, double *ln_new,
-                              double *colsum, mxm_em_state *state, double tol, int32_t max_iter, int64_t n,
-                              void *ws, size_t ws_bytes, hipStream_t s, bool p_is_f32) {
-    for (int64_t i = 0; i < n; ++i) {
-        int rc = p_is_f32 ? mxm_em_iter_f32(reinterpret_cast<const float *>(P), ldp, w, props_cur, R, H, B, state,
-                                            colsum, ws, ws_bytes, s)
-                          : mxm_em_iter(M, ldm, P, ldp, w, props_cur, ln_cur, R, H, B, state, colsum, ws, ws_bytes, s);
-        if (rc != 0) return rc;
-        rc = mxm_m_finalize(colsum, ln_cur, ln_new, props_cur, H, B, tol, max_iter, state, s);
-        if (rc != 0) return rc;
-    }
-    return 0;
-}
-
 // ---- one-launch loop for cache-resident matrices (fused_kernels.hpp) ---------------------------
 static int g_loop_fused = -1;          // -1 auto (R * H below g_fused_cells), 0 never, 1 whenever the shape allows
 static int g_fused_chunk = 0;          // iterations per launch (0 = run to the end in one launch)
-static double g_fused_cells = 2.5e7;   // 200 MB of fp64: the matrix stays in L2 / Infinity Cache between iterations
+static double g_fused_cells = 1.0e8;   // ~18 000 rows at H = 5408 (800 MB of fp64): measured break-even against the
+                                       // per-iteration kernels is ~30 000 rows (profiles/r02/small_runs.txt)
 extern "C" int mxm_set_loop_fused(int32_t mode, int32_t chunk) {
     g_loop_fused = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
     g_fused_chunk = chunk > 0 ? chunk : 0;
@@ -654,24 +692,56 @@ static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t 
     }
 }
 
+// One iteration of the restarts named by `tile` (nb <= the restart tile): E+M pass, column reduce,
+// finalize.  Linear fp64 matrices share the pass; the other paths (fp32 storage, log-space kernels)
+// run one restart per pass through pointers offset to that restart.
+static int enqueue_tile_iteration(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
+                                  int64_t R, int32_t H, const mxm_slots &tile, int nb, double *props_cur,
+                                  double *ln_cur, double *ln_new, double *colsum, mxm_em_state *state, double tol,
+                                  int32_t max_iter, void *ws, size_t ws_bytes, hipStream_t s, bool p_is_f32,
+                                  bool timed) {
+    const bool linear = !p_is_f32 && P != nullptr && mxm_linear_supported(H);
+    if (linear) {
+        const int rc = em_iter_linear_tile(P, ldp, w, props_cur, R, (int)H, nb, tile, state, colsum, (double *)ws, s, timed);
+        if (rc != 0) return rc;
+    } else {
+        for (int i = 0; i < nb; ++i) {
+            const int64_t off = (int64_t)tile.s[i] * H;
+            const int rc = p_is_f32 ? mxm_em_iter_f32(reinterpret_cast<const float *>(P), ldp, w, props_cur + off, R, H, 1,
+                                                      state + tile.s[i], colsum + off, ws, ws_bytes, s)
+                                    : mxm_em_iter(M, ldm, P, ldp, w, props_cur + off, ln_cur + off, R, H, 1,
+                                                  state + tile.s[i], colsum + off, ws, ws_bytes, s);
+            if (rc != 0) return rc;
+        }
+    }
+    hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(FIN_THREADS), 0, s, colsum, ln_cur, ln_new, props_cur, (int)H, tol,
+                       (int)max_iter, state, 0, 1, tile);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
                         int64_t R, int32_t H, int32_t B, double *props_cur, double *ln_cur, double *ln_new,
                         double *colsum, mxm_em_state *state, double tol, int32_t max_iter,
                         int32_t check_every, void *ws, size_t ws_bytes, void *stream,
                         mxm_em_state *state_host, bool p_is_f32) {
     if (state_host == nullptr || state == nullptr) return fail(-1, "mxm_em_loop: state pointers required%s", "");
+    if (R <= 0 || H <= 0 || B <= 0) return fail(-1, "mxm_em_loop: bad shape R=%s%lld H=%lld", "", R, H);
+    if (ws == nullptr || ws_bytes < mxm_workspace_bytes(R, H, B)) return fail(-1, "mxm_em_loop: workspace too small%s", "");
     if (check_every < 1) check_every = 1;
     hipStream_t caller = (hipStream_t)stream;
     (void)num_cu();                                    // device query outside any capture
     if (fused_eligible(P, ldp, R, (int)H, ws_bytes, p_is_f32)) {
         // cache-resident matrix: the whole loop in one persistent launch on the caller's stream
         // (the host only waits for it; nothing is decided between iterations)
-        if (R <= 0 || H <= 0 || B <= 0 || ws == nullptr) return fail(-1, "mxm_em_loop: bad shape R=%s%lld H=%lld", "", R, H);
         return em_loop_fused(P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, state, tol, max_iter,
                              g_fused_chunk > 0 ? g_fused_chunk : max_iter, ws, caller, state_host);
     }
     const bool want_graph = g_loop_graph == 1 ||
                             (g_loop_graph == -1 && (double)R * (double)H * (double)B < 6.4e7);
+    int window = g_max_bt;                             // the largest restart tile that fits (mxm_em_iter)
+    if (p_is_f32 || P == nullptr || !mxm_linear_supported(H)) window = 1;
+    while (window > 1 && !batch_fits((int)H, window)) --window;
 
     // the loop runs on a private stream (the caller's may be the legacy default stream, which
     // cannot be captured); it is ordered after / before the caller's stream with events
@@ -682,21 +752,17 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     int rc = 0;
     hipGraph_t graph = nullptr;
     hipGraphExec_t exec = nullptr;
-    int64_t graph_iters = 0;
-    int graph_lead = 0;
-    // Restarts stop on different iterations.  The still-running ones are kept packed in the
-    // leading `lead` slots (slot exchanges on the device, undone before returning), so that an
-    // iteration takes ceil(running / tile) passes over the matrix instead of ceil(B / tile).
-    int lead = B, unfinished = B;
-    int window = g_max_bt;                             // the largest restart tile that fits (mxm_em_iter)
-    if (p_is_f32 || P == nullptr || !mxm_linear_supported(H)) window = 1;
-    while (window > 1 && !batch_fits((int)H, window)) --window;
-    std::vector<std::pair<int, int>> swaps;
-    auto swap_slots = [&](int i, int j) {
-        hipLaunchKernelGGL(swap_restart_slots_kernel, dim3((H + 255) / 256, 4), dim3(256), 0, s, props_cur, ln_cur,
-                           ln_new, colsum, state, i, j, (int)H);
-        std::swap(state_host[i], state_host[j]);
-    };
+    std::vector<int> graph_key;
+    // Restarts stop on different iterations, and a pass over the matrix costs nearly the same for one
+    // restart as for a full tile.  Schedules (mxm_set_compact_restarts):
+    //   0  every restart in every iteration, static tiles over all B (a tile idles once all its members stopped)
+    //   1  tiles over the restarts still running, spread evenly (10 -> 4 + 3 + 3)
+    //   2  ONE full tile per iteration, dealt round-robin over the running restarts chunk by chunk: every
+    //      pass carries a full tile until fewer than a tile's worth are left, and all restarts advance at
+    //      the same rate, so they also finish together (no half-empty tail generation).
+    // A tile names its restarts by index (mxm_slots, by value): nothing is moved in memory.  Each restart
+    // counts its own iterations (finalize_kernel), so when it is scheduled changes nothing in its result.
+    std::vector<int> order;                            // unfinished restarts, round-robin order
 #define LOOP_TRY(expr)                                                                        \
     do {                                                                                      \
         hipError_t e_ = (expr);                                                               \
@@ -706,70 +772,81 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     LOOP_TRY(hipStreamWaitEvent(s, ev, 0));
     LOOP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
     LOOP_TRY(hipStreamSynchronize(s));
-    {
-        int64_t issued = 0;
-        for (;;) {
-            if (g_compact_restarts) {
-                // two-pointer partition of the unfinished slots: finished ones go behind them
-                int lo = 0, hi = unfinished - 1;
-                for (;;) {
-                    while (lo < unfinished && state_host[lo].done == 0) ++lo;
-                    while (hi >= 0 && state_host[hi].done != 0) --hi;
-                    if (lo >= hi) break;
-                    swap_slots(lo, hi);
-                    swaps.emplace_back(lo, hi);
-                }
-                unfinished = lo;                       // running + not yet started
+    for (int b = 0; b < B; ++b)
+        if (state_host[b].done == 0) order.push_back(b);
+    if (max_iter <= 0) order.clear();
+    while (!order.empty()) {
+        // the tiles of this chunk: flat list of restart indices + tile sizes
+        std::vector<int> members, sizes;
+        if (g_compact_restarts == 2 && (int)order.size() > window) {
+            members.assign(order.begin(), order.begin() + window);
+            sizes.push_back(window);
+            std::rotate(order.begin(), order.begin() + window, order.end());       // they go to the back of the queue
+        } else {
+            std::vector<int> all;
+            if (g_compact_restarts == 0) { for (int b = 0; b < B; ++b) all.push_back(b); }
+            else all = order;
+            for (size_t at = 0; at < all.size();) {
+                // the fewest passes that cover what is left, restarts spread evenly over them
+                const int left = (int)(all.size() - at);
+                const int passes = (left + window - 1) / window;
+                const int nb = (left + passes - 1) / passes;
+                members.insert(members.end(), all.begin() + at, all.begin() + at + nb);
+                sizes.push_back(nb);
+                at += nb;
             }
-            // Window (mode 2): only the first `tile` unfinished slots iterate -- ONE full pass over the
-            // matrix per iteration (1.70 ms per restart-iteration at 10^6 x 5408 against 1.95 for the
-            // 4 + 3 + 3 tiles of ten restarts advancing together); a slot whose restart has stopped is
-            // refilled from behind the window by the partition above.  Each restart counts its own
-            // iterations (finalize_kernel), so waiting outside the window changes nothing in its result.
-            lead = (g_compact_restarts == 2 && unfinished > window) ? window : unfinished;
-            bool all_done = true;
-            for (int b = 0; b < lead; ++b) all_done = all_done && (state_host[b].done != 0);
-            if (all_done) break;
-            // every restart stops after at most max_iter iterations of its own (finalize_kernel); a full
-            // chunk may overshoot a restart's end: the kernels of a finished restart are no-ops
-            int64_t n = check_every;
-            if (lead == B && (int64_t)max_iter - issued < n) n = (int64_t)max_iter - issued;
-            if (n < 1) break;                          // max_iter reached by all of them: states say done = 2
-            bool launched = false;
-            if (want_graph) {
-                if (exec == nullptr || graph_iters != n || graph_lead != lead) {
-                    if (exec != nullptr) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
-                    if (graph != nullptr) { (void)hipGraphDestroy(graph); graph = nullptr; }
-                    if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
-                        const int crc = enqueue_iterations(M, ldm, P, ldp, w, R, H, lead, props_cur, ln_cur, ln_new, colsum,
-                                                           state, tol, max_iter, n, ws, ws_bytes, s, p_is_f32);
-                        const hipError_t ee = hipStreamEndCapture(s, &graph);
-                        if (crc == 0 && ee == hipSuccess &&
-                            hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
-                            graph_iters = n;
-                            graph_lead = lead;
-                        } else {
-                            exec = nullptr;            // capture unavailable: plain launches below
-                            (void)hipGetLastError();
-                        }
+        }
+        const int64_t n = check_every;                 // finalize stops each restart at its own max_iter;
+                                                       // kernels of a stopped restart are no-ops
+        auto enqueue_chunk = [&]() -> int {
+            for (int64_t it = 0; it < n; ++it) {
+                size_t at = 0;
+                for (size_t ti = 0; ti < sizes.size(); ++ti) {
+                    mxm_slots tile;
+                    for (int i = 0; i < MXM_MAX_BT; ++i) tile.s[i] = members[at + (i < sizes[ti] ? i : 0)];
+                    const int erc = enqueue_tile_iteration(M, ldm, P, ldp, w, R, H, tile, sizes[ti], props_cur, ln_cur,
+                                                           ln_new, colsum, state, tol, max_iter, ws, ws_bytes, s,
+                                                           p_is_f32, ti == 0);
+                    if (erc != 0) return erc;
+                    at += sizes[ti];
+                }
+            }
+            return 0;
+        };
+        bool launched = false;
+        if (want_graph) {
+            std::vector<int> key(members);
+            key.insert(key.end(), sizes.begin(), sizes.end());
+            if (exec == nullptr || key != graph_key) {
+                if (exec != nullptr) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
+                if (graph != nullptr) { (void)hipGraphDestroy(graph); graph = nullptr; }
+                if (hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal) == hipSuccess) {
+                    const int crc = enqueue_chunk();
+                    const hipError_t ee = hipStreamEndCapture(s, &graph);
+                    if (crc == 0 && ee == hipSuccess && hipGraphInstantiate(&exec, graph, nullptr, nullptr, 0) == hipSuccess) {
+                        graph_key = key;
+                    } else {
+                        exec = nullptr;                // capture unavailable: plain launches below
+                        (void)hipGetLastError();
                     }
                 }
-                if (exec != nullptr) {
-                    LOOP_TRY(hipGraphLaunch(exec, s));
-                    launched = true;
-                }
             }
-            if (!launched) {
-                rc = enqueue_iterations(M, ldm, P, ldp, w, R, H, lead, props_cur, ln_cur, ln_new, colsum, state, tol,
-                                        max_iter, n, ws, ws_bytes, s, p_is_f32);
-                if (rc != 0) goto done;
+            if (exec != nullptr) {
+                LOOP_TRY(hipGraphLaunch(exec, s));
+                launched = true;
             }
-            issued += n;
-            LOOP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
-            LOOP_TRY(hipStreamSynchronize(s));
         }
+        if (!launched) {
+            rc = enqueue_chunk();
+            if (rc != 0) goto done;
+        }
+        LOOP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
+        LOOP_TRY(hipStreamSynchronize(s));
+        std::vector<int> still;
+        for (int b : order)
+            if (state_host[b].done == 0) still.push_back(b);
+        order.swap(still);
     }
-    for (size_t k = swaps.size(); k-- > 0;) swap_slots(swaps[k].first, swaps[k].second);   // original order again
     LOOP_TRY(hipGetLastError());
     LOOP_TRY(hipEventRecord(ev, s));
     LOOP_TRY(hipStreamWaitEvent(caller, ev, 0));
@@ -852,7 +929,7 @@ extern "C" int mxm_em_step(const double *M, int64_t ldm, const double *w, const 
     HIP_TRY(hipGetLastError());
     if (colsum != nullptr) {
         hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, s, (const double *)ws, ldpart, nwg,
-                           1, (int)H, (const double *)nullptr, colsum, (const mxm_em_state *)nullptr);
+                           1, (int)H, (const double *)nullptr, colsum, (const mxm_em_state *)nullptr, slots_from(0));
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -947,7 +1024,7 @@ extern "C" int mxm_row_argmax_votes(const double *X, int64_t ldx, const double *
     if (votes != nullptr) {
         hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, (hipStream_t)stream,
                            (const double *)part, ldpart, nwg, 1, (int)H, (const double *)nullptr, votes,
-                           (const mxm_em_state *)nullptr);
+                           (const mxm_em_state *)nullptr, slots_from(0));
         HIP_TRY(hipGetLastError());
     }
     return 0;

@@ -89,13 +89,13 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     identical on every rank.
 
     compact: restarts stop on different iterations; the unfinished ones are
-    kept packed in the leading slots of the loop vectors (as mxm_em_loop does on
-    one GPU).  window: at most that many of them iterate at a time (default: the
-    plan's restart tile, i.e. one full pass over the shard per iteration; a slot
-    whose restart has stopped is refilled with a waiting one); each restart
-    counts its own iterations (mxm_m_finalize), so waiting changes nothing in its
+    kept packed in the leading slots of the loop vectors.  window: at most that
+    many of them iterate at a time (default: the plan's restart tile, i.e. one
+    full pass over the shard per iteration), dealt round-robin over the running
+    restarts chunk by chunk like mxm_em_loop's schedule 2; each restart counts
+    its own iterations (mxm_m_finalize), so when it runs changes nothing in its
     result.  Only the iterating restarts' sums are all-reduced.  Every rank sees
-    the same state, hence takes the same packing decisions.
+    the same state, hence takes the same scheduling decisions.
     verify: at every state check the ranks compare (done, iters) of all restarts
     (two tiny all-reduces, MIN and MAX) and fail loudly if they ever disagree --
     the loop's correctness rests on bit-identical all-reduce results on all ranks.
@@ -116,18 +116,28 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     states = plan.read_state(state)
     if max_iter <= 0:
         return ln_cur, ln_new, states
+    first = True
     while True:
-        running = [s for s in range(n_runs) if states[s][0] == 0]        # slot order: started ones first
+        running = [s for s in range(n_runs) if states[s][0] == 0]        # slot order = round-robin order
         if not running:
             break
-        if compact and running != list(range(len(running))):
-            order = running + [s for s in range(n_runs) if states[s][0] != 0]
-            idx = torch.as_tensor(order, device=props_cur.device)
-            for vec in vectors:
-                vec.copy_(vec[idx])
-            slot_run = [slot_run[s] for s in order]
-            states = [states[s] for s in order]
         lead = min(len(running), window) if compact else n_runs
+        if compact:
+            # one full tile per iteration, dealt round-robin chunk by chunk: the tile that just ran goes
+            # to the back of the queue, so all restarts advance at the same rate and every pass over the
+            # shard carries a full tile until fewer than a tile's worth are left (as mxm_em_loop does)
+            if not first and len(running) > window:
+                was = [s for s in range(window) if states[s][0] == 0]   # the tile that just ran, still running
+                rest = [s for s in running if s >= window]
+                running = rest + was
+            order = running + [s for s in range(n_runs) if states[s][0] != 0]
+            if order != list(range(n_runs)):
+                idx = torch.as_tensor(order, device=props_cur.device)
+                for vec in vectors:
+                    vec.copy_(vec[idx])
+                slot_run = [slot_run[s] for s in order]
+                states = [states[s] for s in order]
+        first = False
         for _ in range(check_every):
             plan.em_iter(props_cur[:lead], ln_cur[:lead], state[:lead], colsum[:lead])
             if exchange:

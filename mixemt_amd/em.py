@@ -30,7 +30,7 @@ import sys
 import numpy
 
 from . import _lib
-from ._dev import as_device, current_stream, device_empty, ptr, require_gpu, torch
+from ._dev import as_device, current_stream, device_empty, ptr, require_gpu, to_host, torch
 
 
 def init_props(nhaps, alpha=1.0):
@@ -99,7 +99,7 @@ def em_step(read_hap_mat, weights, ln_props, read_mix_mat):
     _lib.check(lib.mxm_log_normalize(colsum.data_ptr(), n_haps, ln_new.data_ptr(), stream),
                "mxm_log_normalize")
     if on_host:
-        read_mix_mat[...] = out.cpu().numpy()
+        read_mix_mat[...] = to_host(out)
         return read_mix_mat, ln_new.cpu().numpy()
     return out, ln_new
 
@@ -110,7 +110,7 @@ class EmPlan(object):
     the log matrix, fp64 weights, the linearised copy and scratch.
     """
 
-    def __init__(self, read_hap_mat, weights, n_runs=1, keep_log_matrix=True, storage="f64"):
+    def __init__(self, read_hap_mat, weights, n_runs=1, keep_log_matrix=True, storage="f64", linear=None):
         """
         storage: element type of the linearised matrix the loop streams.
         "f64" (default) is the reference's arithmetic type end to end; "f32" is
@@ -118,6 +118,8 @@ class EmPlan(object):
         iteration) and still multiplies and sums in fp64 -- measured within
         ~1e-8 of the fp64 path on the goldens, inside the 1e-6 parity bar, but
         NOT what the headline benchmark runs.
+        linear = (P, rowmax): the linearised matrix already made by the matrix build
+        (preprocess.build_em_matrix_device(..., linear=...)): nothing is recomputed here.
         """
         if storage not in ("f64", "f32"):
             raise ValueError("storage must be 'f64' or 'f32'")
@@ -135,7 +137,14 @@ class EmPlan(object):
         self.ws, self.ws_bytes = _workspace(self.lib, self.n_rows, self.n_haps, n_runs, self.dev)
         self.lin = None
         self.rowmax = None
-        if self.lib.mxm_linear_supported(self.n_haps) and self.n_rows > 0:
+        if linear is not None:
+            lin, rowmax = linear
+            if (storage != "f64" or not self.lib.mxm_linear_supported(self.n_haps) or lin.dtype != torch.float64
+                    or lin.shape[0] != self.n_rows or lin.stride(0) < self.n_haps or lin.stride(0) % 2
+                    or lin.stride(1) != 1 or rowmax.numel() != self.n_rows):
+                raise ValueError("linear = (P [R][ldp even >= H] float64, rowmax [R]) for an fp64 plan of a wide matrix")
+            self.lin, self.rowmax = lin, rowmax
+        elif self.lib.mxm_linear_supported(self.n_haps) and self.n_rows > 0:
             self.rowmax = torch.empty(self.n_rows, dtype=torch.float64, device=self.dev)
             if storage == "f32":
                 ldp = (self.n_haps + 3) // 4 * 4
@@ -372,5 +381,5 @@ def run_em(read_hap_mat, weights, args):
     res = run_em_ex(read_hap_mat, weights, args)
     read_mix = res["read_mix"]
     if not isinstance(read_hap_mat, torch.Tensor):
-        read_mix = read_mix.cpu().numpy()
+        read_mix = to_host(read_mix)
     return res["props"], read_mix

@@ -25,7 +25,7 @@ import numpy
 
 from . import _lib
 from . import phylotree
-from ._dev import as_device, current_stream, device_empty, require_gpu, torch
+from ._dev import as_device, current_stream, device_empty, require_gpu, to_host, torch
 
 MUT_WT = 0.01       # preprocess.py:39 defaults; not CLI flags (build_em_matrix :182)
 MUT_MAX = 0.5
@@ -61,6 +61,8 @@ class HapVarTables(object):
         self._dev = None
         self._packed = None          # None = not tried, False = does not qualify
         self._packed_dev = None
+        self._lut = None
+        self._lut_dev = None
 
     @classmethod
     def build(cls, refseq, phylo, haplogroups, mut_wt=MUT_WT, mut_max=MUT_MAX):
@@ -130,6 +132,45 @@ class HapVarTables(object):
                         "pairs": numpy.ascontiguousarray(uniq, dtype=numpy.float64),
                         "obsmap": obsmap}
         return self._packed
+
+    def lut(self):
+        """
+        The lookup-table kernel's encoding of the same tables (include/mixemt_hip.h,
+        mxm_build_em_matrix_lut), or None if they do not qualify (more than 14 distinct
+        expected bases, or a table beyond one 2 GiB buffer descriptor):
+            ecode[S][lde] uint8   code of the expected base << 3 (codes 1..14; pad bytes 0)
+            obsmap[256]   uint8   observation byte -> code << 3; 15 << 3 = equals no expected base
+        """
+        if self._lut is not None:
+            return self._lut or None
+        n_sites, n_haps = len(self.sites), self.n_haps
+        alphabet = numpy.unique(self.expected[:, :n_haps])
+        alphabet = alphabet[alphabet != 0]
+        if (len(alphabet) > 14 or n_sites == 0 or n_haps > 8192
+                or n_sites * self.expected.shape[1] >= (1 << 31)):
+            self._lut = False
+            return None
+        code_of = numpy.zeros(256, dtype=numpy.uint8)
+        code_of[alphabet] = numpy.arange(1, len(alphabet) + 1, dtype=numpy.uint8) << 3
+        obsmap = numpy.full(256, 15 << 3, dtype=numpy.uint8)
+        obsmap[alphabet] = code_of[alphabet]
+        ecode = code_of[self.expected]                      # pad byte 0 -> 0: never equals an observation code
+        ecode[:, n_haps:] = 0
+        self._lut = {"ecode": numpy.ascontiguousarray(ecode), "obsmap": obsmap}
+        return self._lut
+
+    def lut_device(self):
+        """Device copies of lut() (plus lhit / lmiss), uploaded once; None if the tables do not qualify."""
+        enc = self.lut()
+        if enc is None:
+            return None
+        if self._lut_dev is None:
+            dev = require_gpu()
+            _, lhit_d, lmiss_d = self.device()
+            self._lut_dev = {"ecode": torch.from_numpy(enc["ecode"]).to(dev),
+                             "obsmap": torch.from_numpy(enc["obsmap"]).to(dev),
+                             "lhit": lhit_d, "lmiss": lmiss_d}
+        return self._lut_dev
 
     def packed_device(self):
         """Device copies of packed(), uploaded once; None if the tables do not qualify."""
@@ -222,18 +263,76 @@ def encode_signatures(reads, tables):
     return _encode_signatures_py(reads, tables)
 
 
-def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto"):
+SORT_ROWS_FROM = 50000       # rows from which "auto" hands the lookup-table kernel a position-sorted row order
+
+
+def row_order_by_position(row_ptr_d, site_d):
+    """
+    Permutation of the rows by the first variant site they observe (stable).  Rows that start at
+    nearby positions read the same rows of the expected-base table, so the kernel that takes
+    them in this order keeps its table traffic in L2.  One small device sort over R keys
+    (set-up of the build, like the uploads; the EM loop has no library op).
+    """
+    n_rows = row_ptr_d.numel() - 1
+    if site_d.numel() == 0:
+        return torch.arange(n_rows, dtype=torch.int64, device=row_ptr_d.device)
+    first = row_ptr_d[:-1].clamp(max=site_d.numel() - 1)
+    keys = site_d[first].to(torch.int32) & 0xFFFF          # uint16 bit patterns stored as int16
+    return torch.argsort(keys, stable=True)
+
+
+def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto", linear=None,
+                           sort_rows="auto"):
     """
     CSR observations (numpy or device tensors) -> device tensor M[R][H] float64.
-    `out` may supply a preallocated [R][>=H] tensor.  kernel: "bytes" is the
-    byte-table kernel (mxm_build_em_matrix, table served from L2 / Infinity
-    Cache), "packed" the LDS-staged 4-bit-table kernel
-    (mxm_build_em_matrix_packed).  Both give the same bits; "auto" takes the
-    faster one as measured on MI355X at 1M x 5408 (bytes: 40.4 ms, packed:
-    76.8 ms -- profiles/r01/build_kernels.txt).
+    `out` may supply a preallocated [R][>=H] tensor.  kernel:
+      "lut"    hit / miss by LDS lookup (mxm_build_em_matrix_lut): the fastest, and the only one
+               that can also emit the loop's linearised matrix (see `linear`)
+      "bytes"  the byte-table kernel (mxm_build_em_matrix), any alphabet, any width
+      "packed" the LDS-staged 4-bit-table kernel (mxm_build_em_matrix_packed)
+      "auto"   "lut" where the tables qualify (at most 14 distinct bases, H <= 8192), else "bytes"
+    All give the same bits (profiles/r02/build_kernels.txt has the timings).
+    linear = (P, rowmax): preallocated [R][ldp] float64 (ldp even, >= H) and [R] float64 tensors
+    that receive mxm_linearize's output in the same pass ("lut" only) -- hand them to
+    em.EmPlan(..., linear=(P, rowmax)) and the EM loop starts without re-reading M.
+    sort_rows: take the rows in position order ("lut" only; True / False / "auto" = from
+    SORT_ROWS_FROM rows); results do not depend on it.
     """
     lib = _lib.load()
     dev = require_gpu()
+    if kernel == "auto":
+        kernel = "lut" if tables.lut() is not None else "bytes"
+    if linear is not None and kernel != "lut":
+        raise ValueError("the linearised matrix is a by-product of the lookup-table kernel only")
+    if kernel == "lut":
+        enc = tables.lut_device()
+        if enc is None:
+            raise ValueError("tables do not qualify for the lookup-table kernel")
+        row_ptr_d = as_device(row_ptr, torch.int64, dev)
+        site_d = as_device(site, torch.uint16, dev)
+        obs_d = as_device(obs, torch.uint8, dev)
+        n_rows = row_ptr_d.numel() - 1
+        n_haps = tables.n_haps
+        if out is None:
+            out = device_empty((n_rows, n_haps), torch.float64, dev, "the EM input matrix")
+        if n_rows == 0:
+            return out
+        order = None
+        if sort_rows is True or (sort_rows == "auto" and n_rows >= SORT_ROWS_FROM):
+            order = row_order_by_position(row_ptr_d, site_d)
+        p_ptr = ldp = rm_ptr = 0
+        if linear is not None:
+            lin, rowmax = linear
+            if (lin.dtype != torch.float64 or lin.shape[0] != n_rows or lin.stride(1) != 1
+                    or rowmax.dtype != torch.float64 or rowmax.numel() != n_rows):
+                raise ValueError("linear = (P [R][ldp] float64, rowmax [R] float64)")
+            p_ptr, ldp, rm_ptr = lin.data_ptr(), lin.stride(0), rowmax.data_ptr()
+        _lib.check(lib.mxm_build_em_matrix_lut(
+            enc["ecode"].data_ptr(), enc["ecode"].stride(0), enc["lhit"].data_ptr(), enc["lmiss"].data_ptr(),
+            enc["obsmap"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(),
+            0 if order is None else order.data_ptr(), n_rows, n_haps, len(tables.sites),
+            out.data_ptr(), out.stride(0), p_ptr, ldp, rm_ptr, current_stream()), "mxm_build_em_matrix_lut")
+        return out
     packed = tables.packed_device() if kernel == "packed" else None
     if kernel == "packed" and packed is None:
         raise ValueError("tables do not qualify for the packed-table kernel")
@@ -286,7 +385,7 @@ def build_em_matrix(refseq, phylo, reads, haplogroups, args, as_device_tensor=Fa
         sys.stderr.write("  processed %d fragments...\nDone.\n\n" % len(reads))
     if as_device_tensor:
         return mat
-    return mat.cpu().numpy()
+    return to_host(mat)
 
 
 # --------------------------------------------------------------------------

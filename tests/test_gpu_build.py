@@ -135,9 +135,10 @@ def test_reference_phylotree_object_is_accepted(toy):
     assert numpy.array_equal(preprocess.build_em_matrix(ref, bare, reads, haps, em_args()), g["mat"])
 
 
-@pytest.mark.parametrize("kernel", ["packed", "bytes"])
-def test_both_kernels_give_reference_bits(b17, kernel):
-    """The LDS-staged packed-table kernel and the byte-table kernel are interchangeable."""
+@pytest.mark.parametrize("kernel", ["packed", "bytes", "lut"])
+def test_all_kernels_give_reference_bits(b17, kernel):
+    """The lookup-table kernel, the LDS-staged packed-table kernel and the byte-table kernel are
+    interchangeable."""
     from mixemt_amd import preprocess
     refseq, phy, haps, tables = b17
     g = golden("g2_build_b17")
@@ -213,3 +214,76 @@ def test_prob_for_vars_closed_forms(toy):
         row = preprocess.build_em_matrix_device(tables, rp, si, ob).cpu().numpy()[0]
         for hap, prob in want.items():
             assert abs(row[haps.index(hap)] - math.log(prob)) < 1e-7          # assertAlmostEqual (7 places)
+
+
+@pytest.mark.parametrize("n_cols", [1, 3, 4, 5, 255, 1023, 1024, 1025, 2050])
+def test_lut_kernel_ragged_widths_rows_and_order(b17, n_cols):
+    """Widths around the 4-column lane and the 1024-column tile; a handful to a few thousand rows;
+    position-sorted row order on and off: always the oracle's bits."""
+    from mixemt_amd import preprocess, synth
+    refseq, phy, haps, tables = b17
+    sub = haps[50:50 + n_cols]
+    sub_tables = preprocess.HapVarTables.build(refseq, phy, sub)
+    assert sub_tables.lut() is not None
+    for n_rows, seed in ((1, 1), (7, 2), (300, 3), (2100, 4)):
+        row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=seed)
+        want = c_oracle.build_em_matrix(sub_tables.expected, sub_tables.lhit, sub_tables.lmiss, row_ptr,
+                                        site, obs, n_cols)
+        for sort_rows in (False, True):
+            got = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="lut",
+                                                    sort_rows=sort_rows).cpu().numpy()
+            assert numpy.array_equal(got, want), (n_cols, n_rows, sort_rows)
+
+
+def test_lut_kernel_long_reads_unusual_bases_and_strided_output(b17):
+    import torch
+    from mixemt_amd import preprocess, synth
+    refseq, phy, haps, tables = b17
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 5, seed=9, read_len=3000)
+    assert numpy.diff(row_ptr).max() > 256           # several staging passes per row
+    obs = obs.copy()
+    obs[::17] = ord("N")                 # never matches an expected base
+    obs[5::29] = ord("a")                # lower case is a different string in the reference
+    obs[3::31] = 0                       # multi-character observation (encoded as 0)
+    want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, row_ptr, site, obs,
+                                    len(haps))
+    got = preprocess.build_em_matrix_device(tables, row_ptr, site, obs, kernel="lut").cpu().numpy()
+    assert numpy.array_equal(got, want)
+    out = torch.full((5, len(haps) + 3), -1.0, dtype=torch.float64, device="cuda")     # odd leading dimension
+    preprocess.build_em_matrix_device(tables, row_ptr, site, obs, out=out, kernel="lut")
+    host = out.cpu().numpy()
+    assert numpy.array_equal(host[:, :len(haps)], want) and (host[:, len(haps):] == -1.0).all()
+
+
+@pytest.mark.parametrize("n_cols,n_rows,read_len", [(5408, 700, 150), (777, 90, 150), (66, 33, 150),
+                                                    (5408, 4, 3000), (1024, 257, 150)])
+def test_lut_kernel_emits_the_linearised_matrix(b17, n_cols, n_rows, read_len):
+    """
+    linear = (P, rowmax): the build's by-product equals mxm_linearize's output on the same matrix bit
+    for bit (rowmax = max_h M, P = exp(M - rowmax), pad column of an odd width zero), and a plan made
+    from it runs the same EM.
+    """
+    import torch
+    from conftest import em_args as mk
+    from mixemt_amd import em, preprocess, synth
+    refseq, phy, haps, tables = b17
+    sub_tables = tables if n_cols == len(haps) else preprocess.HapVarTables.build(refseq, phy, haps[:n_cols])
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=21, read_len=read_len)
+    ldp = (n_cols + 1) // 2 * 2
+    lin = torch.full((n_rows, ldp), -7.0, dtype=torch.float64, device="cuda")
+    rowmax = torch.full((n_rows,), -7.0, dtype=torch.float64, device="cuda")
+    mat = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="lut", linear=(lin, rowmax))
+    want = c_oracle.build_em_matrix(sub_tables.expected, sub_tables.lhit, sub_tables.lmiss, row_ptr, site, obs,
+                                    n_cols)
+    assert numpy.array_equal(mat.cpu().numpy(), want)
+    wts = torch.ones(n_rows, dtype=torch.float64, device="cuda")
+    plain = em.EmPlan(mat, wts)                               # mxm_linearize on the same matrix
+    assert torch.equal(plain.rowmax, rowmax)
+    assert torch.equal(plain.lin, lin)
+    assert numpy.array_equal(rowmax.cpu().numpy(), want.max(axis=1))
+    fused = em.EmPlan(mat, wts, linear=(lin, rowmax))
+    numpy.random.seed(3)
+    init = em.init_props(n_cols, 1.0)[None, :]
+    a = em.em_loop(plain, init, 1e-4, 40)
+    b = em.em_loop(fused, init, 1e-4, 40)
+    assert a[2] == b[2] and torch.equal(a[1], b[1])

@@ -1,0 +1,139 @@
+"""
+The one-launch EM loop (em_fused_loop_kernel: the whole run_em inner loop, em.py:126-143, of a
+cache-resident matrix inside one persistent grid with grid barriers) against the reference's
+goldens, against the oracle, and against the per-iteration kernels it replaces at these sizes.
+"""
+import numpy
+import pytest
+
+from conftest import em_args, golden
+from oracle import c_oracle, em_oracle
+
+pytestmark = pytest.mark.gpu
+
+PROPS_ATOL = 1e-9
+
+
+@pytest.fixture()
+def lib():
+    from mixemt_amd import _lib
+    handle = _lib.load()
+    yield handle
+    handle.mxm_set_loop_fused(-1, 0)
+
+
+def _b17_matrix(tables, g, n_haps):
+    return c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, g["row_ptr"],
+                                    g["site"], g["obs"], n_haps)
+
+
+@pytest.mark.parametrize("name,seed,n_multi", [("g4_run_em", 7, 1), ("g5_run_em_multi", 11, 3)])
+def test_fused_loop_reproduces_the_reference_runs(b17, lib, name, seed, n_multi):
+    """600 x 5408: same init draws, same stopping iterations, proportions within 1e-9, identical
+    calls -- through the one-launch loop, through the per-iteration kernels, and in launches of 7."""
+    from mixemt_amd import em
+    refseq, phy, haps, tables = b17
+    g = golden(name)
+    mat = _b17_matrix(tables, g, len(haps))
+    runs = {}
+    for label, mode, chunk in (("fused", 1, 0), ("kernels", 0, 0), ("chunks", 1, 7)):
+        lib.mxm_set_loop_fused(mode, chunk)
+        numpy.random.seed(seed)
+        res = em.run_em_ex(mat, g["wts"], em_args(n_multi=n_multi))
+        assert numpy.array_equal(res["inits"], g["inits"])
+        assert res["iters"] == list(g["iters"]), label
+        assert res["done"] == [1] * n_multi
+        assert numpy.abs(res["props"] - g["props"]).max() < PROPS_ATOL
+        mix = res["read_mix"].cpu().numpy()
+        assert numpy.array_equal(mix.argmax(axis=1), g["mix_argmax"])
+        assert numpy.allclose(mix.max(axis=1), g["mix_rowmax"], rtol=0, atol=1e-8)
+        runs[label] = res
+    # a resumed launch continues from the saved proportions: chunking changes nothing at all
+    assert numpy.array_equal(runs["fused"]["run_props"], runs["chunks"]["run_props"])
+    assert runs["fused"]["l1"] == runs["chunks"]["l1"]
+    # against the per-iteration kernels: another summation order, nothing more
+    assert numpy.abs(runs["fused"]["run_props"] - runs["kernels"]["run_props"]).max() < 1e-12
+
+
+@pytest.mark.parametrize("n_rows,n_haps,seed", [(1, 5408, 1), (5, 777, 2), (300, 66, 3), (257, 6144, 4),
+                                                (1500, 1001, 5), (64, 5408, 6), (4000, 512, 7)])
+def test_fused_loop_matches_oracle_on_random_shapes(lib, n_rows, n_haps, seed):
+    """Fewer rows than workgroups, odd widths, the widest instance: iteration count and result of
+    the oracle's run_em (weights with repeats, a zero weight, -inf entries)."""
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(seed)
+    mat = rng.normal(size=(n_rows, n_haps)) * 3.0 - 10.0
+    hot = rng.integers(0, n_haps, size=n_rows)
+    mat[numpy.arange(n_rows), hot % 7] += 12.0                 # a few haplogroups explain most rows
+    mat[rng.random(mat.shape) < 0.01] = -numpy.inf
+    mat[numpy.arange(n_rows), hot % 7] = numpy.maximum(mat[numpy.arange(n_rows), hot % 7], -5.0)
+    wts = rng.integers(0, 5, size=n_rows).astype(numpy.float64)
+    wts[0] = 2.0
+    args = em_args(max_iter=300)
+    lib.mxm_set_loop_fused(1, 0)
+    numpy.random.seed(seed)
+    res = em.run_em_ex(mat, wts, args)
+    trace = []
+    numpy.random.seed(seed)
+    props, mix = em_oracle.run_em(mat, wts, args, trace=trace)
+    assert res["iters"] == [trace[0]["iters"]]
+    assert numpy.abs(res["props"] - props).max() < PROPS_ATOL
+    got = res["read_mix"].cpu().numpy()
+    finite = numpy.isfinite(mix)
+    assert numpy.array_equal(numpy.isfinite(got), finite)
+    assert numpy.abs(numpy.exp(got) - numpy.exp(mix)).max() < 1e-9
+
+
+def test_fused_loop_runs_out_of_iterations_like_the_reference(lib):
+    """max_iter exhausted (em.py:141-143: the for-else swaps back): theta_{k+1} with the posterior
+    under theta_k, done = 2, and the iteration count is max_iter."""
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(9)
+    mat = rng.normal(size=(200, 900)) * 2.0
+    lib.mxm_set_loop_fused(1, 0)
+    numpy.random.seed(4)
+    res = em.run_em_ex(mat, numpy.ones(200), em_args(max_iter=9))
+    assert res["iters"] == [9] and res["done"] == [2]
+    trace = []
+    numpy.random.seed(4)
+    props, mix = em_oracle.run_em(mat, numpy.ones(200), em_args(max_iter=9), trace=trace)
+    assert numpy.abs(res["props"] - props).max() < PROPS_ATOL
+    assert numpy.abs(res["read_mix"].cpu().numpy() - mix).max() < 1e-9
+
+
+def test_fused_loop_poisons_like_the_reference(lib):
+    """A row that is -inf in every column makes every proportion NaN (em.py:81-83, :87) and the loop
+    runs to max_iter; with weight 0 scipy drops the row and nothing happens."""
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(10)
+    mat = rng.normal(size=(50, 300))
+    mat[7, :] = -numpy.inf
+    lib.mxm_set_loop_fused(1, 0)
+    wts = numpy.ones(50)
+    numpy.random.seed(1)
+    res = em.run_em_ex(mat, wts, em_args(max_iter=12), want_read_mix=False)
+    assert res["iters"] == [12] and res["done"] == [2] and numpy.isnan(res["props"]).all()
+    wts[7] = 0.0
+    numpy.random.seed(1)
+    res = em.run_em_ex(mat, wts, em_args(max_iter=500), want_read_mix=False)
+    trace = []
+    numpy.random.seed(1)
+    with numpy.errstate(invalid="ignore"):
+        props, _ = em_oracle.run_em(mat, wts, em_args(max_iter=500), trace=trace)
+    assert res["iters"] == [trace[0]["iters"]] and numpy.abs(res["props"] - props).max() < PROPS_ATOL
+
+
+def test_auto_selection_by_size(b17, lib):
+    """Automatic mode: the 600-row golden takes the one-launch loop, and says so by its speed-independent
+    trace -- identical bits to forcing it; a matrix above the cache-resident bound does not."""
+    from mixemt_amd import em
+    refseq, phy, haps, tables = b17
+    g = golden("g4_run_em")
+    mat = _b17_matrix(tables, g, len(haps))
+    lib.mxm_set_loop_fused(-1, 0)
+    numpy.random.seed(7)
+    auto = em.run_em_ex(mat, g["wts"], em_args(), want_read_mix=False)
+    lib.mxm_set_loop_fused(1, 0)
+    numpy.random.seed(7)
+    forced = em.run_em_ex(mat, g["wts"], em_args(), want_read_mix=False)
+    assert numpy.array_equal(auto["props"], forced["props"]) and auto["iters"] == forced["iters"]

@@ -54,10 +54,11 @@ def test_random_tables_build_bitwise(seed):
     got = preprocess.build_em_matrix(phy.refseq, phy, reads, haps, em_args())
     assert numpy.array_equal(got, want)
     tables = preprocess.HapVarTables.build(phy.refseq, phy, haps)
-    if tables.packed() is not None:
-        rp, si, ob = preprocess.encode_signatures(reads, tables)
-        alt = preprocess.build_em_matrix_device(tables, rp, si, ob, kernel="packed").cpu().numpy()
-        assert numpy.array_equal(alt, want)
+    rp, si, ob = preprocess.encode_signatures(reads, tables)
+    for kernel, ok in (("bytes", True), ("packed", tables.packed() is not None), ("lut", tables.lut() is not None)):
+        if ok:
+            alt = preprocess.build_em_matrix_device(tables, rp, si, ob, kernel=kernel).cpu().numpy()
+            assert numpy.array_equal(alt, want), kernel
 
 
 @pytest.mark.parametrize("seed", range(16))

@@ -1,23 +1,40 @@
 #!/bin/bash
 # Re-create the judged profile files of a round on the GPU box (run through gpurun from the
-# repo root):  bash tools/profile_round.sh r01
+# repo root):  bash tools/profile_round.sh r02
 # Writes under gpurun_out/<round>/; copy what should be kept into profiles/<round>/.
+# rocprofv3 gets the program itself after `--` (python3 <script>), never a shell or env hop, and
+# counter passes (--pmc) are separate runs with --kernel-trace only.
 set -u
-round=${1:-r01}
+round=${1:-r02}
 repo=$PWD
 out=$repo/gpurun_out/$round
 mkdir -p "$out"
 export TMPDIR=/tmp
 cd /tmp
+# --- the headline line and its kernel trace -------------------------------------------------------
 python3 $repo/bench.py > $out/bench_1m.json 2> $out/bench_1m.log
 rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt -o kt -- python3 $repo/bench.py --no-cpu-baseline > $out/bench_1m_under_rocprof.json 2> $out/kt.log
+# --- HBM traffic of the same command: FETCH_SIZE and WRITE_SIZE in passes of their own -------------
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch -o f -- python3 $repo/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_fetch.log
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write -o w -- python3 $repo/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_write.log
+python3 $repo/tools/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv > $out/pmc_traffic_1m.json
 # where the waves' time goes (one SQ pass: 8 slots) + the effective clock (GRBM)
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $out/pmc_sq -o sq -- python3 $repo/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_sq.log
+python3 $repo/tools/sq_summary.py $out/pmc_sq/sq_counter_collection.csv > $out/pmc_sq_summary.txt 2>&1
+# --- other configurations of the same script --------------------------------------------------------
 python3 $repo/bench.py --restarts 10 --no-cpu-baseline > $out/bench_1m_10restarts.json 2> /dev/null
-rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt10 -o kt -- python3 $repo/bench.py --restarts 10 --no-cpu-baseline > /dev/null 2> $out/kt10.log
-python3 $repo/bench.py --storage f32 --no-cpu-baseline > $out/bench_1m_f32_storage_variant.json 2> /dev/null
-python3 $repo/bench.py --rows 100000 --no-cpu-baseline > $out/bench_100k.json 2> /dev/null
-python3 $repo/tools/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/pmc_write/w_counter_collection.csv > $out/pmc_traffic_1m.json
-find $out -name "*.csv" | head -40
+python3 $repo/bench.py --total-rows 100000 --no-cpu-baseline > $out/bench_100k.json 2> /dev/null
+python3 $repo/bench.py --mode restarts --restarts 10 --no-cpu-baseline > $out/bench_restarts10_run.json 2> /dev/null
+python3 $repo/bench.py --mode restarts --restarts 16 --no-cpu-baseline > $out/bench_restarts16_run.json 2> /dev/null
+# --- the one-launch loop (cache-resident matrices) and the matrix build kernels ------------------------
+rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt_small -o kt -- python3 $repo/tools/time_small_runs.py --rows 600,2400,10000 > $out/small_runs_under_rocprof.txt 2> $out/kt_small.log
+python3 $repo/tools/time_small_runs.py > $out/small_runs.txt 2>&1
+rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt_build -o kt -- python3 $repo/tools/run_build_only.py 1000000 bytes lut lut+sort lut+sort+P linearize > $out/build_under_rocprof.txt 2> $out/kt_build.log
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch_build -o f -- python3 $repo/tools/run_build_only.py 1000000 bytes lut lut+sort > /dev/null 2> $out/pmc_fetch_build.log
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write_build -o w -- python3 $repo/tools/run_build_only.py 1000000 bytes lut lut+sort > /dev/null 2> $out/pmc_write_build.log
+rocprofv3 --output-format csv --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $out/pmc_l2_build -o l2 -- python3 $repo/tools/run_build_only.py 1000000 bytes lut lut+sort > /dev/null 2> $out/pmc_l2_build.log
+python3 $repo/tools/pmc_summary.py $out/pmc_fetch_build/f_counter_collection.csv $out/pmc_write_build/w_counter_collection.csv > $out/pmc_traffic_build_1m.json
+python3 $repo/tools/run_build_only.py > $out/build_kernels.txt 2>&1
+python3 $repo/tools/time_restarts.py > $out/restart_schedules.txt 2>&1
+python3 $repo/tools/time_dropin_build.py > $out/dropin_build.txt 2>&1
+find $out -name "*.csv" | head -60

@@ -33,6 +33,10 @@ torch.cuda.synchronize()
 t3 = time.perf_counter()
 host = dev.cpu().numpy()
 t4 = time.perf_counter()
+from mixemt_amd._dev import to_host
+pinned = to_host(dev)
+t5 = time.perf_counter()
+assert numpy.array_equal(pinned, host)
 whole0 = time.perf_counter()
 mat = preprocess.build_em_matrix(refseq, phy, reads, haps, None)
 whole = time.perf_counter() - whole0
@@ -41,5 +45,7 @@ print("%d reads x %d haplogroups" % (n, len(haps)))
 print("  signatures -> CSR, library host parser : %.3f s" % (t1 - t0))
 print("  signatures -> CSR, item-by-item Python : %.3f s (extrapolated from 20000 reads)" % ((t2 - t1) * n / 20000.0))
 print("  H2D + build kernel                     : %.3f s" % (t3 - t2))
-print("  matrix D2H (%.1f GB, pageable)          : %.3f s" % (host.nbytes / 1e9, t4 - t3))
+print("  matrix D2H (%.1f GB, pageable .cpu())   : %.3f s (%.1f GB/s)" % (host.nbytes / 1e9, t4 - t3, host.nbytes / 1e9 / (t4 - t3)))
+print("  matrix D2H through page-locked staging : %.3f s (%.1f GB/s) -- what the drop-in returns with"
+      % (t5 - t4, host.nbytes / 1e9 / (t5 - t4)))
 print("  build_em_matrix() as called by the reference's host code: %.3f s" % whole)

@@ -1,29 +1,50 @@
 #!/usr/bin/env python
-"""Wall time of whole run_em calls on small matrices with / without the hipGraph loop."""
+"""
+Wall time per EM iteration of whole run_em calls on cache-resident matrices (the regime real
+mixemt inputs live in: de-duplicated signatures, preprocess.py:163-174): the one-launch loop
+(em_fused_loop_kernel) against the per-iteration kernels, with and without the hipGraph replay.
+
+    python tools/time_small_runs.py [--rows 600,2400,10000,...]
+"""
+import argparse
 import os
 import sys
 import time
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-import argparse
 import numpy
 import torch
-from mixemt_amd import _lib, em, phylotree, preprocess
+from mixemt_amd import _lib, em, phylotree, preprocess, synth
 
-g = numpy.load(os.path.join(os.path.dirname(__file__), "..", "tests", "golden", "g4_run_em.npz"))
+ap = argparse.ArgumentParser()
+ap.add_argument("--rows", default="600,2400,4600,10000,30000,100000")
+ap.add_argument("--max-iter", type=int, default=200)
+opts = ap.parse_args()
 refseq = phylotree.load_rsrs(); phy = phylotree.load_build17(refseq); haps = sorted(phy.hap_var)
 tables = preprocess.HapVarTables.build(refseq, phy, haps)
-mat = preprocess.build_em_matrix_device(tables, g["row_ptr"], g["site"], g["obs"])
-wts = torch.from_numpy(g["wts"]).cuda()
-args = argparse.Namespace(init_alpha=1.0, tolerance=1e-4, max_iter=10000, n_multi=1, verbose=False)
+args = argparse.Namespace(init_alpha=1.0, tolerance=1e-4, max_iter=opts.max_iter, n_multi=1, verbose=False)
 lib = _lib.load()
-sub = mat[:, torch.tensor([10, 11, 2000, 3000, 4000], device="cuda")].contiguous()
-for name, m in (("600 x 5408", mat), ("600 x 5", sub)):
-    for mode in (0, 1, 0, 1):
-        lib.mxm_set_loop_graph(mode)
-        numpy.random.seed(7)
+print("one MI355X; %d haplogroups; fixed %d iterations (tolerance never met that early); wall time of "
+      "em.em_loop incl. launch and final state read-back" % (len(haps), opts.max_iter))
+for n_rows in [int(x) for x in opts.rows.split(",")]:
+    row_ptr, site, obs, _ = synth.synth_rows(tables, len(refseq), 0, n_rows, seed=1)
+    mat = preprocess.build_em_matrix_device(tables, row_ptr, site, obs)
+    wts = torch.ones(n_rows, dtype=torch.float64, device="cuda")
+    plan = em.EmPlan(mat, wts)
+    numpy.random.seed(7)
+    init = em.init_props(len(haps), 1.0)[None, :]
+    out = {}
+    for label, fused, graph in (("one launch", 1, 0), ("kernels", 0, 0), ("kernels+graph", 0, 1),
+                                ("one launch", 1, 0), ("kernels", 0, 0)):
+        lib.mxm_set_loop_fused(fused, 0)
+        lib.mxm_set_loop_graph(graph)
         torch.cuda.synchronize(); t0 = time.perf_counter()
-        res = em.run_em_ex(m, wts, args, want_read_mix=False)
+        ln_cur, ln_new, states = em.em_loop(plan, init, 0.0, opts.max_iter)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        print("%-10s graph=%d  %4d iterations  %.2f ms  (%.1f us/iteration)" % (name, mode, res["iters"][0], dt * 1e3, dt * 1e6 / res["iters"][0]))
+        out[label] = ln_new.cpu().numpy()
+        print("%7d rows (%6.1f MB)  %-14s %4d iterations  %8.2f ms  %7.1f us/iteration"
+              % (n_rows, n_rows * len(haps) * 8 / 1e6, label, states[0][1], dt * 1e3, dt * 1e6 / states[0][1]))
+    print("        max |delta ln p| one launch vs kernels over finite entries: %.2e"
+          % float(numpy.nanmax(numpy.abs(numpy.where(numpy.isfinite(out["kernels"]), out["one launch"] - out["kernels"], 0.0)))))
+lib.mxm_set_loop_fused(-1, 0)
 lib.mxm_set_loop_graph(-1)
