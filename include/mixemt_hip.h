@@ -102,7 +102,8 @@ int mxm_build_em_matrix_packed(const uint32_t *Epk, const uint8_t *muidx, const 
  * mxm_build_em_matrix (preprocess.py:177-198 with :69-96 inlined); the hit / miss choice of _prob
  * (:75-84) is a 16-entry LDS lookup instead of two selects.  The host pre-encodes
  *   Ecode[S][lde]  uint8: 4-bit code of the expected base, SHIFTED LEFT BY 3 (code 1..14 names the
- *                  alphabet of the table, at most 14 letters; pad bytes 0); lde a multiple of 4
+ *                  alphabet of the table, at most 14 letters; pad bytes 0); 8-byte aligned, lde a
+ *                  multiple of 8 and >= H rounded up to 8
  *   obsmap[256]    uint8: observation byte -> its code << 3; 15 << 3 for a byte that equals no expected base
  * order[R] (nullable): a permutation of the rows -- the order in which the grid takes them (rows that
  *   start at nearby positions share table rows; dealing them out together keeps those in L2).

@@ -17,6 +17,8 @@
 extern "C" {
 #endif
 
+struct mxm_em_state;             /* include/mixemt_hip.h */
+
 /*
  * Measurement hook (bench.py): when both handles are non-NULL, mxm_em_iter
  * records hipEvent_t `ev_start` / `ev_stop` on its stream immediately before /
@@ -35,6 +37,15 @@ int mxm_set_timing_events(void *ev_start, void *ev_stop);
  */
 int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_per_cu, int32_t blocked,
                          void *sink, void *stream);
+
+/*
+ * Progress hook for mxm_em_loop (the reference prints a dot every 10 iterations while it runs,
+ * em.py:127-135): fn(state_host, B, user) is called on the calling host thread after every read-back
+ * of the loop state, which then happens at least every `every` iterations.  NULL switches it off.
+ * Host-side only; results do not depend on it.
+ */
+int mxm_set_progress_callback(void (*fn)(const struct mxm_em_state *state_host, int32_t B, void *user),
+                              void *user, int32_t every);
 
 /*
  * mxm_em_loop replays its chunk of iterations from a hipGraph when that pays

@@ -36,46 +36,21 @@ def as_device(x, dtype, dev):
     if dtype == torch.uint16:
         # torch has no first-class uint16 arithmetic; only the bytes matter here
         arr = numpy.ascontiguousarray(arr.astype(numpy.uint16, copy=False)).view(numpy.int16)
-        return _upload(torch.from_numpy(arr), dev)
-    return _upload(torch.from_numpy(arr), dev).to(dtype).contiguous()
-
-
-def _upload(host, dev):
-    """Host tensor -> device; large ones through a page-locked staging buffer (see to_host)."""
-    if host.numel() * host.element_size() < PINNED_FROM_BYTES:
-        return host.to(dev)
-    try:
-        staged = torch.empty(host.shape, dtype=host.dtype, pin_memory=True)
-    except RuntimeError:
-        return host.to(dev)
-    staged.copy_(host)
-    out = staged.to(dev, non_blocking=True)
-    torch.cuda.current_stream(dev).synchronize()      # the staging buffer may go away after this
-    return out
-
-
-PINNED_FROM_BYTES = 1 << 20      # host <-> device copies of at least this size go through page-locked staging
+        return torch.from_numpy(arr).to(dev)
+    return torch.from_numpy(arr).to(device=dev).to(dtype).contiguous()
 
 
 def to_host(t):
     """
-    Device tensor -> numpy array.  Large results (the drop-in path returns whole R x H matrices to
-    numpy callers) are copied into a page-locked buffer first: a pageable destination makes the
-    runtime bounce through its own small pinned chunks at ~10 GB/s, a pinned one runs at the PCIe
-    rate.  The pinned buffer backs the returned array (no second host copy).
+    Device tensor -> numpy array (the drop-in path returns whole R x H matrices to numpy callers).
+    A plain pageable copy: measured on the MI355X box at 8.7 GB, `.cpu()` runs at 14.2 GB/s while
+    staging through a freshly page-locked buffer of that size took twice as long (7.0 GB/s: locking
+    the pages costs more than the faster DMA saves; profiles/r02/dropin_build.txt).  Callers that care
+    keep the matrices on the device (tensors in -> tensors out).
     """
     if not isinstance(t, torch.Tensor):
         return numpy.asarray(t)
-    if t.device.type != "cuda" or t.numel() * t.element_size() < PINNED_FROM_BYTES:
-        return t.detach().cpu().numpy()
-    src = t.detach().contiguous()
-    try:
-        host = torch.empty(src.shape, dtype=src.dtype, pin_memory=True)
-    except RuntimeError:                     # no page-locked memory left: the plain copy still works
-        return src.cpu().numpy()
-    host.copy_(src, non_blocking=True)
-    torch.cuda.current_stream(src.device).synchronize()
-    return host.numpy()
+    return t.detach().cpu().numpy()
 
 
 def ptr(t):

@@ -64,6 +64,7 @@ SIGNATURES = {
     "mxm_set_compact_restarts": (ctypes.c_int, [c_i32]),
     "mxm_set_loop_graph": (ctypes.c_int, [c_i32]),
     "mxm_set_loop_fused": (ctypes.c_int, [c_i32, c_i32]),
+    "mxm_set_progress_callback": (ctypes.c_int, [c_ptr, c_ptr, c_i32]),
     "mxm_set_min_rows_per_wg": (ctypes.c_int, [c_i32]),
     "mxm_set_v1_shape": (ctypes.c_int, [c_i32]),
     "mxm_row_argmax_votes": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
@@ -72,6 +73,8 @@ SIGNATURES = {
     "mxm_fold_logaddexp": (ctypes.c_int, [c_ptr, c_i64, ctypes.POINTER(c_ptr), ctypes.POINTER(c_i64), c_i32,
                                           c_i64, c_i32, c_f64, c_ptr]),
 }
+
+PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.POINTER(EmState), c_i32, c_ptr)
 
 _lib = None
 

@@ -32,15 +32,32 @@
 #define LUT_THREADS 256
 #define LUT_CAP 128                // observations staged per pass (longer rows take several passes)
 #define LUT_NOMATCH (15u << 3)     // observation code that equals no expected code
+#ifndef LUT_CPL
+#define LUT_CPL 4                  // columns per lane and tile: 4 (dword table loads) or 8 (dwordx2)
+#endif
+#ifndef LUT_UNROLL
+#define LUT_UNROLL 8               // sites per block of the inner loop = table loads in flight per wave (x2 when pipelined)
+#endif
+#ifndef LUT_PIPE
+#define LUT_PIPE 0                 // 1: the next block's table loads are issued before the current block is added up
+#endif
+// Measured at 10^6 x 5408, rows in position order (profiles/r02/lut_variants.txt), matrix only / with P:
+//   CPL 4, blocks of 8, plain (default)  24.9 / 65.2 ms      CPL 8, blocks of 8, plain      40.0 / 65.9 ms
+//   CPL 4, blocks of 8, pipelined        30.5 / 49.6 ms      CPL 8, blocks of 8, pipelined  36.6 / 60.6 ms
+//   CPL 4, blocks of 16, plain           44.8 / 73.2 ms      CPL 8, blocks of 4, pipelined  35.0 / 58.5 ms
+// More table bytes in flight per wave do not pay: the kernel is bound by its VALU + LDS instruction
+// streams (2.9 VALU + 1.25 LDS per cell and site; the two pipes add up at 4 waves per SIMD), and every
+// variant that holds more registers loses a wave per SIMD.
 
-template <bool FUSE_P, int NT>
+template <bool FUSE_P, int NT, int CPL>
 __global__ __launch_bounds__(LUT_THREADS) void build_lut_kernel(
     const uint8_t *__restrict__ E, int64_t lde, int64_t e_bytes, const double *__restrict__ lhit,
     const double *__restrict__ lmiss, const uint8_t *__restrict__ obsmap, const int64_t *__restrict__ row_ptr,
     const uint16_t *__restrict__ site, const uint8_t *__restrict__ obs, const int64_t *__restrict__ order,
     int64_t R, int H, double *__restrict__ M, int64_t ldm, double *__restrict__ P, int64_t ldp,
     double *__restrict__ rowmax, int vec_ok) {
-    constexpr int CPL = 4;                              // columns per lane and tile: one 4-byte table load per site
+    static_assert(CPL == 4 || CPL == 8, "one 4- or 8-byte table load per lane, site and tile");
+    constexpr int EW = CPL / 4;                         // dwords per table load
     __shared__ double s_lut[2][LUT_CAP][16];            // per observation: [0] = log hit, [1..15] = log miss
     __shared__ uint2 s_rec[2][LUT_CAP];                 // per observation: {table row byte offset, obs code << 3 in 4 bytes}
     __shared__ double s_red[LUT_THREADS / 64];
@@ -89,16 +106,60 @@ __global__ __launch_bounds__(LUT_THREADS) void build_lut_kernel(
             for (int c = 0; c < CPL; ++c) a[c] = 0.0;
             auto add_sites = [&](int n) {
                 const char *lut = reinterpret_cast<const char *>(&s_lut[cur][0][0]);
-#pragma unroll 8
-                for (int j = 0; j < n; ++j) {
-                    const uint2 rc = s_rec[cur][j];
-                    const uint32_t e = __builtin_amdgcn_raw_buffer_load_b32(e_rsrc, (int)(rc.x + (uint32_t)h), 0, 0);
-                    const uint32_t x = e ^ rc.y;
+                auto fetch = [&](uint32_t(&e)[EW], int j) {         // the table bytes of site j for this lane's columns
+                    const uint32_t off = s_rec[cur][j].x + (uint32_t)h;
+                    if constexpr (EW == 1) {
+                        e[0] = __builtin_amdgcn_raw_buffer_load_b32(e_rsrc, (int)off, 0, 0);
+                    } else {
+                        typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+                        const u2v v = __builtin_amdgcn_raw_buffer_load_b64(e_rsrc, (int)off, 0, 0);
+                        e[0] = v.x;
+                        e[1] = v.y;
+                    }
+                };
+                auto add_site = [&](const uint32_t(&e)[EW], int j) {
+                    const uint32_t o4 = s_rec[cur][j].y;
                     const char *row = lut + j * 128;
 #pragma unroll
-                    for (int c = 0; c < CPL; ++c)
-                        a[c] += *reinterpret_cast<const double *>(row + ((x >> (8 * c)) & 0xffu));
+                    for (int q = 0; q < EW; ++q) {
+                        const uint32_t x = e[q] ^ o4;
+#pragma unroll
+                        for (int c = 0; c < 4; ++c)
+                            a[4 * q + c] += *reinterpret_cast<const double *>(row + ((x >> (8 * c)) & 0xffu));
+                    }
+                };
+#if LUT_PIPE
+                // software pipeline over blocks of LUT_UNROLL sites: the table loads of block b + 1 are in
+                // flight while block b goes through the LDS lookups and the adds (the loads are what a wave
+                // waits for: L2 latency x bytes in flight).  Sites past n are clamped for the loads and
+                // skipped for the adds (n is wave uniform: scalar branches).
+                uint32_t ec[LUT_UNROLL][EW], en[LUT_UNROLL][EW];
+#pragma unroll
+                for (int u = 0; u < LUT_UNROLL; ++u) fetch(ec[u], u < n ? u : n - 1);
+                for (int j0 = 0; j0 < n; j0 += LUT_UNROLL) {
+                    if (j0 + LUT_UNROLL < n) {
+#pragma unroll
+                        for (int u = 0; u < LUT_UNROLL; ++u) {
+                            const int j = j0 + LUT_UNROLL + u;
+                            fetch(en[u], j < n ? j : n - 1);
+                        }
+                    }
+#pragma unroll
+                    for (int u = 0; u < LUT_UNROLL; ++u)
+                        if (j0 + u < n) add_site(ec[u], j0 + u);
+#pragma unroll
+                    for (int u = 0; u < LUT_UNROLL; ++u)
+#pragma unroll
+                        for (int q = 0; q < EW; ++q) ec[u][q] = en[u][q];
                 }
+#else
+#pragma unroll LUT_UNROLL
+                for (int j = 0; j < n; ++j) {
+                    uint32_t e[EW];
+                    fetch(e, j);
+                    add_site(e, j);
+                }
+#endif
             };
             if (fast) {
                 if (h < H) add_sites((int)n_all);

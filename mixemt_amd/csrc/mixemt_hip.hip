@@ -138,7 +138,7 @@ static int launch_build_lut(int nt, int grid, hipStream_t s, const uint8_t *E, i
                             const uint16_t *site, const uint8_t *obs, const int64_t *order, int64_t R, int H, double *M,
                             int64_t ldm, double *P, int64_t ldp, double *rowmax, int vec_ok) {
     switch (nt) {
-#define BL_CASE(n) case n: hipLaunchKernelGGL((build_lut_kernel<FUSE_P, n>), dim3(grid), dim3(LUT_THREADS), 0, s, E, lde, e_bytes, lhit, lmiss, obsmap, row_ptr, site, obs, order, R, H, M, ldm, P, ldp, rowmax, vec_ok); break;
+#define BL_CASE(n) case n: hipLaunchKernelGGL((build_lut_kernel<FUSE_P, n, LUT_CPL>), dim3(grid), dim3(LUT_THREADS), 0, s, E, lde, e_bytes, lhit, lmiss, obsmap, row_ptr, site, obs, order, R, H, M, ldm, P, ldp, rowmax, vec_ok); break;
         BL_CASE(1) BL_CASE(2) BL_CASE(3) BL_CASE(4) BL_CASE(5) BL_CASE(6) BL_CASE(7) BL_CASE(8)
 #undef BL_CASE
         default: return 1;
@@ -152,8 +152,8 @@ extern "C" int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const 
                                        double *M, int64_t ldm, double *P, int64_t ldp, double *rowmax, void *stream) {
     if (R < 0 || H <= 0 || S <= 0) return fail(-1, "mxm_build_em_matrix_lut: bad shape R=%s%lld H=%lld", "", R, H);
     if (H > 8192) return fail(-1, "mxm_build_em_matrix_lut: more than 8192 haplogroups%s (H=%lld): use mxm_build_em_matrix", "", H);
-    if (lde < (((int64_t)H + 3) & ~(int64_t)3) || (lde & 3) != 0 || (reinterpret_cast<uintptr_t>(Ecode) & 3) != 0)
-        return fail(-1, "mxm_build_em_matrix_lut: Ecode must be 4-byte aligned with lde a multiple of 4 and >= H rounded up to 4%s (lde=%lld)", "", lde);
+    if (lde < (((int64_t)H + 7) & ~(int64_t)7) || (lde & 7) != 0 || (reinterpret_cast<uintptr_t>(Ecode) & 7) != 0)
+        return fail(-1, "mxm_build_em_matrix_lut: Ecode must be 8-byte aligned with lde a multiple of 8 and >= H rounded up to 8%s (lde=%lld)", "", lde);
     if (ldm < H) return fail(-1, "mxm_build_em_matrix_lut: ldm < H%s", "");
     if (S > 65536 || (int64_t)S * lde >= ((int64_t)1 << 31))
         return fail(-1, "mxm_build_em_matrix_lut: table of %s%lld x %lld bytes exceeds one buffer descriptor", "", S, lde);
@@ -161,7 +161,7 @@ extern "C" int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const 
         return fail(-1, "mxm_build_em_matrix_lut: P needs an even ldp >= H and rowmax%s", "");
     if (R == 0) return 0;
     const int grid = clamp_grid(R, num_cu() * 8);
-    const int nt = (H + LUT_THREADS * 4 - 1) / (LUT_THREADS * 4);
+    const int nt = (H + LUT_THREADS * LUT_CPL - 1) / (LUT_THREADS * LUT_CPL);
     int vec_ok = ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
     if (P != nullptr) vec_ok = vec_ok && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
     const int rc = (P != nullptr)
@@ -623,6 +623,18 @@ extern "C" int mxm_set_loop_graph(int32_t mode) {
     return 0;
 }
 
+// ---- progress hook: called on the host thread inside mxm_em_loop after every state read-back ------
+typedef void (*mxm_progress_fn)(const mxm_em_state *state_host, int32_t B, void *user);
+static mxm_progress_fn g_progress = nullptr;
+static void *g_progress_user = nullptr;
+static int g_progress_every = 10;
+extern "C" int mxm_set_progress_callback(mxm_progress_fn fn, void *user, int32_t every) {
+    g_progress = fn;
+    g_progress_user = user;
+    g_progress_every = every > 0 ? every : 10;
+    return 0;
+}
+
 // ---- one-launch loop for cache-resident matrices (fused_kernels.hpp) ---------------------------
 static int g_loop_fused = -1;          // -1 auto (R * H below g_fused_cells), 0 never, 1 whenever the shape allows
 static int g_fused_chunk = 0;          // iterations per launch (0 = run to the end in one launch)
@@ -680,6 +692,7 @@ static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t 
                                 "workgroups resident?  mxm_set_loop_fused(0) selects the per-iteration kernels", "", b, nwg);
             all_done = all_done && state_host[b].done != 0;
         }
+        if (g_progress != nullptr) g_progress(state_host, B, g_progress_user);
         if (all_done) return 0;
         HIP_TRY(hipMemsetAsync(sync, 0, fused_sync_bytes(), s));       // every polled word, before EVERY launch
         switch (nch) {
@@ -729,13 +742,16 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     if (R <= 0 || H <= 0 || B <= 0) return fail(-1, "mxm_em_loop: bad shape R=%s%lld H=%lld", "", R, H);
     if (ws == nullptr || ws_bytes < mxm_workspace_bytes(R, H, B)) return fail(-1, "mxm_em_loop: workspace too small%s", "");
     if (check_every < 1) check_every = 1;
+    if (g_progress != nullptr && check_every > g_progress_every) check_every = g_progress_every;
     hipStream_t caller = (hipStream_t)stream;
     (void)num_cu();                                    // device query outside any capture
     if (fused_eligible(P, ldp, R, (int)H, ws_bytes, p_is_f32)) {
         // cache-resident matrix: the whole loop in one persistent launch on the caller's stream
         // (the host only waits for it; nothing is decided between iterations)
-        return em_loop_fused(P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, state, tol, max_iter,
-                             g_fused_chunk > 0 ? g_fused_chunk : max_iter, ws, caller, state_host);
+        int chunk = g_fused_chunk > 0 ? g_fused_chunk : max_iter;
+        if (g_progress != nullptr && chunk > g_progress_every) chunk = g_progress_every;     // someone is watching
+        return em_loop_fused(P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, state, tol, max_iter, chunk, ws, caller,
+                             state_host);
     }
     const bool want_graph = g_loop_graph == 1 ||
                             (g_loop_graph == -1 && (double)R * (double)H * (double)B < 6.4e7);
@@ -842,6 +858,7 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
         }
         LOOP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
         LOOP_TRY(hipStreamSynchronize(s));
+        if (g_progress != nullptr) g_progress(state_host, B, g_progress_user);
         std::vector<int> still;
         for (int b : order)
             if (state_host[b].done == 0) still.push_back(b);

@@ -367,9 +367,30 @@ def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, stora
         inits = numpy.stack([init_props(plan.n_haps, alpha=args.init_alpha)
                              for _ in range(n_multi)])
     inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
-    ln_cur, ln_new, states = em_loop(plan, inits, args.tolerance, args.max_iter)
+    verbose = getattr(args, "verbose", False)
+    live = verbose and n_multi == 1
+    if live:
+        # the reference's own progress text, while the loop runs (em.py:119-135): a dot per 10 iterations
+        sys.stderr.write("Starting EM run 1...\n")
+        shown = [0]
+
+        def on_state(state_host, n_runs, _user):
+            dots = state_host[0].iters // 10 - shown[0]
+            if dots > 0:
+                sys.stderr.write("." * dots)
+                sys.stderr.flush()
+                shown[0] += dots
+        hook = _lib.PROGRESS_FN(on_state)
+        plan.lib.mxm_set_progress_callback(ctypes.cast(hook, ctypes.c_void_p), None, 10)
+    try:
+        ln_cur, ln_new, states = em_loop(plan, inits, args.tolerance, args.max_iter)
+    finally:
+        if live:
+            plan.lib.mxm_set_progress_callback(None, None, 10)
+    if live and states[0][0] == 1:
+        sys.stderr.write("\nConverged! (%d)\n" % states[0][1])
     return collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix,
-                          getattr(args, "verbose", False), reuse_linear=True)
+                          verbose and not live, reuse_linear=True)
 
 
 def run_em(read_hap_mat, weights, args):

@@ -574,3 +574,22 @@ def test_row_without_any_possible_haplogroup_poisons_like_the_reference(n_rows, 
         else:
             assert numpy.abs(res["props"] - numpy.exp(theta)).max() < 1e-12
             assert numpy.abs(new - want_new).max() < 1e-12
+
+
+@pytest.mark.parametrize("fused", [1, 0])
+def test_verbose_progress_text_is_the_references(capsys, fused):
+    """-v: 'Starting EM run 1...', a dot per 10 iterations WHILE the loop runs, 'Converged! (n)'
+    (em.py:119-135) -- through the one-launch loop (chunks of 10) and the per-iteration kernels."""
+    from mixemt_amd import _lib, em
+    g = golden("g7_config1")
+    lib = _lib.load()
+    lib.mxm_set_loop_fused(fused, 0)
+    try:
+        numpy.random.seed(7)
+        res = em.run_em_ex(g["mat"], numpy.ones(1000, dtype=numpy.int64), em_args(verbose=True), want_read_mix=False)
+    finally:
+        lib.mxm_set_loop_fused(-1, 0)
+    n = int(g["iters"][0])
+    assert res["iters"] == [n]
+    assert capsys.readouterr().err == "Starting EM run 1...\n" + "." * (n // 10) + "\nConverged! (%d)\n" % n
+    assert numpy.abs(res["props"] - g["props"]).max() < PROPS_ATOL

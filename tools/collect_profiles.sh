@@ -1,0 +1,25 @@
+#!/bin/bash
+# Copy the summaries of a tools/profile_round.sh run from gpurun_out/<round>/ (scratch) into
+# profiles/<round>/ (tracked).  usage: bash tools/collect_profiles.sh r02
+set -u
+round=${1:-r02}
+src=gpurun_out/$round
+dst=profiles/$round
+mkdir -p $dst
+for f in bench_1m.json bench_1m_under_rocprof.json bench_1m_10restarts.json bench_100k.json \
+         bench_restarts10_run.json bench_restarts16_run.json pmc_traffic_1m.json pmc_traffic_build_1m.json \
+         pmc_sq_summary.txt small_runs.txt small_runs_under_rocprof.txt build_kernels.txt build_under_rocprof.txt \
+         restart_schedules.txt dropin_build.txt lut_variants.txt barrier_variants.txt; do
+  [ -f $src/$f ] && cp $src/$f $dst/$f
+done
+[ -f $src/bench_1m.log ] && cp $src/bench_1m.log $dst/bench_1m.log
+cp $src/kt/kt_kernel_stats.csv $dst/bench_1m_kernel_stats.csv 2>/dev/null
+cp $src/kt_small/kt_kernel_stats.csv $dst/small_runs_kernel_stats.csv 2>/dev/null
+cp $src/kt_build/kt_kernel_stats.csv $dst/build_kernel_stats.csv 2>/dev/null
+cp $src/pmc_fetch/f_counter_collection.csv $dst/pmc_fetch_size.csv 2>/dev/null
+cp $src/pmc_write/w_counter_collection.csv $dst/pmc_write_size.csv 2>/dev/null
+cp $src/pmc_sq/sq_counter_collection.csv $dst/pmc_sq.csv 2>/dev/null
+cp $src/pmc_fetch_build/f_counter_collection.csv $dst/pmc_fetch_size_build.csv 2>/dev/null
+cp $src/pmc_write_build/w_counter_collection.csv $dst/pmc_write_size_build.csv 2>/dev/null
+cp $src/pmc_l2_build/l2_counter_collection.csv $dst/pmc_l2_build.csv 2>/dev/null
+ls -la $dst

@@ -33,8 +33,11 @@ torch.cuda.synchronize()
 t3 = time.perf_counter()
 host = dev.cpu().numpy()
 t4 = time.perf_counter()
-from mixemt_amd._dev import to_host
-pinned = to_host(dev)
+# the alternative that was tried for the drop-in return path: one page-locked staging buffer
+staged = torch.empty(dev.shape, dtype=dev.dtype, pin_memory=True)
+staged.copy_(dev, non_blocking=True)
+torch.cuda.synchronize()
+pinned = staged.numpy()
 t5 = time.perf_counter()
 assert numpy.array_equal(pinned, host)
 whole0 = time.perf_counter()
@@ -46,6 +49,6 @@ print("  signatures -> CSR, library host parser : %.3f s" % (t1 - t0))
 print("  signatures -> CSR, item-by-item Python : %.3f s (extrapolated from 20000 reads)" % ((t2 - t1) * n / 20000.0))
 print("  H2D + build kernel                     : %.3f s" % (t3 - t2))
 print("  matrix D2H (%.1f GB, pageable .cpu())   : %.3f s (%.1f GB/s)" % (host.nbytes / 1e9, t4 - t3, host.nbytes / 1e9 / (t4 - t3)))
-print("  matrix D2H through page-locked staging : %.3f s (%.1f GB/s) -- what the drop-in returns with"
+print("  matrix D2H into a fresh page-locked buffer (alloc + copy): %.3f s (%.1f GB/s) -- not used: slower"
       % (t5 - t4, host.nbytes / 1e9 / (t5 - t4)))
 print("  build_em_matrix() as called by the reference's host code: %.3f s" % whole)
