@@ -300,6 +300,7 @@ def bench_rows(opts, env):
     import torch
     import torch.distributed as dist
     from mixemt_amd import _lib, em
+    from mixemt_amd import dist as mdist
     (lib, dev, rank, world, use_dist, mat, wts, n_rows, n_haps, total_rows, scaling, build_s) = (
         env[k] for k in ("lib", "dev", "rank", "world", "use_dist", "mat", "wts", "n_rows", "n_haps",
                          "total_rows", "scaling", "build_s"))
@@ -354,30 +355,64 @@ def bench_rows(opts, env):
             dist.barrier()
         torch.cuda.synchronize()
 
-    for _ in range(opts.warmup):
-        step()
-    fence()
-    t0 = time.perf_counter()
-    for i in range(opts.steps):
-        step(evs[i])
-    fence()
-    elapsed = time.perf_counter() - t0
+    def run_loop(n_iters):
+        """n_iters iterations of EVERY restart through the product's own loop driver (mxm_em_loop on one
+        rank, dist.sharded_em_loop over several): restarts advance in full tiles dealt round-robin, so
+        a "step" of B restarts costs B / tile passes over the matrix, not ceil(B / tile)."""
+        if use_dist:
+            _, _, sts = mdist.sharded_em_loop(plan, init, 0.0, n_iters, check_every=16)
+        else:
+            _, _, sts = em.em_loop(plan, init, 0.0, n_iters)
+        return sts
+
+    batched = n_runs > 1
+    if batched:
+        if opts.warmup > 0:
+            run_loop(opts.warmup)
+        fence()
+        t0 = time.perf_counter()
+        loop_states = run_loop(opts.steps)
+        fence()
+        elapsed = time.perf_counter() - t0
+    else:
+        for _ in range(opts.warmup):
+            step()
+        fence()
+        t0 = time.perf_counter()
+        for i in range(opts.steps):
+            step(evs[i])
+        fence()
+        elapsed = time.perf_counter() - t0
     if use_dist:
         tmax = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
 
-    kernel_ms = numpy.array([q[0].elapsed_time(q[1]) for q in evs])
-    # colreduce done -> all-reduced sums visible to this rank's stream (includes waiting for the slowest rank)
-    all_reduce_us = float(numpy.mean([q[2].elapsed_time(q[3]) for q in evs]) * 1e3) if use_dist else None
-    st = em.read_state(state)[0]
+    if batched:
+        # one pass of a full tile, measured after the timed region (the loop driver's last launches are
+        # no-ops of restarts that have already done their iterations)
+        tile = min(n_runs, plan.restart_tile())
+        lib.mxm_set_timing_events(evs[0][0].cuda_event, evs[0][1].cuda_event)
+        plan.em_iter(props_cur[:tile], ln_cur[:tile], state[:tile], colsum[:tile])
+        lib.mxm_set_timing_events(None, None)
+        torch.cuda.synchronize()
+        kernel_ms = numpy.array([evs[0][0].elapsed_time(evs[0][1])])
+        all_reduce_us = None
+        st = (loop_states[0][0], loop_states[0][1] + opts.warmup, loop_states[0][2])
+        total_ok = all(s[0] == 2 and s[1] == opts.steps for s in loop_states)
+    else:
+        kernel_ms = numpy.array([q[0].elapsed_time(q[1]) for q in evs])
+        # colreduce done -> all-reduced sums visible to this rank's stream (includes waiting for the slowest rank)
+        all_reduce_us = float(numpy.mean([q[2].elapsed_time(q[3]) for q in evs]) * 1e3) if use_dist else None
+        st = em.read_state(state)[0]
+        total_ok = st[1] == total
     # sanity (untimed): one more E+M pass; the M-step sums  sum_h p_h T_h  must add up to the
     # total weight of all ranks' rows, once per restart
     plan.em_iter(props_cur, ln_cur, state, colsum)
     if use_dist:
         dist.all_reduce(colsum, op=dist.ReduceOp.SUM)
     mass = float((props_cur * colsum).sum().item())
-    sane = (st[1] == total) and abs(mass - total_rows * n_runs) < 1e-6 * total_rows * n_runs
+    sane = total_ok and abs(mass - total_rows * n_runs) < 1e-6 * total_rows * n_runs
     if rank == 0:
         log("%d steps in %.4f s; streaming kernel avg %.4f ms (min %.4f, max %.4f); "
             "sum(colsum)=%.6f iters=%d%s" % (opts.steps, elapsed, kernel_ms.mean(), kernel_ms.min(),
@@ -436,7 +471,8 @@ def bench_rows(opts, env):
         "dtype": "f64" if opts.storage == "f64" else "f64 arithmetic on f32-stored matrix (opt-in variant)",
         "data": "synthetic (synth-v1 reads in blocks of %d, matrix built on device)" % 125000,
         "config": {"workload": "%d reads x %d haplogroups in total (Phylotree B17 + RSRS), %d per rank, "
-                               "%d EM restart(s) advanced together (tile %d), %s matrix"
+                               "%d EM restart(s) advanced together (tile %d; several restarts: full tiles "
+                               "dealt round-robin by the loop driver), %s matrix"
                                % (total_rows, n_haps, n_rows, n_runs, opts.batch_tile,
                                   "fp64" if opts.storage == "f64" else "fp32-stored"),
                    "total_rows": total_rows, "rows_per_gpu": n_rows, "haps": n_haps, "restarts": n_runs,

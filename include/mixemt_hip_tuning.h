@@ -66,6 +66,14 @@ int mxm_set_loop_graph(int32_t mode);
 int mxm_set_loop_fused(int32_t mode, int32_t chunk);
 
 /*
+ * Diagnostic: per-phase clock sums (100 MHz ticks) of the last one-launch loop that used workspace
+ * `ws`, workgroup 0: [0] row pass, [1] barrier 1, [2] slice reduce, [3] barrier 2, [4] normalise + test,
+ * [5] iterations.  Filled only by a library built with -DFUSED_STAMPS (a diagnostic build whose stamps
+ * serialise the phases); zeros otherwise.  out_host[8].
+ */
+int mxm_diag_fused_stamps(const void *ws, unsigned long long *out_host);
+
+/*
  * How many restarts at most share one pass over the matrix in mxm_em_iter (1..4,
  * default 4; B restarts take ceil(B / tile) passes with the restarts spread evenly:
  * 10 -> 4 + 3 + 3).  1 reproduces the unbatched schedule (B passes per iteration).

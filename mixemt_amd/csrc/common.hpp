@@ -134,12 +134,13 @@ __device__ __forceinline__ double weight_over_norm(double wr, double z) {
 // all groups (they sit in different lanes) instead of once per group.
 template <int NW, int N>
 __device__ __forceinline__ void group_ratio_to_sgpr(const double *red, int lane, double num, double (&c)[N]) {
-    static_assert(NW == 4 || NW == 8, "waves per workgroup");
+    static_assert(NW == 4 || NW == 8 || NW == 16, "waves per workgroup");
     static_assert(N * NW <= 64, "one partial per lane");
     double v = red[lane < N * NW ? lane : 0];
     v += dpp_mov_f64<0xB1>(v);                      // quad_perm [1,0,3,2]: lane ^ 1
     v += dpp_mov_f64<0x4E>(v);                      // quad_perm [2,3,0,1]: lane ^ 2
-    if constexpr (NW == 8) v += dpp_mov_f64<0x141>(v);   // row_half_mirror: lane i <-> 7 - i
+    if constexpr (NW >= 8) v += dpp_mov_f64<0x141>(v);   // row_half_mirror: lane i <-> 7 - i
+    if constexpr (NW == 16) v += dpp_mov_f64<0x140>(v);  // row_mirror: lane i <-> 15 - i
     v = weight_over_norm(num, v);
 #pragma unroll
     for (int g = 0; g < N; ++g) c[g] = readlane_f64(v, g * NW);

@@ -37,10 +37,20 @@
 // workgroup that gives up poisons the generation word and raises `abort`, all others leave
 // their spin at once, and the launch returns with state.done = -1 (the host reports it).
 // ------------------------------------------------------------------------------------------
+// Shape: one workgroup per CU.  Measured per iteration at 600 / 2400 / 10 000 x 5408
+// (profiles/r02/fused_shapes.txt): 512 threads, ring 2: 17.2 / 26.1 / 80.0 us; 1024 threads, ring 3:
+// 18.6 / 28.3 / 82.2; 1024 threads, ring 4: 18.6 / 28.9 / 81.8.  More rows in flight or more waves do not
+// shorten the row pass: per workgroup it moves 43 KB per row at the rate one CU gets from the Infinity
+// Cache / HBM (~1.5-1.9 us per row, i.e. 23-29 GB/s per CU, 6-7.4 TB/s over the chip), whatever the ring.
+#ifndef FUSED_THREADS
 #define FUSED_THREADS 512
+#endif
+#ifndef FUSED_NBUF
+#define FUSED_NBUF 2                       // row ring: NBUF - 1 rows in flight per workgroup
+#endif
 #define FUSED_SPIN_LIMIT (1u << 22)        // poll rounds (>= ~1 us each) before a workgroup gives up: seconds
 #define FUSED_MAX_M 4                      // column pairs per slice <= 16 * FUSED_MAX_M
-#define FUSED_MAX_NCH 6                    // column chunks per thread the kernel is instantiated for (H <= 6144)
+#define FUSED_MAX_NCH (FUSED_THREADS == 1024 ? 3 : 6)   // column chunks per thread whose row loop compiles without scratch (H <= 6144)
 
 #ifndef FUSED_BARRIER
 #define FUSED_BARRIER 0                    // 0: two-level counter tree; 1: one flat counter; 2: flag word per workgroup
@@ -54,7 +64,26 @@ struct fused_sync {                        // every polled word on a 128-byte li
     unsigned gen[32];
     unsigned abort_[32];
     unsigned flag[MXM_MAX_WG];             // FUSED_BARRIER == 2 only
+    unsigned long long stamps[8];          // -DFUSED_STAMPS diagnostic build only: time per phase, workgroup 0
 };
+
+// Diagnostic build (-DFUSED_STAMPS, never the shipped library): thread 0 of workgroup 0 adds up the
+// constant-rate clock (s_memrealtime, 100 MHz) over each phase of every iteration and leaves the sums
+// in sync->stamps: [0] row pass incl. partial stores, [1] barrier 1, [2] slice reduce, [3] barrier 2,
+// [4] normalise + test, [5] iterations.  The stamps serialise what the real kernel overlaps: read the
+// shares, not the total (tools/time_small_runs.py --stamps).
+#ifdef FUSED_STAMPS
+#define FUSED_STAMP(i)                                                             \
+    do {                                                                           \
+        if (blockIdx.x == 0 && threadIdx.x == 0) {                                 \
+            const unsigned long long now_ = __builtin_amdgcn_s_memrealtime();      \
+            stamp_acc[i] += now_ - stamp_last;                                     \
+            stamp_last = now_;                                                     \
+        }                                                                          \
+    } while (0)
+#else
+#define FUSED_STAMP(i) do { } while (0)
+#endif
 
 // Grid barrier.  Contract (MI355X_MICROARCH.md, "Valid forms", row 1): all waves of the workgroup have
 // drained their write-through payload stores (s_waitcnt vmcnt(0)) before calling; the other waves load
@@ -131,7 +160,7 @@ typedef unsigned int fu4 __attribute__((ext_vector_type(4)));
 #define FUSED_SC1 16                       // aux bit of raw buffer loads / stores: sc1 (device scope, write-through)
 
 template <int NCH, int NBUF>
-__global__ __launch_bounds__(FUSED_THREADS, 2) void em_fused_loop_kernel(
+__global__ __launch_bounds__(FUSED_THREADS, FUSED_THREADS / 256) void em_fused_loop_kernel(
     const double *__restrict__ P, int64_t ldp, const double *__restrict__ w, int64_t R, int H, int B,
     double *ln_cur, double *ln_new, double *props_cur, mxm_em_state *state, double tol, int max_iter,
     int chunk, double *partial, int64_t ldpart, double *tbuf, fused_sync *sync) {
@@ -169,6 +198,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void em_fused_loop_kernel(
     const int my_part = (int)((int64_t)blockIdx.x * ldpart * 8);
 
     unsigned epoch = 0;
+#ifdef FUSED_STAMPS
+    unsigned long long stamp_acc[6] = {0, 0, 0, 0, 0, 0};
+    unsigned long long stamp_last = __builtin_amdgcn_s_memrealtime();
+#endif
     for (int b = 0; b < B; ++b) {
         mxm_em_state *st = state + b;
         if (st->done != 0) continue;                       // written before the launch: plain load is fine
@@ -192,12 +225,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void em_fused_loop_kernel(
         int done = 0;
         double l1 = 0.0;
         for (int it = 0; it < chunk && done == 0; ++it) {
+#ifdef FUSED_STAMPS
+            if (blockIdx.x == 0 && threadIdx.x == 0) { stamp_last = __builtin_amdgcn_s_memrealtime(); stamp_acc[5] += 1; }
+#endif
             // ================= phase A: row pass =================
             d2 acc[NCH];
 #pragma unroll
             for (int k = 0; k < NCH; ++k) acc[k] = d2{0.0, 0.0};
             if (nq > 0) {
-                d2 x[NBUF][NCH];
+                d2 x[NBUF][NCH];                            // row ring: NBUF - 1 rows in flight
                 int buf = 0;
                 auto process = [&](d2(&xr)[NCH], int64_t q) {
                     double s = 0.0;
@@ -227,7 +263,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void em_fused_loop_kernel(
 #pragma unroll
                     for (int j = 0; j < NBUF; ++j) {
                         load_row(x[(j + NBUF - 1) % NBUF], q + j + NBUF - 1);
-                        process(x[j], q + j);
+                        if (q + j < nq) process(x[j], q + j);             // workgroup uniform
                     }
                 }
             }
@@ -239,12 +275,15 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void em_fused_loop_kernel(
                                                            FUSED_SC1);
             }
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            FUSED_STAMP(0);
             if (!fused_grid_barrier(sync, ++epoch, nwg, &ok_flag)) { done = -1; break; }
+            FUSED_STAMP(1);
 
             // ================= phase B: this workgroup's slice of the column sums =================
             {
-                const int l16 = t & 15, gsub = t >> 4;      // 32 sub-groups of 16 lanes walk the partial rows
-#pragma unroll
+                constexpr int G = THREADS / 16;             // sub-groups of 16 lanes that walk the partial rows
+                const int l16 = t & 15, gsub = t >> 4;
+#pragma unroll 1
                 for (int m = 0; m < FUSED_MAX_M; ++m) {
                     if (m * 16 < cp2) {
                         const int pi = l16 + 16 * m;
@@ -253,19 +292,28 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void em_fused_loop_kernel(
                         if (!valid) c2 = 0;
                         d2 s = d2{0.0, 0.0};
                         int g = gsub;
-                        for (; g + 224 < nwg; g += 256) {   // eight loads in flight per lane: one round trip at 256 workgroups
-                            d2 v[8];
+                        auto load_part = [&](int gg) {
+                            return __builtin_bit_cast(d2, (fu4)__builtin_amdgcn_raw_buffer_load_b128(
+                                                              part_rsrc, (int)((int64_t)gg * ldpart * 8) + c2 * 16, 0, FUSED_SC1));
+                        };
+                        if constexpr (G <= 32) {
+                            for (; g + 7 * G < nwg; g += 8 * G) {   // eight loads in flight per lane
+                                d2 v[8];
 #pragma unroll
-                            for (int u = 0; u < 8; ++u)
-                                v[u] = __builtin_bit_cast(d2, (fu4)__builtin_amdgcn_raw_buffer_load_b128(
-                                                                  part_rsrc, (int)((int64_t)(g + 32 * u) * ldpart * 8) + c2 * 16,
-                                                                  0, FUSED_SC1));
+                                for (int u = 0; u < 8; ++u) v[u] = load_part(g + G * u);
 #pragma unroll
-                            for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; }
+                                for (int u = 0; u < 8; ++u) { s.x += v[u].x; s.y += v[u].y; }
+                            }
                         }
-                        for (; g < nwg; g += 32) {
-                            const d2 v = __builtin_bit_cast(d2, (fu4)__builtin_amdgcn_raw_buffer_load_b128(
-                                                                    part_rsrc, (int)((int64_t)g * ldpart * 8) + c2 * 16, 0, FUSED_SC1));
+                        for (; g + 3 * G < nwg; g += 4 * G) {   // four (all of them at 256 workgroups x 1024 threads)
+                            d2 v[4];
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) v[u] = load_part(g + G * u);
+#pragma unroll
+                            for (int u = 0; u < 4; ++u) { s.x += v[u].x; s.y += v[u].y; }
+                        }
+                        for (; g < nwg; g += G) {
+                            const d2 v = load_part(g);
                             s.x += v.x; s.y += v.y;
                         }
                         // the wave's four sub-groups (lanes l, l+16, l+32, l+48), fixed tree
@@ -291,7 +339,9 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void em_fused_loop_kernel(
                 }
                 asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             }
+            FUSED_STAMP(2);
             if (!fused_grid_barrier(sync, ++epoch, nwg, &ok_flag)) { done = -1; break; }
+            FUSED_STAMP(3);
 
             // ================= phase C: normalise, convergence test (every workgroup alike) =================
             d2 T[NCH], LT[NCH];
@@ -352,6 +402,7 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void em_fused_loop_kernel(
                     if (c + 1 < H) ln_g[c + 1] = l.y + LT[k].y - ltot;
                 }
             }
+            FUSED_STAMP(4);
         }
         // ---- results of this restart (workgroup 0): ln_cur = log theta_k, ln_new = log theta_{k+1} ----
         if (blockIdx.x == 0) {
@@ -370,6 +421,10 @@ __global__ __launch_bounds__(FUSED_THREADS, 2) void em_fused_loop_kernel(
         }
         if (done < 0) return;                              // the grid gave up: every workgroup leaves
     }
+#ifdef FUSED_STAMPS
+    if (blockIdx.x == 0 && threadIdx.x == 0)
+        for (int i = 0; i < 6; ++i) sync->stamps[i] = stamp_acc[i];
+#endif
 }
 
 #endif  // MIXEMT_FUSED_KERNELS_HPP

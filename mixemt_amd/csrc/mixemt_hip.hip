@@ -654,18 +654,27 @@ static bool fused_eligible(const double *P, int64_t ldp, int64_t R, int H, size_
     int nwg = num_cu() < MXM_MAX_WG ? num_cu() : MXM_MAX_WG;
     const int ncol2 = (H + 1) / 2;
     if ((ncol2 + nwg - 1) / nwg > 16 * FUSED_MAX_M) return false;           // slice wider than the column reduce covers
-    if ((ncol2 + FUSED_THREADS - 1) / FUSED_THREADS > FUSED_MAX_NCH) return false;   // spill-free instances only (H <= 6144)
+    if ((ncol2 + FUSED_THREADS - 1) / FUSED_THREADS > FUSED_MAX_NCH) return false;   // spill-free instances only
     if ((int64_t)nwg * part_ld(H) * 8 >= ((int64_t)1 << 31)) return false;  // one buffer descriptor over the partials
     if (ws_bytes < fused_sync_bytes() + (size_t)(nwg + 2) * part_ld(H) * sizeof(double)) return false;
     if (g_loop_fused == 1) return true;
     return (double)R * (double)H <= g_fused_cells;
 }
 
+// Diagnostic (-DFUSED_STAMPS builds): the per-phase clock sums of the last one-launch loop, from the
+// sync block at the start of `ws`; all zeros in the shipped library.
+extern "C" int mxm_diag_fused_stamps(const void *ws, unsigned long long *out_host) {
+    if (ws == nullptr || out_host == nullptr) return fail(-1, "mxm_diag_fused_stamps: bad arguments%s", "");
+    const fused_sync *sync = reinterpret_cast<const fused_sync *>(ws);
+    HIP_TRY(hipMemcpy(out_host, sync->stamps, sizeof(sync->stamps), hipMemcpyDeviceToHost));
+    return 0;
+}
+
 template <int NCH>
 static void launch_fused(int nwg, hipStream_t s, const double *P, int64_t ldp, const double *w, int64_t R, int H, int B,
                          double *ln_cur, double *ln_new, double *props_cur, mxm_em_state *state, double tol,
                          int max_iter, int chunk, double *partial, int64_t ldpart, double *tbuf, fused_sync *sync) {
-    hipLaunchKernelGGL((em_fused_loop_kernel<NCH, 2>), dim3(nwg), dim3(FUSED_THREADS), 0, s, P, ldp, w, R, H, B, ln_cur,
+    hipLaunchKernelGGL((em_fused_loop_kernel<NCH, FUSED_NBUF>), dim3(nwg), dim3(FUSED_THREADS), 0, s, P, ldp, w, R, H, B, ln_cur,
                        ln_new, props_cur, state, tol, max_iter, chunk, partial, ldpart, tbuf, sync);
 }
 
@@ -697,7 +706,10 @@ static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t 
         HIP_TRY(hipMemsetAsync(sync, 0, fused_sync_bytes(), s));       // every polled word, before EVERY launch
         switch (nch) {
 #define FU_CASE(n) case n: launch_fused<n>(nwg, s, P, ldp, w, R, (int)H, (int)B, ln_cur, ln_new, props_cur, state, tol, (int)max_iter, (int)chunk, partial, ldpart, tbuf, sync); break;
-            FU_CASE(1) FU_CASE(2) FU_CASE(3) FU_CASE(4) FU_CASE(5) FU_CASE(6)
+            FU_CASE(1) FU_CASE(2) FU_CASE(3)
+#if FUSED_MAX_NCH > 3
+            FU_CASE(4) FU_CASE(5) FU_CASE(6)
+#endif
 #undef FU_CASE
             default: return fail(-1, "mxm_em_loop: H=%s%lld outside the one-launch loop's range", "", H);
         }

@@ -131,3 +131,116 @@ def test_world_of_one_needs_no_process_group(b17):
     res = mdist.run_em_sharded(mat, g["wts"], em_args(), want_read_mix=False)
     assert res["iters"] == list(g["iters"])
     assert numpy.abs(res["props"] - g["props"]).max() < 1e-9
+
+
+def _run_bench(args, timeout=600):
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py")] + args, stdout=subprocess.PIPE,
+                          stderr=subprocess.PIPE, text=True, timeout=timeout)
+    lines = [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    return proc, (json.loads(lines[-1]) if lines else None)
+
+
+def test_bench_starts_its_own_ranks_and_reports_the_world_it_ran():
+    """`python bench.py --gpus 2` with no launcher: two rank processes, ONE json line, n_gpus = 2, strong
+    scaling of the named total (the two ranks share this box's GPU over gloo; RCCL needs one GPU each)."""
+    proc, line = _run_bench(["--gpus", "2", "--backend", "gloo", "--total-rows", "30000", "--steps", "4",
+                             "--warmup", "1", "--no-cpu-baseline"])
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert line["n_gpus"] == 2 and line["scaling"] == "strong" and line["sanity_ok"]
+    assert line["config"]["total_rows"] == 30000 and line["config"]["rows_per_gpu"] == 15000
+    assert line["all_reduce_us"] is not None and line["all_reduce_us"] > 0
+    assert line["steps"] == 4 and line["roofline"]["kernel_ms"] > 0
+
+
+def test_bench_line_carries_parity_observables():
+    """N = 1: cpu_baseline and parity_in_run come from the same oracle leg, and sanity_ok needs them."""
+    proc, line = _run_bench(["--total-rows", "20000", "--steps", "3", "--warmup", "1", "--cpu-rows", "512",
+                             "--cpu-iters", "3"])
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    par = line["parity_in_run"]
+    assert par["rows"] == 512 and par["iters"] == 3 and par["iters_equal"] and par["argmax_equal"]
+    assert par["max_abs_dprops"] < 1e-9 and line["sanity_ok"]
+    assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
+    assert line["n_gpus"] == 1 and line["config"]["total_rows"] == 20000
+
+
+def test_bench_restart_mode_runs_to_convergence():
+    """--mode restarts (config 5's shape on one rank): every restart converges, the folded posterior is
+    row-normalised, restart-iterations are what is counted."""
+    proc, line = _run_bench(["--mode", "restarts", "--restarts", "5", "--rows", "3000", "--no-cpu-baseline"])
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert line["sanity_ok"] and len(line["iters_per_restart"]) == 5
+    assert line["steps"] == sum(line["iters_per_restart"]) and line["restart_iters_per_s"] > 0
+    assert line["idle_tail_s_per_rank"] == [0.0]
+
+
+def test_bench_refuses_a_world_that_differs_from_gpus():
+    """A launcher that started another number of ranks than --gpus names is an error, not a silent downgrade."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0")
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2"], env=env,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=300)
+    assert proc.returncode != 0 and "must agree" in proc.stderr and not proc.stdout.strip()
+
+
+@pytest.mark.parametrize("mode", ["rows", "restarts"])
+def test_two_ranks_over_rccl_on_two_gpus(tmp_path, mode):
+    """The real thing where the box has two GPUs: RCCL all-reduce between mxm_em_iter and mxm_m_finalize,
+    the rank-agreement check, the direct row-block exchange.  Skipped on a one-GPU box."""
+    import torch
+    import torch.multiprocessing as mp
+    if torch.cuda.device_count() < 2:
+        pytest.skip("needs two GPUs")
+    g = golden("g5_run_em_multi")
+    mp.spawn(_worker_multi_gpu, args=(2, _free_port(), str(tmp_path), mode), nprocs=2, join=True)
+    res = [numpy.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(2)]
+    for r in res:
+        lo, hi = int(r["lo"]), int(r["hi"])
+        assert list(r["iters"]) == list(g["iters"])
+        assert numpy.abs(r["props"] - g["props"]).max() < 1e-9
+        assert numpy.array_equal(r["props"], res[0]["props"])
+        assert numpy.array_equal(r["best"], g["mix_argmax"][lo:hi])
+        assert numpy.allclose(r["rowmax"], g["mix_rowmax"][lo:hi], rtol=0, atol=1e-8)
+
+
+def _worker_multi_gpu(rank, world, port, out_dir, mode):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    import torch
+    import torch.distributed as dist
+    from conftest import em_args as mk
+    from mixemt_amd import dist as mdist, phylotree, preprocess
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    dev = torch.device("cuda", rank)
+    torch.cuda.set_device(dev)
+    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+    try:
+        g = numpy.load(os.path.join(here, "golden", "g5_run_em_multi.npz"))
+        refseq = phylotree.load_rsrs()
+        phy = phylotree.load_build17(refseq)
+        haps = sorted(phy.hap_var)
+        tables = preprocess.HapVarTables.build(refseq, phy, haps)
+        full = preprocess.build_em_matrix_device(tables, g["row_ptr"], g["site"], g["obs"])
+        wts = torch.from_numpy(g["wts"]).to(dev)
+        numpy.random.seed(11 if rank == 0 else 999)
+        if mode == "rows":
+            lo, hi = mdist.shard_bounds(full.shape[0], rank, world)
+            res = mdist.run_em_sharded(full[lo:hi], wts[lo:hi], mk(n_multi=3), check_every=5)
+        else:
+            res = mdist.run_em_restart_parallel(full, wts, mk(n_multi=3))
+            lo, hi = res["rows"]
+        mix = res["read_mix"].cpu().numpy()
+        numpy.savez(os.path.join(out_dir, "rank%d.npz" % rank), props=res["props"], iters=numpy.array(res["iters"]),
+                    best=mix.argmax(axis=1), lo=lo, hi=hi, rowmax=mix.max(axis=1))
+    finally:
+        dist.destroy_process_group()

@@ -4,6 +4,7 @@ Phylotree parsing, table encoding, signature encoding, the synthetic generator.
 CPU only (no kernels are called).
 """
 import hashlib
+import os
 
 import numpy
 import pytest
@@ -190,3 +191,19 @@ def test_other_trees_and_flags_match_reference_digests():
         assert len(names) == int(g[tag + "_n_haps"]) and len(tree.variants) == int(g[tag + "_n_sites"])
         assert hashlib.sha256(text.encode()).hexdigest() == str(g[tag + "_hap_var_sha256"]), tag
         assert hashlib.sha256(counts.encode()).hexdigest() == str(g[tag + "_variants_sha256"]), tag
+
+
+def test_bench_without_a_gpu_fails_loudly_instead_of_downgrading():
+    """`python bench.py --gpus 2` where no GPU exists: the ranks it starts report the missing GPU and the
+    parent exits non-zero with no JSON line (never a silent n_gpus = 1 result)."""
+    import subprocess
+    import sys
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    proc = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--total-rows", "1000"],
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True, timeout=600)
+    assert proc.returncode != 0
+    assert not [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
+    assert "no ROCm GPU" in proc.stderr

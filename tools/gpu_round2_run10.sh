@@ -1,0 +1,14 @@
+set -x
+mkdir -p gpurun_out/r02
+timeout -k 10 400 python -m pytest tests/test_gpu_fused.py tests/test_gpu_em.py -x -q > gpurun_out/r02/pytest10.log 2>&1; rc=$?; echo "pytest rc=$rc" >> gpurun_out/r02/pytest10.log
+tail -6 gpurun_out/r02/pytest10.log
+if [ $rc -ne 0 ]; then exit $rc; fi
+echo "== 1024 threads, ring 4 (default)" > gpurun_out/r02/fused_shapes.txt
+timeout -k 10 200 python tools/time_small_runs.py --rows 600,2400,4600,10000,18000 >> gpurun_out/r02/fused_shapes.txt 2>&1
+echo "== 1024 threads, ring 3" >> gpurun_out/r02/fused_shapes.txt
+MXM_LIB=$PWD/mixemt_amd/lib/tune/fused_1024x3.so timeout -k 10 200 python tools/time_small_runs.py --rows 600,2400,4600,10000,18000 >> gpurun_out/r02/fused_shapes.txt 2>&1
+echo "== 512 threads, ring 2" >> gpurun_out/r02/fused_shapes.txt
+MXM_LIB=$PWD/mixemt_amd/lib/tune/fused_512x2.so timeout -k 10 200 python tools/time_small_runs.py --rows 600,2400,4600,10000,18000 >> gpurun_out/r02/fused_shapes.txt 2>&1
+grep -v "amdgpu.ids\|kernels\|^one MI355X" gpurun_out/r02/fused_shapes.txt
+MXM_LIB=$PWD/mixemt_amd/lib/tune/fused_stamps.so timeout -k 10 200 python tools/time_small_runs.py --rows 600,2400,10000 --stamps > gpurun_out/r02/fused_stamps.txt 2>&1; echo "rc=$?"
+grep -v "amdgpu.ids\|kernels" gpurun_out/r02/fused_stamps.txt

@@ -19,6 +19,8 @@ from mixemt_amd import _lib, em, phylotree, preprocess, synth
 ap = argparse.ArgumentParser()
 ap.add_argument("--rows", default="600,2400,4600,10000,30000,100000")
 ap.add_argument("--max-iter", type=int, default=200)
+ap.add_argument("--stamps", action="store_true",
+                help="with a -DFUSED_STAMPS build of the library (MXM_LIB=...): per-phase time shares of the one-launch loop")
 opts = ap.parse_args()
 refseq = phylotree.load_rsrs(); phy = phylotree.load_build17(refseq); haps = sorted(phy.hap_var)
 tables = preprocess.HapVarTables.build(refseq, phy, haps)
@@ -42,6 +44,15 @@ for n_rows in [int(x) for x in opts.rows.split(",")]:
         ln_cur, ln_new, states = em.em_loop(plan, init, 0.0, opts.max_iter)
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
         out[label] = ln_new.cpu().numpy()
+        if opts.stamps and fused:
+            import ctypes
+            st = (ctypes.c_ulonglong * 8)()
+            _lib.check(lib.mxm_diag_fused_stamps(plan.ws.data_ptr(), st), "mxm_diag_fused_stamps")
+            if st[5]:
+                names = ("row pass", "barrier 1", "slice reduce", "barrier 2", "normalise+test")
+                print("        workgroup 0, us per iteration (stamped build): "
+                      + ", ".join("%s %.2f" % (n, st[i] * 0.01 / st[5]) for i, n in enumerate(names))
+                      + "  (sum %.2f)" % (sum(st[:5]) * 0.01 / st[5]))
         print("%7d rows (%6.1f MB)  %-14s %4d iterations  %8.2f ms  %7.1f us/iteration"
               % (n_rows, n_rows * len(haps) * 8 / 1e6, label, states[0][1], dt * 1e3, dt * 1e6 / states[0][1]))
     print("        max |delta ln p| one launch vs kernels over finite entries: %.2e"
