@@ -280,10 +280,9 @@ def main(argv=None):
     if opts.min_rows_per_wg > 0:
         lib.mxm_set_min_rows_per_wg(opts.min_rows_per_wg)
 
-    if opts.mode == "restarts":
-        line = bench_restarts(opts, locals())
-    else:
-        line = bench_rows(opts, locals())
+    env = dict(lib=lib, dev=dev, rank=rank, world=world, use_dist=use_dist, mat=mat, wts=wts, n_rows=n_rows,
+               n_haps=n_haps, total_rows=total_rows, scaling=scaling, build_s=build_s)
+    line = bench_restarts(opts, env) if opts.mode == "restarts" else bench_rows(opts, env)
     if rank == 0:
         print(json.dumps(line))
         sys.stdout.flush()
