@@ -207,3 +207,23 @@ def test_bench_without_a_gpu_fails_loudly_instead_of_downgrading():
     assert proc.returncode != 0
     assert not [ln for ln in proc.stdout.splitlines() if ln.startswith("{")]
     assert "no ROCm GPU" in proc.stderr
+
+
+def test_synth_rows_is_one_global_read_set_whatever_the_slice(b17):
+    """bench.py's strong scaling: every rank generates ITS rows of one block-defined read set; any
+    slicing of the row range gives the same observations."""
+    refseq, phy, haps, tables = b17
+    whole = synth.synth_rows(tables, len(refseq), 0, 1000, seed=3, block=300)
+    lo, hi = 250, 910
+    part = synth.synth_rows(tables, len(refseq), lo, hi, seed=3, block=300)
+    rp = whole[0]
+    assert numpy.array_equal(part[0], rp[lo:hi + 1] - rp[lo])
+    assert numpy.array_equal(part[1], whole[1][rp[lo]:rp[hi]])
+    assert numpy.array_equal(part[2], whole[2][rp[lo]:rp[hi]])
+    assert numpy.array_equal(part[3], whole[3][lo:hi])
+    again = synth.synth_rows(tables, len(refseq), lo, hi, seed=3, block=300)
+    assert all(numpy.array_equal(a, b) for a, b in zip(part, again))
+    other = synth.synth_rows(tables, len(refseq), lo, hi, seed=4, block=300)
+    assert not numpy.array_equal(part[2], other[2][:len(part[2])])
+    empty = synth.synth_rows(tables, len(refseq), 5, 5)
+    assert empty[0].tolist() == [0] and empty[1].size == 0

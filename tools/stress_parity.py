@@ -1,0 +1,120 @@
+#!/usr/bin/env python
+"""
+Randomised parity stress on the GPU box (not part of the suite: minutes of oracle time):
+run_em end to end -- one-launch loop, per-iteration kernels, chunked launches -- against the oracle on
+random shapes, weights, -inf patterns and restart counts; build kernels against the C oracle on random
+row sets.  Every case prints one line; the script exits non-zero on the first mismatch.
+
+    python tools/stress_parity.py [--cases N] [--seed S] [--budget SECONDS]
+"""
+import argparse
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy
+import torch
+from mixemt_amd import _lib, em, phylotree, preprocess, synth
+from oracle import c_oracle, em_oracle
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--cases", type=int, default=60)
+ap.add_argument("--seed", type=int, default=1)
+ap.add_argument("--budget", type=float, default=600.0)
+opts = ap.parse_args()
+lib = _lib.load()
+rng = numpy.random.default_rng(opts.seed)
+t_start = time.time()
+fails = 0
+
+
+def ns(**kw):
+    a = argparse.Namespace(init_alpha=1.0, tolerance=1e-4, max_iter=400, n_multi=1, verbose=False)
+    for k, v in kw.items():
+        setattr(a, k, v)
+    return a
+
+
+widths = [65, 66, 67, 127, 128, 129, 255, 256, 511, 512, 513, 1000, 1023, 1024, 1025, 2047, 2048, 2049,
+          3000, 4095, 4096, 4097, 5407, 5408, 5409, 6143, 6144, 6145, 7000, 8191, 8192]
+for case in range(opts.cases):
+    if time.time() - t_start > opts.budget:
+        print("budget used up after %d cases" % case)
+        break
+    n_haps = int(rng.choice(widths))
+    n_rows = int(rng.choice([1, 2, 3, 7, 64, 255, 256, 257, 300, 511, 513, 768, 769, 1000, 1500, 2500]))
+    n_rows = min(n_rows, max(1, int(4.0e6 // n_haps)))           # keep the oracle affordable
+    n_multi = int(rng.choice([1, 1, 1, 2, 3, 5]))
+    mat = rng.normal(size=(n_rows, n_haps)) * rng.choice([1.0, 3.0, 8.0]) - 10.0
+    hot = rng.integers(0, min(n_haps, 9), size=n_rows)
+    mat[numpy.arange(n_rows), hot] += rng.choice([5.0, 12.0, 30.0])
+    if rng.random() < 0.5:
+        mat[rng.random(mat.shape) < rng.choice([0.001, 0.01, 0.2])] = -numpy.inf
+        mat[numpy.arange(n_rows), hot] = numpy.where(numpy.isfinite(mat[numpy.arange(n_rows), hot]),
+                                                     mat[numpy.arange(n_rows), hot], -3.0)
+    wts = rng.integers(0, 6, size=n_rows).astype(numpy.float64)
+    wts[rng.integers(0, n_rows)] = 3.0
+    if rng.random() < 0.3:
+        wts = wts * rng.random(n_rows)                           # fractional weights
+        wts[0] = 1.5
+    args = ns(n_multi=n_multi, max_iter=int(rng.choice([5, 60, 400])))
+    seed = int(rng.integers(1, 1 << 30))
+    trace = []
+    numpy.random.seed(seed)
+    with numpy.errstate(all="ignore"):
+        want_props, want_mix = em_oracle.run_em(mat, wts, args, trace=trace)
+    want_iters = [t["iters"] for t in trace]
+    line = "case %3d: %5d x %5d, n_multi %d, max_iter %3d, iterations %s" % (case, n_rows, n_haps, n_multi,
+                                                                             args.max_iter, want_iters)
+    for label, mode, chunk in (("one-launch", 1, 0), ("kernels", 0, 0), ("chunks", 1, int(rng.integers(1, 9)))):
+        lib.mxm_set_loop_fused(mode, chunk)
+        numpy.random.seed(seed)
+        res = em.run_em_ex(mat, wts, args)
+        got_mix = res["read_mix"].cpu().numpy()
+        ok = res["iters"] == want_iters
+        ok = ok and float(numpy.nanmax(numpy.abs(res["props"] - want_props))) < 1e-9
+        ok = ok and numpy.array_equal(numpy.isfinite(got_mix), numpy.isfinite(want_mix))
+        with numpy.errstate(all="ignore"):
+            ok = ok and float(numpy.nanmax(numpy.abs(numpy.exp(got_mix) - numpy.exp(want_mix)))) < 1e-9
+        if not ok:
+            fails += 1
+            line += "  %s MISMATCH (iters %s, dprops %.2e)" % (label, res["iters"],
+                                                              float(numpy.nanmax(numpy.abs(res["props"] - want_props))))
+    print(line + ("" if "MISMATCH" in line else "  ok"))
+    sys.stdout.flush()
+lib.mxm_set_loop_fused(-1, 0)
+
+# ---- build kernels on random row sets of Build 17 ------------------------------------------------------
+refseq = phylotree.load_rsrs()
+phy = phylotree.load_build17(refseq)
+haps = sorted(phy.hap_var)
+for case in range(12):
+    if time.time() - t_start > opts.budget * 1.3:
+        break
+    n_cols = int(rng.choice([1, 3, 4, 5, 63, 64, 65, 1023, 1024, 1025, 3000, 5408]))
+    first = int(rng.integers(0, len(haps) - n_cols + 1))
+    sub = haps[first:first + n_cols]
+    tables = preprocess.HapVarTables.build(refseq, phy, sub)
+    n_rows = int(rng.choice([1, 9, 130, 1000, 5000]))
+    read_len = int(rng.choice([30, 150, 150, 600, 3000]))
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=int(rng.integers(1, 1 << 30)),
+                                              read_len=read_len, contrib=(0, n_cols // 2, n_cols - 1))
+    obs = obs.copy()
+    obs[rng.random(obs.size) < 0.02] = ord("N")
+    want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, row_ptr, site, obs, n_cols)
+    line = "build %2d: %5d rows x %4d columns, read length %4d (up to %d sites per row):" % (
+        case, n_rows, n_cols, read_len, int(numpy.diff(row_ptr).max()))
+    for kernel in ("lut", "bytes", "packed"):
+        if kernel == "packed" and tables.packed() is None:
+            continue
+        for sort_rows in ((False, True) if kernel == "lut" else (False,)):
+            got = preprocess.build_em_matrix_device(tables, row_ptr, site, obs, kernel=kernel,
+                                                    sort_rows=sort_rows).cpu().numpy()
+            if not numpy.array_equal(got, want):
+                fails += 1
+                line += "  %s%s MISMATCH" % (kernel, "+sort" if sort_rows else "")
+    print(line + ("" if "MISMATCH" in line else "  bit-exact"))
+    sys.stdout.flush()
+print("%d mismatches" % fails)
+sys.exit(1 if fails else 0)
