@@ -455,7 +455,21 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(const double *__r
     for (int h = t; h < H; h += FIN_THREADS) s += pc[h] * cs[h];
     const double ltot = log(block_reduce<FIN_THREADS, false>(s, scratch));
     double l1 = 0.0;
-    for (int h = t; h < H; h += FIN_THREADS) {
+    constexpr int FIN_KEEP = 8;                     // columns per thread whose new value stays in registers (8192 columns)
+    double vk[FIN_KEEP], ek[FIN_KEEP];
+#pragma unroll
+    for (int q = 0; q < FIN_KEEP; ++q) {
+        const int h = t + q * FIN_THREADS;
+        vk[q] = 0.0;
+        ek[q] = 0.0;
+        if (h < H) {
+            vk[q] = lc[h] + log(cs[h]) - ltot;
+            ek[q] = exp(vk[q]);
+            ln[h] = vk[q];
+            l1 += fabs(ek[q] - pc[h]);
+        }
+    }
+    for (int h = t + FIN_KEEP * FIN_THREADS; h < H; h += FIN_THREADS) {       // wider than 8192 (log-space paths only)
         const double v = lc[h] + log(cs[h]) - ltot;
         ln[h] = v;
         l1 += fabs(exp(v) - pc[h]);
@@ -464,12 +478,22 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(const double *__r
     const int iters = st->iters + 1;
     const bool conv = l1 < tol;
     const bool stop = conv || iters >= max_iter;
-    if (!stop)
-        for (int h = t; h < H; h += FIN_THREADS) {
+    if (!stop) {
+        // the exponential computed for the L1 test IS the next pass's proportion: same bits, one exp less
+#pragma unroll
+        for (int q = 0; q < FIN_KEEP; ++q) {
+            const int h = t + q * FIN_THREADS;
+            if (h < H) {
+                lc[h] = vk[q];
+                pc[h] = ek[q];
+            }
+        }
+        for (int h = t + FIN_KEEP * FIN_THREADS; h < H; h += FIN_THREADS) {
             const double v = ln[h];
             lc[h] = v;
             pc[h] = exp(v);
         }
+    }
     __syncthreads();
     if (t == 0) {
         st->iters = iters;
