@@ -226,6 +226,10 @@ def main(argv=None):
         else:
             dist.init_process_group(opts.backend, rank=rank, world_size=world)
     lib = _lib.load()
+    if world > n_dev:
+        # ranks sharing a GPU (gloo test set-up only): two persistent one-launch loops on one device could
+        # starve each other (include/mixemt_hip.h, mxm_em_loop)
+        lib.mxm_set_loop_fused(0, 0)
 
     # ---- which rows live here ---------------------------------------------------------------
     scaling = opts.scaling or ("weak" if opts.rows is not None else "strong")

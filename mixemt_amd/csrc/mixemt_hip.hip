@@ -28,6 +28,7 @@
 #include <string.h>
 #include <math.h>
 #include <algorithm>
+#include <mutex>
 #include <utility>
 #include <vector>
 
@@ -683,6 +684,12 @@ static void launch_fused(int nwg, hipStream_t s, const double *P, int64_t ldp, c
 static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t R, int32_t H, int32_t B,
                          double *props_cur, double *ln_cur, double *ln_new, mxm_em_state *state, double tol,
                          int32_t max_iter, int32_t chunk, void *ws, hipStream_t s, mxm_em_state *state_host) {
+    // The persistent grid needs every workgroup resident, one per CU.  Two such grids in flight on one
+    // device (two host threads, two streams) can each hold a part of the CUs and wait for the rest for
+    // ever -- the bounded spins would end both with an error after seconds.  Inside one process the
+    // launches are therefore serialised here; across processes sharing a GPU nothing can (see the header).
+    static std::mutex one_loop_at_a_time;
+    std::lock_guard<std::mutex> guard(one_loop_at_a_time);
     const int nwg = num_cu() < MXM_MAX_WG ? num_cu() : MXM_MAX_WG;
     const int64_t ldpart = part_ld(H);
     char *base = static_cast<char *>(ws);

@@ -35,6 +35,11 @@ def _worker(rank, world, port, out_dir, name, seed, n_multi, mode, backend="gloo
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     torch.cuda.set_device(0)
+    if world > 1:
+        # two rank PROCESSES share this box's one GPU: two persistent one-launch loops at once could
+        # starve each other (include/mixemt_hip.h, mxm_em_loop), so the shared-GPU runs take the kernels
+        from mixemt_amd import _lib
+        _lib.load().mxm_set_loop_fused(0, 0)
     if backend == "nccl":
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=torch.device("cuda", 0))
     else:
