@@ -813,7 +813,10 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     while (!order.empty()) {
         // the tiles of this chunk: flat list of restart indices + tile sizes
         std::vector<int> members, sizes;
-        if (g_compact_restarts == 2 && (int)order.size() > window) {
+        // (with one restart per pass every schedule costs the same: no rotation, the tile list then only
+        // changes when a restart stops and a captured graph stays valid in between)
+        const bool rotating = g_compact_restarts == 2 && window > 1 && (int)order.size() > window;
+        if (rotating) {
             members.assign(order.begin(), order.begin() + window);
             sizes.push_back(window);
             std::rotate(order.begin(), order.begin() + window, order.end());       // they go to the back of the queue
@@ -849,7 +852,7 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
             return 0;
         };
         bool launched = false;
-        if (want_graph) {
+        if (want_graph && !rotating) {                 // a rotating tile list would be re-captured every chunk
             std::vector<int> key(members);
             key.insert(key.end(), sizes.begin(), sizes.end());
             if (exec == nullptr || key != graph_key) {
