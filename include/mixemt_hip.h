@@ -188,7 +188,7 @@ int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int64_t R, int
 /*
  * The run_em inner loop for ONE rank -- em.py:126-143: repeats
  * {mxm_em_iter; mxm_m_finalize} on `stream` until every restart is done.
- * Matrices of up to 1e8 cells (H <= 6144) run the whole loop in ONE persistent launch instead (one
+ * A single restart on a matrix of up to 1e8 cells (H <= 6144) runs its whole loop in ONE persistent launch instead (one
  * workgroup per CU, grid barriers; same results up to rounding of the summation order).  That grid needs
  * the device to itself while it runs: calls from several threads of one process are serialised by the
  * library; a second PROCESS running such a loop on the same GPU at the same moment can starve both

@@ -649,7 +649,11 @@ extern "C" int mxm_set_loop_fused(int32_t mode, int32_t chunk) {
 
 static size_t fused_sync_bytes() { return (sizeof(fused_sync) + 255) & ~(size_t)255; }
 
-static bool fused_eligible(const double *P, int64_t ldp, int64_t R, int H, size_t ws_bytes, bool p_is_f32) {
+// `running`: restarts that still have iterations to do.  Automatic mode takes the one-launch loop for ONE
+// restart only: it runs restarts one after another (17 / 26 / 80 us per restart-iteration at 600 / 2400 /
+// 10 000 rows), while the per-iteration kernels share each pass between up to four of them (11 / 15 / 27 us
+// from three restarts on; profiles/r02/small_runs_restarts.txt).
+static bool fused_eligible(const double *P, int64_t ldp, int64_t R, int H, size_t ws_bytes, bool p_is_f32, int running) {
     if (g_loop_fused == 0 || p_is_f32 || P == nullptr || !mxm_linear_supported(H)) return false;
     if ((ldp & 1) || (reinterpret_cast<uintptr_t>(P) & 15)) return false;
     int nwg = num_cu() < MXM_MAX_WG ? num_cu() : MXM_MAX_WG;
@@ -659,7 +663,7 @@ static bool fused_eligible(const double *P, int64_t ldp, int64_t R, int H, size_
     if ((int64_t)nwg * part_ld(H) * 8 >= ((int64_t)1 << 31)) return false;  // one buffer descriptor over the partials
     if (ws_bytes < fused_sync_bytes() + (size_t)(nwg + 2) * part_ld(H) * sizeof(double)) return false;
     if (g_loop_fused == 1) return true;
-    return (double)R * (double)H <= g_fused_cells;
+    return running <= 1 && (double)R * (double)H <= g_fused_cells;
 }
 
 // Diagnostic (-DFUSED_STAMPS builds): the per-phase clock sums of the last one-launch loop, from the
@@ -764,7 +768,11 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     if (g_progress != nullptr && check_every > g_progress_every) check_every = g_progress_every;
     hipStream_t caller = (hipStream_t)stream;
     (void)num_cu();                                    // device query outside any capture
-    if (fused_eligible(P, ldp, R, (int)H, ws_bytes, p_is_f32)) {
+    HIP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, caller));
+    HIP_TRY(hipStreamSynchronize(caller));
+    int running = 0;
+    for (int b = 0; b < B; ++b) running += (state_host[b].done == 0) ? 1 : 0;
+    if (fused_eligible(P, ldp, R, (int)H, ws_bytes, p_is_f32, running)) {
         // cache-resident matrix: the whole loop in one persistent launch on the caller's stream
         // (the host only waits for it; nothing is decided between iterations)
         int chunk = g_fused_chunk > 0 ? g_fused_chunk : max_iter;
