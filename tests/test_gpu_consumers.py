@@ -134,6 +134,35 @@ def test_front_end_to_matrix(b17):
     assert numpy.array_equal(mat, want)
 
 
+def test_fragment_without_a_usable_site_is_reported_never_silently_dropped(b17, capsys):
+    """A fragment whose only variant site was seen with two different bases has the empty signature: the
+    reference dies in int('') there (preprocess.py:156-160); here it is skipped -- with a warning on
+    stderr whatever the verbosity, and with its id on record."""
+    import sys as _sys
+    import os
+    _sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    from _fake_aln import FakeAln, FakeBam
+    from mixemt_amd import preprocess
+    refseq, phy, haps, tables = b17
+    sites = [int(p) for p in tables.sites]
+    pos = next(p for a, p, b in zip(sites, sites[1:], sites[2:]) if p - a > 12 and b - p > 12)   # an isolated site
+    start = pos - 5
+    assert [p for p in sites if start <= p < start + 12] == [pos]
+    seq = list(refseq[start:start + 12])
+    other = list(seq)
+    other[5] = "A" if seq[5] != "A" else "C"                  # the mate disagrees at the one variant site
+    clean_start = int(tables.sites[2000]) - 3
+    alns = [FakeAln("conflicted", start, 40, "".join(seq), [35] * 12, "12M"),
+            FakeAln("conflicted", start, 40, "".join(other), [35] * 12, "12M"),
+            FakeAln("fine", clean_start, 40, refseq[clean_start:clean_start + 40], [35] * 40, "40M")]
+    args = argparse.Namespace(min_mq=30, min_bq=30, verbose=False)
+    mat, wts, hap_order, read_ids = preprocess.build_em_input(FakeBam(alns), refseq, phy, args)
+    err = capsys.readouterr().err
+    assert "skipped 1 fragment" in err and "conflicted" in err
+    assert preprocess.build_em_input.last_dropped == ["conflicted"]
+    assert read_ids == [["fine"]] and list(wts) == [1] and mat.shape == (1, len(haps))
+
+
 def test_save_files_stream_from_device(tmp_path, run600):
     """dump_all with device tensors writes numpy.save-compatible files (bin/mixemt:239-242)."""
     from mixemt_amd import io as mio
