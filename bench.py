@@ -409,6 +409,12 @@ def bench_rows(opts, env):
         all_reduce_us = float(numpy.mean([q[2].elapsed_time(q[3]) for q in evs]) * 1e3) if use_dist else None
         st = em.read_state(state)[0]
         total_ok = st[1] == total
+    kernel_ms_per_rank = [float(kernel_ms.mean())]
+    if use_dist:
+        mine = torch.tensor([float(kernel_ms.mean())], dtype=torch.float64, device=dev)
+        every = [torch.zeros_like(mine) for _ in range(world)]
+        dist.all_gather(every, mine)
+        kernel_ms_per_rank = [float(x.item()) for x in every]
     # sanity (untimed): one more E+M pass; the M-step sums  sum_h p_h T_h  must add up to the
     # total weight of all ranks' rows, once per restart
     plan.em_iter(props_cur, ln_cur, state, colsum)
@@ -492,6 +498,7 @@ def bench_rows(opts, env):
         "cpu_baseline": cpu,
         "parity_in_run": parity,
         "all_reduce_us": all_reduce_us,
+        "kernel_ms_per_rank": kernel_ms_per_rank,
         "matrix_build_cells_per_s": float(n_rows) * n_haps / build_s,
         "linearize_ms": linearize_s * 1e3,
         "posterior_pass_ms": posterior_ms,
