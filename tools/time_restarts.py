@@ -46,6 +46,18 @@ for on in (2, 1, 0, 2, 1):
     print("schedule %d: EM loop %.3f s, iterations per restart %s (sum %d) -> %.1f restart-iterations/s"
           % (on, dt, iters, sum(iters), sum(iters) / dt))
 lib.mxm_set_compact_restarts(2)
+# one restart per pass (no sharing of matrix reads at all): the batched kernels' summation order differs,
+# the stopping iterations must not
+lib.mxm_set_batch_tile(1)
+torch.cuda.synchronize(); t0 = time.perf_counter()
+ln_cur, ln_new, states = em.em_loop(plan, inits, args.tolerance, args.max_iter)
+torch.cuda.synchronize(); dt = time.perf_counter() - t0
+lib.mxm_set_batch_tile(4)
+one = (ln_new.cpu().numpy(), [s[1] for s in states])
+print("one restart per pass: EM loop %.3f s, iterations per restart %s -> %.1f restart-iterations/s"
+      % (dt, one[1], sum(one[1]) / dt))
+print("tile 4 vs one per pass: same iteration counts: %s; max |delta props| %.3e"
+      % (one[1] == res[2][1], float(numpy.abs(numpy.exp(one[0]) - numpy.exp(res[2][0])).max())))
 for a in (1, 2):
     print("schedule %d vs 0: same iteration counts: %s; max |delta ln p| over finite entries: %.3e"
           % (a, res[0][1] == res[a][1],
