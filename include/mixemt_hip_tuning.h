@@ -59,7 +59,8 @@ int mxm_set_loop_graph(int32_t mode);
  * the kernels' own break-even is ~1.6e8; several restarts share the per-iteration kernels' passes, which
  * is faster from two restarts on) in ONE persistent launch (em_fused_loop_kernel: grid barriers instead of kernel
  * boundaries): mode -1 = automatic by size, 0 = never (per-iteration kernels), 1 = whenever the
- * shape allows.  chunk > 0 splits the loop into launches of that many iterations per restart
+ * shape allows, 2 = as 1 but always with the rows split over the workgroups (matrices of up to 1536
+ * rows normally take the transposed form, em_fused_cols_kernel: columns split, matrix in registers).  chunk > 0 splits the loop into launches of that many iterations per restart
  * (same bits: a resumed restart continues from its saved proportions); 0 = one launch.
  * Against the per-iteration kernels the results differ by rounding only (another summation
  * order; the linear proportions are carried as p T / tot instead of exp(ln p')).

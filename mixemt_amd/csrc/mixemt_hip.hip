@@ -21,6 +21,7 @@
 //   estep_kernels.hpp   estep_log_kernel (any H), estep_wide_kernel (register-resident posterior pass)
 //   aux_kernels.hpp     log_normalize, l1_exp_diff, add_scalar, row_argmax_votes, assign_reads, gather, fold, diag_stream_read
 //   fused_kernels.hpp   em_fused_loop_kernel (the whole EM loop of a cache-resident matrix in one persistent launch)
+//   fused_cols_kernels.hpp  em_fused_cols_kernel (the same for up to 1536 rows, columns split over the workgroups, matrix in registers)
 // This file: the host side of the C ABI (shape checks, grid sizing, dispatch, the loop driver).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -42,6 +43,7 @@
 #include "estep_kernels.hpp"
 #include "aux_kernels.hpp"
 #include "fused_kernels.hpp"
+#include "fused_cols_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------
 // host side of the C ABI
@@ -639,10 +641,12 @@ extern "C" int mxm_set_progress_callback(mxm_progress_fn fn, void *user, int32_t
 // ---- one-launch loop for cache-resident matrices (fused_kernels.hpp) ---------------------------
 static int g_loop_fused = -1;          // -1 auto (R * H below g_fused_cells), 0 never, 1 whenever the shape allows
 static int g_fused_chunk = 0;          // iterations per launch (0 = run to the end in one launch)
+static int g_fused_cols = 1;           // matrices of up to 1536 rows take the transposed form (columns split)
 static double g_fused_cells = 1.0e8;   // ~18 000 rows at H = 5408 (800 MB of fp64): measured break-even against the
                                        // per-iteration kernels is ~30 000 rows (profiles/r02/small_runs.txt)
 extern "C" int mxm_set_loop_fused(int32_t mode, int32_t chunk) {
     g_loop_fused = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+    g_fused_cols = (mode == 2) ? 0 : 1;                // mode 2: one launch, rows split (A/B against the transposed form)
     g_fused_chunk = chunk > 0 ? chunk : 0;
     return 0;
 }
@@ -673,6 +677,26 @@ extern "C" int mxm_diag_fused_stamps(const void *ws, unsigned long long *out_hos
     const fused_sync *sync = reinterpret_cast<const fused_sync *>(ws);
     HIP_TRY(hipMemcpy(out_host, sync->stamps, sizeof(sync->stamps), hipMemcpyDeviceToHost));
     return 0;
+}
+
+// The transposed one-launch loop (fused_cols_kernels.hpp): up to 1536 rows, a 256-CU grid.
+static bool fused_cols_eligible(int64_t R, int H, int nwg) {
+    if (!g_fused_cols || nwg != 256) return false;          // the Z reduce is laid out for 256 partials per row
+    if (R > (int64_t)FCOLS_MAX_RPT * FCOLS_THREADS || (R + nwg - 1) / nwg > 2 * FCOLS_NQ) return false;
+    const int cp = (H + nwg - 1) / nwg;
+    if (cp > FCOLS_MAX_CP) return false;
+    // 24 columns x 3 rows per thread do not fit the register file without scratch (22 x 3 -- Build 17's width
+    // on 256 CUs -- do): the widest matrices up to 1024 rows
+    return cp <= 22 || R <= 2 * (int64_t)FCOLS_THREADS;
+}
+
+template <int CP, int RPT>
+static void launch_fused_cols(int nwg, hipStream_t s, const double *P, int64_t ldp, const double *w, int64_t R, int H,
+                              int B, double *ln_cur, double *ln_new, double *props_cur, mxm_em_state *state, double tol,
+                              int max_iter, int chunk, double *zpart, int64_t ldz, double *cbuf, double *l1part,
+                              fused_sync *sync) {
+    hipLaunchKernelGGL((em_fused_cols_kernel<CP, RPT>), dim3(nwg), dim3(FCOLS_THREADS), 0, s, P, ldp, w, R, H, B, ln_cur,
+                       ln_new, props_cur, state, tol, max_iter, chunk, zpart, ldz, cbuf, l1part, sync);
 }
 
 template <int NCH>
@@ -715,6 +739,32 @@ static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t 
         if (g_progress != nullptr) g_progress(state_host, B, g_progress_user);
         if (all_done) return 0;
         HIP_TRY(hipMemsetAsync(sync, 0, fused_sync_bytes(), s));       // every polled word, before EVERY launch
+        if (fused_cols_eligible(R, (int)H, nwg)) {
+            // smallest matrices: columns split over the workgroups, the matrix in registers (workspace:
+            // [sync][z partials nwg x ldz][c ldz][l1 partials nwg], far inside what mxm_workspace_bytes reserves)
+            const int64_t ldz = (R + 1) & ~(int64_t)1;
+            double *zpart = reinterpret_cast<double *>(base + fused_sync_bytes());
+            double *cbuf = zpart + (int64_t)nwg * ldz;
+            double *l1part = cbuf + ldz;
+            const int cp = ((int)H + nwg - 1) / nwg;
+            const int rpt = (int)((R + FCOLS_THREADS - 1) / FCOLS_THREADS);
+#define FC_ARGS nwg, s, P, ldp, w, R, (int)H, (int)B, ln_cur, ln_new, props_cur, state, tol, (int)max_iter, (int)chunk, zpart, ldz, cbuf, l1part, sync
+            if (cp <= 12) {
+                if (rpt <= 1) launch_fused_cols<12, 1>(FC_ARGS);
+                else if (rpt == 2) launch_fused_cols<12, 2>(FC_ARGS);
+                else launch_fused_cols<12, 3>(FC_ARGS);
+            } else if (cp <= 22) {
+                if (rpt <= 1) launch_fused_cols<22, 1>(FC_ARGS);
+                else if (rpt == 2) launch_fused_cols<22, 2>(FC_ARGS);
+                else launch_fused_cols<22, 3>(FC_ARGS);
+            } else {
+                if (rpt <= 1) launch_fused_cols<24, 1>(FC_ARGS);
+                else launch_fused_cols<24, 2>(FC_ARGS);
+            }
+#undef FC_ARGS
+            HIP_TRY(hipGetLastError());
+            continue;
+        }
         switch (nch) {
 #define FU_CASE(n) case n: launch_fused<n>(nwg, s, P, ldp, w, R, (int)H, (int)B, ln_cur, ln_new, props_cur, state, tol, (int)max_iter, (int)chunk, partial, ldpart, tbuf, sync); break;
             FU_CASE(1) FU_CASE(2) FU_CASE(3)

@@ -576,10 +576,10 @@ def test_row_without_any_possible_haplogroup_poisons_like_the_reference(n_rows, 
             assert numpy.abs(new - want_new).max() < 1e-12
 
 
-@pytest.mark.parametrize("fused", [1, 0])
+@pytest.mark.parametrize("fused", [1, 2, 0])
 def test_verbose_progress_text_is_the_references(capsys, fused):
     """-v: 'Starting EM run 1...', a dot per 10 iterations WHILE the loop runs, 'Converged! (n)'
-    (em.py:119-135) -- through the one-launch loop (chunks of 10) and the per-iteration kernels."""
+    (em.py:119-135) -- through both one-launch loops (chunks of 10) and the per-iteration kernels."""
     from mixemt_amd import _lib, em
     g = golden("g7_config1")
     lib = _lib.load()

@@ -36,7 +36,10 @@ def test_fused_loop_reproduces_the_reference_runs(b17, lib, name, seed, n_multi)
     g = golden(name)
     mat = _b17_matrix(tables, g, len(haps))
     runs = {}
-    for label, mode, chunk in (("fused", 1, 0), ("kernels", 0, 0), ("chunks", 1, 7)):
+    # 600 rows: mode 1 takes the transposed one-launch loop (columns split over the workgroups, matrix in
+    # registers), mode 2 the row-split one-launch loop, mode 0 the per-iteration kernels
+    for label, mode, chunk in (("fused", 1, 0), ("rows", 2, 0), ("kernels", 0, 0), ("chunks", 1, 7),
+                               ("rows-chunks", 2, 5)):
         lib.mxm_set_loop_fused(mode, chunk)
         numpy.random.seed(seed)
         res = em.run_em_ex(mat, g["wts"], em_args(n_multi=n_multi))
@@ -51,12 +54,16 @@ def test_fused_loop_reproduces_the_reference_runs(b17, lib, name, seed, n_multi)
     # a resumed launch continues from the saved proportions: chunking changes nothing at all
     assert numpy.array_equal(runs["fused"]["run_props"], runs["chunks"]["run_props"])
     assert runs["fused"]["l1"] == runs["chunks"]["l1"]
+    assert numpy.array_equal(runs["rows"]["run_props"], runs["rows-chunks"]["run_props"])
+    # the two one-launch forms differ by summation order and by how the normaliser is formed
+    assert numpy.abs(runs["fused"]["run_props"] - runs["rows"]["run_props"]).max() < 1e-12
     # against the per-iteration kernels: another summation order, nothing more
     assert numpy.abs(runs["fused"]["run_props"] - runs["kernels"]["run_props"]).max() < 1e-12
 
 
 @pytest.mark.parametrize("n_rows,n_haps,seed", [(1, 5408, 1), (5, 777, 2), (300, 66, 3), (257, 6144, 4),
-                                                (1500, 1001, 5), (64, 5408, 6), (4000, 512, 7)])
+                                                (1500, 1001, 5), (64, 5408, 6), (4000, 512, 7), (1024, 5408, 8),
+                                                (1025, 5408, 9), (1536, 3072, 10), (1537, 3000, 11), (513, 6100, 12)])
 def test_fused_loop_matches_oracle_on_random_shapes(lib, n_rows, n_haps, seed):
     """Fewer rows than workgroups, odd widths, the widest instance: iteration count and result of
     the oracle's run_em (weights with repeats, a zero weight, -inf entries)."""
@@ -70,18 +77,19 @@ def test_fused_loop_matches_oracle_on_random_shapes(lib, n_rows, n_haps, seed):
     wts = rng.integers(0, 5, size=n_rows).astype(numpy.float64)
     wts[0] = 2.0
     args = em_args(max_iter=300)
-    lib.mxm_set_loop_fused(1, 0)
-    numpy.random.seed(seed)
-    res = em.run_em_ex(mat, wts, args)
     trace = []
     numpy.random.seed(seed)
     props, mix = em_oracle.run_em(mat, wts, args, trace=trace)
-    assert res["iters"] == [trace[0]["iters"]]
-    assert numpy.abs(res["props"] - props).max() < PROPS_ATOL
-    got = res["read_mix"].cpu().numpy()
     finite = numpy.isfinite(mix)
-    assert numpy.array_equal(numpy.isfinite(got), finite)
-    assert numpy.abs(numpy.exp(got) - numpy.exp(mix)).max() < 1e-9
+    for mode in (1, 2):                          # transposed form where it applies / rows split
+        lib.mxm_set_loop_fused(mode, 0)
+        numpy.random.seed(seed)
+        res = em.run_em_ex(mat, wts, args)
+        assert res["iters"] == [trace[0]["iters"]], mode
+        assert numpy.abs(res["props"] - props).max() < PROPS_ATOL
+        got = res["read_mix"].cpu().numpy()
+        assert numpy.array_equal(numpy.isfinite(got), finite)
+        assert numpy.abs(numpy.exp(got) - numpy.exp(mix)).max() < 1e-9
 
 
 def test_fused_loop_runs_out_of_iterations_like_the_reference(lib):
@@ -90,15 +98,16 @@ def test_fused_loop_runs_out_of_iterations_like_the_reference(lib):
     from mixemt_amd import em
     rng = numpy.random.default_rng(9)
     mat = rng.normal(size=(200, 900)) * 2.0
-    lib.mxm_set_loop_fused(1, 0)
-    numpy.random.seed(4)
-    res = em.run_em_ex(mat, numpy.ones(200), em_args(max_iter=9))
-    assert res["iters"] == [9] and res["done"] == [2]
     trace = []
     numpy.random.seed(4)
     props, mix = em_oracle.run_em(mat, numpy.ones(200), em_args(max_iter=9), trace=trace)
-    assert numpy.abs(res["props"] - props).max() < PROPS_ATOL
-    assert numpy.abs(res["read_mix"].cpu().numpy() - mix).max() < 1e-9
+    for mode in (1, 2):
+        lib.mxm_set_loop_fused(mode, 0)
+        numpy.random.seed(4)
+        res = em.run_em_ex(mat, numpy.ones(200), em_args(max_iter=9))
+        assert res["iters"] == [9] and res["done"] == [2]
+        assert numpy.abs(res["props"] - props).max() < PROPS_ATOL
+        assert numpy.abs(res["read_mix"].cpu().numpy() - mix).max() < 1e-9
 
 
 def test_fused_loop_poisons_like_the_reference(lib):
@@ -108,19 +117,20 @@ def test_fused_loop_poisons_like_the_reference(lib):
     rng = numpy.random.default_rng(10)
     mat = rng.normal(size=(50, 300))
     mat[7, :] = -numpy.inf
-    lib.mxm_set_loop_fused(1, 0)
-    wts = numpy.ones(50)
-    numpy.random.seed(1)
-    res = em.run_em_ex(mat, wts, em_args(max_iter=12), want_read_mix=False)
-    assert res["iters"] == [12] and res["done"] == [2] and numpy.isnan(res["props"]).all()
-    wts[7] = 0.0
-    numpy.random.seed(1)
-    res = em.run_em_ex(mat, wts, em_args(max_iter=500), want_read_mix=False)
-    trace = []
-    numpy.random.seed(1)
-    with numpy.errstate(invalid="ignore"):
-        props, _ = em_oracle.run_em(mat, wts, em_args(max_iter=500), trace=trace)
-    assert res["iters"] == [trace[0]["iters"]] and numpy.abs(res["props"] - props).max() < PROPS_ATOL
+    for mode in (1, 2):
+        lib.mxm_set_loop_fused(mode, 0)
+        wts = numpy.ones(50)
+        numpy.random.seed(1)
+        res = em.run_em_ex(mat, wts, em_args(max_iter=12), want_read_mix=False)
+        assert res["iters"] == [12] and res["done"] == [2] and numpy.isnan(res["props"]).all()
+        wts[7] = 0.0
+        numpy.random.seed(1)
+        res = em.run_em_ex(mat, wts, em_args(max_iter=500), want_read_mix=False)
+        trace = []
+        numpy.random.seed(1)
+        with numpy.errstate(invalid="ignore"):
+            props, _ = em_oracle.run_em(mat, wts, em_args(max_iter=500), trace=trace)
+        assert res["iters"] == [trace[0]["iters"]] and numpy.abs(res["props"] - props).max() < PROPS_ATOL
 
 
 def test_auto_selection_by_size(b17, lib):

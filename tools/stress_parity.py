@@ -67,7 +67,8 @@ for case in range(opts.cases):
     want_iters = [t["iters"] for t in trace]
     line = "case %3d: %5d x %5d, n_multi %d, max_iter %3d, iterations %s" % (case, n_rows, n_haps, n_multi,
                                                                              args.max_iter, want_iters)
-    for label, mode, chunk in (("one-launch", 1, 0), ("kernels", 0, 0), ("chunks", 1, int(rng.integers(1, 9)))):
+    for label, mode, chunk in (("one-launch", 1, 0), ("rows-split", 2, 0), ("kernels", 0, 0),
+                               ("chunks", 1, int(rng.integers(1, 9))), ("rows-chunks", 2, int(rng.integers(1, 9)))):
         lib.mxm_set_loop_fused(mode, chunk)
         numpy.random.seed(seed)
         res = em.run_em_ex(mat, wts, args)

@@ -2,7 +2,9 @@
 """
 Wall time per EM iteration of whole run_em calls on cache-resident matrices (the regime real
 mixemt inputs live in: de-duplicated signatures, preprocess.py:163-174): the one-launch loop
-(em_fused_loop_kernel) against the per-iteration kernels, with and without the hipGraph replay.
+("one launch": em_fused_cols_kernel up to 1536 rows -- columns split over the workgroups, matrix in
+registers -- and em_fused_loop_kernel above; "rows split" forces the latter) against the per-iteration
+kernels, with and without the hipGraph replay.
 
     python tools/time_small_runs.py [--rows 600,2400,10000,...]
 """
@@ -38,8 +40,9 @@ for n_rows in [int(x) for x in opts.rows.split(",")]:
     numpy.random.seed(7)
     init = numpy.stack([em.init_props(len(haps), 1.0) for _ in range(opts.restarts)])
     out = {}
-    for label, fused, graph in (("one launch", 1, 0), ("kernels", 0, 0), ("kernels+graph", 0, 1),
-                                ("one launch", 1, 0), ("kernels", 0, 0)):
+    for label, fused, graph in (("one launch", 1, 0), ("one launch, rows split", 2, 0), ("kernels", 0, 0),
+                                ("kernels+graph", 0, 1), ("one launch", 1, 0), ("one launch, rows split", 2, 0),
+                                ("kernels", 0, 0)):
         lib.mxm_set_loop_fused(fused, 0)
         lib.mxm_set_loop_graph(graph)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -56,7 +59,7 @@ for n_rows in [int(x) for x in opts.rows.split(",")]:
                       + ", ".join("%s %.2f" % (n, st[i] * 0.01 / st[5]) for i, n in enumerate(names))
                       + "  (sum %.2f)" % (sum(st[:5]) * 0.01 / st[5]))
         n_it = sum(st[1] for st in states)
-        print("%7d rows (%6.1f MB)  %-14s %4d restart-iterations  %8.2f ms  %7.1f us per restart-iteration"
+        print("%7d rows (%6.1f MB)  %-23s %4d restart-iterations  %8.2f ms  %7.1f us per restart-iteration"
               % (n_rows, n_rows * len(haps) * 8 / 1e6, label, n_it, dt * 1e3, dt * 1e6 / n_it))
     print("        max |delta ln p| one launch vs kernels over finite entries: %.2e"
           % float(numpy.nanmax(numpy.abs(numpy.where(numpy.isfinite(out["kernels"]), out["one launch"] - out["kernels"], 0.0)))))
