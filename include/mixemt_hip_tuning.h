@@ -55,7 +55,7 @@ int mxm_set_progress_callback(void (*fn)(const struct mxm_em_state *state_host, 
 int mxm_set_loop_graph(int32_t mode);
 
 /*
- * mxm_em_loop runs the whole loop of ONE restart on a small matrix (R * H <= 1e8 cells = 800 MB of fp64;
+ * mxm_em_loop runs the whole loop of ONE restart (up to three on matrices of at most 1536 rows) on a small matrix (R * H <= 1e8 cells = 800 MB of fp64;
  * the kernels' own break-even is ~1.6e8; several restarts share the per-iteration kernels' passes, which
  * is faster from two restarts on) in ONE persistent launch (em_fused_loop_kernel: grid barriers instead of kernel
  * boundaries): mode -1 = automatic by size, 0 = never (per-iteration kernels), 1 = whenever the

@@ -89,7 +89,12 @@ __global__ __launch_bounds__(FCOLS_THREADS, 2) void em_fused_cols_kernel(
 
     const auto z_rsrc = __builtin_amdgcn_make_buffer_rsrc(zpart, 0, (int)((int64_t)nwg * ldz * 8), 0x00020000);
     const auto c_rsrc = __builtin_amdgcn_make_buffer_rsrc(cbuf, 0, (int)(ldz * 8), 0x00020000);
-    const auto l_rsrc = __builtin_amdgcn_make_buffer_rsrc(l1part, 0, nwg * 8, 0x00020000);
+    // L1 partials are double buffered by publish: a workgroup that leaves a restart right after the test (stop
+    // or end of chunk) publishes the NEXT restart's partials with no barrier in between, while a slower one
+    // may still be summing this test's -- they must not share a buffer.  (Two publishes later a barrier has
+    // passed that the slow one could only reach after its reads.)
+    const auto l_rsrc = __builtin_amdgcn_make_buffer_rsrc(l1part, 0, 2 * nwg * 8, 0x00020000);
+    int lbuf = 0;
     typedef unsigned int u2v __attribute__((ext_vector_type(2)));
     auto ld_f64 = [&](decltype(z_rsrc) rsrc, int byte_off) -> double {
         return __builtin_bit_cast(double, (u2v)__builtin_amdgcn_raw_buffer_load_b64(rsrc, byte_off, 0, FUSED_SC1));
@@ -133,7 +138,8 @@ __global__ __launch_bounds__(FCOLS_THREADS, 2) void em_fused_cols_kernel(
                 const int64_t r = (int64_t)t + (int64_t)i * THREADS;
                 if (r < R) st_f64(z_rsrc, (int)(((int64_t)blockIdx.x * ldz + r) * 8), z[i]);
             }
-            if (t == 0) st_f64(l_rsrc, (int)blockIdx.x * 8, l1_mine);
+            lbuf ^= 1;
+            if (t == 0) st_f64(l_rsrc, (lbuf * nwg + (int)blockIdx.x) * 8, l1_mine);
             asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (!fused_grid_barrier(sync, ++epoch, nwg, &ok_flag)) { done = -1; break; }
 
@@ -152,7 +158,7 @@ __global__ __launch_bounds__(FCOLS_THREADS, 2) void em_fused_cols_kernel(
             }
             if (pending) {
                 double v = 0.0;
-                for (int gg = t; gg < nwg; gg += THREADS) v += ld_f64(l_rsrc, gg * 8);
+                for (int gg = t; gg < nwg; gg += THREADS) v += ld_f64(l_rsrc, (lbuf * nwg + gg) * 8);
                 l1 = block_sum(v);
                 ++iters;
                 ++decided;

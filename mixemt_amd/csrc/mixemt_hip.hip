@@ -653,6 +653,17 @@ extern "C" int mxm_set_loop_fused(int32_t mode, int32_t chunk) {
 
 static size_t fused_sync_bytes() { return (sizeof(fused_sync) + 255) & ~(size_t)255; }
 
+// The transposed one-launch loop (fused_cols_kernels.hpp): up to 1536 rows, a 256-CU grid.
+static bool fused_cols_eligible(int64_t R, int H, int nwg) {
+    if (!g_fused_cols || nwg != 256) return false;          // the Z reduce is laid out for 256 partials per row
+    if (R > (int64_t)FCOLS_MAX_RPT * FCOLS_THREADS || (R + nwg - 1) / nwg > 2 * FCOLS_NQ) return false;
+    const int cp = (H + nwg - 1) / nwg;
+    if (cp > FCOLS_MAX_CP) return false;
+    // 24 columns x 3 rows per thread do not fit the register file without scratch (22 x 3 -- Build 17's width
+    // on 256 CUs -- do): the widest matrices up to 1024 rows
+    return cp <= 22 || R <= 2 * (int64_t)FCOLS_THREADS;
+}
+
 // `running`: restarts that still have iterations to do.  Automatic mode takes the one-launch loop for ONE
 // restart only: it runs restarts one after another (17 / 26 / 80 us per restart-iteration at 600 / 2400 /
 // 10 000 rows), while the per-iteration kernels share each pass between up to four of them (11 / 15 / 27 us
@@ -667,6 +678,9 @@ static bool fused_eligible(const double *P, int64_t ldp, int64_t R, int H, size_
     if ((int64_t)nwg * part_ld(H) * 8 >= ((int64_t)1 << 31)) return false;  // one buffer descriptor over the partials
     if (ws_bytes < fused_sync_bytes() + (size_t)(nwg + 2) * part_ld(H) * sizeof(double)) return false;
     if (g_loop_fused == 1) return true;
+    // the transposed form runs a restart-iteration in 12 us at 600 rows whatever the number of restarts; the
+    // batched kernels need 18 / 13 / 11 us with 2 / 3 / 4 restarts per pass: up to three restarts stay here
+    if (running <= 3 && fused_cols_eligible(R, H, nwg)) return true;
     return running <= 1 && (double)R * (double)H <= g_fused_cells;
 }
 
@@ -677,17 +691,6 @@ extern "C" int mxm_diag_fused_stamps(const void *ws, unsigned long long *out_hos
     const fused_sync *sync = reinterpret_cast<const fused_sync *>(ws);
     HIP_TRY(hipMemcpy(out_host, sync->stamps, sizeof(sync->stamps), hipMemcpyDeviceToHost));
     return 0;
-}
-
-// The transposed one-launch loop (fused_cols_kernels.hpp): up to 1536 rows, a 256-CU grid.
-static bool fused_cols_eligible(int64_t R, int H, int nwg) {
-    if (!g_fused_cols || nwg != 256) return false;          // the Z reduce is laid out for 256 partials per row
-    if (R > (int64_t)FCOLS_MAX_RPT * FCOLS_THREADS || (R + nwg - 1) / nwg > 2 * FCOLS_NQ) return false;
-    const int cp = (H + nwg - 1) / nwg;
-    if (cp > FCOLS_MAX_CP) return false;
-    // 24 columns x 3 rows per thread do not fit the register file without scratch (22 x 3 -- Build 17's width
-    // on 256 CUs -- do): the widest matrices up to 1024 rows
-    return cp <= 22 || R <= 2 * (int64_t)FCOLS_THREADS;
 }
 
 template <int CP, int RPT>
@@ -741,7 +744,7 @@ static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t 
         HIP_TRY(hipMemsetAsync(sync, 0, fused_sync_bytes(), s));       // every polled word, before EVERY launch
         if (fused_cols_eligible(R, (int)H, nwg)) {
             // smallest matrices: columns split over the workgroups, the matrix in registers (workspace:
-            // [sync][z partials nwg x ldz][c ldz][l1 partials nwg], far inside what mxm_workspace_bytes reserves)
+            // [sync][z partials nwg x ldz][c ldz][l1 partials 2 x nwg], far inside what mxm_workspace_bytes reserves)
             const int64_t ldz = (R + 1) & ~(int64_t)1;
             double *zpart = reinterpret_cast<double *>(base + fused_sync_bytes());
             double *cbuf = zpart + (int64_t)nwg * ldz;
