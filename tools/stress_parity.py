@@ -67,6 +67,7 @@ for case in range(opts.cases):
     want_iters = [t["iters"] for t in trace]
     line = "case %3d: %5d x %5d, n_multi %d, max_iter %3d, iterations %s" % (case, n_rows, n_haps, n_multi,
                                                                              args.max_iter, want_iters)
+    seen = {}
     for label, mode, chunk in (("one-launch", 1, 0), ("rows-split", 2, 0), ("kernels", 0, 0),
                                ("chunks", 1, int(rng.integers(1, 9))), ("rows-chunks", 2, int(rng.integers(1, 9)))):
         lib.mxm_set_loop_fused(mode, chunk)
@@ -78,6 +79,13 @@ for case in range(opts.cases):
         ok = ok and numpy.array_equal(numpy.isfinite(got_mix), numpy.isfinite(want_mix))
         with numpy.errstate(all="ignore"):
             ok = ok and float(numpy.nanmax(numpy.abs(numpy.exp(got_mix) - numpy.exp(want_mix)))) < 1e-9
+        seen[label] = res
+        # chunked launches of one form must reproduce its single launch bit for bit, the reported L1 included
+        twin = {"chunks": "one-launch", "rows-chunks": "rows-split"}.get(label)
+        if twin is not None:
+            same = numpy.array_equal(res["run_props"], seen[twin]["run_props"], equal_nan=True)
+            same = same and all((a == b) or (a != a and b != b) for a, b in zip(res["l1"], seen[twin]["l1"]))
+            ok = ok and same
         if not ok:
             fails += 1
             line += "  %s MISMATCH (iters %s, dprops %.2e)" % (label, res["iters"],
