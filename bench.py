@@ -80,9 +80,10 @@ def parse_args(argv=None):
                          "restarts in total (config 5 uses 64)")
     ap.add_argument("--batch-tile", type=int, default=4,
                     help="restarts sharing one pass over the matrix (1 = unbatched schedule)")
-    ap.add_argument("--storage", default="f64", choices=["f64", "f32"],
-                    help="element type of the streamed matrix; f32 is a labelled opt-in variant "
-                         "(fp64 math on float-stored P), never the default")
+    ap.add_argument("--storage", default="f64", choices=["f64", "f32", "coded"],
+                    help="form of the streamed matrix; f32 is a labelled opt-in variant (fp64 math on "
+                         "float-stored P); coded = lossless row dictionaries (one byte per cell + the row's "
+                         "distinct fp64 values).  The default line measures f64 and reports coded beside it")
     ap.add_argument("--min-rows-per-wg", type=int, default=0, help="tuning knob (0 = library default)")
     ap.add_argument("--build-kernel", default="auto", choices=["auto", "packed", "bytes", "lut"])
     ap.add_argument("--force-dist", action="store_true",
@@ -143,7 +144,7 @@ def cpu_reference_leg(mat_rows, n_iters, tol=1e-4):
             "init": init, "ln_new": ln_props, "best": buf.argmax(axis=1)}
 
 
-def parity_in_run(em, torch, slab, cpu, n_iters, tol=1e-4):
+def parity_in_run(em, torch, slab, cpu, n_iters, tol=1e-4, storage="f64"):
     """
     The HIP path on the same slab, same init, same loop bounds as the oracle leg above
     (outside the timed region): proportions, stopping iteration and haplogroup calls.
@@ -151,7 +152,7 @@ def parity_in_run(em, torch, slab, cpu, n_iters, tol=1e-4):
     import numpy
     n_rows = slab.shape[0]
     wts = torch.ones(n_rows, dtype=torch.float64, device=slab.device)
-    plan = em.EmPlan(slab, wts, n_runs=1)
+    plan = em.EmPlan(slab, wts, n_runs=1, storage=storage)
     ln_cur, ln_new, states = em.em_loop(plan, cpu["init"][None, :], tol, n_iters)
     done, iters, l1 = states[0]
     post = em.posterior(plan, ln_cur[0])
@@ -163,6 +164,61 @@ def parity_in_run(em, torch, slab, cpu, n_iters, tol=1e-4):
             "l1_gpu": float(l1), "l1_cpu": cpu["l1"],
             "against": "oracle em_step x%d (em.py:57-91, :126-143) on the first %d rows of the same "
                        "matrix, same Dirichlet init" % (cpu["iters"], n_rows)}
+
+
+def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
+    """
+    The EM iteration of the default line over the SAME matrix in row-dictionary storage
+    (EmPlan(storage="coded")): same proportions in, column sums compared with the dense pass,
+    `steps` iterations timed the same way (HIP events around the whole step).
+    """
+    n_rows, n_haps = mat.shape
+    torch.cuda.synchronize()
+    cplan = em.EmPlan(mat, wts, n_runs=1, storage="coded")
+    if cplan.coded is None:
+        return None
+    t0 = time.perf_counter()
+    cplan._encode()
+    torch.cuda.synchronize()
+    encode_ms = (time.perf_counter() - t0) * 1e3
+    state = em.new_state(1, mat.device)
+    cs_dense = torch.zeros_like(props)
+    cs_coded = torch.zeros_like(props)
+    plan.em_iter(props, ln_props, state, cs_dense)
+    cplan.em_iter(props, ln_props, state, cs_coded)
+    rel = float(((cs_coded - cs_dense).abs() / cs_dense.abs().clamp_min(1e-300)).max().item())
+    ln_a, ln_b = ln_props.clone(), ln_props.clone()
+    p_cur = props.clone()
+    beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    kev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
+    for ev in kev:
+        ev.record()
+
+    def one(timed=False):
+        if timed:
+            lib.mxm_set_timing_events(kev[0].cuda_event, kev[1].cuda_event)
+        cplan.em_iter(p_cur, ln_a, state, cs_coded)
+        if timed:
+            lib.mxm_set_timing_events(None, None)
+        cplan.finalize(cs_coded, ln_a, ln_b, p_cur, state, 0.0, 1 << 30)
+    for _ in range(3):
+        one()
+    torch.cuda.synchronize()
+    beg.record()
+    for _ in range(steps):
+        one()
+    end.record()
+    one(timed=True)
+    torch.cuda.synchronize()
+    ms = beg.elapsed_time(end) / steps
+    kernel_ms = kev[0].elapsed_time(kev[1])
+    return {"ms_per_step": ms, "value": float(n_rows) * n_haps / (ms * 1e-3), "unit": "cells/s",
+            "kernel": "em_iter_coded_kernel", "kernel_ms": kernel_ms,
+            "bytes_per_iteration": float(cplan.coded_bytes),
+            "hbm_frac": cplan.coded_bytes / (kernel_ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
+            "rows_left_dense": int(cplan.coded_rest), "encode_ms": encode_ms, "max_rel_dcolsum": rel,
+            "note": "same iteration, matrix stored as one byte per cell + each row's distinct fp64 values "
+                    "(decodes to the dense matrix bit for bit); not the headline value"}
 
 
 def pmc_traffic(n_rows, n_haps):
@@ -311,10 +367,13 @@ def bench_rows(opts, env):
     plan = em.EmPlan(mat, wts, n_runs=n_runs, storage=opts.storage)     # allocates P and linearises once (untimed: hipMalloc)
     torch.cuda.synchronize()
     t0 = time.perf_counter()                      # timed again on the now-resident buffers
-    lin_fn = lib.mxm_linearize_f32 if opts.storage == "f32" else lib.mxm_linearize
-    _lib.check(lin_fn(mat.data_ptr(), mat.stride(0), n_rows, n_haps, plan.lin.data_ptr(),
-                      plan.lin.stride(0), plan.rowmax.data_ptr(),
-                      torch.cuda.current_stream().cuda_stream), "mxm_linearize")
+    if plan.coded is not None:
+        plan._encode()                            # mxm_encode_rows + the dense rest, second time
+    else:
+        lin_fn = lib.mxm_linearize_f32 if opts.storage == "f32" else lib.mxm_linearize
+        _lib.check(lin_fn(mat.data_ptr(), mat.stride(0), n_rows, n_haps, plan.lin.data_ptr(),
+                          plan.lin.stride(0), plan.rowmax.data_ptr(),
+                          torch.cuda.current_stream().cuda_stream), "mxm_linearize")
     torch.cuda.synchronize()
     linearize_s = time.perf_counter() - t0
     if rank == 0:
@@ -455,17 +514,30 @@ def bench_rows(opts, env):
                          "x %d haps of the same matrix, %.1f s; host has %d cores, 1 used like the "
                          "reference" % (leg["iters"], n_cpu, n_haps, leg["seconds"], os.cpu_count())}
         log("cpu baseline: %.3g cells/s (%.1f s)" % (leg["rate"], leg["seconds"]))
-        parity = parity_in_run(em, torch, mat[:n_cpu], leg, opts.cpu_iters)
+        parity = parity_in_run(em, torch, mat[:n_cpu], leg, opts.cpu_iters, storage=opts.storage)
         log("parity in run: max |dprops| %.2e, iterations equal %s, haplogroup calls equal %s"
             % (parity["max_abs_dprops"], parity["iters_equal"], parity["argmax_equal"]))
         sane = sane and parity["max_abs_dprops"] < PARITY_PROPS_BAR and parity["iters_equal"] \
             and parity["argmax_equal"]
+
+    # ---- the same iteration over row dictionaries (lossless; reported beside the dense fp64 line) ----
+    coded_info = None
+    if rank == 0 and world == 1 and opts.storage == "f64" and n_runs == 1:
+        try:
+            coded_info = coded_leg(em, torch, lib, plan, mat, wts, props_cur, ln_cur, opts.steps)
+            log("row dictionaries: %.3f ms per iteration (%.2f GB read), encode %.1f ms, column sums within %.1e"
+                % (coded_info["ms_per_step"], coded_info["bytes_per_iteration"] / 1e9, coded_info["encode_ms"],
+                   coded_info["max_rel_dcolsum"]))
+        except Exception as exc:
+            log("coded-storage leg skipped: %s" % exc)
 
     if rank != 0:
         return None
     cells = float(total_rows) * n_haps
     elem = 4.0 if opts.storage == "f32" else 8.0
     algo_bytes = float(n_rows) * n_haps * elem        # this rank's stored matrix is read once per iteration
+    if plan.coded is not None:
+        algo_bytes = float(plan.coded_bytes)          # records (codes + tables) + the rows that stay dense
     achieved = algo_bytes / (kernel_ms.mean() * 1e-3)
     traffic = pmc_traffic(n_rows, n_haps) if (opts.storage == "f64" and n_runs == 1) else None
     return {
@@ -477,13 +549,14 @@ def bench_rows(opts, env):
         "n_gpus": world, "steps": opts.steps, "warmup": opts.warmup,
         "ms_per_step": elapsed / opts.steps * 1e3,
         "higher_is_better": True, "scaling": scaling, "vs_baseline": None,
-        "dtype": "f64" if opts.storage == "f64" else "f64 arithmetic on f32-stored matrix (opt-in variant)",
+        "dtype": {"f64": "f64", "f32": "f64 arithmetic on f32-stored matrix (opt-in variant)",
+                  "coded": "f64 (matrix stored as lossless row dictionaries: opt-in variant)"}[plan.storage],
         "data": "synthetic (synth-v1 reads in blocks of %d, matrix built on device)" % 125000,
         "config": {"workload": "%d reads x %d haplogroups in total (Phylotree B17 + RSRS), %d per rank, "
                                "%d EM restart(s) advanced together (tile %d; several restarts: full tiles "
                                "dealt round-robin by the loop driver), %s matrix"
                                % (total_rows, n_haps, n_rows, n_runs, opts.batch_tile,
-                                  "fp64" if opts.storage == "f64" else "fp32-stored"),
+                                  {"f64": "fp64", "f32": "fp32-stored", "coded": "row-dictionary (lossless fp64)"}[plan.storage]),
                    "total_rows": total_rows, "rows_per_gpu": n_rows, "haps": n_haps, "restarts": n_runs,
                    "scaling": scaling,
                    "sharding": "rows over %d rank(s), 1 all-reduce of %d fp64 per iteration"
@@ -492,11 +565,13 @@ def bench_rows(opts, env):
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S,
                      "traffic": traffic[0] if traffic else None,
                      "traffic_source": traffic[1] if traffic else None,
-                     "kernel": "em_iter_wide_kernel" if opts.storage == "f64" else "em_iter_wide_f32_kernel",
+                     "kernel": {"f64": "em_iter_wide_kernel", "f32": "em_iter_wide_f32_kernel",
+                                "coded": "em_iter_coded_kernel"}[plan.storage],
                      "kernel_ms": float(kernel_ms.mean()),
                      "algorithmic_bytes_per_launch": algo_bytes},
         "cpu_baseline": cpu,
         "parity_in_run": parity,
+        "coded_storage": coded_info,
         "all_reduce_us": all_reduce_us,
         "kernel_ms_per_rank": kernel_ms_per_rank,
         "matrix_build_cells_per_s": float(n_rows) * n_haps / build_s,

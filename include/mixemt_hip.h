@@ -186,6 +186,43 @@ int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int64_t R, int
                     mxm_em_state *state_host);
 
 /*
+ * ROW-DICTIONARY storage of the linearised matrix (lossless; opt-in like the fp32 variant, but it keeps
+ * every bit).  A row of build_em_matrix's output (preprocess.py:177-198) is a sum of per-site terms with
+ * two possible values each, so its H cells hold few DISTINCT doubles.  Row r is stored as one record
+ *     codes[ldc] (uint8 per column, ldc = H rounded up to 8)  ++  table[ndist[r]] (doubles),
+ *     P[r][h] = exp(M[r][h] - rowmax[r]) = table[codes[h]]          -- the bits mxm_linearize writes
+ * at rec + rec_off[r]: ~5.7 KB instead of 43 KB at H = 5408.  Rows with more than 256 distinct values
+ * get ndist[r] = 0; the caller keeps those dense (P_rest / w_rest: their mxm_linearize rows and
+ * weights, in any fixed order) and both parts are summed by one column reduce.
+ *   mxm_coded_bytes(R, H)   record buffer size that can never overflow (R * (ldc + 2048))
+ *   mxm_encode_rows         M -> records; stats[0] = bytes used, stats[1] = rows left dense (device int64[2]);
+ *                           needs an even H in [66, 8192], even ldm, 16-byte aligned M and rec
+ *   mxm_decode_rows         P[r][:] = row r decoded, coded rows only (tests; posterior passes)
+ *   mxm_em_iter_coded / mxm_em_loop_coded   = mxm_em_iter / mxm_em_loop over a coded matrix
+ *                           (one restart per pass; w[R] indexes all rows, coded or not)
+ */
+typedef struct mxm_coded {
+    const uint8_t *rec;          /* records */
+    const int64_t *rec_off;      /* [R] byte offset of row r's record */
+    const int32_t *ndist;        /* [R] table entries of row r; 0 = row r is one of the dense rest */
+    int64_t        R;            /* rows, coded or not */
+    const double  *P_rest;       /* [R_rest][ldp_rest] linearised rows that did not code (NULL if none) */
+    int64_t        ldp_rest;
+    const double  *w_rest;       /* their weights (NULL = 1) */
+    int64_t        R_rest;
+} mxm_coded;
+size_t mxm_coded_bytes(int64_t R, int32_t H);
+int mxm_encode_rows(const double *M, int64_t ldm, int64_t R, int32_t H, uint8_t *rec, size_t rec_bytes,
+                    int64_t *rec_off, int32_t *ndist, double *rowmax, int64_t *stats, void *stream);
+int mxm_decode_rows(const mxm_coded *c, int32_t H, double *P, int64_t ldp, void *stream);
+int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, int32_t H, int32_t B,
+                      const mxm_em_state *state, double *colsum, void *ws, size_t ws_bytes, void *stream);
+int mxm_em_loop_coded(const mxm_coded *c, const double *w, int32_t H, int32_t B,
+                      double *props_cur, double *ln_cur, double *ln_new, double *colsum,
+                      mxm_em_state *state, double tol, int32_t max_iter, int32_t check_every,
+                      void *ws, size_t ws_bytes, void *stream, mxm_em_state *state_host);
+
+/*
  * The run_em inner loop for ONE rank -- em.py:126-143: repeats
  * {mxm_em_iter; mxm_m_finalize} on `stream` until every restart is done.
  * A single restart on a matrix of up to 1e8 cells (H <= 6144) runs its whole loop in ONE persistent launch instead (one

@@ -21,6 +21,12 @@ class EmState(ctypes.Structure):
     _fields_ = [("done", c_i32), ("iters", c_i32), ("l1", c_f64)]
 
 
+class Coded(ctypes.Structure):
+    """mxm_coded (include/mixemt_hip.h): a matrix in row-dictionary storage."""
+    _fields_ = [("rec", c_ptr), ("rec_off", c_ptr), ("ndist", c_ptr), ("R", c_i64),
+                ("P_rest", c_ptr), ("ldp_rest", c_i64), ("w_rest", c_ptr), ("R_rest", c_i64)]
+
+
 # name -> (restype, argtypes); must list every symbol the two headers declare
 # (include/mixemt_hip.h: the boundary; include/mixemt_hip_tuning.h: measurement / shape knobs)
 SIGNATURES = {
@@ -50,6 +56,14 @@ SIGNATURES = {
     "mxm_em_loop_f32": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
                                        c_ptr, c_f64, c_i32, c_i32, c_ptr, c_size, c_ptr,
                                        ctypes.POINTER(EmState)]),
+    "mxm_coded_bytes": (c_size, [c_i64, c_i32]),
+    "mxm_encode_rows": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_size, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mxm_decode_rows": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_ptr, c_i64, c_ptr]),
+    "mxm_em_iter_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr,
+                                         c_size, c_ptr]),
+    "mxm_em_loop_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
+                                         c_ptr, c_f64, c_i32, c_i32, c_ptr, c_size, c_ptr,
+                                         ctypes.POINTER(EmState)]),
     "mxm_em_step": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i64, c_i32, c_ptr, c_i64, c_i32,
                                    c_ptr, c_ptr, c_size, c_ptr]),
     "mxm_log_normalize": (ctypes.c_int, [c_ptr, c_i32, c_ptr, c_ptr]),
@@ -68,6 +82,7 @@ SIGNATURES = {
     "mxm_set_progress_callback": (ctypes.c_int, [c_ptr, c_ptr, c_i32]),
     "mxm_set_min_rows_per_wg": (ctypes.c_int, [c_i32]),
     "mxm_set_v1_shape": (ctypes.c_int, [c_i32]),
+    "mxm_set_coded_shape": (ctypes.c_int, [c_i32]),
     "mxm_row_argmax_votes": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                             c_ptr, c_size, c_ptr]),
     "mxm_gather_columns": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),

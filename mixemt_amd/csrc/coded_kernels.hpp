@@ -1,0 +1,367 @@
+// coded_kernels.hpp -- part of libmixemt_hip.so (gfx950); included by mixemt_hip.hip only.
+// Row-dictionary storage of the linearised matrix and the EM iteration that streams it.
+#ifndef MIXEMT_CODED_KERNELS_HPP
+#define MIXEMT_CODED_KERNELS_HPP
+
+// ------------------------------------------------------------------------------------------
+// A row of build_em_matrix's output (preprocess.py:177-198) is a sum of per-site terms that take one
+// of two values each, so the 5408 cells of a row hold only a few DISTINCT doubles (one per pattern of
+// mismatching sites among the haplogroups: median 25, 98 % of synth-v1 rows at most 256).  The
+// dictionary form of row r of P = exp(M - rowmax) (mxm_linearize's output) is
+//     record(r) = codes[ldc] (one byte per column, pad columns 0)  ++  table[D_r] (doubles)
+//     P[r][h]   = table[codes[h]]                       -- the SAME bits as the dense P
+// 5.4 KB + 8 D bytes instead of 43 KB per row.  Rows with more than 256 distinct values stay dense
+// (ndist[r] = 0) and go through em_iter_wide_kernel; the two kernels' column partials are summed by one
+// colreduce.  Every cell still gets its own two FMAs: nothing is skipped, only the bytes shrink.
+// ------------------------------------------------------------------------------------------
+#define ENC_THREADS 256
+#define ENC_SLOTS 1024                 // hash slots per row (>= 4 x the 256 codes a row may use)
+#define ENC_MAX_CODES 256
+#define ENC_EMPTY 0xFFFFFFFFFFFFFFFFull
+
+__device__ __forceinline__ unsigned long long readlane_u64(unsigned long long v, int src_lane) {
+    const unsigned int lo = __builtin_amdgcn_readlane((int)(unsigned int)v, src_lane);
+    const unsigned int hi = __builtin_amdgcn_readlane((int)(unsigned int)(v >> 32), src_lane);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+// K7  encode_rows: one workgroup per row (strided).  Thread t holds the columns 4 (t + 256 k) .. + 3.
+//   1. row maximum (mxm_linearize's shift);
+//   2. the row's distinct bit patterns go into an LDS hash table (64-bit compare-and-swap, linear
+//      probing); a wave first folds equal keys among its lanes so the CAS runs once per distinct key
+//      and step, not once per cell (85 % of a row is one value);
+//   3. occupied slots are numbered by a workgroup scan -> codes; more than 256 -> the row stays dense;
+//   4. the record is bump-allocated (one atomic per row; the order of records is irrelevant, every row
+//      carries its offset) and written: table[code] = exp(key - shift), one code byte per column.
+template <int NCH>
+__global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
+    const double *__restrict__ M, int64_t ldm, int64_t R, int H, int ldc, uint8_t *__restrict__ rec, int64_t rec_cap,
+    int64_t *__restrict__ rec_off, int32_t *__restrict__ ndist, double *__restrict__ rowmax,
+    unsigned long long *__restrict__ stats) {
+    constexpr int NW = ENC_THREADS / 64;
+    __shared__ unsigned long long s_key[ENC_SLOTS];
+    __shared__ unsigned short s_code[ENC_SLOTS];
+    __shared__ double s_red[NW];
+    __shared__ int s_wcnt[NW];
+    __shared__ int s_flag, s_n;
+    __shared__ long long s_off;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(M + r * ldm), 0, H * 8, 0x00020000);
+        double x[NCH][4];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int off = (t + k * ENC_THREADS) * 32;     // past the row: the descriptor returns 0 (masked below)
+            const d2 a = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2));
+            const d2 b = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 16, 2));
+            x[k][0] = a.x;
+            x[k][1] = a.y;
+            x[k][2] = b.x;
+            x[k][3] = b.y;
+        }
+#pragma unroll
+        for (int q = 0; q < ENC_SLOTS / ENC_THREADS; ++q) s_key[t + q * ENC_THREADS] = ENC_EMPTY;
+        if (t == 0) {
+            s_flag = 0;
+            s_n = 0;
+        }
+        double m = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (4 * (t + k * ENC_THREADS) + e < H) m = fmax(m, x[k][e]);
+        m = wave_max(m);
+        if (lane == 0) s_red[wv] = m;
+        __syncthreads();                                    // table cleared, wave maxima in place
+        m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+        const double shift = isfinite(m) ? m : 0.0;
+
+        int slot[NCH][4];
+        unsigned long long prev_key = ENC_EMPTY;
+        int prev_slot = 0;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const bool valid = 4 * (t + k * ENC_THREADS) + e < H;
+                const unsigned long long key = (unsigned long long)__double_as_longlong(x[k][e]);
+                int sl = 0;
+                bool need = valid;
+                if (valid && key == ENC_EMPTY) {            // the one pattern the table cannot hold
+                    s_flag = 1;
+                    need = false;
+                }
+                if (need && key == prev_key) {              // same value as the thread's previous column
+                    sl = prev_slot;
+                    need = false;
+                }
+                if (*(volatile int *)&s_flag) need = false; // the row is already known to stay dense
+                unsigned long long todo = __ballot(need);
+                while (todo) {
+                    const int leader = __builtin_ctzll(todo);
+                    const unsigned long long k0 = readlane_u64(key, leader);
+                    int s = 0;
+                    if (lane == leader) {
+                        unsigned int h = (unsigned int)((k0 ^ (k0 >> 29)) * 0x9E3779B97F4A7C15ull >> 40) & (ENC_SLOTS - 1);
+                        for (int probes = 0;; ++probes) {
+                            const unsigned long long old = atomicCAS(&s_key[h], ENC_EMPTY, k0);
+                            if (old == ENC_EMPTY) {
+                                if (atomicAdd(&s_n, 1) >= ENC_MAX_CODES) s_flag = 1;
+                                break;
+                            }
+                            if (old == k0) break;
+                            h = (h + 1) & (ENC_SLOTS - 1);
+                            if (probes >= ENC_SLOTS) {
+                                s_flag = 1;
+                                break;
+                            }
+                        }
+                        s = (int)h;
+                    }
+                    s = __builtin_amdgcn_readlane(s, leader);
+                    if (need && key == k0) {
+                        sl = s;
+                        need = false;
+                    }
+                    todo = __ballot(need);
+                }
+                slot[k][e] = sl;
+                if (valid) {
+                    prev_key = key;
+                    prev_slot = sl;
+                }
+            }
+        }
+        __syncthreads();                                    // every key is in the table
+        const bool dense = (s_flag != 0);
+
+        // number the occupied slots: thread t scans slots 4 t .. 4 t + 3
+        unsigned long long kk[4];
+        int cnt = 0;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            kk[j] = s_key[4 * t + j];
+            cnt += (kk[j] != ENC_EMPTY) ? 1 : 0;
+        }
+        int incl = cnt;
+#pragma unroll
+        for (int off = 1; off < 64; off <<= 1) {
+            const int up = __shfl_up(incl, off, 64);
+            if (lane >= off) incl += up;
+        }
+        if (lane == 63) s_wcnt[wv] = incl;
+        __syncthreads();                                    // wave totals in place; s_flag read by everyone
+        int base = 0, D = 0;
+#pragma unroll
+        for (int q = 0; q < NW; ++q) {
+            if (q < wv) base += s_wcnt[q];
+            D += s_wcnt[q];
+        }
+        const int64_t bytes = (int64_t)ldc + 8 * (int64_t)D;
+        const bool coded = !dense && D <= ENC_MAX_CODES;
+        if (t == 0) {
+            long long off = -1;
+            if (coded) {
+                off = (long long)atomicAdd(&stats[0], (unsigned long long)bytes);
+                if (off + bytes > rec_cap) off = -1;         // cannot happen with mxm_coded_bytes(R, H)
+            }
+            s_off = off;
+        }
+        int code = base + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            if (kk[j] != ENC_EMPTY) s_code[4 * t + j] = (unsigned short)code++;
+        }
+        __syncthreads();                                    // codes of the slots and the record offset in place
+        const long long off = s_off;
+        if (off >= 0) {
+            double *tbl = reinterpret_cast<double *>(rec + off + ldc);
+            code = base + incl - cnt;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (kk[j] != ENC_EMPTY) tbl[code++] = exp(__longlong_as_double((long long)kk[j]) - shift);
+            }
+            unsigned int *cw = reinterpret_cast<unsigned int *>(rec + off);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                const int c0 = 4 * (t + k * ENC_THREADS);
+                if (c0 < ldc) {
+                    unsigned int word = 0;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e)
+                        if (c0 + e < H) word |= (unsigned int)s_code[slot[k][e]] << (8 * e);
+                    cw[t + k * ENC_THREADS] = word;
+                }
+            }
+        }
+        if (t == 0) {
+            rowmax[r] = shift;
+            ndist[r] = (off >= 0) ? D : 0;
+            rec_off[r] = (off >= 0) ? off : 0;
+            if (off < 0) atomicAdd(&stats[1], 1ull);
+        }
+        __syncthreads();                                    // the next row clears the table
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3c  em_iter_coded: em_iter_wide_kernel's step over dictionary rows.
+//
+// Same decomposition (rows dealt round-robin, thread t owns fixed columns, the row waits in VGPRs
+// between its dot product and the accumulation, column partials in registers for the whole launch),
+// but a row arrives as 4 code bytes per thread and chunk plus its table (<= 2 KB), which the first 256
+// threads park in LDS one row ahead (double buffered; the same barrier that publishes the wave sums
+// publishes it).  Per cell: one shift-by-3 of a code byte, one ds_read_b64, two fp64 FMAs.
+// 8x fewer HBM bytes per row make the per-row chain (reduce -> barrier -> divide) the bound, so two or
+// three workgroups share a CU and overlap each other's chains.
+// ------------------------------------------------------------------------------------------
+// Shapes (A/B with mxm_set_coded_shape): threads per workgroup, rows in flight (NBUF - 1 rows of codes
+// are on their way while one is processed; the row's table follows one step behind), workgroups per CU.
+template <int THREADS, int NCH, int NBUF, int MINWG>
+__global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_kernel(
+    const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off, const int32_t *__restrict__ ndist, int ldc,
+    const double *__restrict__ w, const double *__restrict__ props, int64_t R, int H, double *__restrict__ partial,
+    int64_t ldpart, const mxm_em_state *__restrict__ state, int run) {
+    static_assert(NBUF >= 3, "codes NBUF - 1 rows ahead, tables NBUF - 2");
+    constexpr int NW = THREADS / 64;
+    __shared__ double s_tbl[NBUF][ENC_MAX_CODES];
+    __shared__ double red[NBUF][NW];
+    if (state != nullptr && state[run].done != 0) return;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nword = ldc >> 2;
+    props += (int64_t)run * H;
+
+    double p[NCH][4], acc[NCH][4];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (t + k * THREADS) + e;
+            p[k][e] = (c < H) ? props[c] : 0.0;
+            acc[k][e] = 0.0;
+        }
+    }
+    const row_deal deal(R);
+    const int voff = t * 4;
+    int last_w = t + (NCH - 1) * THREADS;               // words past the row are clamped: their columns have p = 0
+    if (last_w > nword - 1) last_w = nword - 1;
+    const int voff_last = last_w * 4;
+    const bool tbl_thread = (THREADS <= ENC_MAX_CODES) || t < ENC_MAX_CODES;
+    const int tslot = t & (ENC_MAX_CODES - 1);
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+
+    // Per-step metadata {record offset, table entries, weight} of THREADS steps at a time in LDS (double
+    // buffered): fetched by one thread per step, read back at a uniform address.  As scalar loads inside the
+    // step they were three dependent L2 round trips per row -- the whole step time.
+    __shared__ long long s_off[2][THREADS];
+    __shared__ double s_wr[2][THREADS];
+    __shared__ int s_nd[2][THREADS];
+    auto fetch_meta = [&](int half, int64_t q0) {       // steps q0 .. q0 + THREADS - 1, thread t takes step q0 + t
+        const int64_t q = q0 + t;
+        const int64_t r = deal.row(q);
+        const int nd = ndist[r];
+        s_off[half][t] = rec_off[r];
+        s_nd[half][t] = nd;
+        s_wr[half][t] = (deal.live(q) && nd > 0) ? (w != nullptr ? w[r] : 1.0) : 0.0;   // dense rows are not ours
+    };
+
+    unsigned int cw[NBUF][NCH];
+    double tring[NBUF];
+    // row q's record: codes into cws, entry t of its table into tbl_entry (lanes past the table read 0)
+    auto load_row = [&](unsigned int(&cws)[NCH], double &tbl_entry, int64_t q) {
+        const int half = (int)((q / THREADS) & 1), idx = (int)(q % THREADS);
+        const long long off = s_off[half][idx];
+        const int nd = __builtin_amdgcn_readfirstlane(s_nd[half][idx]);
+        const uint8_t *base = rec + (((long long)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+                                     (unsigned int)__builtin_amdgcn_readfirstlane((int)off));
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, ldc, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NCH - 1; ++k) cws[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, k * THREADS * 4, 2);
+        cws[NCH - 1] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_last, 0, 2);
+        if (tbl_thread) {
+            const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base + ldc), 0, nd * 8, 0x00020000);
+            const u2v v = __builtin_amdgcn_raw_buffer_load_b64(rt, tslot * 8, 0, 2);
+            tbl_entry = __hiloint2double((int)v.y, (int)v.x);
+        }
+    };
+
+    auto step = [&](auto J, int64_t q) {
+        constexpr int j = decltype(J)::value;
+        constexpr int jn = (j + 1) % NBUF, jl = (j + NBUF - 1) % NBUF;
+        if ((q % THREADS) == 0) fetch_meta((int)((q / THREADS + 1) & 1), q + THREADS);   // the block after this one
+        load_row(cw[jl], tring[jl], q + NBUF - 1);       // slot jl held row q - 1: consumed
+        const double wr = s_wr[(q / THREADS) & 1][q % THREADS];
+        const char *tb = reinterpret_cast<const char *>(&s_tbl[j][0]);
+        double v[NCH][4];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                v[k][e] = *reinterpret_cast<const double *>(tb + (((cw[j][k] >> (8 * e)) & 0xffu) << 3));
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};             // four independent chains (a dependent fp64 FMA stalls its wave)
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s4[e] = fma(v[k][e], p[k][e], s4[e]);
+        double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        s = wave_sum_lane63(s);
+        if (lane == 63) red[j][wv] = s;
+        if (tbl_thread) s_tbl[jn][tslot] = tring[jn];    // row q + 1's table, published by the same barrier
+        __syncthreads();
+        double cs[1];
+        group_ratio_to_sgpr<NW, 1>(&red[j][0], lane, wr, cs);
+        const double cf = cs[0];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                acc[k][e] = fma(cf, v[k][e], acc[k][e]);
+                // pin the update here: left alone, the compiler sinks all NBUF steps' updates to the end of
+                // the unrolled loop body and keeps (spills) every step's row values until then
+                asm volatile("" : "+v"(acc[k][e]));
+            }
+    };
+
+    fetch_meta(0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j) load_row(cw[j], tring[j], j);
+    if (tbl_thread) s_tbl[0][tslot] = tring[0];
+    __syncthreads();
+    for (int64_t q = 0; q < deal.nq; q += NBUF) {
+        step(std::integral_constant<int, 0>{}, q);
+        step(std::integral_constant<int, 1>{}, q + 1);
+        step(std::integral_constant<int, 2>{}, q + 2);
+        if constexpr (NBUF > 3) step(std::integral_constant<int, 3>{}, q + 3);
+        if constexpr (NBUF > 4) step(std::integral_constant<int, 4>{}, q + 4);
+        if constexpr (NBUF > 5) step(std::integral_constant<int, 5>{}, q + 5);
+        static_assert(NBUF <= 6, "unrolled by hand");
+    }
+
+    double *dst = partial + (int64_t)blockIdx.x * ldpart;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = 4 * (t + k * THREADS);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < H) dst[c + e] = acc[k][e];
+    }
+}
+
+// decode (tests, posterior pass from records): P[r][h] = table[codes[h]] for coded rows; others untouched
+__global__ __launch_bounds__(256) void decode_rows_kernel(const uint8_t *__restrict__ rec,
+                                                          const int64_t *__restrict__ rec_off,
+                                                          const int32_t *__restrict__ ndist, int ldc, int64_t R, int H,
+                                                          double *__restrict__ P, int64_t ldp) {
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        if (ndist[r] <= 0) continue;
+        const uint8_t *codes = rec + rec_off[r];
+        const double *tbl = reinterpret_cast<const double *>(codes + ldc);
+        for (int h = threadIdx.x; h < H; h += 256) P[r * ldp + h] = tbl[codes[h]];
+    }
+}
+
+#endif  // MIXEMT_CODED_KERNELS_HPP

@@ -22,6 +22,7 @@
 //   aux_kernels.hpp     log_normalize, l1_exp_diff, add_scalar, row_argmax_votes, assign_reads, gather, fold, diag_stream_read
 //   fused_kernels.hpp   em_fused_loop_kernel (the whole EM loop of a cache-resident matrix in one persistent launch)
 //   fused_cols_kernels.hpp  em_fused_cols_kernel (the same for up to 1536 rows, columns split over the workgroups, matrix in registers)
+//   coded_kernels.hpp   encode_rows_kernel, em_iter_coded_kernel (row-dictionary storage: one byte per cell + the row's distinct values)
 // This file: the host side of the C ABI (shape checks, grid sizing, dispatch, the loop driver).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -30,6 +31,7 @@
 #include <math.h>
 #include <algorithm>
 #include <mutex>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -44,6 +46,7 @@
 #include "aux_kernels.hpp"
 #include "fused_kernels.hpp"
 #include "fused_cols_kernels.hpp"
+#include "coded_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------
 // host side of the C ABI
@@ -400,9 +403,10 @@ static inline mxm_slots slots_from(int first) {
 
 // One tile of nb (<= MXM_MAX_BT) restarts over the linear matrix: streaming kernel + column reduce.
 // props / state / colsum are the BASES of the loop vectors; the tile's members are slots.s[0 .. nb).
-static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
-                               int H, int nb, mxm_slots slots, const mxm_em_state *state, double *colsum,
-                               double *partial, hipStream_t stream, bool timed) {
+// stream_linear_tile: the streaming kernel alone, partial rows [0, *nwg_out) of `partial`.
+static int stream_linear_tile(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
+                              int H, int nb, mxm_slots &slots, const mxm_em_state *state,
+                              double *partial, hipStream_t stream, bool timed, int *nwg_out) {
     const int64_t ldpart = part_ld(H);
     const int ncol2 = (H + 1) / 2;
     const bool alt = (nb == 1) && (g_v1_shape == 1);        // the second single-restart shape
@@ -431,7 +435,17 @@ static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, co
     if (rc != 0) return rc;
     HIP_TRY(hipGetLastError());
     if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
-    hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, nb), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg, nb,
+    *nwg_out = nwg;
+    return 0;
+}
+
+static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
+                               int H, int nb, mxm_slots slots, const mxm_em_state *state, double *colsum,
+                               double *partial, hipStream_t stream, bool timed) {
+    int nwg = 0;
+    const int rc = stream_linear_tile(P, ldp, w, props, R, H, nb, slots, state, partial, stream, timed, &nwg);
+    if (rc != 0) return rc;
+    hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, nb), dim3(COLRED_THREADS), 0, stream, partial, part_ld(H), nwg, nb,
                        H, (const double *)nullptr, colsum, state, slots);
     HIP_TRY(hipGetLastError());
     return 0;
@@ -595,6 +609,133 @@ extern "C" int mxm_em_iter_f32(const float *P, int64_t ldp, const double *w, con
         const int rc = em_iter_f32_one(P, ldp, w, props + (int64_t)b * H, R, (int)H, state ? state + b : nullptr,
                                        colsum + (int64_t)b * H, (double *)ws, (hipStream_t)stream, b == 0);
         if (rc != 0) return rc;
+    }
+    return 0;
+}
+
+// ---- row-dictionary storage (coded_kernels.hpp) ------------------------------------------------
+static inline int coded_ld(int H) { return (H + 7) & ~7; }
+
+extern "C" size_t mxm_coded_bytes(int64_t R, int32_t H) {
+    if (R < 0 || H <= 0) return 0;
+    return (size_t)(R > 0 ? R : 1) * ((size_t)coded_ld(H) + 8 * ENC_MAX_CODES);
+}
+
+extern "C" int mxm_encode_rows(const double *M, int64_t ldm, int64_t R, int32_t H, uint8_t *rec, size_t rec_bytes,
+                               int64_t *rec_off, int32_t *ndist, double *rowmax, int64_t *stats, void *stream) {
+    if (R <= 0 || H <= 0 || ldm < H) return fail(-1, "mxm_encode_rows: bad shape R=%s%lld H=%lld", "", R, H);
+    if (!mxm_linear_supported(H) || !wide_rows_ok(M, ldm, H))
+        return fail(-1, "mxm_encode_rows: needs an even H in [66, 8192] and 16-byte aligned rows%s (H=%lld ldm=%lld)", "", H, ldm);
+    if (rec == nullptr || (reinterpret_cast<uintptr_t>(rec) & 15) || rec_bytes < (size_t)coded_ld(H) + 8 * ENC_MAX_CODES)
+        return fail(-1, "mxm_encode_rows: record buffer missing, unaligned or smaller than one record%s", "");
+    if (rec_off == nullptr || ndist == nullptr || rowmax == nullptr || stats == nullptr)
+        return fail(-1, "mxm_encode_rows: output arrays required%s", "");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(stats, 0, 2 * sizeof(int64_t), s));
+    const int ldc = coded_ld(H);
+    const int nch = (ldc / 4 + ENC_THREADS - 1) / ENC_THREADS;
+    const int grid = clamp_grid(R, num_cu() * 4);
+    switch (nch) {
+#define ENC_CASE(n) case n: hipLaunchKernelGGL((encode_rows_kernel<n>), dim3(grid), dim3(ENC_THREADS), 0, s, M, ldm, R, (int)H, ldc, rec, (int64_t)rec_bytes, rec_off, ndist, rowmax, reinterpret_cast<unsigned long long *>(stats)); break;
+        ENC_CASE(1) ENC_CASE(2) ENC_CASE(3) ENC_CASE(4) ENC_CASE(5) ENC_CASE(6) ENC_CASE(7) ENC_CASE(8)
+#undef ENC_CASE
+        default: return fail(-1, "mxm_encode_rows: H=%s%lld outside the kernel's range", "", H);
+    }
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int coded_check(const mxm_coded *c, int32_t H, const char *who) {
+    if (c == nullptr || c->R <= 0 || H <= 0 || !mxm_linear_supported(H) || (H & 1))
+        return fail(-1, "%s: bad coded matrix (rows %lld, H %lld)", who, c ? c->R : 0, H);
+    if (c->rec == nullptr || c->rec_off == nullptr || c->ndist == nullptr) return fail(-1, "%s: coded matrix arrays missing", who);
+    if (c->R_rest < 0 || (c->R_rest > 0 && (c->P_rest == nullptr || c->ldp_rest < H || (c->ldp_rest & 1) ||
+                                            (reinterpret_cast<uintptr_t>(c->P_rest) & 15))))
+        return fail(-1, "%s: the dense rest needs 16-byte aligned rows with an even ld >= H", who);
+    return 0;
+}
+
+extern "C" int mxm_decode_rows(const mxm_coded *c, int32_t H, double *P, int64_t ldp, void *stream) {
+    const int rc = coded_check(c, H, "mxm_decode_rows");
+    if (rc != 0) return rc;
+    if (P == nullptr || ldp < H) return fail(-1, "mxm_decode_rows: ldp < H%s", "");
+    hipLaunchKernelGGL(decode_rows_kernel, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(256), 0, (hipStream_t)stream, c->rec,
+                       c->rec_off, c->ndist, coded_ld(H), c->R, (int)H, P, ldp);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Shapes of em_iter_coded_kernel (mxm_set_coded_shape; measured in profiles/r02/coded_shapes.txt)
+struct coded_shape { int threads, nbuf, wg_per_cu; };
+static const coded_shape g_coded_shapes[] = {{256, 4, 2}, {256, 3, 2}, {512, 4, 2}, {512, 6, 2}, {256, 6, 2}, {512, 3, 2}};
+static int g_coded_shape = 0;
+extern "C" int mxm_set_coded_shape(int32_t shape) {
+    if (shape < 0 || shape >= (int)(sizeof(g_coded_shapes) / sizeof(g_coded_shapes[0])))
+        return fail(-1, "mxm_set_coded_shape: unknown shape%s", "");
+    g_coded_shape = shape;
+    return 0;
+}
+
+template <int THREADS, int NBUF, int MINWG>
+static int launch_coded(int nch, int nwg, hipStream_t stream, const mxm_coded *c, int ldc, const double *w, const double *props,
+                        int H, double *partial, int64_t ldpart, const mxm_em_state *state, int run) {
+    switch (nch) {
+#define COD_CASE(n) case n: if constexpr (n * THREADS <= 2048) { hipLaunchKernelGGL((em_iter_coded_kernel<THREADS, n, NBUF, MINWG>), dim3(nwg), dim3(THREADS), 0, stream, c->rec, c->rec_off, c->ndist, ldc, w, props, c->R, H, partial, ldpart, state, run); return 0; } break;
+        COD_CASE(1) COD_CASE(2) COD_CASE(3) COD_CASE(4) COD_CASE(5) COD_CASE(6) COD_CASE(7) COD_CASE(8)
+#undef COD_CASE
+        default: break;
+    }
+    return fail(-1, "mxm_em_iter_coded: H=%s%lld outside the kernel's range", "", H);
+}
+
+// One restart's pass over a coded matrix: dictionary rows through em_iter_coded_kernel, the dense rest
+// through em_iter_wide_kernel into the partial rows behind, one column reduce over both.
+static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *props, int H, int run,
+                             const mxm_em_state *state, double *colsum, double *partial, hipStream_t stream, bool timed) {
+    const int64_t ldpart = part_ld(H);
+    const int ldc = coded_ld(H);
+    const coded_shape sh = g_coded_shapes[g_coded_shape];
+    const int nch = (ldc / 4 + sh.threads - 1) / sh.threads;
+    int cap = num_cu() * sh.wg_per_cu;
+    if (cap > MXM_MAX_WG - 2 * num_cu()) cap = MXM_MAX_WG - 2 * num_cu();     // the dense rest's rows come behind
+    if (cap < 1) cap = 1;
+    const int nwg = clamp_grid((c->R + sh.nbuf - 1) / sh.nbuf, cap);
+    if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
+    int lrc;
+    switch (g_coded_shape) {
+        case 0: lrc = launch_coded<256, 4, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
+        case 1: lrc = launch_coded<256, 3, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
+        case 2: lrc = launch_coded<512, 4, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
+        case 3: lrc = launch_coded<512, 6, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
+        case 4: lrc = launch_coded<256, 6, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
+        default: lrc = launch_coded<512, 3, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
+    }
+    if (lrc != 0) return lrc;
+    HIP_TRY(hipGetLastError());
+    if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
+    int nwg_rest = 0;
+    mxm_slots sl;
+    for (int i = 0; i < MXM_MAX_BT; ++i) sl.s[i] = run;
+    if (c->R_rest > 0) {
+        const int rc = stream_linear_tile(c->P_rest, c->ldp_rest, c->w_rest, props, c->R_rest, H, 1, sl, state,
+                                          partial + (int64_t)nwg * ldpart, stream, false, &nwg_rest);
+        if (rc != 0) return rc;
+    }
+    hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart,
+                       nwg + nwg_rest, 1, H, (const double *)nullptr, colsum, state, sl);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, int32_t H, int32_t B,
+                                 const mxm_em_state *state, double *colsum, void *ws, size_t ws_bytes, void *stream) {
+    const int rc = coded_check(c, H, "mxm_em_iter_coded");
+    if (rc != 0) return rc;
+    if (B <= 0 || props == nullptr || colsum == nullptr) return fail(-1, "mxm_em_iter_coded: bad arguments%s", "");
+    if (ws == nullptr || ws_bytes < mxm_workspace_bytes(c->R, H, B)) return fail(-1, "mxm_em_iter_coded: workspace too small%s", "");
+    for (int b = 0; b < B; ++b) {
+        const int irc = em_iter_coded_one(c, w, props, (int)H, b, state, colsum, (double *)ws, (hipStream_t)stream, b == 0);
+        if (irc != 0) return irc;
     }
     return 0;
 }
@@ -788,9 +929,14 @@ static int enqueue_tile_iteration(const double *M, int64_t ldm, const double *P,
                                   int64_t R, int32_t H, const mxm_slots &tile, int nb, double *props_cur,
                                   double *ln_cur, double *ln_new, double *colsum, mxm_em_state *state, double tol,
                                   int32_t max_iter, void *ws, size_t ws_bytes, hipStream_t s, bool p_is_f32,
-                                  bool timed) {
+                                  bool timed, const mxm_coded *coded) {
     const bool linear = !p_is_f32 && P != nullptr && mxm_linear_supported(H);
-    if (linear) {
+    if (coded != nullptr) {
+        for (int i = 0; i < nb; ++i) {
+            const int rc = em_iter_coded_one(coded, w, props_cur, (int)H, tile.s[i], state, colsum, (double *)ws, s, timed && i == 0);
+            if (rc != 0) return rc;
+        }
+    } else if (linear) {
         const int rc = em_iter_linear_tile(P, ldp, w, props_cur, R, (int)H, nb, tile, state, colsum, (double *)ws, s, timed);
         if (rc != 0) return rc;
     } else {
@@ -813,7 +959,7 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
                         int64_t R, int32_t H, int32_t B, double *props_cur, double *ln_cur, double *ln_new,
                         double *colsum, mxm_em_state *state, double tol, int32_t max_iter,
                         int32_t check_every, void *ws, size_t ws_bytes, void *stream,
-                        mxm_em_state *state_host, bool p_is_f32) {
+                        mxm_em_state *state_host, bool p_is_f32, const mxm_coded *coded = nullptr) {
     if (state_host == nullptr || state == nullptr) return fail(-1, "mxm_em_loop: state pointers required%s", "");
     if (R <= 0 || H <= 0 || B <= 0) return fail(-1, "mxm_em_loop: bad shape R=%s%lld H=%lld", "", R, H);
     if (ws == nullptr || ws_bytes < mxm_workspace_bytes(R, H, B)) return fail(-1, "mxm_em_loop: workspace too small%s", "");
@@ -905,7 +1051,7 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
                     for (int i = 0; i < MXM_MAX_BT; ++i) tile.s[i] = members[at + (i < sizes[ti] ? i : 0)];
                     const int erc = enqueue_tile_iteration(M, ldm, P, ldp, w, R, H, tile, sizes[ti], props_cur, ln_cur,
                                                            ln_new, colsum, state, tol, max_iter, ws, ws_bytes, s,
-                                                           p_is_f32, ti == 0);
+                                                           p_is_f32, ti == 0, coded);
                     if (erc != 0) return erc;
                     at += sizes[ti];
                 }
@@ -966,6 +1112,16 @@ extern "C" int mxm_em_loop(const double *M, int64_t ldm, const double *P, int64_
                            mxm_em_state *state_host) {
     return em_loop_impl(M, ldm, P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, colsum, state, tol, max_iter,
                         check_every, ws, ws_bytes, stream, state_host, false);
+}
+
+extern "C" int mxm_em_loop_coded(const mxm_coded *c, const double *w, int32_t H, int32_t B, double *props_cur,
+                                 double *ln_cur, double *ln_new, double *colsum, mxm_em_state *state, double tol,
+                                 int32_t max_iter, int32_t check_every, void *ws, size_t ws_bytes, void *stream,
+                                 mxm_em_state *state_host) {
+    const int rc = coded_check(c, H, "mxm_em_loop_coded");
+    if (rc != 0) return rc;
+    return em_loop_impl(nullptr, 0, nullptr, 0, w, c->R, H, B, props_cur, ln_cur, ln_new, colsum, state, tol, max_iter,
+                        check_every, ws, ws_bytes, stream, state_host, false, c);
 }
 
 extern "C" int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int64_t R, int32_t H, int32_t B,

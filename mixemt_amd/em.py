@@ -117,12 +117,17 @@ class EmPlan(object):
         an opt-in variant that stores P as float (half the HBM traffic per
         iteration) and still multiplies and sums in fp64 -- measured within
         ~1e-8 of the fp64 path on the goldens, inside the 1e-6 parity bar, but
-        NOT what the headline benchmark runs.
+        NOT what the headline benchmark runs.  "coded" keeps every fp64 bit and
+        stores each row as one byte per column plus the row's distinct values
+        (mxm_encode_rows; rows with more than 256 of them stay dense): the matrix
+        build's rows hold a few dozen distinct sums, so the loop reads ~8x fewer
+        bytes.  Matrices it does not apply to (odd / narrow H, unaligned rows)
+        iterate as "f64".
         linear = (P, rowmax): the linearised matrix already made by the matrix build
         (preprocess.build_em_matrix_device(..., linear=...)): nothing is recomputed here.
         """
-        if storage not in ("f64", "f32"):
-            raise ValueError("storage must be 'f64' or 'f32'")
+        if storage not in ("f64", "f32", "coded"):
+            raise ValueError("storage must be 'f64', 'f32' or 'coded'")
         self.storage = storage
         self.lib = _lib.load()
         self.dev = require_gpu()
@@ -137,7 +142,18 @@ class EmPlan(object):
         self.ws, self.ws_bytes = _workspace(self.lib, self.n_rows, self.n_haps, n_runs, self.dev)
         self.lin = None
         self.rowmax = None
-        if linear is not None:
+        self.coded = None
+        if storage == "coded":
+            if linear is not None:
+                raise ValueError("linear = (P, rowmax) is the dense fp64 plan's input")
+            if (self.n_rows > 0 and self.lib.mxm_linear_supported(self.n_haps) and self.n_haps % 2 == 0
+                    and self.mat.stride(1) == 1 and self.mat.stride(0) % 2 == 0 and self.mat.data_ptr() % 16 == 0):
+                self._encode()
+            else:
+                self.storage = storage = "f64"
+        if self.coded is not None:
+            pass
+        elif linear is not None:
             lin, rowmax = linear
             if (storage != "f64" or not self.lib.mxm_linear_supported(self.n_haps) or lin.dtype != torch.float64
                     or lin.shape[0] != self.n_rows or lin.stride(0) < self.n_haps or lin.stride(0) % 2
@@ -162,8 +178,39 @@ class EmPlan(object):
                                                   current_stream()), "mxm_linearize")
         elif storage == "f32":
             self.storage = "f64"             # narrow matrices iterate the fp64 log-space kernel
-        if not keep_log_matrix and self.lin is not None:
+        if not keep_log_matrix and (self.lin is not None or self.coded is not None):
             self.mat = None
+
+    def _encode(self):
+        """Row-dictionary form of this plan's matrix (mxm_encode_rows) + the dense rest."""
+        lib, dev, n_rows, n_haps = self.lib, self.dev, self.n_rows, self.n_haps
+        cap = lib.mxm_coded_bytes(n_rows, n_haps)
+        rec = device_empty((cap,), torch.uint8, dev, "the coded matrix")
+        rec_off = torch.empty(n_rows, dtype=torch.int64, device=dev)
+        ndist = torch.empty(n_rows, dtype=torch.int32, device=dev)
+        self.rowmax = torch.empty(n_rows, dtype=torch.float64, device=dev)
+        stats = torch.zeros(2, dtype=torch.int64, device=dev)
+        _lib.check(lib.mxm_encode_rows(self.mat.data_ptr(), self.mat.stride(0), n_rows, n_haps, rec.data_ptr(), cap,
+                                       rec_off.data_ptr(), ndist.data_ptr(), self.rowmax.data_ptr(), stats.data_ptr(),
+                                       current_stream()), "mxm_encode_rows")
+        used, n_rest = (int(v) for v in stats.cpu())
+        p_rest = w_rest = None
+        if n_rest:
+            # rows with more than 256 distinct values: dense, in row order (fixed -> same sums on every run)
+            idx = torch.nonzero(ndist == 0).flatten()
+            m_rest = self.mat.index_select(0, idx)
+            ldp = (n_haps + 1) // 2 * 2
+            p_rest = torch.empty((n_rest, ldp), dtype=torch.float64, device=dev)
+            rm = torch.empty(n_rest, dtype=torch.float64, device=dev)
+            _lib.check(lib.mxm_linearize(m_rest.data_ptr(), m_rest.stride(0), n_rest, n_haps, p_rest.data_ptr(),
+                                         p_rest.stride(0), rm.data_ptr(), current_stream()), "mxm_linearize")
+            w_rest = self.wts.index_select(0, idx).contiguous()
+        self.coded_bytes = used + (n_rest * n_haps * 8)
+        self.coded_rest = n_rest
+        self._coded_keep = (rec, rec_off, ndist, p_rest, w_rest)
+        self.coded = _lib.Coded(rec.data_ptr(), rec_off.data_ptr(), ndist.data_ptr(), n_rows,
+                                p_rest.data_ptr() if n_rest else None, p_rest.stride(0) if n_rest else 0,
+                                w_rest.data_ptr() if n_rest else None, n_rest)
 
     # pointers for the C ABI ------------------------------------------------
     def mat_args(self):
@@ -193,7 +240,7 @@ class EmPlan(object):
     def restart_tile(self):
         """Restarts that share one pass over this plan's matrix (mxm_restart_tile; 1 for the
         fp32-storage variant and for narrow matrices, which iterate one restart per pass)."""
-        if self.lin is None or self.storage == "f32":
+        if self.lin is None or self.storage != "f64":
             return 1
         return int(self.lib.mxm_restart_tile(self.n_haps))
 
@@ -214,6 +261,12 @@ class EmPlan(object):
             raise ValueError("this plan's linearised matrix has been released (release_linear)")
         m_ptr, ldm = self.mat_args()
         p_ptr, ldp = self.lin_args()
+        if self.coded is not None:
+            _lib.check(self.lib.mxm_em_iter_coded(ctypes.byref(self.coded), self.wts.data_ptr(), props.data_ptr(),
+                                                  self.n_haps, props.shape[0], ptr(state), colsum.data_ptr(),
+                                                  self.ws.data_ptr(), self.ws_bytes, current_stream()),
+                       "mxm_em_iter_coded")
+            return
         if self.storage == "f32":
             _lib.check(self.lib.mxm_em_iter_f32(p_ptr, ldp, self.wts.data_ptr(), props.data_ptr(),
                                                 self.n_rows, self.n_haps, props.shape[0], ptr(state),
@@ -272,7 +325,13 @@ def em_loop(plan, inits, tolerance, max_iter, check_every=16):
     colsum = torch.zeros_like(props_cur)
     state = new_state(n_runs, dev)
     host_state = (_lib.EmState * n_runs)()
-    if max_iter > 0 and plan.storage == "f32":
+    if max_iter > 0 and plan.coded is not None:
+        _lib.check(lib.mxm_em_loop_coded(ctypes.byref(plan.coded), plan.wts.data_ptr(), n_haps, n_runs,
+                                         props_cur.data_ptr(), ln_cur.data_ptr(), ln_new.data_ptr(),
+                                         colsum.data_ptr(), state.data_ptr(), float(tolerance),
+                                         int(max_iter), int(check_every), plan.ws.data_ptr(),
+                                         plan.ws_bytes, current_stream(), host_state), "mxm_em_loop_coded")
+    elif max_iter > 0 and plan.storage == "f32":
         p_ptr, ldp = plan.lin_args()
         _lib.check(lib.mxm_em_loop_f32(p_ptr, ldp, plan.wts.data_ptr(), plan.n_rows, n_haps, n_runs,
                                        props_cur.data_ptr(), ln_cur.data_ptr(), ln_new.data_ptr(),

@@ -1,0 +1,186 @@
+"""
+Row-dictionary storage (mxm_encode_rows / mxm_em_iter_coded / mxm_em_loop_coded; EmPlan(storage="coded")):
+lossless by construction, so the bar is the dense fp64 path's own -- decoded rows equal mxm_linearize's
+output bit for bit, and the EM run reproduces the reference's goldens (same iteration counts, same
+haplogroup calls, proportions within 1e-9).
+"""
+import ctypes
+
+import numpy
+import pytest
+
+from conftest import em_args, golden
+from oracle import c_oracle, em_oracle
+
+pytestmark = pytest.mark.gpu
+
+PROPS_ATOL = 1e-9
+
+
+def _b17_matrix(tables, g, n_haps):
+    return c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, g["row_ptr"],
+                                    g["site"], g["obs"], n_haps)
+
+
+def _decode(plan):
+    """The coded plan's rows back as a dense P (coded rows only; the others stay NaN)."""
+    import torch
+    from mixemt_amd import _lib
+    from mixemt_amd._dev import current_stream
+    out = torch.full((plan.n_rows, plan.n_haps), float("nan"), dtype=torch.float64, device=plan.dev)
+    _lib.check(plan.lib.mxm_decode_rows(ctypes.byref(plan.coded), plan.n_haps, out.data_ptr(), out.stride(0),
+                                        current_stream()), "mxm_decode_rows")
+    return out
+
+
+def _ndist(plan):
+    return plan._coded_keep[2].cpu().numpy()
+
+
+@pytest.mark.parametrize("name", ["g4_run_em", "g9_run_em_2400"])
+def test_encoded_rows_decode_to_the_linearised_matrix_bit_for_bit(b17, name):
+    import torch
+    from mixemt_amd import em
+    refseq, phy, haps, tables = b17
+    g = golden(name)
+    mat = _b17_matrix(tables, g, len(haps))
+    dense = em.EmPlan(mat, g["wts"], storage="f64")
+    coded = em.EmPlan(mat, g["wts"], storage="coded")
+    assert coded.coded is not None and coded.lin is None
+    nd = _ndist(coded)
+    assert (nd > 0).sum() + coded.coded_rest == len(nd) and (nd <= 256).all()
+    assert (nd > 0).mean() > 0.9                      # build_em_matrix rows hold few distinct sums
+    # the dictionary of a row has exactly as many entries as the row has distinct values
+    for r in numpy.flatnonzero(nd > 0)[:50]:
+        assert nd[r] == len(numpy.unique(mat[r]))
+    for r in numpy.flatnonzero(nd == 0):
+        assert len(numpy.unique(mat[r])) > 256
+    dec = _decode(coded)
+    rows = torch.from_numpy(nd > 0).to(dec.device)
+    assert torch.equal(dec[rows].view(torch.int64), dense.lin[rows][:, :len(haps)].view(torch.int64))
+    assert torch.equal(coded.rowmax, dense.rowmax)
+    assert coded.coded_bytes < 0.25 * mat.size * 8    # ~8x smaller on these matrices
+
+
+@pytest.mark.parametrize("shape", [0, 1, 2, 3, 4, 5])
+def test_one_iteration_equals_the_dense_pass(b17, shape):
+    """Same proportions in -> same column sums out (summation order differs: 1e-13 relative), every kernel shape."""
+    import torch
+    from mixemt_amd import em
+    refseq, phy, haps, tables = b17
+    g = golden("g9_run_em_2400")
+    mat = _b17_matrix(tables, g, len(haps))
+    dense = em.EmPlan(mat, g["wts"])
+    coded = em.EmPlan(mat, g["wts"], storage="coded")
+    rng = numpy.random.default_rng(shape)
+    init = rng.dirichlet([1.0] * len(haps), size=2)
+    props = torch.from_numpy(init).to(dense.dev)
+    lnp = torch.log(props)
+    state = em.new_state(2, dense.dev)
+    a, b = torch.zeros_like(props), torch.zeros_like(props)
+    dense.em_iter(props, lnp, state, a)
+    try:
+        assert coded.lib.mxm_set_coded_shape(shape) == 0
+        coded.em_iter(props, lnp, state, b)
+    finally:
+        coded.lib.mxm_set_coded_shape(0)
+    assert float(((a - b).abs() / a.abs()).max()) < 1e-12
+    # and against the oracle's M-step: sum_r w_r posterior = p_h T_h
+    buf = numpy.empty_like(mat)
+    _, theta = em_oracle.em_step(mat, g["wts"], numpy.log(init[0]), buf)
+    mine = (props[0] * b[0]).cpu().numpy()
+    assert numpy.allclose(mine / mine.sum(), numpy.exp(theta), rtol=0, atol=1e-13)
+
+
+def test_run_em_goldens_in_coded_storage(b17):
+    """g4 (600 rows), g9 (2400 rows, repeat weights, 1209 iterations), g5 (three restarts): the reference's
+    iteration counts, haplogroup calls and proportions from the coded loop."""
+    from mixemt_amd import assign, em
+    refseq, phy, haps, tables = b17
+    for name, seed, n_multi in (("g4_run_em", 7, 1), ("g9_run_em_2400", 17, 1), ("g5_run_em_multi", 11, 3)):
+        g = golden(name)
+        mat = _b17_matrix(tables, g, len(haps))
+        numpy.random.seed(seed)
+        res = em.run_em_ex(mat, g["wts"], em_args(n_multi=n_multi), storage="coded")
+        assert numpy.array_equal(res["inits"], g["inits"])
+        assert res["iters"] == list(g["iters"]), name
+        assert numpy.abs(res["props"] - g["props"]).max() < PROPS_ATOL
+        best, votes = assign.row_argmax_votes(res["read_mix"], g["wts"])
+        assert numpy.array_equal(best, g["mix_argmax"])
+        if "votes" in g.files:
+            assert numpy.array_equal(votes, g["votes"])
+
+
+def test_rows_that_do_not_code_stay_dense_and_count():
+    """Random matrices have H distinct values per row: every row takes the dense rest, the result is the
+    dense path's; a mixed matrix (half dictionary rows) sums both parts."""
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(5)
+    n_rows, n_haps = 300, 1000
+    mat = rng.normal(-25.0, 8.0, size=(n_rows, n_haps))
+    few = rng.normal(-25.0, 8.0, size=(n_rows, 7))
+    pick = rng.integers(0, 7, size=(n_rows, n_haps))
+    half = numpy.arange(n_rows) % 2 == 0
+    mat[half] = numpy.take_along_axis(few, pick, axis=1)[half]       # 7 distinct values per even row
+    mat[4, :] = -3.0                                                 # one value
+    mat[6, :300] = -numpy.inf                                        # -inf is a value like any other
+    wts = rng.integers(1, 5, size=n_rows)
+    init = rng.dirichlet([1.0] * n_haps)
+    plan = em.EmPlan(mat, wts, storage="coded")
+    nd = _ndist(plan)
+    assert plan.coded_rest == n_rows // 2 and (nd[~half] == 0).all() and (nd[half] > 0).all() and nd[4] == 1
+    res = em.run_em_ex(mat, wts, em_args(max_iter=6, tolerance=0.0), inits=init[None, :], storage="coded")
+    theta = numpy.log(init)
+    buf = numpy.empty_like(mat)
+    for _ in range(6):
+        buf, theta = em_oracle.em_step(mat, wts, theta, buf)
+    assert res["iters"] == [6]
+    assert numpy.abs(res["props"] - numpy.exp(theta)).max() < 1e-12
+    # all rows dense / all rows coded
+    for sub in (mat[~half], mat[half]):
+        r2 = em.run_em_ex(sub, wts[:len(sub)], em_args(max_iter=3, tolerance=0.0), inits=init[None, :], storage="coded")
+        theta = numpy.log(init)
+        buf = numpy.empty_like(sub)
+        for _ in range(3):
+            buf, theta = em_oracle.em_step(sub, wts[:len(sub)], theta, buf)
+        assert numpy.abs(r2["props"] - numpy.exp(theta)).max() < 1e-12
+
+
+@pytest.mark.parametrize("n_rows,n_haps", [(1, 66), (5, 5408), (700, 130), (513, 8192), (40, 2050)])
+def test_shapes_and_ragged_ends(n_rows, n_haps):
+    """Widths across the kernel's chunk counts (H % 4 == 2 included), fewer rows than workgroups."""
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(n_rows + n_haps)
+    few = rng.normal(-20.0, 6.0, size=(n_rows, 40))
+    mat = numpy.take_along_axis(few, rng.integers(0, 40, size=(n_rows, n_haps)), axis=1)
+    wts = rng.integers(1, 4, size=n_rows)
+    init = rng.dirichlet([1.0] * n_haps)
+    res = em.run_em_ex(mat, wts, em_args(max_iter=4, tolerance=0.0), inits=init[None, :], storage="coded")
+    theta = numpy.log(init)
+    buf = numpy.empty_like(mat)
+    for _ in range(4):
+        buf, theta = em_oracle.em_step(mat, wts, theta, buf)
+    assert numpy.abs(res["props"] - numpy.exp(theta)).max() < 1e-12
+
+
+def test_unsupported_shapes_iterate_as_fp64():
+    """Odd or narrow H: the plan says so and runs the dense path (same as the f32 variant's rule)."""
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(3)
+    for n_haps in (9, 67):
+        mat = rng.normal(-20.0, 5.0, size=(50, n_haps))
+        plan = em.EmPlan(mat, numpy.ones(50), storage="coded")
+        assert plan.coded is None and plan.storage == "f64"
+
+
+def test_row_sharded_loop_over_coded_plans(b17):
+    """dist.sharded_em_loop drives plan.em_iter / finalize: a coded plan is a drop-in there (one rank)."""
+    from mixemt_amd import dist as mdist
+    from mixemt_amd import em
+    refseq, phy, haps, tables = b17
+    g = golden("g4_run_em")
+    mat = _b17_matrix(tables, g, len(haps))
+    plan = em.EmPlan(mat, g["wts"], storage="coded")
+    ln_cur, ln_new, states = mdist.sharded_em_loop(plan, g["inits"], 1e-4, 10000)
+    assert [s[1] for s in states] == list(g["iters"])
+    assert numpy.abs(numpy.exp(ln_new[0].cpu().numpy()) - g["props"]).max() < PROPS_ATOL
