@@ -102,7 +102,7 @@ int mxm_set_v1_shape(int32_t shape);
 int mxm_set_min_rows_per_wg(int32_t n);
 
 /* Tuning knob: shape of the row-dictionary streaming kernel {threads, rows in flight, workgroups per CU}:
- * 0 {256, 4, 2} (default), 1 {256, 3, 2}, 2 {512, 4, 2}, 3 {512, 6, 2}, 4 {256, 6, 2}, 5 {512, 3, 2}. */
+ * 0 {256, 4, 2} (default), 1 {256, 3, 2}, 2 {512, 4, 2}, 3 {256, 6, 2}, 4 {512, 3, 2}. */
 int mxm_set_coded_shape(int32_t shape);
 
 #ifdef __cplusplus

@@ -220,6 +220,13 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
 // ------------------------------------------------------------------------------------------
 // Shapes (A/B with mxm_set_coded_shape): threads per workgroup, rows in flight (NBUF - 1 rows of codes
 // are on their way while one is processed; the row's table follows one step behind), workgroups per CU.
+// Measured at 10^6 x 5408 (profiles/r02/coded_shapes.txt; iteration = this kernel + 0.14 ms dense rest + reduce):
+//   256 threads x 2 per CU: 1.75-1.77 ms with 3, 4 or 6 rows in flight      512 x 2 per CU: 1.96-2.20 ms
+//   256 x 3 per CU without the kept row values (second LDS lookup in the accumulation): 2.37-2.46 ms
+// i.e. neither more rows in flight nor more waves help: the kernel is bound by its VALU + LDS instruction
+// streams (per wave and row ~70 instructions of reduction / exchange / division beside 3.25 per cell; SQ
+// counters: 50 % of the wave cycles issuing at 2 waves per SIMD, profiles/r02/coded_pmc_sq_summary.txt),
+// which is why fewer, fatter waves per row win over more, thinner ones.
 template <int THREADS, int NCH, int NBUF, int MINWG>
 __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_kernel(
     const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off, const int32_t *__restrict__ ndist, int ldc,

@@ -406,7 +406,7 @@ static inline mxm_slots slots_from(int first) {
 // stream_linear_tile: the streaming kernel alone, partial rows [0, *nwg_out) of `partial`.
 static int stream_linear_tile(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
                               int H, int nb, mxm_slots &slots, const mxm_em_state *state,
-                              double *partial, hipStream_t stream, bool timed, int *nwg_out) {
+                              double *partial, hipStream_t stream, bool timed, int *nwg_out, int max_wg = MXM_MAX_WG) {
     const int64_t ldpart = part_ld(H);
     const int ncol2 = (H + 1) / 2;
     const bool alt = (nb == 1) && (g_v1_shape == 1);        // the second single-restart shape
@@ -414,7 +414,7 @@ static int stream_linear_tile(const double *P, int64_t ldp, const double *w, con
     const int wg_per_cu = alt ? 1 : ((nb == 1) ? MXM_V1_WG_PER_CU : 1);
     const int nch = (ncol2 + threads - 1) / threads;
     int cap = num_cu() * wg_per_cu;
-    if (cap > MXM_MAX_WG) cap = MXM_MAX_WG;
+    if (cap > max_wg) cap = max_wg;
     // rows are dealt round-robin over the workgroups (row_deal, common.hpp).  Small matrices:
     // fewer workgroups with more rows each (every workgroup pays 2 x H x 8 bytes of proportion
     // loads and partial stores, which colreduce then reads back)
@@ -667,7 +667,7 @@ extern "C" int mxm_decode_rows(const mxm_coded *c, int32_t H, double *P, int64_t
 
 // Shapes of em_iter_coded_kernel (mxm_set_coded_shape; measured in profiles/r02/coded_shapes.txt)
 struct coded_shape { int threads, nbuf, wg_per_cu; };
-static const coded_shape g_coded_shapes[] = {{256, 4, 2}, {256, 3, 2}, {512, 4, 2}, {512, 6, 2}, {256, 6, 2}, {512, 3, 2}};
+static const coded_shape g_coded_shapes[] = {{256, 4, 2}, {256, 3, 2}, {512, 4, 2}, {256, 6, 2}, {512, 3, 2}};
 static int g_coded_shape = 0;
 extern "C" int mxm_set_coded_shape(int32_t shape) {
     if (shape < 0 || shape >= (int)(sizeof(g_coded_shapes) / sizeof(g_coded_shapes[0])))
@@ -697,7 +697,7 @@ static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *
     const coded_shape sh = g_coded_shapes[g_coded_shape];
     const int nch = (ldc / 4 + sh.threads - 1) / sh.threads;
     int cap = num_cu() * sh.wg_per_cu;
-    if (cap > MXM_MAX_WG - 2 * num_cu()) cap = MXM_MAX_WG - 2 * num_cu();     // the dense rest's rows come behind
+    if (cap > MXM_MAX_WG - num_cu()) cap = MXM_MAX_WG - num_cu();             // the dense rest's rows come behind
     if (cap < 1) cap = 1;
     const int nwg = clamp_grid((c->R + sh.nbuf - 1) / sh.nbuf, cap);
     if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
@@ -706,8 +706,7 @@ static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *
         case 0: lrc = launch_coded<256, 4, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
         case 1: lrc = launch_coded<256, 3, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
         case 2: lrc = launch_coded<512, 4, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
-        case 3: lrc = launch_coded<512, 6, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
-        case 4: lrc = launch_coded<256, 6, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
+        case 3: lrc = launch_coded<256, 6, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
         default: lrc = launch_coded<512, 3, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
     }
     if (lrc != 0) return lrc;
@@ -718,7 +717,7 @@ static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *
     for (int i = 0; i < MXM_MAX_BT; ++i) sl.s[i] = run;
     if (c->R_rest > 0) {
         const int rc = stream_linear_tile(c->P_rest, c->ldp_rest, c->w_rest, props, c->R_rest, H, 1, sl, state,
-                                          partial + (int64_t)nwg * ldpart, stream, false, &nwg_rest);
+                                          partial + (int64_t)nwg * ldpart, stream, false, &nwg_rest, MXM_MAX_WG - nwg);
         if (rc != 0) return rc;
     }
     hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart,

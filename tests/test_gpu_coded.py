@@ -62,7 +62,7 @@ def test_encoded_rows_decode_to_the_linearised_matrix_bit_for_bit(b17, name):
     assert coded.coded_bytes < 0.25 * mat.size * 8    # ~8x smaller on these matrices
 
 
-@pytest.mark.parametrize("shape", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("shape", [0, 1, 2, 3, 4])
 def test_one_iteration_equals_the_dense_pass(b17, shape):
     """Same proportions in -> same column sums out (summation order differs: 1e-13 relative), every kernel shape."""
     import torch

@@ -6,7 +6,7 @@ synthetic reads, device-resident end to end:
     CSR observations -> build_em_matrix_device -> run_em -> contributors from read votes
     -> refinement EM on the contributor columns -> read assignment -> contributor table
 
-    python tools/run_pipeline.py [--reads N] [--seed S] [--multi M]
+    python tools/run_pipeline.py [--reads N] [--seed S] [--multi M] [--storage f64|coded]
 """
 import argparse
 import os
@@ -26,9 +26,11 @@ def main():
     ap.add_argument("--reads", type=int, default=20000)
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--multi", type=int, default=1)
+    ap.add_argument("--storage", default="f64", choices=["f64", "f32", "coded"],
+                    help="form of the matrix the EM loop streams (EmPlan): coded = lossless row dictionaries")
     opts = ap.parse_args()
     args = argparse.Namespace(init_alpha=1.0, tolerance=1e-4, max_iter=10000, n_multi=opts.multi,
-                              verbose=True, min_reads=10, min_fold=2.0)
+                              verbose=True, min_reads=10, min_fold=2.0, storage=opts.storage)
     numpy.random.seed(opts.seed)                       # bin/mixemt:507-508
 
     t0 = time.perf_counter()

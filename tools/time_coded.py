@@ -104,7 +104,7 @@ def coded_iter():
 
 
 t_dense = timed(dense_iter)
-shapes = ["256 threads, 4 rows in flight, 2 workgroups per CU", "256, 3, 2", "512, 4, 2", "512, 6, 2", "256, 6, 2", "512, 3, 2"]
+shapes = ["256 threads, 4 rows in flight, 2 workgroups per CU", "256, 3, 2", "512, 4, 2", "256, 6, 2", "512, 3, 2"]
 best = None
 for shape, label in enumerate(shapes):
     if only is not None and shape not in only:
