@@ -215,7 +215,8 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
     return {"ms_per_step": ms, "value": float(n_rows) * n_haps / (ms * 1e-3), "unit": "cells/s",
             "kernel": "em_iter_coded_kernel", "kernel_ms": kernel_ms,
             "bytes_per_iteration": float(cplan.coded_bytes),
-            "hbm_frac": cplan.coded_bytes / (kernel_ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
+            "kernel_bytes": float(cplan.coded_record_bytes),
+            "hbm_frac": cplan.coded_record_bytes / (kernel_ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
             "rows_left_dense": int(cplan.coded_rest), "encode_ms": encode_ms, "max_rel_dcolsum": rel,
             "note": "same iteration, matrix stored as one byte per cell + each row's distinct fp64 values "
                     "(decodes to the dense matrix bit for bit); not the headline value"}
@@ -537,7 +538,8 @@ def bench_rows(opts, env):
     elem = 4.0 if opts.storage == "f32" else 8.0
     algo_bytes = float(n_rows) * n_haps * elem        # this rank's stored matrix is read once per iteration
     if plan.coded is not None:
-        algo_bytes = float(plan.coded_bytes)          # records (codes + tables) + the rows that stay dense
+        algo_bytes = float(plan.coded_record_bytes)   # the records em_iter_coded_kernel reads (the rows that stay
+                                                      # dense go through em_iter_wide_kernel afterwards)
     achieved = algo_bytes / (kernel_ms.mean() * 1e-3)
     traffic = pmc_traffic(n_rows, n_haps) if (opts.storage == "f64" and n_runs == 1) else None
     return {

@@ -226,7 +226,10 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
 // i.e. neither more rows in flight nor more waves help: the kernel is bound by its VALU + LDS instruction
 // streams (per wave and row ~70 instructions of reduction / exchange / division beside 3.25 per cell; SQ
 // counters: 50 % of the wave cycles issuing at 2 waves per SIMD, profiles/r02/coded_pmc_sq_summary.txt),
-// which is why fewer, fatter waves per row win over more, thinner ones.
+// which is why fewer, fatter waves per row win over more, thinner ones.  Two attempts on the fixed part
+// (profiles/r02/coded_reduce_division_variants.txt): the wave sum as an xor butterfly on the LDS crossbar (6 VALU
+// ops instead of 22, but six dependent ds_bpermute round trips) 2.07 ms; reciprocal + two Newton steps instead of
+// the IEEE division 1.73 ms (-2 %, not taken: it would change the quotient's last bit against the dense kernel).
 template <int THREADS, int NCH, int NBUF, int MINWG>
 __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_kernel(
     const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off, const int32_t *__restrict__ ndist, int ldc,

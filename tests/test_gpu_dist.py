@@ -23,7 +23,7 @@ def _free_port():
         return s.getsockname()[1]
 
 
-def _worker(rank, world, port, out_dir, name, seed, n_multi, mode, backend="gloo"):
+def _worker(rank, world, port, out_dir, name, seed, n_multi, mode, backend="gloo", storage="f64"):
     import sys
     here = os.path.dirname(os.path.abspath(__file__))
     sys.path.insert(0, here)
@@ -55,7 +55,10 @@ def _worker(rank, world, port, out_dir, name, seed, n_multi, mode, backend="gloo
         numpy.random.seed(seed if rank == 0 else 999)      # only rank 0's stream may matter
         if mode == "rows":
             lo, hi = mdist.shard_bounds(full.shape[0], rank, world)
-            res = mdist.run_em_sharded(full[lo:hi], wts[lo:hi], mk(n_multi=n_multi), check_every=5)
+            if storage == "coded":                         # the shard really takes the dictionary form
+                from mixemt_amd import em as _em
+                assert _em.EmPlan(full[lo:hi], wts[lo:hi], storage="coded").coded is not None
+            res = mdist.run_em_sharded(full[lo:hi], wts[lo:hi], mk(n_multi=n_multi, storage=storage), check_every=5)
         else:
             res = mdist.run_em_restart_parallel(full, wts, mk(n_multi=n_multi))
             lo, hi = res["rows"]                               # each rank returns ITS row block
@@ -85,6 +88,21 @@ def test_two_ranks_row_sharded_match_reference(tmp_path, name, seed, n_multi):
         assert numpy.array_equal(r["best"], g["mix_argmax"][lo:hi])     # identical calls, per shard
         assert numpy.allclose(r["rowmax"], g["mix_rowmax"][lo:hi], rtol=0, atol=1e-8)
     assert int(res[0]["hi"]) == int(res[1]["lo"]) and int(res[1]["hi"]) == 600
+
+
+def test_two_ranks_row_sharded_coded_storage_match_reference(tmp_path):
+    """The row-sharded loop over shards in row-dictionary storage (EmPlan(storage="coded")): same bar."""
+    import torch.multiprocessing as mp
+    g = golden("g4_run_em")
+    mp.spawn(_worker, args=(2, _free_port(), str(tmp_path), "g4_run_em", 7, 1, "rows", "gloo", "coded"),
+             nprocs=2, join=True)
+    res = [numpy.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(2)]
+    for r in res:
+        assert list(r["iters"]) == list(g["iters"])
+        assert numpy.abs(r["props"] - g["props"]).max() < 1e-9
+        assert numpy.array_equal(r["props"], res[0]["props"])
+        lo, hi = int(r["lo"]), int(r["hi"])
+        assert numpy.array_equal(r["best"], g["mix_argmax"][lo:hi])
 
 
 def test_two_ranks_restart_parallel_match_reference(tmp_path):
