@@ -204,6 +204,11 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && NBUF == 2) ? MXM_V1_MINW : TH
     int buf = 0;
     auto process = [&](d2(&xr)[NCH], int64_t q) {
         double d[BT];
+        // the row's weight is a scalar load with a cache line of its own (rows of a workgroup are a grid
+        // apart): asked for here, it arrives during the dot products; asked for after the barrier it was an
+        // L2 round trip on every row's critical path (batches of 3 / 4: 6.47 -> 6.21 / 6.80 -> 6.54 ms per pass)
+        double wr = deal.live(q) ? (w != nullptr ? w[deal.row(q)] : 1.0) : 0.0;
+        asm volatile("" : "+s"(wr));
         // keep the batch's proportions IN LDS: without this the loads are loop-invariant
         // and get hoisted back into (BT * NCH * 4) VGPRs
         if constexpr (P_IN_LDS) asm volatile("" ::: "memory");
@@ -227,7 +232,6 @@ __global__ __launch_bounds__(THREADS, ((BT == 1 && NBUF == 2) ? MXM_V1_MINW : TH
             for (int b = 0; b < BT; ++b) red[buf][b][wv] = d[b];
         }
         __syncthreads();
-        const double wr = deal.live(q) ? (w != nullptr ? w[deal.row(q)] : 1.0) : 0.0;
         double cs[BT];                                  // w_r / Z_r per restart
         group_ratio_to_sgpr<NW, BT>(&red[buf][0][0], lane, wr, cs);
 #pragma unroll
@@ -314,6 +318,8 @@ __global__ __launch_bounds__(THREADS, 2) void em_iter_wide_f32_kernel(
 
     int buf = 0;
     auto process = [&](f4(&xr)[NCH], int64_t q) {
+        double wr = deal.live(q) ? (w != nullptr ? w[deal.row(q)] : 1.0) : 0.0;   // asked for before the barrier
+        asm volatile("" : "+s"(wr));
         double s = 0.0;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
@@ -323,7 +329,6 @@ __global__ __launch_bounds__(THREADS, 2) void em_iter_wide_f32_kernel(
         s = wave_sum_lane63(s);
         if (lane == 63) red[buf][wv] = s;
         __syncthreads();
-        const double wr = deal.live(q) ? (w != nullptr ? w[deal.row(q)] : 1.0) : 0.0;
         double cs[1];
         group_ratio_to_sgpr<NW, 1>(&red[buf][0], lane, wr, cs);
         const double c = cs[0];

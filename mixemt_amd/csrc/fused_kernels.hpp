@@ -236,6 +236,10 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_THREADS / 256) void em_fused_l
                 d2 x[NBUF][NCH];                            // row ring: NBUF - 1 rows in flight
                 int buf = 0;
                 auto process = [&](d2(&xr)[NCH], int64_t q) {
+                    // the weight's scalar load is issued before the dot product, not after the barrier
+                    const int64_t r = (int64_t)blockIdx.x + (q < nq ? q : nq - 1) * (int64_t)nwg;
+                    double wr = (q < nq) ? (w != nullptr ? w[r] : 1.0) : 0.0;
+                    asm volatile("" : "+s"(wr));
                     double s = 0.0;
 #pragma unroll
                     for (int k = 0; k < NCH; ++k) {
@@ -245,8 +249,6 @@ __global__ __launch_bounds__(FUSED_THREADS, FUSED_THREADS / 256) void em_fused_l
                     s = wave_sum_lane63(s);
                     if (lane == 63) red[buf][wv] = s;
                     __syncthreads();
-                    const int64_t r = (int64_t)blockIdx.x + (q < nq ? q : nq - 1) * (int64_t)nwg;
-                    const double wr = (q < nq) ? (w != nullptr ? w[r] : 1.0) : 0.0;
                     double cs[1];
                     group_ratio_to_sgpr<NW, 1>(&red[buf][0], lane, wr, cs);
                     const double c = cs[0];
