@@ -178,7 +178,7 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
     if cplan.coded is None:
         return None
     t0 = time.perf_counter()
-    cplan._encode()
+    cplan.encode()
     torch.cuda.synchronize()
     encode_ms = (time.perf_counter() - t0) * 1e3
     state = em.new_state(1, mat.device)
@@ -369,7 +369,7 @@ def bench_rows(opts, env):
     torch.cuda.synchronize()
     t0 = time.perf_counter()                      # timed again on the now-resident buffers
     if plan.coded is not None:
-        plan._encode()                            # mxm_encode_rows + the dense rest, second time
+        plan.encode()                            # mxm_encode_rows + the dense rest, second time
     else:
         lin_fn = lib.mxm_linearize_f32 if opts.storage == "f32" else lib.mxm_linearize
         _lib.check(lin_fn(mat.data_ptr(), mat.stride(0), n_rows, n_haps, plan.lin.data_ptr(),

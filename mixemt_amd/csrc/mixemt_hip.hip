@@ -406,10 +406,12 @@ static inline mxm_slots slots_from(int first) {
 // stream_linear_tile: the streaming kernel alone, partial rows [0, *nwg_out) of `partial`.
 static int stream_linear_tile(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
                               int H, int nb, mxm_slots &slots, const mxm_em_state *state,
-                              double *partial, hipStream_t stream, bool timed, int *nwg_out, int max_wg = MXM_MAX_WG) {
+                              double *partial, hipStream_t stream, bool timed, int *nwg_out, int max_wg = MXM_MAX_WG,
+                              int v1_shape = -1) {
     const int64_t ldpart = part_ld(H);
     const int ncol2 = (H + 1) / 2;
-    const bool alt = (nb == 1) && (g_v1_shape == 1);        // the second single-restart shape
+    if (v1_shape < 0) v1_shape = g_v1_shape;
+    const bool alt = (nb == 1) && (v1_shape == 1);          // the second single-restart shape
     const int threads = alt ? MXM_V1B_THREADS : variant_threads(nb);
     const int wg_per_cu = alt ? 1 : ((nb == 1) ? MXM_V1_WG_PER_CU : 1);
     const int nch = (ncol2 + threads - 1) / threads;
@@ -717,7 +719,9 @@ static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *
     for (int i = 0; i < MXM_MAX_BT; ++i) sl.s[i] = run;
     if (c->R_rest > 0) {
         const int rc = stream_linear_tile(c->P_rest, c->ldp_rest, c->w_rest, props, c->R_rest, H, 1, sl, state,
-                                          partial + (int64_t)nwg * ldpart, stream, false, &nwg_rest, MXM_MAX_WG - nwg);
+                                          partial + (int64_t)nwg * ldpart, stream, false, &nwg_rest, MXM_MAX_WG - nwg,
+                                          0 /* the 256-thread instance: the few dense rows show up under a kernel
+                                               name of their own in a trace, apart from the dense matrix's passes */);
         if (rc != 0) return rc;
     }
     hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart,

@@ -148,7 +148,7 @@ class EmPlan(object):
                 raise ValueError("linear = (P, rowmax) is the dense fp64 plan's input")
             if (self.n_rows > 0 and self.lib.mxm_linear_supported(self.n_haps) and self.n_haps % 2 == 0
                     and self.mat.stride(1) == 1 and self.mat.stride(0) % 2 == 0 and self.mat.data_ptr() % 16 == 0):
-                self._encode()
+                self.encode()
             else:
                 self.storage = storage = "f64"
         if self.coded is not None:
@@ -181,7 +181,7 @@ class EmPlan(object):
         if not keep_log_matrix and (self.lin is not None or self.coded is not None):
             self.mat = None
 
-    def _encode(self):
+    def encode(self):
         """Row-dictionary form of this plan's matrix (mxm_encode_rows) + the dense rest."""
         lib, dev, n_rows, n_haps = self.lib, self.dev, self.n_rows, self.n_haps
         cap = lib.mxm_coded_bytes(n_rows, n_haps)
@@ -211,7 +211,8 @@ class EmPlan(object):
         self.coded_record_bytes = used                # what em_iter_coded_kernel reads per pass
         self.coded_bytes = used + (n_rest * n_haps * 8)
         self.coded_rest = n_rest
-        self._coded_keep = (rec, rec_off, ndist, p_rest, w_rest)
+        self._coded_keep = (rec, rec_off, ndist, p_rest, w_rest)      # the tensors self.coded points into
+        self.coded_ndist = ndist                      # [R] int32: table entries per row, 0 = the row stays dense
         self.coded = _lib.Coded(rec.data_ptr(), rec_off.data_ptr(), ndist.data_ptr(), n_rows,
                                 p_rest.data_ptr() if n_rest else None, p_rest.stride(0) if n_rest else 0,
                                 w_rest.data_ptr() if n_rest else None, n_rest)

@@ -34,7 +34,7 @@ def _decode(plan):
 
 
 def _ndist(plan):
-    return plan._coded_keep[2].cpu().numpy()
+    return plan.coded_ndist.cpu().numpy()
 
 
 @pytest.mark.parametrize("name", ["g4_run_em", "g9_run_em_2400"])

@@ -9,12 +9,17 @@ mkdir -p $dst
 for f in bench_1m.json bench_1m_under_rocprof.json bench_1m_10restarts.json bench_100k.json \
          bench_restarts10_run.json bench_restarts16_run.json pmc_traffic_1m.json pmc_traffic_build_1m.json \
          pmc_sq_summary.txt small_runs.txt small_runs_under_rocprof.txt build_kernels.txt build_under_rocprof.txt \
-         restart_schedules.txt dropin_build.txt lut_variants.txt barrier_variants.txt; do
+         restart_schedules.txt dropin_build.txt lut_variants.txt barrier_variants.txt \
+         bench_1m_coded.json bench_1m_coded_under_rocprof.json bench_1m_coded_10restarts.json \
+         bench_125k_coded_one_rank_rccl.json bench_125k_one_rank_rccl.json bench_1250k_per_gpu.json \
+         pmc_traffic_coded_1m.json coded_pmc_sq_summary.txt coded_shapes.txt pipeline_1m.txt pipeline_1m_coded.txt; do
   [ -f $src/$f ] && cp $src/$f $dst/$f
 done
 [ -f $src/bench_1m.log ] && cp $src/bench_1m.log $dst/bench_1m.log
 cp $src/kt/kt_kernel_stats.csv $dst/bench_1m_kernel_stats.csv 2>/dev/null
 cp $src/kt_small/kt_kernel_stats.csv $dst/small_runs_kernel_stats.csv 2>/dev/null
+cp $src/kt_coded/kt_kernel_stats.csv $dst/coded_kernel_stats.csv 2>/dev/null
+cp $src/pmc_fetch_coded/f_counter_collection.csv $dst/pmc_fetch_size_coded.csv 2>/dev/null
 cp $src/kt_build/kt_kernel_stats.csv $dst/build_kernel_stats.csv 2>/dev/null
 cp $src/pmc_fetch/f_counter_collection.csv $dst/pmc_fetch_size.csv 2>/dev/null
 cp $src/pmc_write/w_counter_collection.csv $dst/pmc_write_size.csv 2>/dev/null

@@ -21,6 +21,21 @@ python3 $repo/tools/pmc_summary.py $out/pmc_fetch/f_counter_collection.csv $out/
 # where the waves' time goes (one SQ pass: 8 slots) + the effective clock (GRBM)
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $out/pmc_sq -o sq -- python3 $repo/bench.py --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_sq.log
 python3 $repo/tools/sq_summary.py $out/pmc_sq/sq_counter_collection.csv > $out/pmc_sq_summary.txt 2>&1
+# --- the same iteration over row dictionaries (opt-in lossless storage) -------------------
+python3 $repo/bench.py --storage coded > $out/bench_1m_coded.json 2> $out/bench_1m_coded.log
+rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt_coded -o kt -- python3 $repo/bench.py --storage coded --no-cpu-baseline > $out/bench_1m_coded_under_rocprof.json 2> $out/kt_coded.log
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch_coded -o f -- python3 $repo/bench.py --storage coded --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_fetch_coded.log
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write_coded -o w -- python3 $repo/bench.py --storage coded --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_write_coded.log
+python3 $repo/tools/pmc_summary.py $out/pmc_fetch_coded/f_counter_collection.csv $out/pmc_write_coded/w_counter_collection.csv > $out/pmc_traffic_coded_1m.json
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $out/pmc_sq_coded -o sq -- python3 $repo/bench.py --storage coded --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_sq_coded.log
+python3 $repo/tools/sq_summary.py $out/pmc_sq_coded/sq_counter_collection.csv > $out/coded_pmc_sq_summary.txt 2>&1
+python3 $repo/tools/time_coded.py > $out/coded_shapes.txt 2>&1
+python3 $repo/bench.py --storage coded --restarts 10 --no-cpu-baseline > $out/bench_1m_coded_10restarts.json 2> /dev/null
+python3 $repo/bench.py --storage coded --total-rows 125000 --force-dist --no-cpu-baseline > $out/bench_125k_coded_one_rank_rccl.json 2> /dev/null
+python3 $repo/bench.py --total-rows 125000 --force-dist --no-cpu-baseline > $out/bench_125k_one_rank_rccl.json 2> /dev/null
+python3 $repo/bench.py --rows 1250000 --no-cpu-baseline > $out/bench_1250k_per_gpu.json 2> /dev/null
+python3 $repo/tools/run_pipeline.py --reads 1000000 > $out/pipeline_1m.txt 2>&1
+python3 $repo/tools/run_pipeline.py --reads 1000000 --storage coded > $out/pipeline_1m_coded.txt 2>&1
 # --- other configurations of the same script --------------------------------------------------------
 python3 $repo/bench.py --restarts 10 --no-cpu-baseline > $out/bench_1m_10restarts.json 2> /dev/null
 python3 $repo/bench.py --total-rows 100000 --no-cpu-baseline > $out/bench_100k.json 2> /dev/null
