@@ -104,6 +104,10 @@ def em_step(read_hap_mat, weights, ln_props, read_mix_mat):
     return out, ln_new
 
 
+AUTO_CODED_MIN_CELLS = 1.0e8        # storage="auto": the one-launch loops' range ends here (mxm_em_loop)
+AUTO_CODED_MAX_REST = 0.25          # ... and at most this share of the rows may stay dense
+
+
 class EmPlan(object):
     """
     Device-resident inputs of the EM loop for one (rank-local) matrix:
@@ -122,12 +126,15 @@ class EmPlan(object):
         (mxm_encode_rows; rows with more than 256 of them stay dense): the matrix
         build's rows hold a few dozen distinct sums, so the loop reads ~8x fewer
         bytes.  Matrices it does not apply to (odd / narrow H, unaligned rows)
-        iterate as "f64".
+        iterate as "f64".  "auto" = "coded" where it pays: more than 10^8 cells
+        (below that the one-launch loops over the dense matrix are faster) and at
+        most a quarter of the rows left dense by the encoder; otherwise "f64".
+        `plan.storage` says what the plan iterates.
         linear = (P, rowmax): the linearised matrix already made by the matrix build
         (preprocess.build_em_matrix_device(..., linear=...)): nothing is recomputed here.
         """
-        if storage not in ("f64", "f32", "coded"):
-            raise ValueError("storage must be 'f64', 'f32' or 'coded'")
+        if storage not in ("f64", "f32", "coded", "auto"):
+            raise ValueError("storage must be 'f64', 'f32', 'coded' or 'auto'")
         self.storage = storage
         self.lib = _lib.load()
         self.dev = require_gpu()
@@ -143,13 +150,20 @@ class EmPlan(object):
         self.lin = None
         self.rowmax = None
         self.coded = None
+        auto = storage == "auto"
+        if auto:
+            storage = "coded" if (linear is None and float(self.n_rows) * self.n_haps > AUTO_CODED_MIN_CELLS) else "f64"
+            self.storage = storage
         if storage == "coded":
             if linear is not None:
                 raise ValueError("linear = (P, rowmax) is the dense fp64 plan's input")
             if (self.n_rows > 0 and self.lib.mxm_linear_supported(self.n_haps) and self.n_haps % 2 == 0
                     and self.mat.stride(1) == 1 and self.mat.stride(0) % 2 == 0 and self.mat.data_ptr() % 16 == 0):
                 self.encode()
-            else:
+                if auto and self.coded_rest > AUTO_CODED_MAX_REST * self.n_rows:
+                    self.coded = None                 # rows do not compress (not a build_em_matrix matrix): dense
+                    self._coded_keep = self.coded_ndist = None
+            if self.coded is None:
                 self.storage = storage = "f64"
         if self.coded is not None:
             pass

@@ -184,3 +184,54 @@ def test_row_sharded_loop_over_coded_plans(b17):
     ln_cur, ln_new, states = mdist.sharded_em_loop(plan, g["inits"], 1e-4, 10000)
     assert [s[1] for s in states] == list(g["iters"])
     assert numpy.abs(numpy.exp(ln_new[0].cpu().numpy()) - g["props"]).max() < PROPS_ATOL
+
+
+def test_auto_storage_codes_large_build_matrices_only(b17):
+    """storage="auto": dictionary rows above the one-launch loops' range when the rows compress; dense otherwise."""
+    import torch
+    from mixemt_amd import em, preprocess, synth
+    refseq, phy, haps, tables = b17
+    g = golden("g4_run_em")
+    small = _b17_matrix(tables, g, len(haps))
+    assert em.EmPlan(small, g["wts"], storage="auto").storage == "f64"          # 600 rows: the one-launch loop's
+    n_rows = 20000                                                              # 1.08e8 cells
+    row_ptr, site, obs, _ = synth.synth_rows(tables, len(refseq), 0, n_rows, seed=3)
+    big = preprocess.build_em_matrix_device(tables, row_ptr, site, obs)
+    plan = em.EmPlan(big, torch.ones(n_rows, dtype=torch.float64, device=big.device), storage="auto")
+    assert plan.storage == "coded" and plan.coded is not None and plan.coded_rest < 0.05 * n_rows
+    noise = torch.empty((12500, 8192), dtype=torch.float64, device=big.device).normal_(-25.0, 8.0)
+    plan = em.EmPlan(noise, torch.ones(12500, dtype=torch.float64, device=big.device), storage="auto")
+    assert plan.storage == "f64" and plan.coded is None and plan.lin is not None  # nothing to compress: dense
+
+
+def test_special_values_and_weights():
+    """NaN-free edge values: a row that is -inf everywhere with weight 0 is dropped like scipy drops it, with
+    weight > 0 it poisons the run exactly like the dense path; fractional weights; the all-ones bit pattern
+    (the hash table's empty marker) sends its row to the dense rest instead of being mis-coded."""
+    import struct
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(9)
+    n_rows, n_haps = 64, 256
+    few = rng.normal(-15.0, 4.0, size=(n_rows, 9))
+    mat = numpy.take_along_axis(few, rng.integers(0, 9, size=(n_rows, n_haps)), axis=1)
+    mat[5, :] = -numpy.inf
+    wts = rng.random(n_rows) + 0.5
+    wts[5] = 0.0
+    init = rng.dirichlet([1.0] * n_haps)
+    res = em.run_em_ex(mat, wts, em_args(max_iter=5, tolerance=0.0), inits=init[None, :], storage="coded")
+    theta = numpy.log(init)
+    buf = numpy.empty_like(mat)
+    with numpy.errstate(invalid="ignore"):
+        for _ in range(5):
+            buf, theta = em_oracle.em_step(mat, wts, theta, buf)
+    assert numpy.abs(res["props"] - numpy.exp(theta)).max() < 1e-12
+    wts[5] = 1.0                                        # now the empty row counts: NaN everywhere, as in the reference
+    bad = em.run_em_ex(mat, wts, em_args(max_iter=3, tolerance=0.0), inits=init[None, :], storage="coded")
+    ref = em.run_em_ex(mat, wts, em_args(max_iter=3, tolerance=0.0), inits=init[None, :], storage="f64")
+    assert numpy.isnan(bad["props"]).all() and numpy.isnan(ref["props"]).all()
+    # the reserved bit pattern (a NaN payload of all ones)
+    mat2 = numpy.take_along_axis(few, rng.integers(0, 9, size=(n_rows, n_haps)), axis=1)
+    mat2[7, 3] = struct.unpack("<d", b"\xff" * 8)[0]
+    plan = em.EmPlan(mat2, numpy.ones(n_rows), storage="coded")
+    nd = plan.coded_ndist.cpu().numpy()
+    assert nd[7] == 0 and plan.coded_rest == 1 and (numpy.delete(nd, 7) > 0).all()

@@ -26,7 +26,7 @@ def main():
     ap.add_argument("--reads", type=int, default=20000)
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--multi", type=int, default=1)
-    ap.add_argument("--storage", default="f64", choices=["f64", "f32", "coded"],
+    ap.add_argument("--storage", default="f64", choices=["f64", "f32", "coded", "auto"],
                     help="form of the matrix the EM loop streams (EmPlan): coded = lossless row dictionaries")
     opts = ap.parse_args()
     args = argparse.Namespace(init_alpha=1.0, tolerance=1e-4, max_iter=10000, n_multi=opts.multi,
