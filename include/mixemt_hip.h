@@ -120,6 +120,26 @@ int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const double *lhi
                             double *M, int64_t ldm, double *P, int64_t ldp, double *rowmax, void *stream);
 
 /*
+ * build_em_matrix from the haplogroups' MARKERS -- preprocess.py:177-198, the same bits as the kernels
+ * above, formed once per distinct cell value of a row instead of once per cell:
+ *   maj[S]            the base most haplogroups expect at site s
+ *   mk_ptr[S+1], mk_hap[], mk_base[]   CSR over sites of the (haplogroup, expected base) pairs that
+ *                     differ from maj[s]  (Build 17: 113 027 entries)
+ *   obs[]             the observation's byte itself (it hits where it equals the expected base's byte)
+ * A haplogroup's cell is decided by the set of the row's sites where its term differs from the
+ * majority's (a 64-bit mask OR-ed together from the marker lists); the row's distinct masks are
+ * deduplicated and each one's sum is formed in signature order from 0.0, as prob_for_vars does
+ * (preprocess.py:86-96).  Rows with more than 64 observations (or more than 704 distinct values) are NOT
+ * written: their indices are appended to fallback[] (device int64[R], *n_fallback = how many, device) and
+ * the caller builds them with mxm_build_em_matrix_lut / mxm_build_em_matrix (order = fallback).
+ */
+int mxm_build_em_matrix_sparse(const uint8_t *maj, const double *lhit, const double *lmiss,
+                               const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
+                               const int64_t *row_ptr, const uint16_t *site, const uint8_t *obs,
+                               const int64_t *order, int64_t R, int32_t H, int32_t S,
+                               double *M, int64_t ldm, int64_t *fallback, int64_t *n_fallback, void *stream);
+
+/*
  * One-time change of variables for the streaming loop:
  *   rowmax[r] = max_h M[r][h]   (0 if not finite),  P[r][h] = exp(M[r][h] - rowmax[r])
  * ldp must be even and >= H; pad columns [H, ldp) are written as 0.

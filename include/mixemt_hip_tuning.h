@@ -105,6 +105,13 @@ int mxm_set_min_rows_per_wg(int32_t n);
  * 0 {256, 4, 2} (default), 1 {256, 3, 2}, 2 {512, 4, 2}, 3 {256, 6, 2}, 4 {512, 3, 2}. */
 int mxm_set_coded_shape(int32_t shape);
 
+/* Tuning knob: column ranges per row of the marker build kernel (1, 2 or 4; default 2: 16.4 ms at 10^6 x 5408 against 22.5 with one range and 21.3 with four): its per-haplogroup
+ * mask array is 1 / passes of a row, which decides how many rows a CU has in flight. */
+int mxm_set_sparse_passes(int32_t passes);
+/* Test knob: distinct non-zero masks a row of the marker build kernel may have before it goes to the
+ * fallback list (0 ... 704, default 704); lowering it drives ordinary rows through the fallback path. */
+int mxm_set_sparse_max_distinct(int32_t n);
+
 #ifdef __cplusplus
 }
 #endif

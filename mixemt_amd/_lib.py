@@ -39,6 +39,8 @@ SIGNATURES = {
                                            c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     "mxm_build_em_matrix_lut": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                                c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
+    "mxm_build_em_matrix_sparse": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                                  c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     "mxm_build_packed_lds_bytes": (c_size, [c_i32, c_i32]),
     "mxm_build_em_matrix_packed": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
                                                   c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
@@ -83,6 +85,8 @@ SIGNATURES = {
     "mxm_set_min_rows_per_wg": (ctypes.c_int, [c_i32]),
     "mxm_set_v1_shape": (ctypes.c_int, [c_i32]),
     "mxm_set_coded_shape": (ctypes.c_int, [c_i32]),
+    "mxm_set_sparse_passes": (ctypes.c_int, [c_i32]),
+    "mxm_set_sparse_max_distinct": (ctypes.c_int, [c_i32]),
     "mxm_row_argmax_votes": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                             c_ptr, c_size, c_ptr]),
     "mxm_gather_columns": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),

@@ -15,6 +15,7 @@
 //   common.hpp          error plumbing, reductions
 //   build_kernels.hpp   build_em_matrix_kernel (byte table, L2/MALL), build_tile_kernel (LDS-staged 4-bit table)
 //   build_lut_kernels.hpp  build_lut_kernel (hit/miss by LDS lookup; optionally emits the linearised matrix too)
+//   build_sparse_kernels.hpp  build_sparse_kernel (the row from the haplogroups' markers: one in-order sum per distinct cell value)
 //   em_kernels.hpp      linearize, em_iter_wide_kernel (THE hot kernel: R*H*8 B read per EM iteration,
 //                       1-4 restarts per pass), em_iter_wide_f32_kernel (opt-in storage variant),
 //                       colreduce_kernel, finalize_kernel
@@ -41,6 +42,7 @@
 #include "common.hpp"
 #include "build_kernels.hpp"
 #include "build_lut_kernels.hpp"
+#include "build_sparse_kernels.hpp"
 #include "em_kernels.hpp"
 #include "estep_kernels.hpp"
 #include "aux_kernels.hpp"
@@ -176,6 +178,54 @@ extern "C" int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const 
                        : launch_build_lut<false>(nt, grid, (hipStream_t)stream, Ecode, lde, (int64_t)S * lde, lhit, lmiss, obsmap,
                                                  row_ptr, site, obs, order, R, (int)H, M, ldm, P, ldp, rowmax, vec_ok);
     if (rc != 0) return fail(-1, "mxm_build_em_matrix_lut: H=%s%lld outside the kernel's range", "", H);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+static int g_sparse_passes = 2;        // column ranges per row of the marker kernel (1, 2 or 4): LDS per workgroup
+static int g_sparse_maxd = SPB_MAXD;   // distinct non-zero masks a row may have before it is handed to the fallback
+extern "C" int mxm_set_sparse_max_distinct(int32_t n) {
+    g_sparse_maxd = n < 0 ? 0 : (n > SPB_MAXD ? SPB_MAXD : n);
+    return 0;
+}
+extern "C" int mxm_set_sparse_passes(int32_t passes) {
+    if (passes != 1 && passes != 2 && passes != 4) return fail(-1, "mxm_set_sparse_passes: 1, 2 or 4%s", "");
+    g_sparse_passes = passes;
+    return 0;
+}
+
+extern "C" int mxm_build_em_matrix_sparse(const uint8_t *maj, const double *lhit, const double *lmiss,
+                                          const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
+                                          const int64_t *row_ptr, const uint16_t *site, const uint8_t *obs,
+                                          const int64_t *order, int64_t R, int32_t H, int32_t S, double *M, int64_t ldm,
+                                          int64_t *fallback, int64_t *n_fallback, void *stream) {
+    if (R < 0 || H <= 0 || S <= 0) return fail(-1, "mxm_build_em_matrix_sparse: bad shape R=%s%lld H=%lld", "", R, H);
+    if (H > 8192) return fail(-1, "mxm_build_em_matrix_sparse: more than 8192 haplogroups%s (H=%lld): use mxm_build_em_matrix", "", H);
+    if (ldm < H) return fail(-1, "mxm_build_em_matrix_sparse: ldm < H%s", "");
+    if (maj == nullptr || mk_ptr == nullptr || fallback == nullptr || n_fallback == nullptr)
+        return fail(-1, "mxm_build_em_matrix_sparse: marker tables and the fallback list are required%s", "");
+    hipStream_t s = (hipStream_t)stream;
+    HIP_TRY(hipMemsetAsync(n_fallback, 0, sizeof(int64_t), s));
+    if (R == 0) return 0;
+    const int hpad = (H + 1) & ~1;
+    const int nch = (hpad / 2 + SPB_THREADS - 1) / SPB_THREADS;
+    const int vec_ok = ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
+    const int passes = g_sparse_passes;
+    const int kpp = (nch + passes - 1) / passes;
+    const size_t lds = (size_t)kpp * 2 * SPB_THREADS * 8 + 12 * 1024;      // mask array + the kernel's other LDS
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const int grid = clamp_grid(R, num_cu() * per_cu * 2);
+#define SPB_LAUNCH(n, p) hipLaunchKernelGGL((build_sparse_kernel<n, p>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), g_sparse_maxd)
+#define SPB_CASE(n) case n: if (passes == 1) { if constexpr (n <= 7) SPB_LAUNCH(n, 1); else return fail(-1, "mxm_build_em_matrix_sparse: one pass covers H <= 3584%s", ""); } else if (passes == 2) SPB_LAUNCH(n, 2); else SPB_LAUNCH(n, 4); break;
+    switch (nch) {
+        SPB_CASE(1) SPB_CASE(2) SPB_CASE(3) SPB_CASE(4) SPB_CASE(5) SPB_CASE(6) SPB_CASE(7) SPB_CASE(8)
+        SPB_CASE(9) SPB_CASE(10) SPB_CASE(11) SPB_CASE(12) SPB_CASE(13) SPB_CASE(14) SPB_CASE(15) SPB_CASE(16)
+        default: return fail(-1, "mxm_build_em_matrix_sparse: H=%s%lld outside the kernel's range", "", H);
+    }
+#undef SPB_CASE
+#undef SPB_LAUNCH
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -63,6 +63,8 @@ class HapVarTables(object):
         self._packed_dev = None
         self._lut = None
         self._lut_dev = None
+        self._sparse = None
+        self._sparse_dev = None
 
     @classmethod
     def build(cls, refseq, phylo, haplogroups, mut_wt=MUT_WT, mut_max=MUT_MAX):
@@ -158,6 +160,39 @@ class HapVarTables(object):
         ecode[:, n_haps:] = 0
         self._lut = {"ecode": numpy.ascontiguousarray(ecode), "obsmap": obsmap}
         return self._lut
+
+    def sparse(self):
+        """
+        The marker form of the expected-base table (include/mixemt_hip.h, mxm_build_em_matrix_sparse):
+            maj[S] uint8          the base most haplogroups expect at the site
+            mk_ptr[S+1] int32, mk_hap[] uint16, mk_base[] uint8
+                                  CSR over sites of the (haplogroup, expected base) pairs that differ from maj
+        """
+        if self._sparse is None:
+            exp = self.expected[:, :self.n_haps]
+            n_sites = exp.shape[0]
+            maj = numpy.zeros(n_sites, dtype=numpy.uint8)
+            for s in range(n_sites):
+                maj[s] = numpy.bincount(exp[s], minlength=256).argmax()
+            site_i, hap_i = numpy.nonzero(exp != maj[:, None])           # row-major: sorted by site
+            mk_ptr = numpy.zeros(n_sites + 1, dtype=numpy.int32)
+            numpy.cumsum(numpy.bincount(site_i, minlength=n_sites), out=mk_ptr[1:])
+            self._sparse = {"maj": maj, "mk_ptr": mk_ptr, "mk_hap": hap_i.astype(numpy.uint16),
+                            "mk_base": numpy.ascontiguousarray(exp[site_i, hap_i])}
+        return self._sparse
+
+    def sparse_device(self):
+        """Device copies of sparse() (plus lhit / lmiss), uploaded once."""
+        if self._sparse_dev is None:
+            dev = require_gpu()
+            enc = self.sparse()
+            _, lhit_d, lmiss_d = self.device()
+            self._sparse_dev = {key: torch.from_numpy(val).to(dev) for key, val in enc.items()}
+            if self._sparse_dev["mk_hap"].numel() == 0:                  # keep the pointers valid
+                self._sparse_dev["mk_hap"] = torch.zeros(1, dtype=torch.uint16, device=dev)
+                self._sparse_dev["mk_base"] = torch.zeros(1, dtype=torch.uint8, device=dev)
+            self._sparse_dev["lhit"], self._sparse_dev["lmiss"] = lhit_d, lmiss_d
+        return self._sparse_dev
 
     def lut_device(self):
         """Device copies of lut() (plus lhit / lmiss), uploaded once; None if the tables do not qualify."""
@@ -290,6 +325,8 @@ def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto", 
                that can also emit the loop's linearised matrix (see `linear`)
       "bytes"  the byte-table kernel (mxm_build_em_matrix), any alphabet, any width
       "packed" the LDS-staged 4-bit-table kernel (mxm_build_em_matrix_packed)
+      "sparse" the marker kernel (mxm_build_em_matrix_sparse): one in-order sum per distinct cell value of a
+               row instead of one per cell; rows with more than 64 observations go through "lut"
       "auto"   "lut" where the tables qualify (at most 14 distinct bases, H <= 8192), else "bytes"
     All give the same bits (profiles/r02/build_kernels.txt has the timings).
     linear = (P, rowmax): preallocated [R][ldp] float64 (ldp even, >= H) and [R] float64 tensors
@@ -304,6 +341,38 @@ def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto", 
         kernel = "lut" if tables.lut() is not None else "bytes"
     if linear is not None and kernel != "lut":
         raise ValueError("the linearised matrix is a by-product of the lookup-table kernel only")
+    if kernel == "sparse":
+        if tables.lut() is None or tables.n_haps > 8192:
+            raise ValueError("tables do not qualify for the marker kernel (its leftover rows need the lookup-table kernel)")
+        enc = tables.sparse_device()
+        row_ptr_d = as_device(row_ptr, torch.int64, dev)
+        site_d = as_device(site, torch.uint16, dev)
+        obs_d = as_device(obs, torch.uint8, dev)
+        n_rows = row_ptr_d.numel() - 1
+        n_haps = tables.n_haps
+        if out is None:
+            out = device_empty((n_rows, n_haps), torch.float64, dev, "the EM input matrix")
+        if n_rows == 0:
+            return out
+        fallback = torch.empty(n_rows, dtype=torch.int64, device=dev)
+        n_fallback = torch.zeros(1, dtype=torch.int64, device=dev)
+        _lib.check(lib.mxm_build_em_matrix_sparse(
+            enc["maj"].data_ptr(), enc["lhit"].data_ptr(), enc["lmiss"].data_ptr(), enc["mk_ptr"].data_ptr(),
+            enc["mk_hap"].data_ptr(), enc["mk_base"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(),
+            obs_d.data_ptr(), 0, n_rows, n_haps, len(tables.sites), out.data_ptr(), out.stride(0),
+            fallback.data_ptr(), n_fallback.data_ptr(), current_stream()), "mxm_build_em_matrix_sparse")
+        left = int(n_fallback.item())
+        build_em_matrix_device.last_fallback = left
+        if left:
+            # rows with more than 64 observations (or thousands of distinct values): cell by cell
+            lut = tables.lut_device()
+            rows = fallback[:left].sort().values          # any order gives the same rows; sorted = reproducible launch
+            _lib.check(lib.mxm_build_em_matrix_lut(
+                lut["ecode"].data_ptr(), lut["ecode"].stride(0), lut["lhit"].data_ptr(), lut["lmiss"].data_ptr(),
+                lut["obsmap"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(),
+                rows.data_ptr(), left, n_haps, len(tables.sites), out.data_ptr(), out.stride(0), 0, 0, 0,
+                current_stream()), "mxm_build_em_matrix_lut")
+        return out
     if kernel == "lut":
         enc = tables.lut_device()
         if enc is None:

@@ -135,7 +135,7 @@ def test_reference_phylotree_object_is_accepted(toy):
     assert numpy.array_equal(preprocess.build_em_matrix(ref, bare, reads, haps, em_args()), g["mat"])
 
 
-@pytest.mark.parametrize("kernel", ["packed", "bytes", "lut"])
+@pytest.mark.parametrize("kernel", ["packed", "bytes", "lut", "sparse"])
 def test_all_kernels_give_reference_bits(b17, kernel):
     """The lookup-table kernel, the LDS-staged packed-table kernel and the byte-table kernel are
     interchangeable."""
@@ -287,3 +287,81 @@ def test_lut_kernel_emits_the_linearised_matrix(b17, n_cols, n_rows, read_len):
     a = em.em_loop(plain, init, 1e-4, 40)
     b = em.em_loop(fused, init, 1e-4, 40)
     assert a[2] == b[2] and torch.equal(a[1], b[1])
+
+
+@pytest.mark.parametrize("n_cols", [1, 2, 3, 255, 1024, 1025, 2050, 5408])
+def test_sparse_kernel_ragged_widths_and_rows(b17, n_cols):
+    """The marker kernel (one in-order sum per distinct cell value of a row): the oracle's bits at every width,
+    from one row to a few thousand, rows longer than its 64-observation mask included (they take the
+    lookup-table kernel through the fallback list)."""
+    from mixemt_amd import preprocess, synth
+    refseq, phy, haps, tables = b17
+    sub = haps[50:50 + n_cols] if n_cols < len(haps) else haps
+    sub_tables = tables if n_cols == len(haps) else preprocess.HapVarTables.build(refseq, phy, sub)
+    for n_rows, seed, read_len in ((1, 1, 150), (7, 2, 150), (300, 3, 150), (2100, 4, 150), (40, 5, 400)):
+        row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=seed, read_len=read_len)
+        want = c_oracle.build_em_matrix(sub_tables.expected, sub_tables.lhit, sub_tables.lmiss, row_ptr,
+                                        site, obs, n_cols)
+        got = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="sparse").cpu().numpy()
+        assert numpy.array_equal(got, want), (n_cols, n_rows)
+        left = preprocess.build_em_matrix_device.last_fallback
+        assert left == int((numpy.diff(row_ptr) > 64).sum())
+        if read_len == 400:
+            assert 0 < left < n_rows                      # both paths in one call
+
+
+def test_sparse_kernel_unusual_bases_strided_output_and_golden(b17):
+    import hashlib
+    import torch
+    from mixemt_amd import preprocess, synth
+    refseq, phy, haps, tables = b17
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 600, seed=9)
+    obs = obs.copy()
+    obs[::17] = ord("N")                 # never matches an expected base
+    obs[5::29] = ord("a")                # lower case is a different string in the reference
+    obs[3::31] = 0                       # multi-character observation (encoded as 0)
+    want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, row_ptr, site, obs,
+                                    len(haps))
+    out = torch.full((600, len(haps) + 3), -1.0, dtype=torch.float64, device="cuda")     # odd leading dimension
+    preprocess.build_em_matrix_device(tables, row_ptr, site, obs, out=out, kernel="sparse")
+    host = out.cpu().numpy()
+    assert numpy.array_equal(host[:, :len(haps)], want) and (host[:, len(haps):] == -1.0).all()
+    g = golden("g9_run_em_2400")         # the reference's own 2400 x 5408 matrix
+    mat = preprocess.build_em_matrix_device(tables, g["row_ptr"], g["site"], g["obs"], kernel="sparse")
+    assert hashlib.sha256(mat.cpu().numpy().tobytes()).hexdigest() == str(g["mat_sha256"])
+
+
+def test_sparse_tables_are_the_dense_table(b17):
+    """maj + markers reproduce expected[S][H] exactly."""
+    refseq, phy, haps, tables = b17
+    sp = tables.sparse()
+    dense = numpy.repeat(sp["maj"][:, None], len(haps), axis=1)
+    site_of = numpy.repeat(numpy.arange(len(sp["maj"])), numpy.diff(sp["mk_ptr"]))
+    dense[site_of, sp["mk_hap"]] = sp["mk_base"]
+    assert numpy.array_equal(dense, tables.expected[:, :len(haps)])
+    assert len(sp["mk_hap"]) < 0.01 * dense.size
+
+
+@pytest.mark.parametrize("passes", [1, 2, 4])
+def test_sparse_kernel_column_ranges_and_full_table_fallback(b17, passes):
+    """Every number of column ranges gives the same bits; rows with more distinct values than the dedup table
+    is allowed to hold (limit lowered to 6 here, so a third of ordinary rows qualify) go through the fallback."""
+    from mixemt_amd import _lib, preprocess, synth
+    refseq, phy, haps, tables = b17
+    lib = _lib.load()
+    sub_tables = preprocess.HapVarTables.build(refseq, phy, haps[:3000]) if passes == 1 else tables
+    n_cols = 3000 if passes == 1 else len(haps)
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 700, seed=31)
+    want = c_oracle.build_em_matrix(sub_tables.expected, sub_tables.lhit, sub_tables.lmiss, row_ptr, site, obs, n_cols)
+    try:
+        lib.mxm_set_sparse_passes(passes)
+        got = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="sparse").cpu().numpy()
+        assert numpy.array_equal(got, want)
+        plain = preprocess.build_em_matrix_device.last_fallback
+        lib.mxm_set_sparse_max_distinct(6)
+        got = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="sparse").cpu().numpy()
+        assert numpy.array_equal(got, want)
+        assert plain + 50 < preprocess.build_em_matrix_device.last_fallback < 700      # both paths, many rows each
+    finally:
+        lib.mxm_set_sparse_passes(2)
+        lib.mxm_set_sparse_max_distinct(704)

@@ -2,7 +2,7 @@
 """
 Build the synth-v1 matrix once per kernel variant (timing / profiling target):
     python tools/run_build_only.py [rows] [variant ...]
-variants: bytes, packed, lut (rows in given order), lut+sort (position-sorted row order),
+variants: bytes, packed, sparse (marker kernel), lut (rows in given order), lut+sort (position-sorted row order),
           lut+P (also emits the linearised matrix), lut+sort+P; "linearize" times mxm_linearize alone.
 """
 import os
@@ -28,7 +28,7 @@ ob = torch.from_numpy(obs).to(dev)
 out = torch.empty((rows, len(haps)), dtype=torch.float64, device=dev)
 lin = torch.empty((rows, len(haps)), dtype=torch.float64, device=dev)
 rowmax = torch.empty(rows, dtype=torch.float64, device=dev)
-tables.device(); tables.packed_device(); tables.lut_device()
+tables.device(); tables.packed_device(); tables.lut_device(); tables.sparse_device()
 lib = _lib.load()
 cells = rows * len(haps)
 print("one MI355X; %d synth-v1 reads x %d haplogroups (%.1f observed sites per read); wall time per call, "
@@ -41,6 +41,9 @@ for var in variants:
                                          rowmax.data_ptr(), torch.cuda.current_stream().cuda_stream), "mxm_linearize")
         else:
             parts = var.split("+")
+            if parts[0].startswith("sparse"):           # sparse, sparse1, sparse2, sparse4: column ranges per row
+                lib.mxm_set_sparse_passes(int(parts[0][6:] or 4))
+                parts[0] = "sparse"
             preprocess.build_em_matrix_device(tables, rp, si, ob, out=out, kernel=parts[0],
                                               sort_rows=("sort" in parts) if parts[0] == "lut" else "auto",
                                               linear=(lin, rowmax) if "P" in parts else None)
