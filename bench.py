@@ -85,7 +85,7 @@ def parse_args(argv=None):
                          "float-stored P); coded = lossless row dictionaries (one byte per cell + the row's "
                          "distinct fp64 values).  The default line measures f64 and reports coded beside it")
     ap.add_argument("--min-rows-per-wg", type=int, default=0, help="tuning knob (0 = library default)")
-    ap.add_argument("--build-kernel", default="auto", choices=["auto", "packed", "bytes", "lut"])
+    ap.add_argument("--build-kernel", default="auto", choices=["auto", "packed", "bytes", "lut", "sparse"])
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and issue the per-iteration all-reduce even with "
                          "one rank (exercises the RCCL path on a single-GPU box)")

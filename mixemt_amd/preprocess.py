@@ -327,7 +327,8 @@ def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto", 
       "packed" the LDS-staged 4-bit-table kernel (mxm_build_em_matrix_packed)
       "sparse" the marker kernel (mxm_build_em_matrix_sparse): one in-order sum per distinct cell value of a
                row instead of one per cell; rows with more than 64 observations go through "lut"
-      "auto"   "lut" where the tables qualify (at most 14 distinct bases, H <= 8192), else "bytes"
+      "auto"   "sparse" where the tables qualify for "lut" (at most 14 distinct bases, H <= 8192; "lut" itself when
+               `linear` is asked for), else "bytes"
     All give the same bits (profiles/r02/build_kernels.txt has the timings).
     linear = (P, rowmax): preallocated [R][ldp] float64 (ldp even, >= H) and [R] float64 tensors
     that receive mxm_linearize's output in the same pass ("lut" only) -- hand them to
@@ -338,7 +339,10 @@ def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto", 
     lib = _lib.load()
     dev = require_gpu()
     if kernel == "auto":
-        kernel = "lut" if tables.lut() is not None else "bytes"
+        if tables.lut() is None:
+            kernel = "bytes"
+        else:
+            kernel = "lut" if linear is not None else "sparse"
     if linear is not None and kernel != "lut":
         raise ValueError("the linearised matrix is a by-product of the lookup-table kernel only")
     if kernel == "sparse":
@@ -511,6 +515,9 @@ def reduce_reads(read_obs):
     for read_id, obs in read_obs.items():
         by_sig[read_signature(obs)].append(read_id)
     return by_sig
+
+
+build_em_matrix_device.last_fallback = 0       # rows the marker kernel handed to the lookup-table kernel, last call
 
 
 def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False):

@@ -44,9 +44,9 @@ python3 $repo/bench.py --mode restarts --restarts 16 --no-cpu-baseline > $out/be
 # --- the one-launch loop (cache-resident matrices) and the matrix build kernels ------------------------
 rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt_small -o kt -- python3 $repo/tools/time_small_runs.py --rows 600,2400,10000 > $out/small_runs_under_rocprof.txt 2> $out/kt_small.log
 python3 $repo/tools/time_small_runs.py > $out/small_runs.txt 2>&1
-rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt_build -o kt -- python3 $repo/tools/run_build_only.py 1000000 bytes lut lut+sort lut+sort+P linearize > $out/build_under_rocprof.txt 2> $out/kt_build.log
-rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch_build -o f -- python3 $repo/tools/run_build_only.py 1000000 bytes lut+sort > /dev/null 2> $out/pmc_fetch_build.log
-rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write_build -o w -- python3 $repo/tools/run_build_only.py 1000000 bytes lut+sort > /dev/null 2> $out/pmc_write_build.log
+rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt_build -o kt -- python3 $repo/tools/run_build_only.py 1000000 sparse bytes lut lut+sort lut+sort+P linearize > $out/build_under_rocprof.txt 2> $out/kt_build.log
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch_build -o f -- python3 $repo/tools/run_build_only.py 1000000 sparse bytes lut+sort > /dev/null 2> $out/pmc_fetch_build.log
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write_build -o w -- python3 $repo/tools/run_build_only.py 1000000 sparse bytes lut+sort > /dev/null 2> $out/pmc_write_build.log
 rocprofv3 --output-format csv --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $out/pmc_l2_build -o l2 -- python3 $repo/tools/run_build_only.py 1000000 bytes lut+sort > /dev/null 2> $out/pmc_l2_build.log
 python3 $repo/tools/pmc_summary.py $out/pmc_fetch_build/f_counter_collection.csv $out/pmc_write_build/w_counter_collection.csv > $out/pmc_traffic_build_1m.json
 python3 $repo/tools/run_build_only.py > $out/build_kernels.txt 2>&1

@@ -15,7 +15,7 @@ import torch
 from mixemt_amd import _lib, phylotree, preprocess, synth
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-variants = sys.argv[2:] or ["bytes", "lut", "lut+sort", "lut+P", "lut+sort+P", "linearize"]
+variants = sys.argv[2:] or ["sparse", "sparse4", "bytes", "lut", "lut+sort", "lut+P", "lut+sort+P", "linearize"]
 refseq = phylotree.load_rsrs()
 phy = phylotree.load_build17(refseq)
 haps = sorted(phy.hap_var)
@@ -42,7 +42,7 @@ for var in variants:
         else:
             parts = var.split("+")
             if parts[0].startswith("sparse"):           # sparse, sparse1, sparse2, sparse4: column ranges per row
-                lib.mxm_set_sparse_passes(int(parts[0][6:] or 4))
+                lib.mxm_set_sparse_passes(int(parts[0][6:] or 2))
                 parts[0] = "sparse"
             preprocess.build_em_matrix_device(tables, rp, si, ob, out=out, kernel=parts[0],
                                               sort_rows=("sort" in parts) if parts[0] == "lut" else "auto",
