@@ -26,6 +26,7 @@ legacy RNG exactly as the reference does (em.py:36, :123).
 import ctypes
 import math
 import sys
+import time
 
 import numpy
 
@@ -439,7 +440,10 @@ def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, stora
     """
     n_multi = int(args.n_multi)
     storage = storage or getattr(args, "storage", "f64")
+    t_plan = time.perf_counter()
     plan = EmPlan(read_hap_mat, weights, n_runs=n_multi, storage=storage)
+    torch.cuda.synchronize()
+    t_plan = time.perf_counter() - t_plan
     if inits is None:
         # sequential draws in run order: same RNG consumption as em.py:123
         inits = numpy.stack([init_props(plan.n_haps, alpha=args.init_alpha)
@@ -460,15 +464,21 @@ def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, stora
                 shown[0] += dots
         hook = _lib.PROGRESS_FN(on_state)
         plan.lib.mxm_set_progress_callback(ctypes.cast(hook, ctypes.c_void_p), None, 10)
+    t_loop = time.perf_counter()
     try:
         ln_cur, ln_new, states = em_loop(plan, inits, args.tolerance, args.max_iter)
     finally:
+        t_loop = time.perf_counter() - t_loop
         if live:
             plan.lib.mxm_set_progress_callback(None, None, 10)
     if live and states[0][0] == 1:
         sys.stderr.write("\nConverged! (%d)\n" % states[0][1])
-    return collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix,
-                          verbose and not live, reuse_linear=True)
+    res = collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix,
+                         verbose and not live, reuse_linear=True)
+    # where the call's time went: plan (allocations -- a 43 GB hipMalloc alone varies between 0.3 and 3 s
+    # from process to process -- plus linearise / encode) and the loop itself (blocking, so wall time = device time)
+    res["plan_s"], res["loop_s"], res["storage"] = t_plan, t_loop, plan.storage
+    return res
 
 
 def run_em(read_hap_mat, weights, args):

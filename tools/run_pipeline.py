@@ -50,9 +50,13 @@ def main():
                      % (em_mat.shape[0], em_mat.shape[1], (time.perf_counter() - t0) * 1e3))
 
     t0 = time.perf_counter()
-    props, read_mix = em.run_em(em_mat, wts, args)
+    res = em.run_em_ex(em_mat, wts, args)
+    props, read_mix = res["props"], res["read_mix"]
     torch.cuda.synchronize()
-    sys.stderr.write("run_em: %.1f ms\n" % ((time.perf_counter() - t0) * 1e3))
+    sys.stderr.write("run_em: %.1f ms, of which the EM loop %.1f ms (%d iterations, %s matrix) and the plan "
+                     "(allocation + linearise / encode) %.1f ms\n"
+                     % ((time.perf_counter() - t0) * 1e3, res["loop_s"] * 1e3, sum(res["iters"]), res["storage"],
+                        res["plan_s"] * 1e3))
 
     order = numpy.argsort(props)[::-1]
     sys.stderr.write("\nTop 10 haplogroups by proportion...\n")
