@@ -191,6 +191,23 @@ def test_bench_line_carries_parity_observables():
     assert line["n_gpus"] == 1 and line["config"]["total_rows"] == 20000
 
 
+def test_bench_reports_row_dictionaries_beside_the_dense_line_and_alone():
+    """The default line carries coded_storage (same matrix, column sums against the dense pass); --storage coded
+    makes that form the measured one, with the records' bytes in the roofline object and its own parity leg."""
+    proc, line = _run_bench(["--total-rows", "20000", "--steps", "3", "--warmup", "1", "--cpu-rows", "512",
+                             "--cpu-iters", "3"])
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    cod = line["coded_storage"]
+    assert cod["kernel"] == "em_iter_coded_kernel" and cod["max_rel_dcolsum"] < 1e-12
+    assert cod["kernel_bytes"] < 0.2 * line["roofline"]["algorithmic_bytes_per_launch"] and cod["ms_per_step"] > 0
+    proc, line = _run_bench(["--total-rows", "20000", "--steps", "3", "--warmup", "1", "--cpu-rows", "512",
+                             "--cpu-iters", "3", "--storage", "coded"])
+    assert proc.returncode == 0, proc.stderr[-2000:]
+    assert line["roofline"]["kernel"] == "em_iter_coded_kernel" and line["sanity_ok"] and line["coded_storage"] is None
+    assert line["roofline"]["algorithmic_bytes_per_launch"] < 0.2 * 20000 * 5408 * 8
+    assert line["parity_in_run"]["max_abs_dprops"] < 1e-9 and line["parity_in_run"]["iters_equal"]
+
+
 def test_bench_restart_mode_runs_to_convergence():
     """--mode restarts (config 5's shape on one rank): every restart converges, the folded posterior is
     row-normalised, restart-iterations are what is counted."""
