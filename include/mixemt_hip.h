@@ -140,6 +140,25 @@ int mxm_build_em_matrix_sparse(const uint8_t *maj, const double *lhit, const dou
                                double *M, int64_t ldm, int64_t *fallback, int64_t *n_fallback, void *stream);
 
 /*
+ * The same marker build, leaving each row as a ROW-DICTIONARY RECORD (mxm_coded below) -- the kernel holds
+ * the row's distinct values and every haplogroup's index into them, so no pass over a dense matrix
+ * (mxm_encode_rows) is needed, and with M == NULL no dense matrix is written at all:
+ *     record = codes[ldc] ++ P table[ndist] ++ table of the log sums themselves [ndist]
+ * (P = exp(sum - rowmax[r]); code 0 = the value of a haplogroup without a deviating marker in the window).
+ * Rows that get no record have ndist[r] = 0: with M given, rows of more than 256 distinct values (their dense
+ * row is written); rows on the fallback list (more than 64 observations, more than 704 distinct masks, and --
+ * when M is NULL -- more than 256 values), which the caller builds densely.  stats[0] = bytes used,
+ * stats[1] = rows without a record (device int64[2]); rec_bytes >= mxm_record_bytes(R, H) never overflows.
+ */
+size_t mxm_record_bytes(int64_t R, int32_t H);
+int mxm_build_em_records(const uint8_t *maj, const double *lhit, const double *lmiss,
+                         const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
+                         const int64_t *row_ptr, const uint16_t *site, const uint8_t *obs,
+                         const int64_t *order, int64_t R, int32_t H, int32_t S, double *M, int64_t ldm,
+                         uint8_t *rec, size_t rec_bytes, int64_t *rec_off, int32_t *ndist, double *rowmax,
+                         int64_t *stats, int64_t *fallback, int64_t *n_fallback, void *stream);
+
+/*
  * One-time change of variables for the streaming loop:
  *   rowmax[r] = max_h M[r][h]   (0 if not finite),  P[r][h] = exp(M[r][h] - rowmax[r])
  * ldp must be even and >= H; pad columns [H, ldp) are written as 0.

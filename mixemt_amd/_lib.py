@@ -41,6 +41,10 @@ SIGNATURES = {
                                                c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
     "mxm_build_em_matrix_sparse": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                                   c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
+    "mxm_record_bytes": (c_size, [c_i64, c_i32]),
+    "mxm_build_em_records": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                            c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_size, c_ptr, c_ptr, c_ptr,
+                                            c_ptr, c_ptr, c_ptr, c_ptr]),
     "mxm_build_packed_lds_bytes": (c_size, [c_i32, c_i32]),
     "mxm_build_em_matrix_packed": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
                                                   c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),

@@ -32,13 +32,27 @@
 // NCH column pairs per thread (ceil(H / 2 / 256)); the haplogroups are taken in PASSES column ranges so that the
 // mask array is 1 / PASSES of a row (LDS per workgroup decides how many rows a CU has in flight, and a row is
 // mostly latency: dependent table loads, LDS atomics, eight barriers)
-template <int NCH, int PASSES>
+// EMIT: the row also leaves as a row-dictionary record (coded_kernels.hpp: codes ++ table of P = exp(sum - rowmax),
+// here followed by the table of the sums themselves) -- the kernel has the row's distinct values and every
+// haplogroup's index into them in hand, so mxm_encode_rows' pass over the dense matrix is not needed; with
+// M == nullptr the dense row is not written at all (rows that do not code then go to the fallback list).
+struct spb_records {
+    uint8_t *rec;
+    long long rec_cap;
+    int64_t *rec_off;
+    int32_t *ndist;
+    double *rowmax;
+    unsigned long long *stats;      // [0] bytes used, [1] rows without a record
+    int ldc;
+};
+
+template <int NCH, int PASSES, bool EMIT>
 __global__ __launch_bounds__(SPB_THREADS) void build_sparse_kernel(
     const uint8_t *__restrict__ maj, const double *__restrict__ lhit, const double *__restrict__ lmiss,
     const int32_t *__restrict__ mk_ptr, const uint16_t *__restrict__ mk_hap, const uint8_t *__restrict__ mk_base,
     const int64_t *__restrict__ row_ptr, const uint16_t *__restrict__ site, const uint8_t *__restrict__ obs,
     const int64_t *__restrict__ order, int64_t R, int H, double *__restrict__ M, int64_t ldm, int vec_ok,
-    int64_t *__restrict__ fallback, unsigned long long *__restrict__ n_fallback, int max_distinct) {
+    int64_t *__restrict__ fallback, unsigned long long *__restrict__ n_fallback, int max_distinct, spb_records out) {
     constexpr int NW = SPB_THREADS / 64, SPT = SPB_SLOTS / SPB_THREADS;      // slots scanned per thread
     constexpr int KPP = (NCH + PASSES - 1) / PASSES;       // column-pair chunks per pass
     constexpr int SPAN = KPP * 2 * SPB_THREADS;            // haplogroups per pass
@@ -51,7 +65,18 @@ __global__ __launch_bounds__(SPB_THREADS) void build_sparse_kernel(
     __shared__ int s_wcnt[NW];
     __shared__ double s_sum0;
     __shared__ int s_flag;
+    __shared__ unsigned short s_code[EMIT ? SPB_SLOTS : 1];    // slot -> code (1 + compact index; 0 = the majority value)
+    __shared__ double s_wmax[NW];
+    __shared__ long long s_off;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    auto no_record = [&](int64_t row) {                     // thread 0: the row has no record (dense or fallback)
+        if constexpr (EMIT) {
+            out.ndist[row] = 0;
+            out.rec_off[row] = 0;
+            out.rowmax[row] = 0.0;
+            atomicAdd(&out.stats[1], 1ull);
+        }
+    };
 
     for (int h = t; h < SPAN; h += SPB_THREADS) s_dev[h] = 0ull;     // once: every row leaves both arrays zeroed
 #pragma unroll
@@ -63,7 +88,10 @@ __global__ __launch_bounds__(SPB_THREADS) void build_sparse_kernel(
         const int64_t beg = row_ptr[r];
         const int64_t n64 = row_ptr[r + 1] - beg;
         if (n64 > SPB_MAXN) {                               // uniform: the whole workgroup skips the row
-            if (t == 0) fallback[atomicAdd(n_fallback, 1ull)] = r;
+            if (t == 0) {
+                fallback[atomicAdd(n_fallback, 1ull)] = r;
+                no_record(r);
+            }
             continue;
         }
         const int n = (int)n64;
@@ -187,12 +215,18 @@ __global__ __launch_bounds__(SPB_THREADS) void build_sparse_kernel(
             if (q < wv) base_d += s_wcnt[q];
             D += s_wcnt[q];
         }
-        const bool bad = (s_flag != 0) || D > max_distinct;     // uniform
+        const bool codable = EMIT && (D + 1 <= ENC_MAX_CODES);
+        // uniform: too many distinct values for the table -- or, when no dense row is written, for a record
+        const bool bad = (s_flag != 0) || D > max_distinct || (EMIT && M == nullptr && !codable);
         if (!bad) {
             int d = base_d + incl - cnt;
 #pragma unroll
-            for (int q = 0; q < SPT; ++q)
-                if (kk[q] != 0ull) s_list[d++] = (unsigned short)(SPT * t + q);
+            for (int q = 0; q < SPT; ++q) {
+                if (kk[q] != 0ull) {
+                    if constexpr (EMIT) s_code[SPT * t + q] = (unsigned short)(d + 1);
+                    s_list[d++] = (unsigned short)(SPT * t + q);
+                }
+            }
         }
         __syncthreads();
         if (bad) {
@@ -202,6 +236,7 @@ __global__ __launch_bounds__(SPB_THREADS) void build_sparse_kernel(
             if (t == 0) {
                 fallback[atomicAdd(n_fallback, 1ull)] = r;
                 s_flag = 0;
+                no_record(r);
             }
             __syncthreads();
             continue;
@@ -218,11 +253,28 @@ __global__ __launch_bounds__(SPB_THREADS) void build_sparse_kernel(
             }
             mine[q] = a;
         }
+        double wmax = -INFINITY;
         if (t == SPB_THREADS - 1) {
             double a = 0.0;
 #pragma unroll 4
             for (int j = 0; j < n; ++j) a += s_tref[j];
             s_sum0 = a;
+            wmax = a;
+        }
+        if constexpr (EMIT) {
+            if (codable) {                                  // uniform
+#pragma unroll
+                for (int q = 0; q < (SPB_MAXD + SPB_THREADS - 1) / SPB_THREADS; ++q)
+                    if (t + q * SPB_THREADS < D) wmax = fmax(wmax, mine[q]);
+                wmax = wave_max(wmax);
+                if (lane == 0) s_wmax[wv] = wmax;
+                if (t == 0) {                               // the record: codes ++ P table ++ table of the sums
+                    const long long bytes = (long long)out.ldc + 16ll * (D + 1);
+                    long long off = (long long)atomicAdd(&out.stats[0], (unsigned long long)bytes);
+                    if (off + bytes > out.rec_cap) off = -1;
+                    s_off = off;
+                }
+            }
         }
         __syncthreads();                                     // every mask has been read
 #pragma unroll
@@ -233,11 +285,48 @@ __global__ __launch_bounds__(SPB_THREADS) void build_sparse_kernel(
         __syncthreads();
         // ---- 5. the row -----------------------------------------------------------------------------
         const double sum0 = s_sum0;
+        if constexpr (EMIT) {
+            const long long off = codable ? s_off : -1;
+            if (off >= 0) {
+                const double shift = fmax(fmax(s_wmax[0], s_wmax[1]), fmax(s_wmax[2], s_wmax[3]));   // sums of logs: finite
+                double *ptab = reinterpret_cast<double *>(out.rec + off + out.ldc);
+                double *mtab = ptab + (D + 1);
+#pragma unroll
+                for (int q = 0; q < (SPB_MAXD + SPB_THREADS - 1) / SPB_THREADS; ++q) {
+                    const int d = t + q * SPB_THREADS;
+                    if (d < D) {
+                        ptab[d + 1] = exp(mine[q] - shift);
+                        mtab[d + 1] = mine[q];
+                    }
+                }
+                if (t == SPB_THREADS - 1) {
+                    ptab[0] = exp(sum0 - shift);
+                    mtab[0] = sum0;
+                }
+                unsigned short *cw = reinterpret_cast<unsigned short *>(out.rec + off);
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    const int h = 2 * (t + k * SPB_THREADS);
+                    if (h < out.ldc) {
+                        const unsigned int c0 = (h < H && slot[k][0] >= 0) ? s_code[slot[k][0]] : 0u;
+                        const unsigned int c1 = (h + 1 < H && slot[k][1] >= 0) ? s_code[slot[k][1]] : 0u;
+                        cw[t + k * SPB_THREADS] = (unsigned short)(c0 | (c1 << 8));
+                    }
+                }
+                if (t == 0) {
+                    out.rec_off[r] = off;
+                    out.ndist[r] = D + 1;
+                    out.rowmax[r] = shift;
+                }
+            } else if (t == 0) {
+                no_record(r);                               // more than 256 values: the dense row below is its form
+            }
+        }
         double *dst = M + r * ldm;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
             const int h = 2 * (t + k * SPB_THREADS);
-            if (h < H) {
+            if (M != nullptr && h < H) {
                 const double v0 = slot[k][0] < 0 ? sum0 : __longlong_as_double((long long)s_key[slot[k][0]]);
                 const double v1 = slot[k][1] < 0 ? sum0 : __longlong_as_double((long long)s_key[slot[k][1]]);
                 if (vec_ok && h + 1 < H) {

@@ -40,6 +40,7 @@
 #include "mixemt_hip_tuning.h"
 
 #include "common.hpp"
+#include "coded_kernels.hpp"
 #include "build_kernels.hpp"
 #include "build_lut_kernels.hpp"
 #include "build_sparse_kernels.hpp"
@@ -48,7 +49,6 @@
 #include "aux_kernels.hpp"
 #include "fused_kernels.hpp"
 #include "fused_cols_kernels.hpp"
-#include "coded_kernels.hpp"
 
 // ------------------------------------------------------------------------------------------
 // host side of the C ABI
@@ -194,40 +194,84 @@ extern "C" int mxm_set_sparse_passes(int32_t passes) {
     return 0;
 }
 
-extern "C" int mxm_build_em_matrix_sparse(const uint8_t *maj, const double *lhit, const double *lmiss,
-                                          const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
-                                          const int64_t *row_ptr, const uint16_t *site, const uint8_t *obs,
-                                          const int64_t *order, int64_t R, int32_t H, int32_t S, double *M, int64_t ldm,
-                                          int64_t *fallback, int64_t *n_fallback, void *stream) {
-    if (R < 0 || H <= 0 || S <= 0) return fail(-1, "mxm_build_em_matrix_sparse: bad shape R=%s%lld H=%lld", "", R, H);
-    if (H > 8192) return fail(-1, "mxm_build_em_matrix_sparse: more than 8192 haplogroups%s (H=%lld): use mxm_build_em_matrix", "", H);
-    if (ldm < H) return fail(-1, "mxm_build_em_matrix_sparse: ldm < H%s", "");
+static inline int coded_ld(int H) { return (H + 7) & ~7; }
+
+// marker build: dense rows (M != nullptr) and / or row-dictionary records (out != nullptr)
+static int build_sparse_impl(const char *who, const uint8_t *maj, const double *lhit, const double *lmiss,
+                             const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
+                             const int64_t *row_ptr, const uint16_t *site, const uint8_t *obs, const int64_t *order,
+                             int64_t R, int32_t H, int32_t S, double *M, int64_t ldm, const spb_records *out,
+                             int64_t *fallback, int64_t *n_fallback, hipStream_t s) {
+    if (R < 0 || H <= 0 || S <= 0) return fail(-1, "%s: bad shape R=%lld H=%lld", who, R, H);
+    if (H > 8192) return fail(-1, "%s: more than 8192 haplogroups (H=%lld): use mxm_build_em_matrix", who, H);
+    if (M != nullptr && ldm < H) return fail(-1, "%s: ldm < H", who);
     if (maj == nullptr || mk_ptr == nullptr || fallback == nullptr || n_fallback == nullptr)
-        return fail(-1, "mxm_build_em_matrix_sparse: marker tables and the fallback list are required%s", "");
-    hipStream_t s = (hipStream_t)stream;
+        return fail(-1, "%s: marker tables and the fallback list are required", who);
     HIP_TRY(hipMemsetAsync(n_fallback, 0, sizeof(int64_t), s));
+    if (out != nullptr) HIP_TRY(hipMemsetAsync(out->stats, 0, 2 * sizeof(int64_t), s));
     if (R == 0) return 0;
     const int hpad = (H + 1) & ~1;
     const int nch = (hpad / 2 + SPB_THREADS - 1) / SPB_THREADS;
-    const int vec_ok = ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
+    const int vec_ok = (M != nullptr) && ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
     const int passes = g_sparse_passes;
     const int kpp = (nch + passes - 1) / passes;
-    const size_t lds = (size_t)kpp * 2 * SPB_THREADS * 8 + 12 * 1024;      // mask array + the kernel's other LDS
+    const size_t lds = (size_t)kpp * 2 * SPB_THREADS * 8 + 14 * 1024;      // mask array + the kernel's other LDS
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     const int grid = clamp_grid(R, num_cu() * per_cu * 2);
-#define SPB_LAUNCH(n, p) hipLaunchKernelGGL((build_sparse_kernel<n, p>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), g_sparse_maxd)
-#define SPB_CASE(n) case n: if (passes == 1) { if constexpr (n <= 7) SPB_LAUNCH(n, 1); else return fail(-1, "mxm_build_em_matrix_sparse: one pass covers H <= 3584%s", ""); } else if (passes == 2) SPB_LAUNCH(n, 2); else SPB_LAUNCH(n, 4); break;
+    spb_records none = {};
+    const spb_records rec = out != nullptr ? *out : none;
+#define SPB_LAUNCH(n, p) do { if (out != nullptr) hipLaunchKernelGGL((build_sparse_kernel<n, p, true>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), g_sparse_maxd, rec); \
+                          else hipLaunchKernelGGL((build_sparse_kernel<n, p, false>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), g_sparse_maxd, rec); } while (0)
+#define SPB_CASE(n) case n: if (passes == 1) { if constexpr (n <= 7) SPB_LAUNCH(n, 1); else return fail(-1, "%s: one pass covers H <= 3584", who); } else if (passes == 2) SPB_LAUNCH(n, 2); else SPB_LAUNCH(n, 4); break;
     switch (nch) {
         SPB_CASE(1) SPB_CASE(2) SPB_CASE(3) SPB_CASE(4) SPB_CASE(5) SPB_CASE(6) SPB_CASE(7) SPB_CASE(8)
         SPB_CASE(9) SPB_CASE(10) SPB_CASE(11) SPB_CASE(12) SPB_CASE(13) SPB_CASE(14) SPB_CASE(15) SPB_CASE(16)
-        default: return fail(-1, "mxm_build_em_matrix_sparse: H=%s%lld outside the kernel's range", "", H);
+        default: return fail(-1, "%s: H=%lld outside the kernel's range", who, H);
     }
 #undef SPB_CASE
 #undef SPB_LAUNCH
     HIP_TRY(hipGetLastError());
     return 0;
+}
+
+extern "C" int mxm_build_em_matrix_sparse(const uint8_t *maj, const double *lhit, const double *lmiss,
+                                          const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
+                                          const int64_t *row_ptr, const uint16_t *site, const uint8_t *obs,
+                                          const int64_t *order, int64_t R, int32_t H, int32_t S, double *M, int64_t ldm,
+                                          int64_t *fallback, int64_t *n_fallback, void *stream) {
+    if (M == nullptr) return fail(-1, "mxm_build_em_matrix_sparse: M required%s", "");
+    return build_sparse_impl("mxm_build_em_matrix_sparse", maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs,
+                             order, R, H, S, M, ldm, nullptr, fallback, n_fallback, (hipStream_t)stream);
+}
+
+extern "C" size_t mxm_record_bytes(int64_t R, int32_t H) {
+    if (R < 0 || H <= 0) return 0;
+    return (size_t)(R > 0 ? R : 1) * ((size_t)coded_ld(H) + 16 * ENC_MAX_CODES);
+}
+
+extern "C" int mxm_build_em_records(const uint8_t *maj, const double *lhit, const double *lmiss,
+                                    const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
+                                    const int64_t *row_ptr, const uint16_t *site, const uint8_t *obs,
+                                    const int64_t *order, int64_t R, int32_t H, int32_t S, double *M, int64_t ldm,
+                                    uint8_t *rec, size_t rec_bytes, int64_t *rec_off, int32_t *ndist, double *rowmax,
+                                    int64_t *stats, int64_t *fallback, int64_t *n_fallback, void *stream) {
+    if (!mxm_linear_supported(H) || (H & 1))
+        return fail(-1, "mxm_build_em_records: records need an even H in [66, 8192]%s (H=%lld)", "", H);
+    if (rec == nullptr || (reinterpret_cast<uintptr_t>(rec) & 15) || rec_bytes < (size_t)coded_ld(H) + 16 * ENC_MAX_CODES ||
+        rec_off == nullptr || ndist == nullptr || rowmax == nullptr || stats == nullptr)
+        return fail(-1, "mxm_build_em_records: record buffer (16-byte aligned, >= one record) and output arrays required%s", "");
+    spb_records out;
+    out.rec = rec;
+    out.rec_cap = (long long)rec_bytes;
+    out.rec_off = rec_off;
+    out.ndist = ndist;
+    out.rowmax = rowmax;
+    out.stats = reinterpret_cast<unsigned long long *>(stats);
+    out.ldc = coded_ld(H);
+    return build_sparse_impl("mxm_build_em_records", maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order,
+                             R, H, S, M, ldm, &out, fallback, n_fallback, (hipStream_t)stream);
 }
 
 extern "C" size_t mxm_build_packed_lds_bytes(int32_t S, int32_t n_mu) {
@@ -666,8 +710,6 @@ extern "C" int mxm_em_iter_f32(const float *P, int64_t ldp, const double *w, con
 }
 
 // ---- row-dictionary storage (coded_kernels.hpp) ------------------------------------------------
-static inline int coded_ld(int H) { return (H + 7) & ~7; }
-
 extern "C" size_t mxm_coded_bytes(int64_t R, int32_t H) {
     if (R < 0 || H <= 0) return 0;
     return (size_t)(R > 0 ? R : 1) * ((size_t)coded_ld(H) + 8 * ENC_MAX_CODES);

@@ -115,7 +115,8 @@ class EmPlan(object):
     the log matrix, fp64 weights, the linearised copy and scratch.
     """
 
-    def __init__(self, read_hap_mat, weights, n_runs=1, keep_log_matrix=True, storage="f64", linear=None):
+    def __init__(self, read_hap_mat, weights, n_runs=1, keep_log_matrix=True, storage="f64", linear=None,
+                 records=None):
         """
         storage: element type of the linearised matrix the loop streams.
         "f64" (default) is the reference's arithmetic type end to end; "f32" is
@@ -133,7 +134,13 @@ class EmPlan(object):
         `plan.storage` says what the plan iterates.
         linear = (P, rowmax): the linearised matrix already made by the matrix build
         (preprocess.build_em_matrix_device(..., linear=...)): nothing is recomputed here.
+        records = preprocess.build_em_records_device(...)'s CodedMatrix: the matrix arrives in dictionary
+        form straight from the build (no encode pass); read_hap_mat may then be None -- the plan iterates,
+        but has no log matrix for a posterior pass.
         """
+        if records is not None:
+            self._from_records(records, read_hap_mat, weights, n_runs)
+            return
         if storage not in ("f64", "f32", "coded", "auto"):
             raise ValueError("storage must be 'f64', 'f32', 'coded' or 'auto'")
         self.storage = storage
@@ -195,6 +202,41 @@ class EmPlan(object):
             self.storage = "f64"             # narrow matrices iterate the fp64 log-space kernel
         if not keep_log_matrix and (self.lin is not None or self.coded is not None):
             self.mat = None
+
+    def _from_records(self, cm, read_hap_mat, weights, n_runs):
+        """Plan over a matrix the build left as row-dictionary records (preprocess.CodedMatrix)."""
+        self.storage = "coded"
+        self.lib = _lib.load()
+        self.dev = require_gpu()
+        self.n_rows, self.n_haps = cm.n_rows, cm.n_haps
+        self.mat = None if read_hap_mat is None else as_device(read_hap_mat, torch.float64, self.dev)
+        if self.mat is not None and tuple(self.mat.shape) != (self.n_rows, self.n_haps):
+            raise ValueError("read_hap_mat does not match the records")
+        self.wts = as_device(weights, torch.float64, self.dev)
+        if self.wts.numel() != self.n_rows:
+            raise ValueError("weights do not match the matrix height")
+        self.n_runs = n_runs
+        self.ws, self.ws_bytes = _workspace(self.lib, self.n_rows, self.n_haps, n_runs, self.dev)
+        self.lin = None
+        self.rowmax = cm.rowmax
+        n_rest = int(cm.rest_rows.numel())
+        p_rest = w_rest = None
+        if n_rest:
+            ldp = (self.n_haps + 1) // 2 * 2
+            p_rest = torch.empty((n_rest, ldp), dtype=torch.float64, device=self.dev)
+            rm = torch.empty(n_rest, dtype=torch.float64, device=self.dev)
+            _lib.check(self.lib.mxm_linearize(cm.m_rest.data_ptr(), cm.m_rest.stride(0), n_rest, self.n_haps,
+                                              p_rest.data_ptr(), p_rest.stride(0), rm.data_ptr(), current_stream()),
+                       "mxm_linearize")
+            w_rest = self.wts.index_select(0, cm.rest_rows).contiguous()
+        self.coded_record_bytes = cm.used
+        self.coded_bytes = cm.used + n_rest * self.n_haps * 8
+        self.coded_rest = n_rest
+        self.coded_ndist = cm.ndist
+        self._coded_keep = (cm.rec, cm.rec_off, cm.ndist, p_rest, w_rest, cm)
+        self.coded = _lib.Coded(cm.rec.data_ptr(), cm.rec_off.data_ptr(), cm.ndist.data_ptr(), self.n_rows,
+                                p_rest.data_ptr() if n_rest else None, p_rest.stride(0) if n_rest else 0,
+                                w_rest.data_ptr() if n_rest else None, n_rest)
 
     def encode(self):
         """Row-dictionary form of this plan's matrix (mxm_encode_rows) + the dense rest."""
@@ -428,7 +470,7 @@ def collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix=True, verb
             "l1": [s[2] for s in states]}
 
 
-def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, storage=None):
+def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, storage=None, records=None):
     """
     run_em with the parity observables exposed.  Returns a dict:
         props      [H] numpy, linear (geometric mean over runs, em.py:155-163)
@@ -437,11 +479,15 @@ def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, stora
         run_props  [n_multi][H] numpy, each run's theta_{k+1}
         inits      [n_multi][H] numpy, the initial draws
         done       per-run stop reason (1 converged, 2 max_iter)
+    records: a preprocess.CodedMatrix (the build's row-dictionary output) to iterate instead of encoding
+    read_hap_mat; read_hap_mat may then be None if want_read_mix is False.
     """
     n_multi = int(args.n_multi)
     storage = storage or getattr(args, "storage", "f64")
     t_plan = time.perf_counter()
-    plan = EmPlan(read_hap_mat, weights, n_runs=n_multi, storage=storage)
+    plan = EmPlan(read_hap_mat, weights, n_runs=n_multi, storage=storage, records=records)
+    if want_read_mix and plan.mat is None:
+        raise ValueError("the posterior matrix needs the log matrix: pass it beside the records, or want_read_mix=False")
     torch.cuda.synchronize()
     t_plan = time.perf_counter() - t_plan
     if inits is None:

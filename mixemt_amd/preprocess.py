@@ -517,6 +517,97 @@ def reduce_reads(read_obs):
     return by_sig
 
 
+class CodedMatrix(object):
+    """
+    build_em_matrix's output as row-dictionary records (include/mixemt_hip.h, mxm_build_em_records):
+        rec, rec_off[R], ndist[R], rowmax[R]   the records (ndist[r] = 0: row r has none)
+        used                                   bytes of `rec` in use
+        rest_rows [R_rest] int64 (sorted), m_rest [R_rest][H] float64   the rows without a record, dense
+    em.EmPlan(None, weights, records=this) iterates it.
+    """
+
+    def __init__(self, n_rows, n_haps, rec, rec_off, ndist, rowmax, used, rest_rows, m_rest):
+        self.n_rows, self.n_haps = n_rows, n_haps
+        self.rec, self.rec_off, self.ndist, self.rowmax = rec, rec_off, ndist, rowmax
+        self.used, self.rest_rows, self.m_rest = used, rest_rows, m_rest
+
+
+def _gather_csr(row_ptr_d, site_d, obs_d, rows):
+    """CSR of the given rows only (device tensors; rows int64, any order)."""
+    starts = row_ptr_d.index_select(0, rows)
+    lens = row_ptr_d.index_select(0, rows + 1) - starts
+    new_ptr = torch.zeros(rows.numel() + 1, dtype=torch.int64, device=rows.device)
+    torch.cumsum(lens, 0, out=new_ptr[1:])
+    total = int(new_ptr[-1].item())
+    src = torch.repeat_interleave(starts - new_ptr[:-1], lens, output_size=total) + torch.arange(total, device=rows.device)
+    return new_ptr, site_d.index_select(0, src), obs_d.index_select(0, src)
+
+
+def build_em_records_device(tables, row_ptr, site, obs, dense=False):
+    """
+    CSR observations -> CodedMatrix: the marker kernel writes each row as a row-dictionary record
+    (one byte per haplogroup + the row's distinct values) -- what em.EmPlan(storage="coded") otherwise
+    makes from the dense matrix with a pass of its own.  dense=False: NO dense matrix is written (5.5 GB
+    instead of 43 GB at 10^6 x 5408; 10^7 rows fit one GPU); rows that do not code (more than 64
+    observations or more than 256 distinct values: ~5 %) are built densely into `m_rest`.
+    dense=True: returns (CodedMatrix, M) with the full dense matrix as well.
+    """
+    lib = _lib.load()
+    dev = require_gpu()
+    if tables.lut() is None or tables.n_haps > 8192 or tables.n_haps % 2 or not lib.mxm_linear_supported(tables.n_haps):
+        raise ValueError("records need tables that qualify for the lookup-table kernel and an even H in [66, 8192]")
+    enc = tables.sparse_device()
+    lut = tables.lut_device()
+    row_ptr_d = as_device(row_ptr, torch.int64, dev)
+    site_d = as_device(site, torch.uint16, dev)
+    obs_d = as_device(obs, torch.uint8, dev)
+    n_rows, n_haps, n_sites = row_ptr_d.numel() - 1, tables.n_haps, len(tables.sites)
+    if n_rows <= 0:
+        raise ValueError("no rows")
+    mat = device_empty((n_rows, n_haps), torch.float64, dev, "the EM input matrix") if dense else None
+    cap = lib.mxm_record_bytes(n_rows, n_haps)
+    rec = device_empty((cap,), torch.uint8, dev, "the coded matrix")
+    rec_off = torch.empty(n_rows, dtype=torch.int64, device=dev)
+    ndist = torch.empty(n_rows, dtype=torch.int32, device=dev)
+    rowmax = torch.empty(n_rows, dtype=torch.float64, device=dev)
+    stats = torch.zeros(2, dtype=torch.int64, device=dev)
+    fallback = torch.empty(n_rows, dtype=torch.int64, device=dev)
+    n_fallback = torch.zeros(1, dtype=torch.int64, device=dev)
+    _lib.check(lib.mxm_build_em_records(
+        enc["maj"].data_ptr(), enc["lhit"].data_ptr(), enc["lmiss"].data_ptr(), enc["mk_ptr"].data_ptr(),
+        enc["mk_hap"].data_ptr(), enc["mk_base"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(),
+        0, n_rows, n_haps, n_sites, mat.data_ptr() if dense else 0, mat.stride(0) if dense else 0,
+        rec.data_ptr(), cap, rec_off.data_ptr(), ndist.data_ptr(), rowmax.data_ptr(), stats.data_ptr(),
+        fallback.data_ptr(), n_fallback.data_ptr(), current_stream()), "mxm_build_em_records")
+    used, n_rest = (int(v) for v in stats.cpu())
+    left = int(n_fallback.item())
+    rest_rows = torch.nonzero(ndist == 0).flatten()
+    assert rest_rows.numel() == n_rest
+
+    def lut_rows(rp, si, ob, order, count, out):
+        _lib.check(lib.mxm_build_em_matrix_lut(
+            lut["ecode"].data_ptr(), lut["ecode"].stride(0), lut["lhit"].data_ptr(), lut["lmiss"].data_ptr(),
+            lut["obsmap"].data_ptr(), rp.data_ptr(), si.data_ptr(), ob.data_ptr(), order, count, n_haps, n_sites,
+            out.data_ptr(), out.stride(0), 0, 0, 0, current_stream()), "mxm_build_em_matrix_lut")
+
+    m_rest = None
+    if dense:
+        if left:
+            rows = fallback[:left].sort().values
+            lut_rows(row_ptr_d, site_d, obs_d, rows.data_ptr(), left, mat)
+        if n_rest:
+            m_rest = mat.index_select(0, rest_rows)
+    elif n_rest:
+        assert left == n_rest                     # without a dense matrix every row without a record is on the list
+        sub_ptr, sub_site, sub_obs = _gather_csr(row_ptr_d, site_d, obs_d, rest_rows)
+        m_rest = torch.empty((n_rest, n_haps), dtype=torch.float64, device=dev)
+        lut_rows(sub_ptr, sub_site, sub_obs, 0, n_rest, m_rest)
+    build_em_matrix_device.last_fallback = left
+    cm = CodedMatrix(n_rows, n_haps, rec, rec_off, ndist, rowmax, used,
+                     rest_rows, m_rest if m_rest is not None else torch.empty((0, n_haps), dtype=torch.float64, device=dev))
+    return (cm, mat) if dense else cm
+
+
 build_em_matrix_device.last_fallback = 0       # rows the marker kernel handed to the lookup-table kernel, last call
 
 

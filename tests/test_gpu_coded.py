@@ -235,3 +235,76 @@ def test_special_values_and_weights():
     plan = em.EmPlan(mat2, numpy.ones(n_rows), storage="coded")
     nd = plan.coded_ndist.cpu().numpy()
     assert nd[7] == 0 and plan.coded_rest == 1 and (numpy.delete(nd, 7) > 0).all()
+
+
+def _decode_cm(cm):
+    import torch
+    from mixemt_amd import _lib
+    from mixemt_amd._dev import current_stream
+    lib = _lib.load()
+    out = torch.full((cm.n_rows, cm.n_haps), float("nan"), dtype=torch.float64, device=cm.rec.device)
+    coded = _lib.Coded(cm.rec.data_ptr(), cm.rec_off.data_ptr(), cm.ndist.data_ptr(), cm.n_rows, None, 0, None, 0)
+    _lib.check(lib.mxm_decode_rows(ctypes.byref(coded), cm.n_haps, out.data_ptr(), out.stride(0), current_stream()),
+               "mxm_decode_rows")
+    return out
+
+
+@pytest.mark.parametrize("name,read_len", [("g9_run_em_2400", 0), ("synth", 150), ("synth", 260)])
+def test_records_straight_from_the_build(b17, name, read_len):
+    """mxm_build_em_records: the marker kernel's records decode to mxm_linearize's rows bit for bit, with and
+    without the dense matrix; rows without a record (long rows, more than 256 values) arrive dense."""
+    import torch
+    from mixemt_amd import em, preprocess, synth
+    refseq, phy, haps, tables = b17
+    if name == "synth":
+        row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 1500, seed=41, read_len=read_len)
+    else:
+        g = golden(name)
+        row_ptr, site, obs = g["row_ptr"], g["site"], g["obs"]
+    want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, row_ptr, site, obs, len(haps))
+    cm, mat = preprocess.build_em_records_device(tables, row_ptr, site, obs, dense=True)
+    assert numpy.array_equal(mat.cpu().numpy(), want)                          # the dense matrix, reference bits
+    dense = em.EmPlan(mat, numpy.ones(len(want)))
+    nd = cm.ndist.cpu().numpy()
+    rest = cm.rest_rows.cpu().numpy()
+    assert numpy.array_equal(rest, numpy.flatnonzero(nd == 0)) and (nd <= 256).all()
+    long_rows = numpy.flatnonzero(numpy.diff(row_ptr) > 64)
+    assert set(long_rows) <= set(rest)
+    if read_len == 260:
+        assert len(long_rows) > 100 and len(rest) < len(want)                  # both kinds of rows in one call
+    for r in numpy.flatnonzero(nd > 0)[:40]:
+        assert nd[r] >= len(numpy.unique(want[r]))        # one entry per distinct mask (equal sums may repeat)
+    coded_rows = torch.from_numpy(nd > 0).to(mat.device)
+    dec = _decode_cm(cm)
+    assert torch.equal(dec[coded_rows].view(torch.int64), dense.lin[coded_rows][:, :len(haps)].view(torch.int64))
+    assert torch.equal(cm.rowmax[coded_rows], dense.rowmax[coded_rows])
+    assert numpy.array_equal(cm.m_rest.cpu().numpy(), want[rest])
+    # the same without ever writing the dense matrix
+    cm2 = preprocess.build_em_records_device(tables, row_ptr, site, obs)
+    nd2 = cm2.ndist.cpu().numpy()
+    assert numpy.array_equal(nd2 > 0, nd > 0) or set(numpy.flatnonzero(nd2 == 0)) >= set(rest)
+    dec2 = _decode_cm(cm2)
+    rows2 = torch.from_numpy(nd2 > 0).to(mat.device)
+    assert torch.equal(dec2[rows2].view(torch.int64), dense.lin[rows2][:, :len(haps)].view(torch.int64))
+    assert numpy.array_equal(cm2.m_rest.cpu().numpy(), want[cm2.rest_rows.cpu().numpy()])
+
+
+def test_run_em_from_build_records_reproduces_the_reference(b17):
+    """g9 (2400 rows, repeat weights, 1209 iterations): CSR -> records -> EM, no dense matrix anywhere."""
+    from mixemt_amd import em, preprocess
+    refseq, phy, haps, tables = b17
+    g = golden("g9_run_em_2400")
+    cm = preprocess.build_em_records_device(tables, g["row_ptr"], g["site"], g["obs"])
+    numpy.random.seed(17)
+    res = em.run_em_ex(None, g["wts"], em_args(), want_read_mix=False, records=cm)
+    assert numpy.array_equal(res["inits"], g["inits"])
+    assert res["iters"] == list(g["iters"]) and res["storage"] == "coded"
+    assert numpy.abs(res["props"] - g["props"]).max() < PROPS_ATOL
+    with pytest.raises(ValueError):
+        em.run_em_ex(None, g["wts"], em_args(), records=cm)                    # a posterior needs the log matrix
+    # with the dense matrix beside the records the posterior is there too
+    cm, mat = preprocess.build_em_records_device(tables, g["row_ptr"], g["site"], g["obs"], dense=True)
+    numpy.random.seed(17)
+    res = em.run_em_ex(mat, g["wts"], em_args(), records=cm)
+    assert res["iters"] == list(g["iters"])
+    assert numpy.array_equal(res["read_mix"].argmax(dim=1).cpu().numpy(), g["mix_argmax"])
