@@ -84,6 +84,9 @@ def parse_args(argv=None):
                     help="form of the streamed matrix; f32 is a labelled opt-in variant (fp64 math on "
                          "float-stored P); coded = lossless row dictionaries (one byte per cell + the row's "
                          "distinct fp64 values).  The default line measures f64 and reports coded beside it")
+    ap.add_argument("--records", action="store_true",
+                    help="mode rows: the build leaves the matrix as row-dictionary records and NO dense matrix is "
+                         "made (implies --storage coded; 10^7 rows then fit one GPU); no posterior pass")
     ap.add_argument("--min-rows-per-wg", type=int, default=0, help="tuning knob (0 = library default)")
     ap.add_argument("--build-kernel", default="auto", choices=["auto", "packed", "bytes", "lut", "sparse"])
     ap.add_argument("--force-dist", action="store_true",
@@ -312,7 +315,13 @@ def main(argv=None):
     haps = sorted(phy.hap_var)
     tables = preprocess.HapVarTables.build(refseq, phy, haps)
     n_haps = len(haps)
+    if opts.records:
+        if opts.mode != "rows":
+            raise SystemExit("bench: --records goes with --mode rows")
+        opts.storage = "coded"
     need_gb = (2.0 + (1.0 if opts.mode == "rows" else 0.0)) * n_rows * n_haps * 8 / 1e9
+    if opts.records:
+        need_gb = n_rows * (8.0 + 0.07 * 2 * n_haps * 8 / 1024.0) * 1024 / 1e9       # records + ~7 % dense rows twice
     free_gb = torch.cuda.mem_get_info(dev)[0] / 1e9
     if need_gb > free_gb:
         raise SystemExit("bench: %d rows x %d haplogroups per GPU need about %.0f GB (matrix, linearised copy, "
@@ -324,25 +333,40 @@ def main(argv=None):
     row_ptr_d = torch.from_numpy(row_ptr).to(dev)
     site_d = torch.from_numpy(site.view(numpy.int16)).to(dev)
     obs_d = torch.from_numpy(obs).to(dev)
-    mat = torch.empty((n_rows, n_haps), dtype=torch.float64, device=dev)
     tables.device()
     if opts.build_kernel == "packed":
         tables.packed_device()
-    # built twice, the second call timed: the first one pays one-time library set-up (code object load,
-    # the device sort behind the position-ordered row schedule), which is not the kernel's rate
-    preprocess.build_em_matrix_device(tables, row_ptr_d, site_d, obs_d, out=mat, kernel=opts.build_kernel)
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    preprocess.build_em_matrix_device(tables, row_ptr_d, site_d, obs_d, out=mat, kernel=opts.build_kernel)
-    torch.cuda.synchronize()
-    build_s = time.perf_counter() - t0
+    records = slab = None
+    if opts.records:
+        # CSR -> records, no dense matrix; built twice, the second call timed (as below)
+        records = preprocess.build_em_records_device(tables, row_ptr_d, site_d, obs_d)
+        del records
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        records = preprocess.build_em_records_device(tables, row_ptr_d, site_d, obs_d)
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - t0
+        mat = None
+        n_slab = min(n_rows, opts.cpu_rows)           # the oracle leg's rows, dense (the checker needs them)
+        slab = preprocess.build_em_matrix_device(tables, row_ptr_d[:n_slab + 1].clone(), site_d[:int(row_ptr[n_slab])],
+                                                 obs_d[:int(row_ptr[n_slab])])
+    else:
+        mat = torch.empty((n_rows, n_haps), dtype=torch.float64, device=dev)
+        # built twice, the second call timed: the first one pays one-time library set-up (code object load,
+        # the device sort behind the position-ordered row schedule), which is not the kernel's rate
+        preprocess.build_em_matrix_device(tables, row_ptr_d, site_d, obs_d, out=mat, kernel=opts.build_kernel)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        preprocess.build_em_matrix_device(tables, row_ptr_d, site_d, obs_d, out=mat, kernel=opts.build_kernel)
+        torch.cuda.synchronize()
+        build_s = time.perf_counter() - t0
     wts = torch.ones(n_rows, dtype=torch.float64, device=dev)
     lib.mxm_set_batch_tile(opts.batch_tile)
     if opts.min_rows_per_wg > 0:
         lib.mxm_set_min_rows_per_wg(opts.min_rows_per_wg)
 
     env = dict(lib=lib, dev=dev, rank=rank, world=world, use_dist=use_dist, mat=mat, wts=wts, n_rows=n_rows,
-               n_haps=n_haps, total_rows=total_rows, scaling=scaling, build_s=build_s)
+               n_haps=n_haps, total_rows=total_rows, scaling=scaling, build_s=build_s, records=records, slab=slab)
     line = bench_restarts(opts, env) if opts.mode == "restarts" else bench_rows(opts, env)
     if rank == 0:
         print(json.dumps(line))
@@ -365,10 +389,13 @@ def bench_rows(opts, env):
         env[k] for k in ("lib", "dev", "rank", "world", "use_dist", "mat", "wts", "n_rows", "n_haps",
                          "total_rows", "scaling", "build_s"))
     n_runs = opts.restarts
-    plan = em.EmPlan(mat, wts, n_runs=n_runs, storage=opts.storage)     # allocates P and linearises once (untimed: hipMalloc)
+    records, slab = env.get("records"), env.get("slab")
+    plan = em.EmPlan(mat, wts, n_runs=n_runs, storage=opts.storage, records=records)   # allocates P and linearises once (untimed: hipMalloc)
     torch.cuda.synchronize()
     t0 = time.perf_counter()                      # timed again on the now-resident buffers
-    if plan.coded is not None:
+    if records is not None:
+        pass                                      # the records came out of the build: nothing to convert
+    elif plan.coded is not None:
         plan.encode()                            # mxm_encode_rows + the dense rest, second time
     else:
         lin_fn = lib.mxm_linearize_f32 if opts.storage == "f32" else lib.mxm_linearize
@@ -491,6 +518,8 @@ def bench_rows(opts, env):
     # ---- posterior pass (reported, not part of the step) ----------------------------------------
     posterior_ms = None
     try:
+        if mat is None:
+            raise ValueError("no dense matrix in this run (--records)")
         out = torch.empty((n_rows, n_haps), dtype=torch.float64, device=dev)
         ln_theta = ln_cur[0].clone()
         torch.cuda.synchronize()
@@ -508,14 +537,15 @@ def bench_rows(opts, env):
     parity = None
     if rank == 0 and world == 1 and not opts.no_cpu_baseline:
         n_cpu = min(n_rows, opts.cpu_rows)
-        sample = mat[:n_cpu].cpu().numpy()
+        dense_rows = mat[:n_cpu] if mat is not None else slab
+        sample = dense_rows.cpu().numpy()
         leg = cpu_reference_leg(sample, opts.cpu_iters)
         cpu = {"value": leg["rate"], "unit": "cells/s", "cores": 1, "kind": "port",
                "sample": "oracle em_step (numpy restatement of em.py:57-91) x%d on the first %d rows "
                          "x %d haps of the same matrix, %.1f s; host has %d cores, 1 used like the "
                          "reference" % (leg["iters"], n_cpu, n_haps, leg["seconds"], os.cpu_count())}
         log("cpu baseline: %.3g cells/s (%.1f s)" % (leg["rate"], leg["seconds"]))
-        parity = parity_in_run(em, torch, mat[:n_cpu], leg, opts.cpu_iters, storage=opts.storage)
+        parity = parity_in_run(em, torch, dense_rows, leg, opts.cpu_iters, storage=opts.storage)
         log("parity in run: max |dprops| %.2e, iterations equal %s, haplogroup calls equal %s"
             % (parity["max_abs_dprops"], parity["iters_equal"], parity["argmax_equal"]))
         sane = sane and parity["max_abs_dprops"] < PARITY_PROPS_BAR and parity["iters_equal"] \
@@ -558,7 +588,8 @@ def bench_rows(opts, env):
                                "%d EM restart(s) advanced together (tile %d; several restarts: full tiles "
                                "dealt round-robin by the loop driver), %s matrix"
                                % (total_rows, n_haps, n_rows, n_runs, opts.batch_tile,
-                                  {"f64": "fp64", "f32": "fp32-stored", "coded": "row-dictionary (lossless fp64)"}[plan.storage]),
+                                  {"f64": "fp64", "f32": "fp32-stored", "coded": "row-dictionary (lossless fp64)"}[plan.storage]
+                                  + (", records straight from the build, no dense matrix on the device" if records is not None else "")),
                    "total_rows": total_rows, "rows_per_gpu": n_rows, "haps": n_haps, "restarts": n_runs,
                    "scaling": scaling,
                    "sharding": "rows over %d rank(s), 1 all-reduce of %d fp64 per iteration"
