@@ -228,12 +228,13 @@ int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int64_t R, int
  * ROW-DICTIONARY storage of the linearised matrix (lossless; opt-in like the fp32 variant, but it keeps
  * every bit).  A row of build_em_matrix's output (preprocess.py:177-198) is a sum of per-site terms with
  * two possible values each, so its H cells hold few DISTINCT doubles.  Row r is stored as one record
- *     codes[ldc] (uint8 per column, ldc = H rounded up to 8)  ++  table[ndist[r]] (doubles),
+ *     codes[ldc] (uint8 per column, ldc = H rounded up to 8)  ++  table[ndist[r]] (doubles)  ++  mtable[ndist[r]],
  *     P[r][h] = exp(M[r][h] - rowmax[r]) = table[codes[h]]          -- the bits mxm_linearize writes
+ *     M[r][h] = mtable[codes[h]]                                    -- the log value itself
  * at rec + rec_off[r]: ~5.7 KB instead of 43 KB at H = 5408.  Rows with more than 256 distinct values
  * get ndist[r] = 0; the caller keeps those dense (P_rest / w_rest: their mxm_linearize rows and
  * weights, in any fixed order) and both parts are summed by one column reduce.
- *   mxm_coded_bytes(R, H)   record buffer size that can never overflow (R * (ldc + 2048))
+ *   mxm_coded_bytes(R, H)   record buffer size that can never overflow (R * (ldc + 4096))
  *   mxm_encode_rows         M -> records; stats[0] = bytes used, stats[1] = rows left dense (device int64[2]);
  *                           needs an even H in [66, 8192], even ldm, 16-byte aligned M and rec
  *   mxm_decode_rows         P[r][:] = row r decoded, coded rows only (tests; posterior passes)
@@ -254,6 +255,13 @@ size_t mxm_coded_bytes(int64_t R, int32_t H);
 int mxm_encode_rows(const double *M, int64_t ldm, int64_t R, int32_t H, uint8_t *rec, size_t rec_bytes,
                     int64_t *rec_off, int32_t *ndist, double *rowmax, int64_t *stats, void *stream);
 int mxm_decode_rows(const mxm_coded *c, int32_t H, double *P, int64_t ldp, void *stream);
+/* consumers that need the LOG values (the record's second table), coded rows only -- rows without a record
+ * are left untouched, the caller has them dense:
+ *   best[r] = first index of max_h (ln_props[h] + M[r][h])    assemble.py:115-123 (row argmax of the posterior)
+ *   out[r][i] = M[r][cols[i]]                                  preprocess.py:247-251 (em_mat[:, indexes]) */
+int mxm_row_argmax_coded(const mxm_coded *c, int32_t H, const double *ln_props, int32_t *best, void *stream);
+int mxm_gather_columns_coded(const mxm_coded *c, int32_t H, const int32_t *cols, int32_t nC,
+                             double *out, int64_t ldo, void *stream);
 int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, int32_t H, int32_t B,
                       const mxm_em_state *state, double *colsum, void *ws, size_t ws_bytes, void *stream);
 int mxm_em_loop_coded(const mxm_coded *c, const double *w, int32_t H, int32_t B,

@@ -45,6 +45,38 @@ def row_argmax_votes(read_hap_mat, wts=None):
     return best.cpu().numpy(), votes.cpu().numpy()
 
 
+def row_argmax_votes_records(cm, ln_theta, wts=None, chunk=32768):
+    """
+    row_argmax_votes for a matrix that exists only as records (preprocess.CodedMatrix): the posterior's row
+    argmax under log-proportions ln_theta is argmax_h (ln_theta[h] + M[r][h]) -- the row's normaliser shifts
+    every column alike -- taken from the records' log tables (mxm_row_argmax_coded); rows without a record
+    from their dense copies.  Votes are exact sums for integer weights (the reference's weights are counts,
+    preprocess.py:220).  Returns (best int32[R], votes float64[H]) as numpy arrays.
+    """
+    import ctypes
+    lib = _lib.load()
+    dev = cm.rec.device
+    lnp = as_device(ln_theta, torch.float64, dev).reshape(-1)
+    if lnp.numel() != cm.n_haps:
+        raise ValueError("ln_theta does not match the matrix width")
+    best = torch.zeros(cm.n_rows, dtype=torch.int32, device=dev)
+    coded = cm.struct()
+    _lib.check(lib.mxm_row_argmax_coded(ctypes.byref(coded), cm.n_haps, lnp.data_ptr(), best.data_ptr(),
+                                        current_stream()), "mxm_row_argmax_coded")
+    for lo in range(0, int(cm.rest_rows.numel()), chunk):        # dense rows: first maximum, like numpy.argmax
+        rows = cm.rest_rows[lo:lo + chunk]
+        best[rows] = (cm.m_rest[lo:lo + chunk] + lnp).argmax(dim=1).to(torch.int32)
+    w_d = torch.ones(cm.n_rows, dtype=torch.float64, device=dev) if wts is None else as_device(wts, torch.float64, dev)
+    votes = torch.bincount(best.to(torch.int64), weights=w_d, minlength=cm.n_haps)
+    return best.cpu().numpy(), votes.cpu().numpy()
+
+
+def find_contribs_from_records(cm, ln_theta, wts, args):
+    """find_contribs_from_reads (assemble.py:103-123) from records and the EM's log theta_k."""
+    best, votes = row_argmax_votes_records(cm, ln_theta, wts)
+    return [int(h) for h in _first_seen_order(best) if votes[h] >= args.min_reads]
+
+
 def _first_seen_order(best):
     """Column indexes in the order they first appear in `best` (dict insertion order
     of the reference's vote table, assemble.py:116-119)."""

@@ -8,8 +8,9 @@
 // of two values each, so the 5408 cells of a row hold only a few DISTINCT doubles (one per pattern of
 // mismatching sites among the haplogroups: median 25, 98 % of synth-v1 rows at most 256).  The
 // dictionary form of row r of P = exp(M - rowmax) (mxm_linearize's output) is
-//     record(r) = codes[ldc] (one byte per column, pad columns 0)  ++  table[D_r] (doubles)
+//     record(r) = codes[ldc] (one byte per column, pad columns 0)  ++  table[D_r] (doubles)  ++  mtable[D_r]
 //     P[r][h]   = table[codes[h]]                       -- the SAME bits as the dense P
+//     M[r][h]   = mtable[codes[h]]                      -- the log matrix itself (posterior / argmax / column gathers)
 // 5.4 KB + 8 D bytes instead of 43 KB per row.  Rows with more than 256 distinct values stay dense
 // (ndist[r] = 0) and go through em_iter_wide_kernel; the two kernels' column partials are summed by one
 // colreduce.  Every cell still gets its own two FMAs: nothing is skipped, only the bytes shrink.
@@ -160,7 +161,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
             if (q < wv) base += s_wcnt[q];
             D += s_wcnt[q];
         }
-        const int64_t bytes = (int64_t)ldc + 8 * (int64_t)D;
+        const int64_t bytes = (int64_t)ldc + 16 * (int64_t)D;        // codes ++ table of P ++ table of the log values
         const bool coded = !dense && D <= ENC_MAX_CODES;
         if (t == 0) {
             long long off = -1;
@@ -182,7 +183,12 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
             code = base + incl - cnt;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (kk[j] != ENC_EMPTY) tbl[code++] = exp(__longlong_as_double((long long)kk[j]) - shift);
+                if (kk[j] != ENC_EMPTY) {
+                    const double mval = __longlong_as_double((long long)kk[j]);
+                    tbl[code] = exp(mval - shift);
+                    tbl[D + code] = mval;                   // the log value itself: posterior / argmax passes read it
+                    ++code;
+                }
             }
             unsigned int *cw = reinterpret_cast<unsigned int *>(rec + off);
 #pragma unroll
@@ -371,6 +377,83 @@ __global__ __launch_bounds__(256) void decode_rows_kernel(const uint8_t *__restr
         const uint8_t *codes = rec + rec_off[r];
         const double *tbl = reinterpret_cast<const double *>(codes + ldc);
         for (int h = threadIdx.x; h < H; h += 256) P[r * ldp + h] = tbl[codes[h]];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// Consumers of a coded matrix that need the LOG values (the record's second table):
+//   best[r] = first index of max_h (ln_props[h] + M[r][h])   -- the row argmax of the posterior under theta_k
+//             (assemble.py:115-123; the row's log-sum-exp shifts every column alike, so it drops out)
+//   out[r][i] = M[r][cols[i]]                                 -- preprocess.py:247-251 (em_mat[:, indexes])
+// One workgroup per row; rows without a record are left untouched (the caller has them dense).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void coded_argmax_kernel(const uint8_t *__restrict__ rec,
+                                                          const int64_t *__restrict__ rec_off,
+                                                          const int32_t *__restrict__ ndist, int ldc, int64_t R, int H,
+                                                          const double *__restrict__ ln_props,
+                                                          int32_t *__restrict__ best) {
+    __shared__ double s_m[ENC_MAX_CODES];
+    __shared__ double s_val[4];
+    __shared__ int s_idx[4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const int nd = ndist[r];
+        if (nd <= 0) continue;                               // uniform
+        const uint8_t *codes = rec + rec_off[r];
+        const double *mtab = reinterpret_cast<const double *>(codes + ldc) + nd;
+        if (t < nd) s_m[t] = mtab[t];
+        __syncthreads();
+        double bv = -INFINITY;
+        int bi = 0x7fffffff;
+        for (int h = t; h < H; h += 256) {                   // increasing h per thread: '>' keeps the first maximum
+            const double x = ln_props[h] + s_m[codes[h]];
+            if (x > bv || bi == 0x7fffffff) {
+                bv = x;
+                bi = h;
+            }
+        }
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) {
+            const double ov = __shfl_xor(bv, off, 64);
+            const int oi = __shfl_xor(bi, off, 64);
+            if (ov > bv || (ov == bv && oi < bi)) {
+                bv = ov;
+                bi = oi;
+            }
+        }
+        if (lane == 0) {
+            s_val[wv] = bv;
+            s_idx[wv] = bi;
+        }
+        __syncthreads();
+        if (t == 0) {
+            double v = s_val[0];
+            int i0 = s_idx[0];
+            for (int q = 1; q < 4; ++q)
+                if (s_val[q] > v || (s_val[q] == v && s_idx[q] < i0)) {
+                    v = s_val[q];
+                    i0 = s_idx[q];
+                }
+            best[r] = i0;
+        }
+        __syncthreads();
+    }
+}
+
+__global__ __launch_bounds__(256) void coded_gather_columns_kernel(const uint8_t *__restrict__ rec,
+                                                                  const int64_t *__restrict__ rec_off,
+                                                                  const int32_t *__restrict__ ndist, int ldc, int64_t R,
+                                                                  const int32_t *__restrict__ cols, int nC,
+                                                                  double *__restrict__ out, int64_t ldo) {
+    const int64_t total = R * nC;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < total; e += (int64_t)gridDim.x * 256) {
+        const int64_t r = e / nC;
+        const int i = (int)(e - r * nC);
+        const int nd = ndist[r];
+        if (nd <= 0) continue;
+        const uint8_t *codes = rec + rec_off[r];
+        const double *mtab = reinterpret_cast<const double *>(codes + ldc) + nd;
+        out[r * ldo + i] = mtab[codes[cols[i]]];
     }
 }
 

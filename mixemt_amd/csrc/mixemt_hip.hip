@@ -710,17 +710,14 @@ extern "C" int mxm_em_iter_f32(const float *P, int64_t ldp, const double *w, con
 }
 
 // ---- row-dictionary storage (coded_kernels.hpp) ------------------------------------------------
-extern "C" size_t mxm_coded_bytes(int64_t R, int32_t H) {
-    if (R < 0 || H <= 0) return 0;
-    return (size_t)(R > 0 ? R : 1) * ((size_t)coded_ld(H) + 8 * ENC_MAX_CODES);
-}
+extern "C" size_t mxm_coded_bytes(int64_t R, int32_t H) { return mxm_record_bytes(R, H); }
 
 extern "C" int mxm_encode_rows(const double *M, int64_t ldm, int64_t R, int32_t H, uint8_t *rec, size_t rec_bytes,
                                int64_t *rec_off, int32_t *ndist, double *rowmax, int64_t *stats, void *stream) {
     if (R <= 0 || H <= 0 || ldm < H) return fail(-1, "mxm_encode_rows: bad shape R=%s%lld H=%lld", "", R, H);
     if (!mxm_linear_supported(H) || !wide_rows_ok(M, ldm, H))
         return fail(-1, "mxm_encode_rows: needs an even H in [66, 8192] and 16-byte aligned rows%s (H=%lld ldm=%lld)", "", H, ldm);
-    if (rec == nullptr || (reinterpret_cast<uintptr_t>(rec) & 15) || rec_bytes < (size_t)coded_ld(H) + 8 * ENC_MAX_CODES)
+    if (rec == nullptr || (reinterpret_cast<uintptr_t>(rec) & 15) || rec_bytes < (size_t)coded_ld(H) + 16 * ENC_MAX_CODES)
         return fail(-1, "mxm_encode_rows: record buffer missing, unaligned or smaller than one record%s", "");
     if (rec_off == nullptr || ndist == nullptr || rowmax == nullptr || stats == nullptr)
         return fail(-1, "mxm_encode_rows: output arrays required%s", "");
@@ -755,6 +752,28 @@ extern "C" int mxm_decode_rows(const mxm_coded *c, int32_t H, double *P, int64_t
     if (P == nullptr || ldp < H) return fail(-1, "mxm_decode_rows: ldp < H%s", "");
     hipLaunchKernelGGL(decode_rows_kernel, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(256), 0, (hipStream_t)stream, c->rec,
                        c->rec_off, c->ndist, coded_ld(H), c->R, (int)H, P, ldp);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_row_argmax_coded(const mxm_coded *c, int32_t H, const double *ln_props, int32_t *best, void *stream) {
+    const int rc = coded_check(c, H, "mxm_row_argmax_coded");
+    if (rc != 0) return rc;
+    if (ln_props == nullptr || best == nullptr) return fail(-1, "mxm_row_argmax_coded: ln_props and best required%s", "");
+    hipLaunchKernelGGL(coded_argmax_kernel, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(256), 0, (hipStream_t)stream, c->rec,
+                       c->rec_off, c->ndist, coded_ld(H), c->R, (int)H, ln_props, best);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_gather_columns_coded(const mxm_coded *c, int32_t H, const int32_t *cols, int32_t nC, double *out,
+                                        int64_t ldo, void *stream) {
+    const int rc = coded_check(c, H, "mxm_gather_columns_coded");
+    if (rc != 0) return rc;
+    if (cols == nullptr || out == nullptr || nC <= 0 || ldo < nC) return fail(-1, "mxm_gather_columns_coded: bad arguments%s", "");
+    const int64_t blocks = (c->R * nC + 255) / 256;
+    hipLaunchKernelGGL(coded_gather_columns_kernel, dim3(clamp_grid(blocks, num_cu() * 16)), dim3(256), 0, (hipStream_t)stream,
+                       c->rec, c->rec_off, c->ndist, coded_ld(H), c->R, cols, (int)nC, out, ldo);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -467,7 +467,7 @@ def collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix=True, verb
     props = numpy.exp(res)                            # em.py:163
     return {"props": props, "read_mix": read_mix, "iters": [s[1] for s in states],
             "done": [s[0] for s in states], "run_props": numpy.exp(ln_next), "inits": inits,
-            "l1": [s[2] for s in states]}
+            "l1": [s[2] for s in states], "ln_theta_k": ln_k}
 
 
 def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, storage=None, records=None):
@@ -479,6 +479,7 @@ def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, stora
         run_props  [n_multi][H] numpy, each run's theta_{k+1}
         inits      [n_multi][H] numpy, the initial draws
         done       per-run stop reason (1 converged, 2 max_iter)
+        ln_theta_k [n_multi][H] numpy, log theta_k: the proportions the returned posterior is taken under (em.py:137-143)
     records: a preprocess.CodedMatrix (the build's row-dictionary output) to iterate instead of encoding
     read_hap_mat; read_hap_mat may then be None if want_read_mix is False.
     """

@@ -531,6 +531,11 @@ class CodedMatrix(object):
         self.rec, self.rec_off, self.ndist, self.rowmax = rec, rec_off, ndist, rowmax
         self.used, self.rest_rows, self.m_rest = used, rest_rows, m_rest
 
+    def struct(self):
+        """mxm_coded view of the records alone (the consumers that take it handle coded rows only)."""
+        return _lib.Coded(self.rec.data_ptr(), self.rec_off.data_ptr(), self.ndist.data_ptr(), self.n_rows,
+                          None, 0, None, 0)
+
 
 def _gather_csr(row_ptr_d, site_d, obs_d, rows):
     """CSR of the given rows only (device tensors; rows int64, any order)."""
@@ -656,6 +661,30 @@ def reduce_em_matrix(em_mat, haplogroups, contrib_props):
     if torch is not None and isinstance(em_mat, torch.Tensor):
         return gather_columns_device(em_mat, idx), names
     return em_mat[:, idx], names
+
+
+def reduce_em_records(cm, haplogroups, contrib_props):
+    """
+    reduce_em_matrix (preprocess.py:230-251) for a matrix that exists only as records (CodedMatrix):
+    [R][#contributors] float64 on the device -- coded rows through mxm_gather_columns_coded (the records'
+    log tables), the rows without a record from their dense copies.
+    """
+    import ctypes
+    lib = _lib.load()
+    keep = {con[1] for con in contrib_props}
+    idx = [i for i, hap in enumerate(haplogroups) if hap in keep]
+    names = [haplogroups[i] for i in idx]
+    dev = cm.rec.device
+    out = device_empty((cm.n_rows, len(idx)), torch.float64, dev, "the reduced EM matrix")
+    if cm.n_rows and idx:
+        cols_d = torch.tensor(idx, dtype=torch.int32, device=dev)
+        coded = cm.struct()
+        _lib.check(lib.mxm_gather_columns_coded(ctypes.byref(coded), cm.n_haps, cols_d.data_ptr(), len(idx),
+                                                out.data_ptr(), out.stride(0), current_stream()),
+                   "mxm_gather_columns_coded")
+        if cm.rest_rows.numel():
+            out[cm.rest_rows] = cm.m_rest.index_select(1, cols_d.to(torch.int64))
+    return out, names
 
 
 def gather_columns_device(em_mat, idx):

@@ -308,3 +308,32 @@ def test_run_em_from_build_records_reproduces_the_reference(b17):
     res = em.run_em_ex(mat, g["wts"], em_args(), records=cm)
     assert res["iters"] == list(g["iters"])
     assert numpy.array_equal(res["read_mix"].argmax(dim=1).cpu().numpy(), g["mix_argmax"])
+
+
+def test_consumers_from_records_match_the_dense_pipeline(b17):
+    """Contributors from read votes, the vote table, the reduced matrix and the refinement EM from records
+    alone == the same steps over the dense matrix and posterior (g9: 2400 rows, repeat weights)."""
+    import argparse
+    from mixemt_amd import assign, em, preprocess
+    refseq, phy, haps, tables = b17
+    g = golden("g9_run_em_2400")
+    args = em_args(min_reads=10, min_fold=2.0)
+    cm, mat = preprocess.build_em_records_device(tables, g["row_ptr"], g["site"], g["obs"], dense=True)
+    cm_only = preprocess.build_em_records_device(tables, g["row_ptr"], g["site"], g["obs"])
+    numpy.random.seed(17)
+    full = em.run_em_ex(mat, g["wts"], args)                                     # dense path, posterior included
+    numpy.random.seed(17)
+    lean = em.run_em_ex(None, g["wts"], args, want_read_mix=False, records=cm_only)
+    assert lean["iters"] == full["iters"] == list(g["iters"])
+    best_d, votes_d = assign.row_argmax_votes(full["read_mix"], g["wts"])
+    best_r, votes_r = assign.row_argmax_votes_records(cm_only, lean["ln_theta_k"][0], g["wts"])
+    assert numpy.array_equal(best_r, best_d) and numpy.array_equal(best_r, g["mix_argmax"])
+    assert numpy.array_equal(votes_r, votes_d) and numpy.array_equal(votes_r, g["votes"])
+    con_d = assign.find_contribs_from_reads(full["read_mix"], g["wts"], args)
+    con_r = assign.find_contribs_from_records(cm_only, lean["ln_theta_k"][0], g["wts"], args)
+    assert con_r == con_d and sorted(con_r) == sorted(int(c) for c in g["contributors"])
+    contribs = [["hap%d" % (i + 1), haps[c], 0.0] for i, c in enumerate(con_r)]
+    sub_d, names_d = preprocess.reduce_em_matrix(mat, haps, contribs)
+    sub_r, names_r = preprocess.reduce_em_records(cm_only, haps, contribs)
+    assert names_r == names_d
+    assert numpy.array_equal(sub_r.cpu().numpy(), sub_d.cpu().numpy())           # the log values, bit for bit

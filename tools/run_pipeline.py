@@ -6,7 +6,7 @@ synthetic reads, device-resident end to end:
     CSR observations -> build_em_matrix_device -> run_em -> contributors from read votes
     -> refinement EM on the contributor columns -> read assignment -> contributor table
 
-    python tools/run_pipeline.py [--reads N] [--seed S] [--multi M] [--storage f64|coded]
+    python tools/run_pipeline.py [--reads N] [--seed S] [--multi M] [--storage f64|coded] [--records]
 """
 import argparse
 import os
@@ -26,6 +26,9 @@ def main():
     ap.add_argument("--reads", type=int, default=20000)
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--multi", type=int, default=1)
+    ap.add_argument("--records", action="store_true",
+                    help="the build leaves the matrix as row-dictionary records and NO dense matrix or posterior is "
+                         "ever made: contributors, vote table and the reduced matrix come from the records")
     ap.add_argument("--storage", default="f64", choices=["f64", "f32", "coded", "auto"],
                     help="form of the matrix the EM loop streams (EmPlan): coded = lossless row dictionaries")
     opts = ap.parse_args()
@@ -43,14 +46,24 @@ def main():
                      % (len(tables.sites), len(haps), opts.reads, time.perf_counter() - t0))
 
     t0 = time.perf_counter()
-    em_mat = preprocess.build_em_matrix_device(tables, row_ptr, site, obs)
     wts = torch.ones(opts.reads, dtype=torch.float64, device="cuda")
-    torch.cuda.synchronize()
-    sys.stderr.write("EM input matrix %d x %d built on the device in %.1f ms\n"
-                     % (em_mat.shape[0], em_mat.shape[1], (time.perf_counter() - t0) * 1e3))
+    if opts.records:
+        em_mat = None
+        cm = preprocess.build_em_records_device(tables, row_ptr, site, obs)
+        torch.cuda.synchronize()
+        sys.stderr.write("EM input %d x %d built on the device as records in %.1f ms: %.2f GB, %d rows dense beside them "
+                         "(a dense matrix would be %.1f GB)\n"
+                         % (cm.n_rows, cm.n_haps, (time.perf_counter() - t0) * 1e3, cm.used / 1e9,
+                            cm.rest_rows.numel(), cm.n_rows * cm.n_haps * 8 / 1e9))
+    else:
+        cm = None
+        em_mat = preprocess.build_em_matrix_device(tables, row_ptr, site, obs)
+        torch.cuda.synchronize()
+        sys.stderr.write("EM input matrix %d x %d built on the device in %.1f ms\n"
+                         % (em_mat.shape[0], em_mat.shape[1], (time.perf_counter() - t0) * 1e3))
 
     t0 = time.perf_counter()
-    res = em.run_em_ex(em_mat, wts, args)
+    res = em.run_em_ex(em_mat, wts, args, want_read_mix=not opts.records, records=cm)
     props, read_mix = res["props"], res["read_mix"]
     torch.cuda.synchronize()
     sys.stderr.write("run_em: %.1f ms, of which the EM loop %.1f ms (%d iterations, %s matrix) and the plan "
@@ -62,10 +75,19 @@ def main():
     sys.stderr.write("\nTop 10 haplogroups by proportion...\n")
     for i in range(10):
         sys.stderr.write("%d\t%0.6f\t%s\n" % (i + 1, props[order[i]], haps[order[i]]))
-    assign.report_read_votes(haps, read_mix, 10)
-
     t0 = time.perf_counter()
-    cons = assign.find_contribs_from_reads(read_mix, wts, args)
+    if opts.records:
+        # votes and contributors from the records' log tables under theta_k (no posterior matrix exists)
+        best, votes = assign.row_argmax_votes_records(cm, res["ln_theta_k"][0], None)
+        sys.stderr.write("\nTop 10 haplogroups by read probabilities...\n")
+        seen = assign._first_seen_order(best)
+        for hap_i in sorted(seen, key=lambda h: -votes[h])[:10]:
+            sys.stderr.write("%s\t%d\n" % (haps[hap_i], int(votes[hap_i])))
+        sys.stderr.write("\n")
+        cons = [int(h) for h in seen if votes[h] >= args.min_reads]
+    else:
+        assign.report_read_votes(haps, read_mix, 10)
+        cons = assign.find_contribs_from_reads(read_mix, wts, args)
     torch.cuda.synchronize()
     sys.stderr.write("contributors from read votes: %.1f ms\n" % ((time.perf_counter() - t0) * 1e3))
     contribs = sorted(([haps[c], props[c]] for c in cons), key=lambda c: c[1], reverse=True)
@@ -77,7 +99,10 @@ def main():
 
     sys.stderr.write("Refining contribution estimates...\n")
     t0 = time.perf_counter()
-    sub, sub_haps = preprocess.reduce_em_matrix(em_mat, haps, contribs)
+    if opts.records:
+        sub, sub_haps = preprocess.reduce_em_records(cm, haps, contribs)
+    else:
+        sub, sub_haps = preprocess.reduce_em_matrix(em_mat, haps, contribs)
     results = em.run_em(sub, wts, args)
     torch.cuda.synchronize()
     sys.stderr.write("refinement run_em on %d x %d: %.1f ms\n" % (sub.shape[0], sub.shape[1], (time.perf_counter() - t0) * 1e3))
