@@ -231,7 +231,7 @@ int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int64_t R, int
  *     codes[ldc] (uint8 per column, ldc = H rounded up to 8)  ++  table[ndist[r]] (doubles)  ++  mtable[ndist[r]],
  *     P[r][h] = exp(M[r][h] - rowmax[r]) = table[codes[h]]          -- the bits mxm_linearize writes
  *     M[r][h] = mtable[codes[h]]                                    -- the log value itself
- * at rec + rec_off[r]: ~5.7 KB instead of 43 KB at H = 5408.  Rows with more than 256 distinct values
+ * at rec + rec_off[r]: ~5.9 KB instead of 43 KB at H = 5408.  Rows with more than 256 distinct values
  * get ndist[r] = 0; the caller keeps those dense (P_rest / w_rest: their mxm_linearize rows and
  * weights, in any fixed order) and both parts are summed by one column reduce.
  *   mxm_coded_bytes(R, H)   record buffer size that can never overflow (R * (ldc + 4096))

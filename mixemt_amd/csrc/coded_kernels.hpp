@@ -11,7 +11,7 @@
 //     record(r) = codes[ldc] (one byte per column, pad columns 0)  ++  table[D_r] (doubles)  ++  mtable[D_r]
 //     P[r][h]   = table[codes[h]]                       -- the SAME bits as the dense P
 //     M[r][h]   = mtable[codes[h]]                      -- the log matrix itself (posterior / argmax / column gathers)
-// 5.4 KB + 8 D bytes instead of 43 KB per row.  Rows with more than 256 distinct values stay dense
+// 5.4 KB + 16 D bytes instead of 43 KB per row.  Rows with more than 256 distinct values stay dense
 // (ndist[r] = 0) and go through em_iter_wide_kernel; the two kernels' column partials are summed by one
 // colreduce.  Every cell still gets its own two FMAs: nothing is skipped, only the bytes shrink.
 // ------------------------------------------------------------------------------------------

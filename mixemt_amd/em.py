@@ -229,8 +229,8 @@ class EmPlan(object):
                                               p_rest.data_ptr(), p_rest.stride(0), rm.data_ptr(), current_stream()),
                        "mxm_linearize")
             w_rest = self.wts.index_select(0, cm.rest_rows).contiguous()
-        self.coded_record_bytes = cm.used
-        self.coded_bytes = cm.used + n_rest * self.n_haps * 8
+        self.coded_record_bytes = cm.used - 8 * int(cm.ndist.sum().item())     # codes + P tables: the loop's read
+        self.coded_bytes = self.coded_record_bytes + n_rest * self.n_haps * 8
         self.coded_rest = n_rest
         self.coded_ndist = cm.ndist
         self._coded_keep = (cm.rec, cm.rec_off, cm.ndist, p_rest, w_rest, cm)
@@ -265,8 +265,9 @@ class EmPlan(object):
             _lib.check(lib.mxm_linearize(m_rest.data_ptr(), m_rest.stride(0), n_rest, n_haps, p_rest.data_ptr(),
                                          p_rest.stride(0), rm.data_ptr(), current_stream()), "mxm_linearize")
             w_rest = self.wts.index_select(0, idx).contiguous()
-        self.coded_record_bytes = used                # what em_iter_coded_kernel reads per pass
-        self.coded_bytes = used + (n_rest * n_haps * 8)
+        # what em_iter_coded_kernel reads per pass: codes + P tables (the records' log tables are for other passes)
+        self.coded_record_bytes = used - 8 * int(ndist.sum().item())
+        self.coded_bytes = self.coded_record_bytes + (n_rest * n_haps * 8)
         self.coded_rest = n_rest
         self._coded_keep = (rec, rec_off, ndist, p_rest, w_rest)      # the tensors self.coded points into
         self.coded_ndist = ndist                      # [R] int32: table entries per row, 0 = the row stays dense
