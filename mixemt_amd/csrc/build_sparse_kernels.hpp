@@ -27,7 +27,9 @@
 #define SPB_MAXN 64
 #define SPB_SLOTS 1024                // hash slots for the row's distinct non-zero masks (8 bytes of LDS each)
 #define SPB_MAXD 704                  // ... of which at most this many may fill up (load factor < 0.7); beyond: fallback
-#define SPB_GATHER 4                  // marker entries a thread has in flight during the scatter
+#ifndef SPB_GATHER
+#define SPB_GATHER 4                  // marker entries a thread has in flight during the scatter (2 / 4 / 8: 16.4 / 16.5 / 17.2 ms)
+#endif
 
 // NCH column pairs per thread (ceil(H / 2 / 256)); the haplogroups are taken in PASSES column ranges so that the
 // mask array is 1 / PASSES of a row (LDS per workgroup decides how many rows a CU has in flight, and a row is
