@@ -260,6 +260,11 @@ int mxm_decode_rows(const mxm_coded *c, int32_t H, double *P, int64_t ldp, void 
  *   best[r] = first index of max_h (ln_props[h] + M[r][h])    assemble.py:115-123 (row argmax of the posterior)
  *   out[r][i] = M[r][cols[i]]                                  preprocess.py:247-251 (em_mat[:, indexes]) */
 int mxm_row_argmax_coded(const mxm_coded *c, int32_t H, const double *ln_props, int32_t *best, void *stream);
+/* mxm_em_step for coded rows -- em.py:80-83 (mode 0 store) and :156 (mode 1 logaddexp fold):
+ *   out[r][h] = (ln_props[h] + M[r][h]) - (rowmax[r] + log(sum_h props[h] * P[r][h]))
+ * the row's log-sum-exp taken in the loop's own linear variables (props = exp(ln_props), rowmax from the encoder). */
+int mxm_em_step_coded(const mxm_coded *c, int32_t H, const double *ln_props, const double *props,
+                      const double *rowmax, double *out, int64_t ldo, int32_t mode, void *stream);
 int mxm_gather_columns_coded(const mxm_coded *c, int32_t H, const int32_t *cols, int32_t nC,
                              double *out, int64_t ldo, void *stream);
 int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, int32_t H, int32_t B,

@@ -440,6 +440,46 @@ __global__ __launch_bounds__(256) void coded_argmax_kernel(const uint8_t *__rest
     }
 }
 
+// Posterior pass from records (em.py:80-83, :156): out[r][h] = ln_props[h] + M[r][h] - lse_r, where the row's
+// log-sum-exp is taken in the loop's own variables, lse_r = rowmax_r + log(sum_h props[h] P[r][h]) -- one table
+// lookup and one FMA per cell, one logarithm per row, no exponential.  mode 1 folds with logaddexp (multi-run).
+// (Same limit as the loop: a row whose every supported haplogroup has an underflowed proportion has Z = 0.)
+__global__ __launch_bounds__(256) void coded_posterior_kernel(const uint8_t *__restrict__ rec,
+                                                             const int64_t *__restrict__ rec_off,
+                                                             const int32_t *__restrict__ ndist, int ldc, int64_t R, int H,
+                                                             const double *__restrict__ ln_props,
+                                                             const double *__restrict__ props,
+                                                             const double *__restrict__ rowmax,
+                                                             double *__restrict__ out, int64_t ldo, int mode) {
+    __shared__ double s_p[ENC_MAX_CODES], s_m[ENC_MAX_CODES];
+    __shared__ double s_red[4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const int nd = ndist[r];
+        if (nd <= 0) continue;                               // uniform
+        const uint8_t *codes = rec + rec_off[r];
+        const double *ptab = reinterpret_cast<const double *>(codes + ldc);
+        if (t < nd) {
+            s_p[t] = ptab[t];
+            s_m[t] = ptab[nd + t];
+        }
+        __syncthreads();
+        double z = 0.0;
+        for (int h = t; h < H; h += 256) z = fma(props[h], s_p[codes[h]], z);
+        z = wave_sum(z);
+        if (lane == 0) s_red[wv] = z;
+        __syncthreads();
+        z = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+        const double lse = rowmax[r] + log(z);
+        double *dst = out + r * ldo;
+        for (int h = t; h < H; h += 256) {
+            const double v = (ln_props[h] + s_m[codes[h]]) - lse;
+            dst[h] = (mode == 1) ? logaddexp_f64(dst[h], v) : v;
+        }
+        __syncthreads();
+    }
+}
+
 __global__ __launch_bounds__(256) void coded_gather_columns_kernel(const uint8_t *__restrict__ rec,
                                                                   const int64_t *__restrict__ rec_off,
                                                                   const int32_t *__restrict__ ndist, int ldc, int64_t R,

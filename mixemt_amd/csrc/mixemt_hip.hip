@@ -766,6 +766,18 @@ extern "C" int mxm_row_argmax_coded(const mxm_coded *c, int32_t H, const double 
     return 0;
 }
 
+extern "C" int mxm_em_step_coded(const mxm_coded *c, int32_t H, const double *ln_props, const double *props,
+                                 const double *rowmax, double *out, int64_t ldo, int32_t mode, void *stream) {
+    const int rc = coded_check(c, H, "mxm_em_step_coded");
+    if (rc != 0) return rc;
+    if (ln_props == nullptr || props == nullptr || rowmax == nullptr || out == nullptr || ldo < H)
+        return fail(-1, "mxm_em_step_coded: bad arguments%s", "");
+    hipLaunchKernelGGL(coded_posterior_kernel, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(256), 0, (hipStream_t)stream, c->rec,
+                       c->rec_off, c->ndist, coded_ld(H), c->R, (int)H, ln_props, props, rowmax, out, ldo, (int)mode);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int mxm_gather_columns_coded(const mxm_coded *c, int32_t H, const int32_t *cols, int32_t nC, double *out,
                                         int64_t ldo, void *stream) {
     const int rc = coded_check(c, H, "mxm_gather_columns_coded");

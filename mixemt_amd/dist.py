@@ -177,13 +177,11 @@ def run_em_sharded(local_mat, local_weights, args, inits=None, group=None, want_
     `group`; each rank passes ITS row block and gets back the global proportions
     plus ITS block of the posterior matrix.  Same dict as em.run_em_ex.
     records: the shard as a preprocess.CodedMatrix (build_em_records_device on the rank's own rows);
-    local_mat may then be None with want_read_mix=False.
+    local_mat may then be None.
     """
     n_multi = int(args.n_multi)
     plan = _em.EmPlan(local_mat, local_weights, n_runs=n_multi,
                       storage=storage or getattr(args, "storage", "f64"), records=records)
-    if want_read_mix and plan.mat is None:
-        raise ValueError("the posterior block needs the shard's log matrix: pass it beside the records, or want_read_mix=False")
     if inits is None:
         inits = broadcast_inits(n_multi, plan.n_haps, args.init_alpha, plan.dev, group)
     inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)

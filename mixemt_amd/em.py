@@ -234,6 +234,7 @@ class EmPlan(object):
         self.coded_rest = n_rest
         self.coded_ndist = cm.ndist
         self._coded_keep = (cm.rec, cm.rec_off, cm.ndist, p_rest, w_rest, cm)
+        self.records = cm
         self.coded = _lib.Coded(cm.rec.data_ptr(), cm.rec_off.data_ptr(), cm.ndist.data_ptr(), self.n_rows,
                                 p_rest.data_ptr() if n_rest else None, p_rest.stride(0) if n_rest else 0,
                                 w_rest.data_ptr() if n_rest else None, n_rest)
@@ -419,11 +420,29 @@ def posterior(plan, ln_theta, out=None, fold=False):
     Log posterior under log-proportions `ln_theta` (em.py:80-83) written to
     `out` (mode store) or folded into it with logaddexp (em.py:156).
     """
-    if plan.mat is None:
-        raise ValueError("posterior pass needs the log matrix (keep_log_matrix=True)")
     lnp = as_device(ln_theta, torch.float64, plan.dev)
     if out is None:
         out = device_empty((plan.n_rows, plan.n_haps), torch.float64, plan.dev, "the posterior matrix")
+    if plan.mat is None and getattr(plan, "records", None) is not None:
+        # the matrix exists only as records: coded rows from their log tables, the rest from their dense copies
+        cm = plan.records
+        lnp = lnp.reshape(-1).contiguous()
+        coded = cm.struct()
+        props_d = torch.exp(lnp)
+        _lib.check(plan.lib.mxm_em_step_coded(ctypes.byref(coded), plan.n_haps, lnp.data_ptr(), props_d.data_ptr(),
+                                              cm.rowmax.data_ptr(), out.data_ptr(), out.stride(0), 1 if fold else 0,
+                                              current_stream()), "mxm_em_step_coded")
+        n_rest = int(cm.rest_rows.numel())
+        if n_rest:
+            tmp = out.index_select(0, cm.rest_rows) if fold else torch.empty((n_rest, plan.n_haps), dtype=torch.float64,
+                                                                             device=plan.dev)
+            _lib.check(plan.lib.mxm_em_step(cm.m_rest.data_ptr(), cm.m_rest.stride(0), 0, lnp.data_ptr(), n_rest,
+                                            plan.n_haps, tmp.data_ptr(), tmp.stride(0), 1 if fold else 0, 0, 0, 0,
+                                            current_stream()), "mxm_em_step")
+            out.index_copy_(0, cm.rest_rows, tmp)
+        return out
+    if plan.mat is None:
+        raise ValueError("posterior pass needs the log matrix (keep_log_matrix=True)")
     _lib.check(plan.lib.mxm_em_step(plan.mat.data_ptr(), plan.mat.stride(0), 0, lnp.data_ptr(),
                                     plan.n_rows, plan.n_haps, out.data_ptr(), out.stride(0),
                                     1 if fold else 0, 0, 0, 0, current_stream()),
@@ -482,14 +501,12 @@ def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, stora
         done       per-run stop reason (1 converged, 2 max_iter)
         ln_theta_k [n_multi][H] numpy, log theta_k: the proportions the returned posterior is taken under (em.py:137-143)
     records: a preprocess.CodedMatrix (the build's row-dictionary output) to iterate instead of encoding
-    read_hap_mat; read_hap_mat may then be None if want_read_mix is False.
+    read_hap_mat; read_hap_mat may then be None (the posterior comes from the records' log tables).
     """
     n_multi = int(args.n_multi)
     storage = storage or getattr(args, "storage", "f64")
     t_plan = time.perf_counter()
     plan = EmPlan(read_hap_mat, weights, n_runs=n_multi, storage=storage, records=records)
-    if want_read_mix and plan.mat is None:
-        raise ValueError("the posterior matrix needs the log matrix: pass it beside the records, or want_read_mix=False")
     torch.cuda.synchronize()
     t_plan = time.perf_counter() - t_plan
     if inits is None:

@@ -300,14 +300,26 @@ def test_run_em_from_build_records_reproduces_the_reference(b17):
     assert numpy.array_equal(res["inits"], g["inits"])
     assert res["iters"] == list(g["iters"]) and res["storage"] == "coded"
     assert numpy.abs(res["props"] - g["props"]).max() < PROPS_ATOL
-    with pytest.raises(ValueError):
-        em.run_em_ex(None, g["wts"], em_args(), records=cm)                    # a posterior needs the log matrix
-    # with the dense matrix beside the records the posterior is there too
-    cm, mat = preprocess.build_em_records_device(tables, g["row_ptr"], g["site"], g["obs"], dense=True)
+    # the posterior from the records' log tables (mxm_em_step_coded) against the dense pass over the dense matrix
     numpy.random.seed(17)
-    res = em.run_em_ex(mat, g["wts"], em_args(), records=cm)
-    assert res["iters"] == list(g["iters"])
-    assert numpy.array_equal(res["read_mix"].argmax(dim=1).cpu().numpy(), g["mix_argmax"])
+    lean = em.run_em_ex(None, g["wts"], em_args(), records=cm)
+    cm2, mat = preprocess.build_em_records_device(tables, g["row_ptr"], g["site"], g["obs"], dense=True)
+    numpy.random.seed(17)
+    full = em.run_em_ex(mat, g["wts"], em_args(), records=cm2)
+    assert lean["iters"] == full["iters"] == list(g["iters"])
+    a, b = lean["read_mix"].cpu().numpy(), full["read_mix"].cpu().numpy()
+    assert numpy.array_equal(a.argmax(axis=1), g["mix_argmax"]) and numpy.array_equal(b.argmax(axis=1), g["mix_argmax"])
+    assert numpy.abs(a - b).max() < 1e-10
+    assert numpy.allclose(a[:4], g["mix_rows"], rtol=0, atol=1e-8) and numpy.allclose(a.max(axis=1), g["mix_rowmax"], rtol=0, atol=1e-8)
+    # three restarts: the fold (logaddexp over runs, em.py:156) from records
+    g5 = golden("g5_run_em_multi")
+    cm5 = preprocess.build_em_records_device(tables, g5["row_ptr"], g5["site"], g5["obs"])
+    numpy.random.seed(11)
+    res5 = em.run_em_ex(None, g5["wts"], em_args(n_multi=3), records=cm5)
+    assert res5["iters"] == list(g5["iters"]) and numpy.abs(res5["props"] - g5["props"]).max() < PROPS_ATOL
+    mix5 = res5["read_mix"].cpu().numpy()
+    assert numpy.array_equal(mix5.argmax(axis=1), g5["mix_argmax"])
+    assert numpy.allclose(mix5[:16], g5["mix_rows"], rtol=0, atol=1e-8)
 
 
 def test_consumers_from_records_match_the_dense_pipeline(b17):
