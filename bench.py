@@ -257,6 +257,11 @@ def main(argv=None):
         raise SystemExit("bench: --gpus must be >= 1")
     if opts.gpus > 1 and "RANK" not in os.environ:
         raise SystemExit(spawn_ranks(opts, argv))          # before torch / the GPU are touched
+    # stdout carries ONE line, the JSON: libraries that write to file descriptor 1 themselves (RCCL prints a
+    # version banner there when a communicator is made) are pointed at stderr for the life of the process
+    sys.stdout.flush()
+    json_fd = os.dup(1)
+    os.dup2(2, 1)
 
     import numpy
     import torch
@@ -369,8 +374,7 @@ def main(argv=None):
                n_haps=n_haps, total_rows=total_rows, scaling=scaling, build_s=build_s, records=records, slab=slab)
     line = bench_restarts(opts, env) if opts.mode == "restarts" else bench_rows(opts, env)
     if rank == 0:
-        print(json.dumps(line))
-        sys.stdout.flush()
+        os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
