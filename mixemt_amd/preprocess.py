@@ -553,8 +553,9 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False):
     CSR observations -> CodedMatrix: the marker kernel writes each row as a row-dictionary record
     (one byte per haplogroup + the row's distinct values) -- what em.EmPlan(storage="coded") otherwise
     makes from the dense matrix with a pass of its own.  dense=False: NO dense matrix is written (5.5 GB
-    instead of 43 GB at 10^6 x 5408; 10^7 rows fit one GPU); rows that do not code (more than 64
-    observations or more than 256 distinct values: ~5 %) are built densely into `m_rest`.
+    instead of 43 GB at 10^6 x 5408; 10^7 rows fit one GPU); rows the marker kernel cannot take (more than
+    64 observations, more than 256 distinct values: ~3.5 %) are built densely by the lookup-table kernel and
+    coded from there where they hold at most 256 values; what remains (~2 %) stays dense in `m_rest`.
     dense=True: returns (CodedMatrix, M) with the full dense matrix as well.
     """
     lib = _lib.load()
@@ -607,6 +608,26 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False):
         sub_ptr, sub_site, sub_obs = _gather_csr(row_ptr_d, site_d, obs_d, rest_rows)
         m_rest = torch.empty((n_rest, n_haps), dtype=torch.float64, device=dev)
         lut_rows(sub_ptr, sub_site, sub_obs, 0, n_rest, m_rest)
+    if m_rest is not None:
+        # the dense rows of long reads mostly hold few distinct values too: code them from their dense form
+        # (mxm_encode_rows) into the tail of the same record buffer; what stays dense has more than 256 values
+        base = (used + 15) // 16 * 16
+        sub_off = torch.empty(n_rest, dtype=torch.int64, device=dev)
+        sub_nd = torch.empty(n_rest, dtype=torch.int32, device=dev)
+        sub_rm = torch.empty(n_rest, dtype=torch.float64, device=dev)
+        sub_stats = torch.zeros(2, dtype=torch.int64, device=dev)
+        _lib.check(lib.mxm_encode_rows(m_rest.data_ptr(), m_rest.stride(0), n_rest, n_haps, rec.data_ptr() + base,
+                                       cap - base, sub_off.data_ptr(), sub_nd.data_ptr(), sub_rm.data_ptr(),
+                                       sub_stats.data_ptr(), current_stream()), "mxm_encode_rows")
+        got = sub_nd > 0
+        rows_c = rest_rows[got]
+        rec_off[rows_c] = sub_off[got] + base
+        ndist[rows_c] = sub_nd[got]
+        rowmax[rows_c] = sub_rm[got]
+        used = base + int(sub_stats[0].item())
+        rest_rows = rest_rows[~got]
+        m_rest = m_rest[~got].contiguous()
+        n_rest = int(rest_rows.numel())
     build_em_matrix_device.last_fallback = left
     cm = CodedMatrix(n_rows, n_haps, rec, rec_off, ndist, rowmax, used,
                      rest_rows, m_rest if m_rest is not None else torch.empty((0, n_haps), dtype=torch.float64, device=dev))
