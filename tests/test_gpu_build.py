@@ -331,17 +331,6 @@ def test_sparse_kernel_unusual_bases_strided_output_and_golden(b17):
     assert hashlib.sha256(mat.cpu().numpy().tobytes()).hexdigest() == str(g["mat_sha256"])
 
 
-def test_sparse_tables_are_the_dense_table(b17):
-    """maj + markers reproduce expected[S][H] exactly."""
-    refseq, phy, haps, tables = b17
-    sp = tables.sparse()
-    dense = numpy.repeat(sp["maj"][:, None], len(haps), axis=1)
-    site_of = numpy.repeat(numpy.arange(len(sp["maj"])), numpy.diff(sp["mk_ptr"]))
-    dense[site_of, sp["mk_hap"]] = sp["mk_base"]
-    assert numpy.array_equal(dense, tables.expected[:, :len(haps)])
-    assert len(sp["mk_hap"]) < 0.01 * dense.size
-
-
 @pytest.mark.parametrize("passes", [1, 2, 4])
 def test_sparse_kernel_column_ranges_and_full_table_fallback(b17, passes):
     """Every number of column ranges gives the same bits; rows with more distinct values than the dedup table

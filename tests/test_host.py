@@ -227,3 +227,14 @@ def test_synth_rows_is_one_global_read_set_whatever_the_slice(b17):
     assert not numpy.array_equal(part[2], other[2][:len(part[2])])
     empty = synth.synth_rows(tables, len(refseq), 5, 5)
     assert empty[0].tolist() == [0] and empty[1].size == 0
+
+
+def test_sparse_tables_are_the_dense_table(b17):
+    """maj + markers reproduce expected[S][H] exactly."""
+    refseq, phy, haps, tables = b17
+    sp = tables.sparse()
+    dense = numpy.repeat(sp["maj"][:, None], len(haps), axis=1)
+    site_of = numpy.repeat(numpy.arange(len(sp["maj"])), numpy.diff(sp["mk_ptr"]))
+    dense[site_of, sp["mk_hap"]] = sp["mk_base"]
+    assert numpy.array_equal(dense, tables.expected[:, :len(haps)])
+    assert len(sp["mk_hap"]) < 0.01 * dense.size
