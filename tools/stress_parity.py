@@ -98,10 +98,10 @@ lib.mxm_set_loop_fused(-1, 0)
 refseq = phylotree.load_rsrs()
 phy = phylotree.load_build17(refseq)
 haps = sorted(phy.hap_var)
-for case in range(12):
+for case in range(20):
     if time.time() - t_start > opts.budget * 1.3:
         break
-    n_cols = int(rng.choice([1, 3, 4, 5, 63, 64, 65, 1023, 1024, 1025, 3000, 5408]))
+    n_cols = int(rng.choice([1, 3, 4, 5, 63, 64, 65, 66, 130, 1023, 1024, 1025, 2050, 3000, 5408]))
     first = int(rng.integers(0, len(haps) - n_cols + 1))
     sub = haps[first:first + n_cols]
     tables = preprocess.HapVarTables.build(refseq, phy, sub)
@@ -114,8 +114,10 @@ for case in range(12):
     want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, row_ptr, site, obs, n_cols)
     line = "build %2d: %5d rows x %4d columns, read length %4d (up to %d sites per row):" % (
         case, n_rows, n_cols, read_len, int(numpy.diff(row_ptr).max()))
-    for kernel in ("lut", "bytes", "packed"):
+    for kernel in ("lut", "bytes", "packed", "sparse"):
         if kernel == "packed" and tables.packed() is None:
+            continue
+        if kernel == "sparse" and tables.lut() is None:
             continue
         for sort_rows in ((False, True) if kernel == "lut" else (False,)):
             got = preprocess.build_em_matrix_device(tables, row_ptr, site, obs, kernel=kernel,
@@ -123,6 +125,28 @@ for case in range(12):
             if not numpy.array_equal(got, want):
                 fails += 1
                 line += "  %s%s MISMATCH" % (kernel, "+sort" if sort_rows else "")
+    # row-dictionary forms on the same rows: EM from the encoded dense matrix and from records built without it,
+    # against the oracle's run_em on the reference-exact matrix (even widths in the streaming kernel's range)
+    if n_cols % 2 == 0 and 66 <= n_cols and n_rows * n_cols <= 6.0e6 and tables.lut() is not None:
+        wts = rng.integers(1, 5, size=n_rows).astype(numpy.float64)
+        args = ns(max_iter=int(rng.choice([5, 40])))
+        seed = int(rng.integers(1, 1 << 30))
+        trace = []
+        numpy.random.seed(seed)
+        want_props, want_mix = em_oracle.run_em(want, wts, args, trace=trace)
+        cm = preprocess.build_em_records_device(tables, row_ptr, site, obs)
+        for label, kw in (("coded", dict(read_hap_mat=want, storage="coded")), ("records", dict(read_hap_mat=None, records=cm))):
+            numpy.random.seed(seed)
+            res = em.run_em_ex(kw.pop("read_hap_mat"), wts, args, **kw)
+            got_mix = res["read_mix"].cpu().numpy()
+            ok = res["iters"] == [t["iters"] for t in trace] and res["storage"] == "coded"
+            ok = ok and float(numpy.abs(res["props"] - want_props).max()) < 1e-9
+            ok = ok and float(numpy.abs(numpy.exp(got_mix) - numpy.exp(want_mix)).max()) < 1e-9
+            ok = ok and numpy.array_equal(got_mix.argmax(axis=1), want_mix.argmax(axis=1))
+            if not ok:
+                fails += 1
+                line += "  %s MISMATCH" % label
+        line += "  [coded + records EM, %d rows dense]" % int(cm.rest_rows.numel())
     print(line + ("" if "MISMATCH" in line else "  bit-exact"))
     sys.stdout.flush()
 print("%d mismatches" % fails)
