@@ -105,7 +105,9 @@ def em_step(read_hap_mat, weights, ln_props, read_mix_mat):
     return out, ln_new
 
 
-AUTO_CODED_MIN_CELLS = 1.0e8        # storage="auto": the one-launch loops' range ends here (mxm_em_loop)
+AUTO_CODED_MIN_CELLS = 5.0e7        # storage="auto": measured break-even against the one-launch loops over the dense
+                                    # matrix (profiles/r02/small_runs_coded.txt: 67 vs 80 us per iteration at 10 000 x 5408,
+                                    # 60 vs 39 at 4 600)
 AUTO_CODED_MAX_REST = 0.25          # ... and at most this share of the rows may stay dense
 
 
@@ -128,7 +130,7 @@ class EmPlan(object):
         (mxm_encode_rows; rows with more than 256 of them stay dense): the matrix
         build's rows hold a few dozen distinct sums, so the loop reads ~8x fewer
         bytes.  Matrices it does not apply to (odd / narrow H, unaligned rows)
-        iterate as "f64".  "auto" = "coded" where it pays: more than 10^8 cells
+        iterate as "f64".  "auto" = "coded" where it pays: more than 5 * 10^7 cells
         (below that the one-launch loops over the dense matrix are faster) and at
         most a quarter of the rows left dense by the encoder; otherwise "f64".
         `plan.storage` says what the plan iterates.

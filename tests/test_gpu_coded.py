@@ -194,12 +194,12 @@ def test_auto_storage_codes_large_build_matrices_only(b17):
     g = golden("g4_run_em")
     small = _b17_matrix(tables, g, len(haps))
     assert em.EmPlan(small, g["wts"], storage="auto").storage == "f64"          # 600 rows: the one-launch loop's
-    n_rows = 20000                                                              # 1.08e8 cells
+    n_rows = 20000                                                              # 1.08e8 cells: above auto's threshold
     row_ptr, site, obs, _ = synth.synth_rows(tables, len(refseq), 0, n_rows, seed=3)
     big = preprocess.build_em_matrix_device(tables, row_ptr, site, obs)
     plan = em.EmPlan(big, torch.ones(n_rows, dtype=torch.float64, device=big.device), storage="auto")
     assert plan.storage == "coded" and plan.coded is not None and plan.coded_rest < 0.05 * n_rows
-    noise = torch.empty((12500, 8192), dtype=torch.float64, device=big.device).normal_(-25.0, 8.0)
+    noise = torch.empty((12500, 8192), dtype=torch.float64, device=big.device).normal_(-25.0, 8.0)   # 1.0e8 cells
     plan = em.EmPlan(noise, torch.ones(12500, dtype=torch.float64, device=big.device), storage="auto")
     assert plan.storage == "f64" and plan.coded is None and plan.lin is not None  # nothing to compress: dense
 
