@@ -38,7 +38,7 @@ python3 $repo/bench.py --records > $out/bench_1m_records.json 2> /dev/null
 python3 $repo/bench.py --records --total-rows 125000 --force-dist --no-cpu-baseline > $out/bench_125k_records_one_rank_rccl.json 2> /dev/null
 python3 $repo/tools/run_pipeline.py --reads 1000000 --records > $out/pipeline_1m_records.txt 2>&1
 python3 $repo/tools/run_pipeline.py --reads 10000000 --records > $out/pipeline_10m_records_one_gpu.txt 2>&1
-python3 $repo/bench.py --records --total-rows 10000000 --no-cpu-baseline > $out/bench_10m_records_one_gpu.json 2> $out/bench_10m_records_one_gpu.log
+python3 $repo/bench.py --records --total-rows 10000000 > $out/bench_10m_records_one_gpu.json 2> $out/bench_10m_records_one_gpu.log
 python3 $repo/tools/run_pipeline.py --reads 1000000 > $out/pipeline_1m.txt 2>&1
 python3 $repo/tools/run_pipeline.py --reads 1000000 --storage coded > $out/pipeline_1m_coded.txt 2>&1
 # --- other configurations of the same script --------------------------------------------------------
