@@ -238,3 +238,20 @@ def test_sparse_tables_are_the_dense_table(b17):
     dense[site_of, sp["mk_hap"]] = sp["mk_base"]
     assert numpy.array_equal(dense, tables.expected[:, :len(haps)])
     assert len(sp["mk_hap"]) < 0.01 * dense.size
+
+
+def test_gather_csr_of_a_row_subset():
+    """preprocess._gather_csr (the records build's dense leftover rows): CSR of a row subset, any order."""
+    import torch
+    rng = numpy.random.default_rng(5)
+    lens = rng.integers(0, 9, size=40)
+    row_ptr = numpy.concatenate([[0], numpy.cumsum(lens)]).astype(numpy.int64)
+    site = rng.integers(0, 4000, size=int(row_ptr[-1])).astype(numpy.int16)
+    obs = rng.integers(65, 90, size=int(row_ptr[-1])).astype(numpy.uint8)
+    rows = numpy.array([3, 39, 0, 17, 18, 5], dtype=numpy.int64)
+    new_ptr, sub_site, sub_obs = preprocess._gather_csr(torch.from_numpy(row_ptr), torch.from_numpy(site),
+                                                        torch.from_numpy(obs), torch.from_numpy(rows))
+    assert numpy.array_equal(numpy.diff(new_ptr.numpy()), lens[rows])
+    want_site = numpy.concatenate([site[row_ptr[r]:row_ptr[r + 1]] for r in rows])
+    want_obs = numpy.concatenate([obs[row_ptr[r]:row_ptr[r + 1]] for r in rows])
+    assert numpy.array_equal(sub_site.numpy(), want_site) and numpy.array_equal(sub_obs.numpy(), want_obs)
