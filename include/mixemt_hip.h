@@ -131,7 +131,7 @@ int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const double *lhi
  * deduplicated and each one's sum is formed in signature order from 0.0, as prob_for_vars does
  * (preprocess.py:86-96).  Rows with more than 64 observations (or more than 704 distinct values) are NOT
  * written: their indices are appended to fallback[] (device int64[R], *n_fallback = how many, device) and
- * the caller builds them with mxm_build_em_matrix_lut / mxm_build_em_matrix (order = fallback).
+ * the caller builds them with mxm_build_em_matrix_lut (order = fallback, R = *n_fallback; any order of the list).
  */
 int mxm_build_em_matrix_sparse(const uint8_t *maj, const double *lhit, const double *lmiss,
                                const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
