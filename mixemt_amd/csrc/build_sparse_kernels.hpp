@@ -48,8 +48,10 @@ struct spb_records {
     int ldc;
 };
 
+// (the record variant asks for 4 waves per SIMD: its exponentials would otherwise take 164 VGPRs and the fourth row
+// per CU -- 21.9 against 15 ms; the dense variant gets there by itself, and ran 5 % slower with the hint)
 template <int NCH, int PASSES, bool EMIT>
-__global__ __launch_bounds__(SPB_THREADS) void build_sparse_kernel(
+__global__ __launch_bounds__(SPB_THREADS, (EMIT ? 4 : 1)) void build_sparse_kernel(
     const uint8_t *__restrict__ maj, const double *__restrict__ lhit, const double *__restrict__ lmiss,
     const int32_t *__restrict__ mk_ptr, const uint16_t *__restrict__ mk_hap, const uint8_t *__restrict__ mk_base,
     const int64_t *__restrict__ row_ptr, const uint16_t *__restrict__ site, const uint8_t *__restrict__ obs,
