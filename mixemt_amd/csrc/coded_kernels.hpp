@@ -214,7 +214,8 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
 // Measured at 10^6 x 5408 (profiles/r02/coded_shapes.txt; iteration = this kernel + 0.14 ms dense rest + reduce):
 //   256 threads x 2 per CU: 1.75-1.77 ms with 3, 4 or 6 rows in flight      512 x 2 per CU: 1.96-2.20 ms
 //   256 x 3 per CU without the kept row values (second LDS lookup in the accumulation): 2.37-2.46 ms;
-//   256 x 3 per CU with them (168 VGPRs, 47 spilled into the row loop): 4.2 ms
+//   256 x 3 per CU with them (168 VGPRs, 47 spilled into the row loop): 4.2 ms;
+//   384 threads x 2 per CU (six waves per row, 152 VGPRs, 3 waves per SIMD without spills): 3.2-3.4 ms
 // i.e. neither more rows in flight nor more waves help: the kernel is bound by its VALU + LDS instruction
 // streams (per wave and row ~70 instructions of reduction / exchange / division beside 3.25 per cell; SQ
 // counters: 50 % of the wave cycles issuing at 2 waves per SIMD, profiles/r02/coded_pmc_sq_summary.txt),
