@@ -637,13 +637,15 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False):
 build_em_matrix_device.last_fallback = 0       # rows the marker kernel handed to the lookup-table kernel, last call
 
 
-def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False):
+def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False, as_records=False):
     """
     Drop-in for mixemt.preprocess.build_em_input (preprocess.py:201-227):
     (em_matrix, weights, haplogroups, read_ids) with rows = sorted distinct
     signatures, weights = fragments per signature, columns = sorted(hap_var).
     A fragment whose every site was conflicted away has the empty signature, on
     which the reference dies (int('') at :156-160); it is skipped here.
+    as_records=True: the first element is a CodedMatrix (build_em_records_device: no dense matrix on the
+    device or the host) for em.run_em_ex(None, weights, args, records=...).
     """
     var_pos = phylo.get_variant_pos()
     read_obs = process_reads(bamfile.fetch(), var_pos, args.min_mq, args.min_bq)
@@ -665,8 +667,13 @@ def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False):
     haplogroups = sorted(phylo.hap_var)
     reads = sorted(read_sigs)
     weights = numpy.array([len(read_sigs[r]) for r in reads])
-    em_matrix = build_em_matrix(refseq, phylo, reads, haplogroups, args,
-                                as_device_tensor=as_device_tensor)
+    if as_records:
+        tables = HapVarTables.build(refseq, phylo, haplogroups)
+        row_ptr, site, obs = encode_signatures(reads, tables)
+        em_matrix = build_em_records_device(tables, row_ptr, site, obs)
+    else:
+        em_matrix = build_em_matrix(refseq, phylo, reads, haplogroups, args,
+                                    as_device_tensor=as_device_tensor)
     read_ids = [read_sigs[r] for r in reads]
     return em_matrix, weights, haplogroups, read_ids
 

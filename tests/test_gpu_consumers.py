@@ -132,6 +132,17 @@ def test_front_end_to_matrix(b17):
     assert mat.shape == (len(order), len(haps))
     want = build_oracle.build_em_matrix_np(refseq, phy, order, haps)
     assert numpy.array_equal(mat, want)
+    # the same front end leaving the matrix as records (no dense matrix): same EM as on the dense matrix
+    from conftest import em_args
+    from mixemt_amd import em
+    cm, wts2, hap2, ids2 = preprocess.build_em_input(FakeBam(alns), refseq, phy, args, as_records=True)
+    assert (cm.n_rows, cm.n_haps) == mat.shape and list(wts2) == list(wts) and hap2 == haps and ids2 == read_ids
+    numpy.random.seed(3)
+    lean = em.run_em_ex(None, wts2, em_args(max_iter=50), records=cm)
+    numpy.random.seed(3)
+    full = em.run_em_ex(mat, wts, em_args(max_iter=50))
+    assert lean["iters"] == full["iters"] and numpy.abs(lean["props"] - full["props"]).max() < 1e-12
+    assert numpy.abs(lean["read_mix"].cpu().numpy() - full["read_mix"].cpu().numpy()).max() < 1e-9
 
 
 def test_fragment_without_a_usable_site_is_reported_never_silently_dropped(b17, capsys):
