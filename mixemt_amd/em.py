@@ -137,8 +137,8 @@ class EmPlan(object):
         linear = (P, rowmax): the linearised matrix already made by the matrix build
         (preprocess.build_em_matrix_device(..., linear=...)): nothing is recomputed here.
         records = preprocess.build_em_records_device(...)'s CodedMatrix: the matrix arrives in dictionary
-        form straight from the build (no encode pass); read_hap_mat may then be None -- the plan iterates,
-        but has no log matrix for a posterior pass.
+        form straight from the build (no encode pass); read_hap_mat may then be None -- the posterior
+        pass (em.posterior) then reads the records' log tables (mxm_em_step_coded).
         """
         if records is not None:
             self._from_records(records, read_hap_mat, weights, n_runs)
