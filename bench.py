@@ -88,7 +88,7 @@ def parse_args(argv=None):
                     help="mode rows: the build leaves the matrix as row-dictionary records and NO dense matrix is "
                          "made (implies --storage coded; 10^7 rows then fit one GPU); no posterior pass")
     ap.add_argument("--min-rows-per-wg", type=int, default=0, help="tuning knob (0 = library default)")
-    ap.add_argument("--build-kernel", default="auto", choices=["auto", "packed", "bytes", "lut", "sparse"])
+    ap.add_argument("--build-kernel", default="auto", choices=["auto", "bytes", "lut", "sparse"])
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and issue the per-iteration all-reduce even with "
                          "one rank (exercises the RCCL path on a single-GPU box)")
@@ -254,17 +254,23 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
                     "(decodes to the dense matrix bit for bit); not the headline value"}
 
 
-def pmc_traffic(n_rows, n_haps):
+def pmc_traffic(n_rows, n_haps, storage="f64", kernel=None, algo_bytes=None, root=None):
     """
-    HBM bytes per launch of the streaming kernel from the committed rocprofv3 PMC
-    passes (profiles/*/pmc_traffic_*.json, written by tools/pmc_summary.py from
-    separate --pmc FETCH_SIZE / --pmc WRITE_SIZE runs of this script).  Counters
-    cannot be read from inside the process, so this is the latest profiled value
-    for the same workload shape, or None.
+    HBM bytes per launch of the streaming kernel from the committed rocprofv3 PMC passes
+    (profiles/rNN/pmc_traffic_*.json, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE runs of this script).  Counters cannot be read from inside the process, so this is
+    the latest round's profiled value for the SAME workload (rows per GPU, haplogroups), the SAME storage
+    of the matrix and the SAME kernel instance this run launched (`kernel`, e.g.
+    "em_iter_wide_kernel<512, 6, 1, 3, 1>" from mxm_describe_stream_kernel) -- a plan in row-dictionary
+    storage also launches em_iter_wide_kernel, on its few dense leftover rows, and that figure must never
+    stand in for the dense matrix's.  A value outside [0.9, 1.5] x the algorithmic bytes is refused
+    (it would say the file is not about this kernel).  -> (bytes, path relative to the repo) or None.
     """
     import glob
-    best = None
-    for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_traffic_*.json"))):
+    import re
+    root = root or ROOT
+    found = []
+    for path in glob.glob(os.path.join(root, "profiles", "*", "pmc_traffic_*.json")):
         try:
             with open(path) as fin:
                 data = json.load(fin)
@@ -273,10 +279,24 @@ def pmc_traffic(n_rows, n_haps):
         meta = data.get("_workload", {})
         if meta.get("rows_per_gpu") != n_rows or meta.get("haps") != n_haps:
             continue
+        # files written before the field existed: the coded runs carry it in their name
+        have = meta.get("storage") or ("coded" if "coded" in os.path.basename(path) else "f64")
+        if have != storage:
+            continue
         for name, rec in data.items():
-            if name.startswith("em_iter_wide_kernel"):
-                best = (rec["hbm_bytes_per_launch"], os.path.relpath(path, ROOT))
-    return best
+            if name.startswith("_") or (kernel is not None and name != kernel):
+                continue
+            if kernel is None and not name.startswith("em_iter_wide_kernel"):
+                continue
+            val = float(rec["hbm_bytes_per_launch"])
+            if algo_bytes and not (0.9 * algo_bytes <= val <= 1.5 * algo_bytes):
+                continue
+            rnd = re.search(r"r(\d+)", os.path.basename(os.path.dirname(path)))
+            found.append((int(rnd.group(1)) if rnd else -1, val, os.path.relpath(path, root)))
+    if not found:
+        return None
+    found.sort()
+    return found[-1][1], found[-1][2]
 
 
 def main(argv=None):
@@ -368,8 +388,6 @@ def main(argv=None):
     site_d = torch.from_numpy(site.view(numpy.int16)).to(dev)
     obs_d = torch.from_numpy(obs).to(dev)
     tables.device()
-    if opts.build_kernel == "packed":
-        tables.packed_device()
     records = slab = None
     if opts.records:
         # CSR -> records, no dense matrix; built twice, the second call timed (as below)
@@ -615,7 +633,16 @@ def bench_rows(opts, env):
         algo_bytes = float(plan.coded_record_bytes)   # the records em_iter_coded_kernel reads (the rows that stay
                                                       # dense go through em_iter_wide_kernel afterwards)
     achieved = algo_bytes / (kernel_ms.mean() * 1e-3)
-    traffic = pmc_traffic(n_rows, n_haps) if (opts.storage == "f64" and n_runs == 1) else None
+    traffic = None
+    kernel_name = {"f64": "em_iter_wide_kernel", "f32": "em_iter_wide_f32_kernel", "coded": "em_iter_coded_kernel"}[plan.storage]
+    if plan.storage == "f64":
+        import ctypes
+        name_buf = ctypes.create_string_buffer(96)
+        tile = min(n_runs, plan.restart_tile())
+        if lib.mxm_describe_stream_kernel(n_haps, tile, name_buf, len(name_buf)) == 0:
+            kernel_name = name_buf.value.decode()
+        if n_runs == 1:
+            traffic = pmc_traffic(n_rows, n_haps, "f64", kernel_name, algo_bytes)
     return {
         "metric": "read x hap cells/sec through the EM iteration (EM iters/sec reported beside it as "
                   "em_iters_per_s), %d reads x %d haps in total, whole job" % (total_rows, n_haps),
@@ -642,8 +669,7 @@ def bench_rows(opts, env):
                      "unit": "GB/s", "frac": achieved / HBM_PEAK_BYTES_PER_S,
                      "traffic": traffic[0] if traffic else None,
                      "traffic_source": traffic[1] if traffic else None,
-                     "kernel": {"f64": "em_iter_wide_kernel", "f32": "em_iter_wide_f32_kernel",
-                                "coded": "em_iter_coded_kernel"}[plan.storage],
+                     "kernel": kernel_name,
                      "kernel_ms": float(kernel_ms.mean()),
                      "algorithmic_bytes_per_launch": algo_bytes},
         "cpu_baseline": cpu,

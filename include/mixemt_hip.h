@@ -34,7 +34,14 @@
 extern "C" {
 #endif
 
-#define MXM_VERSION 100          /* 0.1.0 */
+/* 0.3.0.  Bumped whenever a signature or a documented default of this header changes; mxm_version() returns
+ * the value the loaded library was built with, and a binding must refuse a library whose value differs from the
+ * header it was written against (mixemt_amd/_lib.py does).  History: 100 rounds 1-2 (mxm_row_argmax_votes gained
+ * ws / ws_bytes and mxm_set_compact_restarts became 0/1/2 inside that number -- the reason for this rule);
+ * 300 round 3: mxm_build_em_matrix_packed / mxm_build_packed_lds_bytes removed, mxm_build_em_matrix_lut lost its
+ * P / ldp / rowmax outputs, the marker build takes rows of up to 128 observations, mxm_row_argmax_votes_coded,
+ * mxm_em_loop_graph added. */
+#define MXM_VERSION 300
 
 /* per-restart loop state, written by mxm_m_finalize (16 bytes) */
 typedef struct mxm_em_state {
@@ -77,27 +84,6 @@ int mxm_build_em_matrix(const uint8_t *E, int64_t lde,
                         double *M, int64_t ldm, void *stream);
 
 /*
- * build_em_matrix, packed-table fast path -- same arithmetic, same order, same bits as
- * mxm_build_em_matrix; the tables are pre-encoded by the host so that one 64-column slice
- * fits a CU's LDS:
- *   Epk[ntiles][S][8]  uint32: 4-bit expected-base codes, 8 columns per dword, 64 columns
- *                      per tile (ntiles = ceil(H/64)); column c of a tile sits in dword
- *                      (c%16)/2, nibble 2*(c/16) + c%2 (bits 4*nibble..+3), so that the 8 lanes
- *                      of a row store whole 128-byte lines.  Codes 1..14 name the alphabet, 0 pads.
- *   muidx[S]           uint8: index of site s's (log hit, log miss) pair
- *   pairs[n_mu][2]     f64:   (lhit, lmiss) per distinct mutation probability, n_mu <= 255
- *   obsmap[256]        uint8: observation byte -> code (15 = matches nothing)
- * Needs mxm_build_packed_lds_bytes(S, n_mu) <= 158 KiB (S <= ~4900); otherwise call
- * mxm_build_em_matrix.
- */
-size_t mxm_build_packed_lds_bytes(int32_t S, int32_t n_mu);
-int mxm_build_em_matrix_packed(const uint32_t *Epk, const uint8_t *muidx, const double *pairs,
-                               int32_t n_mu, const uint8_t *obsmap,
-                               const int64_t *row_ptr, const uint16_t *site,
-                               const uint8_t *obs, int64_t R, int32_t H, int32_t S,
-                               double *M, int64_t ldm, void *stream);
-
-/*
  * build_em_matrix, lookup-table fast path -- same arithmetic, same order, same bits as
  * mxm_build_em_matrix (preprocess.py:177-198 with :69-96 inlined); the hit / miss choice of _prob
  * (:75-84) is a 16-entry LDS lookup instead of two selects.  The host pre-encodes
@@ -108,16 +94,12 @@ int mxm_build_em_matrix_packed(const uint32_t *Epk, const uint8_t *muidx, const 
  * order[R] (nullable): a permutation of the rows -- the order in which the grid takes them (rows that
  *   start at nearby positions share table rows; dealing them out together keeps those in L2).
  *   Results do not depend on it.
- * P / ldp / rowmax (all or none; NULL = matrix only): the kernel also emits mxm_linearize's output
- *   for the same rows -- rowmax[r] = max_h M[r][h], P[r][h] = exp(M[r][h] - rowmax[r]), pad columns
- *   [H, ldp) zero -- from the sums it still holds in registers, so the loop's one-time change of
- *   variables costs no second pass over M.  ldp even and >= H.
  * H <= 8192, S * lde < 2^31; otherwise call mxm_build_em_matrix.
  */
 int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const double *lhit, const double *lmiss,
                             const uint8_t *obsmap, const int64_t *row_ptr, const uint16_t *site,
                             const uint8_t *obs, const int64_t *order, int64_t R, int32_t H, int32_t S,
-                            double *M, int64_t ldm, double *P, int64_t ldp, double *rowmax, void *stream);
+                            double *M, int64_t ldm, void *stream);
 
 /*
  * build_em_matrix from the haplogroups' MARKERS -- preprocess.py:177-198, the same bits as the kernels

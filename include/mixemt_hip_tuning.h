@@ -3,9 +3,11 @@
  *
  * NOT part of the drop-in boundary (include/mixemt_hip.h): nothing here replaces a line of
  * the reference.  bench.py, tools/ and the parity tests use these to time the dominant kernel
- * without a profiler and to A/B kernel shapes inside one process.  All of them set
- * PROCESS-WIDE, unsynchronised state: call them before the work starts, from one thread.
- * Results never depend on them beyond the rounding of a different summation order.
+ * without a profiler and to A/B kernel shapes inside one process.  The state they set is PROCESS-WIDE
+ * but guarded: setters take a lock, and every entry point of mixemt_hip.h works on a snapshot taken when it
+ * starts, so host threads (one per GPU) never see a half-changed set.  mxm_reset_tuning() restores every
+ * default below (the test suite calls it after each test).  Results never depend on any of this beyond the
+ * rounding of a different summation order.
  */
 #ifndef MIXEMT_HIP_TUNING_H
 #define MIXEMT_HIP_TUNING_H
@@ -19,6 +21,9 @@ extern "C" {
 
 struct mxm_em_state;             /* include/mixemt_hip.h */
 
+/* Every knob below back to its default (and the timing / progress hooks off). */
+int mxm_reset_tuning(void);
+
 /*
  * Measurement hook (bench.py): when both handles are non-NULL, mxm_em_iter
  * records hipEvent_t `ev_start` / `ev_stop` on its stream immediately before /
@@ -26,6 +31,12 @@ struct mxm_em_state;             /* include/mixemt_hip.h */
  * without a profiler.  Pass NULLs to switch it off.
  */
 int mxm_set_timing_events(void *ev_start, void *ev_stop);
+
+/*
+ * The streaming kernel's template instance for a tile of nb restarts at width H, spelled the way rocprofv3 prints it
+ * ("em_iter_wide_kernel<512, 6, 1, 3, 1>"); bench.py selects its committed counter files (profiles/) by this name.
+ */
+int mxm_describe_stream_kernel(int32_t H, int32_t nb, char *buf, size_t len);
 
 /*
  * Diagnostic, not part of the reference boundary: a bare streaming read of `bytes` bytes
@@ -94,22 +105,16 @@ int mxm_set_batch_tile(int32_t bt);
  */
 int mxm_set_compact_restarts(int32_t mode);
 
-/* Tuning knob: shape of the single-restart streaming kernel (0: 256 threads, 2 workgroups per CU,
- * register ring 2; 1: 512 threads, 1 workgroup per CU, ring 3).  Same results up to summation order. */
-int mxm_set_v1_shape(int32_t shape);
-
 /* Tuning knob: rows a workgroup of the streaming kernel handles at least (grid = min(cap, R / n)). */
 int mxm_set_min_rows_per_wg(int32_t n);
 
-/* Tuning knob: shape of the row-dictionary streaming kernel {threads, rows in flight, workgroups per CU}:
- * 0 {256, 4, 2} (default), 1 {256, 3, 2}, 2 {512, 4, 2}, 3 {256, 6, 2}, 4 {512, 3, 2}. */
-int mxm_set_coded_shape(int32_t shape);
+/* Tuning knob: restarts that share one pass of the row-dictionary streaming kernel (1 or 2; default 2: the pass is
+ * bound by its LDS lookups, which two restarts share).  Same results up to nothing: each restart's sums are
+ * formed in the single kernel's order. */
+int mxm_set_coded_batch(int32_t nb);
 
-/* Tuning knob: column ranges per row of the marker build kernel (1, 2 or 4; default 2: 16.4 ms at 10^6 x 5408 against 22.5 with one range and 21.3 with four): its per-haplogroup
- * mask array is 1 / passes of a row, which decides how many rows a CU has in flight. */
-int mxm_set_sparse_passes(int32_t passes);
 /* Test knob: distinct non-zero masks a row of the marker build kernel may have before it goes to the
- * fallback list (0 ... 704, default 704); lowering it drives ordinary rows through the fallback path. */
+ * fallback list (negative = the kernel's own limit, the default); lowering it drives ordinary rows through the fallback path. */
 int mxm_set_sparse_max_distinct(int32_t n);
 
 #ifdef __cplusplus

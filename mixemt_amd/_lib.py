@@ -38,16 +38,13 @@ SIGNATURES = {
     "mxm_build_em_matrix": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                            c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     "mxm_build_em_matrix_lut": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
-                                               c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr]),
+                                               c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     "mxm_build_em_matrix_sparse": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                                   c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     "mxm_record_bytes": (c_size, [c_i64, c_i32]),
     "mxm_build_em_records": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                             c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_size, c_ptr, c_ptr, c_ptr,
                                             c_ptr, c_ptr, c_ptr, c_ptr]),
-    "mxm_build_packed_lds_bytes": (c_size, [c_i32, c_i32]),
-    "mxm_build_em_matrix_packed": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,
-                                                  c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     "mxm_linearize": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
     "mxm_em_iter": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_i32,
                                    c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
@@ -90,9 +87,9 @@ SIGNATURES = {
     "mxm_set_loop_fused": (ctypes.c_int, [c_i32, c_i32]),
     "mxm_set_progress_callback": (ctypes.c_int, [c_ptr, c_ptr, c_i32]),
     "mxm_set_min_rows_per_wg": (ctypes.c_int, [c_i32]),
-    "mxm_set_v1_shape": (ctypes.c_int, [c_i32]),
-    "mxm_set_coded_shape": (ctypes.c_int, [c_i32]),
-    "mxm_set_sparse_passes": (ctypes.c_int, [c_i32]),
+    "mxm_set_coded_batch": (ctypes.c_int, [c_i32]),
+    "mxm_reset_tuning": (ctypes.c_int, []),
+    "mxm_describe_stream_kernel": (ctypes.c_int, [c_i32, c_i32, ctypes.c_char_p, c_size]),
     "mxm_set_sparse_max_distinct": (ctypes.c_int, [c_i32]),
     "mxm_row_argmax_votes": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                             c_ptr, c_size, c_ptr]),
@@ -100,6 +97,9 @@ SIGNATURES = {
     "mxm_fold_logaddexp": (ctypes.c_int, [c_ptr, c_i64, ctypes.POINTER(c_ptr), ctypes.POINTER(c_i64), c_i32,
                                           c_i64, c_i32, c_f64, c_ptr]),
 }
+
+# the MXM_VERSION of include/mixemt_hip.h these signatures were written for; load() refuses any other
+ABI_VERSION = 300
 
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.POINTER(EmState), c_i32, c_ptr)
 
@@ -128,6 +128,10 @@ def load():
         fn = getattr(lib, name)          # AttributeError if the symbol is absent
         fn.restype = restype
         fn.argtypes = argtypes
+    have = lib.mxm_version()
+    if have != ABI_VERSION:
+        raise MixemtHipError("%s reports ABI version %d, this binding was written for %d: rebuild with "
+                             "`python -m mixemt_amd.build --force`" % (LIB_PATH, have, ABI_VERSION))
     _lib = lib
     return lib
 

@@ -1,5 +1,5 @@
 // build_kernels.hpp -- part of libmixemt_hip.so (gfx950); included by mixemt_hip.hip only.
-// build_em_matrix (preprocess.py:177-198): byte-table kernel and LDS-staged packed-table kernel.
+// build_em_matrix (preprocess.py:177-198): byte-table kernel (any alphabet, any width; the fallback of the faster builds).
 #ifndef MIXEMT_BUILD_KERNELS_HPP
 #define MIXEMT_BUILD_KERNELS_HPP
 
@@ -127,115 +127,6 @@ __global__ __launch_bounds__(BUILD_THREADS) void build_em_matrix_kernel(
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// K1b build_em_matrix, LDS-staged table form (alternative to K1: same sums, same order; measured
-//     slower on MI355X -- 76.8 ms vs 40.4 ms at 1M x 5408 -- because it is VALU-bound, see
-//     profiles/r01/build_kernels.txt; kept selectable and parity-tested).
-//
-// A workgroup owns a tile of 64 haplogroup columns and a chunk of rows.  Its slice of the
-// expected-base table -- 4-bit codes, S sites x 32 bytes -- is staged into LDS once (130 KB
-// for S = 4070), with the per-site (log hit, log miss) pair index and the observation-byte ->
-// code map, so the R*H*k look-ups of preprocess.py:188-191 never leave the CU.  A wave works on
-// 8 rows at a time: 8 lanes per row, each lane 8 adjacent columns (one LDS dword = 8 codes).
-// The row's (site, observation) list is fetched 8 entries at a time, one entry per lane, and
-// broadcast inside the 8-lane group with ds_bpermute; terms are added in signature order, so
-// the result is bit-identical to the byte-table kernel and to the reference.
-// Output: 64 B per lane, 512 B contiguous per row and tile.
-// ------------------------------------------------------------------------------------------
-#define TILE_THREADS 1024
-#define TILE_COLS 64
-
-__global__ __launch_bounds__(TILE_THREADS) void build_tile_kernel(
-    const uint32_t *__restrict__ Epk, const uint8_t *__restrict__ muidx,
-    const double *__restrict__ pairs, int n_mu, const uint8_t *__restrict__ obsmap,
-    const int64_t *__restrict__ row_ptr, const uint16_t *__restrict__ site,
-    const uint8_t *__restrict__ obs, int64_t R, int H, int S, double *__restrict__ M, int64_t ldm,
-    int64_t rows_per_chunk, int vec_ok) {
-    extern __shared__ uint32_t lds_tab[];
-    // layout (dwords): E[(S+1)*8] | pairs[(n_mu+1)*4] | obsmap[64] | muidx[S+1 bytes]
-    // Row S / pair n_mu are a NULL site: (hit, miss) = (+0.0, +0.0).  Rows shorter than the
-    // longest row of their wave are padded with it -- x + 0.0 == x bit for bit -- so the
-    // 8-entry inner block is straight-line code (no per-entry branch, LDS reads overlap).
-    uint32_t *lds_e = lds_tab;
-    double *lds_pairs = reinterpret_cast<double *>(lds_tab + ((size_t)S + 1) * 8);
-    uint8_t *lds_map = reinterpret_cast<uint8_t *>(lds_tab + ((size_t)S + 1) * 8 + ((size_t)n_mu + 1) * 4);
-    uint8_t *lds_mu = lds_map + 256;
-
-    const int t = threadIdx.x;
-    const int tile = blockIdx.x;
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(Epk + (size_t)tile * S * 8);
-        uint4 *dst = reinterpret_cast<uint4 *>(lds_e);
-        for (int i = t; i < S * 2; i += TILE_THREADS) dst[i] = src[i];
-        if (t < 8) lds_e[(size_t)S * 8 + t] = 0u;
-        for (int i = t; i < n_mu * 2; i += TILE_THREADS) lds_pairs[i] = pairs[i];
-        if (t < 2) lds_pairs[2 * n_mu + t] = 0.0;
-        for (int i = t; i < 256; i += TILE_THREADS) lds_map[i] = obsmap[i];
-        for (int i = t; i < S; i += TILE_THREADS) lds_mu[i] = muidx[i];
-        if (t == 0) lds_mu[S] = (uint8_t)n_mu;
-    }
-    __syncthreads();
-
-    const int lane = t & 63, wv = t >> 6;
-    const int g = lane >> 3, j = lane & 7;
-    const int group_base = lane & ~7;
-    const uint32_t null_entry = (uint32_t)S | (15u << 16);
-    const int64_t c0 = (int64_t)blockIdx.y * rows_per_chunk;
-    const int64_t c1 = (c0 + rows_per_chunk < R) ? (c0 + rows_per_chunk) : R;
-    // column of accumulator n: 16 * (n / 2) + 2 * j + (n % 2)  (so each store below covers a
-    // full 128-byte line per row across the row's 8 lanes)
-    const int col0 = tile * TILE_COLS + 2 * j;
-
-    for (int64_t base = c0 + (int64_t)wv * 8; base < c1; base += (TILE_THREADS / 64) * 8) {
-        const int64_t r = base + g;
-        const bool live = r < c1;
-        const int64_t beg = live ? row_ptr[r] : 0;
-        const int n = live ? (int)(row_ptr[r + 1] - beg) : 0;
-        int nmax = n;
-#pragma unroll
-        for (int off = 32; off >= 8; off >>= 1) {
-            const int o = __shfl_xor(nmax, off, 64);
-            nmax = o > nmax ? o : nmax;
-        }
-        double acc[8];
-#pragma unroll
-        for (int c = 0; c < 8; ++c) acc[c] = 0.0;
-
-        auto fetch = [&](int k0) -> uint32_t {
-            const int kk = k0 + j;
-            if (kk < n) return (uint32_t)site[beg + kk] | ((uint32_t)lds_map[obs[beg + kk]] << 16);
-            return null_entry;
-        };
-        uint32_t mine = fetch(0);
-        for (int k0 = 0; k0 < nmax; k0 += 8) {
-            const uint32_t next = fetch(k0 + 8);            // in flight while this block is added
-#pragma unroll
-            for (int jj = 0; jj < 8; ++jj) {
-                const uint32_t e = (uint32_t)__shfl((int)mine, group_base | jj, 64);
-                const uint32_t s = e & 0xffffu, oc = e >> 16;
-                const uint32_t ew = lds_e[s * 8 + j];
-                const uint32_t mi = lds_mu[s];
-                const double hit = lds_pairs[2 * mi], miss = lds_pairs[2 * mi + 1];
-#pragma unroll
-                for (int c = 0; c < 8; ++c)
-                    acc[c] += (((ew >> (4 * c)) & 15u) == oc) ? hit : miss;
-            }
-            mine = next;
-        }
-        if (live) {
-            double *dst = M + r * ldm + col0;
-#pragma unroll
-            for (int i = 0; i < 4; ++i) {
-                const int col = col0 + 16 * i;
-                if (vec_ok && col + 2 <= H) {
-                    *reinterpret_cast<d2 *>(dst + 16 * i) = d2{acc[2 * i], acc[2 * i + 1]};
-                } else {
-                    if (col < H) dst[16 * i] = acc[2 * i];
-                    if (col + 1 < H) dst[16 * i + 1] = acc[2 * i + 1];
-                }
-            }
-        }
-    }
-}
-
+// (K1b, an LDS-staged 4-bit-table variant of this kernel, measured 76.8 ms against 36 ms and was removed in
+// round 3; profiles/r01/build_kernels.txt keeps its numbers.)
 #endif  // MIXEMT_BUILD_KERNELS_HPP

@@ -1,6 +1,5 @@
 // build_lut_kernels.hpp -- part of libmixemt_hip.so (gfx950); included by mixemt_hip.hip only.
-// build_em_matrix (preprocess.py:177-198) with the hit/miss choice served by an LDS lookup, and the
-// loop's change of variables (mxm_linearize) fused into the same pass.
+// build_em_matrix (preprocess.py:177-198) with the hit/miss choice served by an LDS lookup.
 #ifndef MIXEMT_BUILD_LUT_KERNELS_HPP
 #define MIXEMT_BUILD_LUT_KERNELS_HPP
 
@@ -21,9 +20,9 @@
 // The 16 entries of a site sit in 16 different 8-byte bank pairs, equal addresses broadcast:
 // the reads are conflict free whatever the mix of hits and misses.
 //
-// FUSE_P: the row's 5408 sums stay in registers until the row is complete; the workgroup takes
-// the row maximum and stores, beside M, rowmax and P = exp(M - rowmax) -- mxm_linearize's output,
-// without reading the 43 GB of M back (em.py:80-83's shift, hoisted out of the loop).
+// (A variant that also emitted mxm_linearize's output from the sums in registers measured 65 ms against
+// 24.6 + 15.0 ms for the two separate passes -- the kernel is instruction-bound, the exponentials land on its
+// critical resource -- and was removed in round 3; profiles/r02/lut_variants.txt.)
 // All stores are non-temporal: the matrix streams past the L2 instead of evicting the table.
 //
 // `order` (nullable): row processing order.  Rows that start at nearby positions touch the same
@@ -49,18 +48,16 @@
 // streams (2.9 VALU + 1.25 LDS per cell and site; the two pipes add up at 4 waves per SIMD), and every
 // variant that holds more registers loses a wave per SIMD.
 
-template <bool FUSE_P, int NT, int CPL>
+template <int NT, int CPL>
 __global__ __launch_bounds__(LUT_THREADS) void build_lut_kernel(
     const uint8_t *__restrict__ E, int64_t lde, int64_t e_bytes, const double *__restrict__ lhit,
     const double *__restrict__ lmiss, const uint8_t *__restrict__ obsmap, const int64_t *__restrict__ row_ptr,
     const uint16_t *__restrict__ site, const uint8_t *__restrict__ obs, const int64_t *__restrict__ order,
-    int64_t R, int H, double *__restrict__ M, int64_t ldm, double *__restrict__ P, int64_t ldp,
-    double *__restrict__ rowmax, int vec_ok) {
+    int64_t R, int H, double *__restrict__ M, int64_t ldm, int vec_ok) {
     static_assert(CPL == 4 || CPL == 8, "one 4- or 8-byte table load per lane, site and tile");
     constexpr int EW = CPL / 4;                         // dwords per table load
     __shared__ double s_lut[2][LUT_CAP][16];            // per observation: [0] = log hit, [1..15] = log miss
     __shared__ uint2 s_rec[2][LUT_CAP];                 // per observation: {table row byte offset, obs code << 3 in 4 bytes}
-    __shared__ double s_red[LUT_THREADS / 64];
     const int t = threadIdx.x;
     const auto e_rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(E), 0, (int)e_bytes, 0x00020000);
 
@@ -97,7 +94,6 @@ __global__ __launch_bounds__(LUT_THREADS) void build_lut_kernel(
             nobs = obs[begn + t];
         }
 
-        double vals[FUSE_P ? NT : 1][CPL];
 #pragma unroll
         for (int tile = 0; tile < NT; ++tile) {
             const int h = tile * (LUT_THREADS * CPL) + CPL * t;
@@ -189,10 +185,6 @@ __global__ __launch_bounds__(LUT_THREADS) void build_lut_kernel(
                         if (h + c < H) dst[c] = a[c];
                 }
             }
-            if constexpr (FUSE_P) {
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) vals[tile][c] = (h + c < H) ? a[c] : -INFINITY;
-            }
         }
         if (t < nn) {                                   // third step: park it in the other buffer
             s_rec[cur ^ 1][t] = make_uint2((uint32_t)(nsite * (uint32_t)lde), ncode * 0x01010101u);
@@ -203,40 +195,6 @@ __global__ __launch_bounds__(LUT_THREADS) void build_lut_kernel(
         }
         have = nn > 0;
 
-        if constexpr (FUSE_P) {
-            // rowmax[r] = max_h M[r][h] (0 if not finite), P[r][h] = exp(M[r][h] - rowmax[r]); pad columns 0
-            double m = -INFINITY;
-#pragma unroll
-            for (int tile = 0; tile < NT; ++tile)
-#pragma unroll
-                for (int c = 0; c < CPL; ++c) m = fmax(m, vals[tile][c]);
-            m = wave_max(m);
-            __syncthreads();                               // s_red free (previous row's readers are done)
-            if ((t & 63) == 0) s_red[t >> 6] = m;
-            __syncthreads();
-            m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-            const double shift = isfinite(m) ? m : 0.0;
-            if (t == 0) rowmax[r] = shift;
-            double *prow = P + r * ldp;
-#pragma unroll
-            for (int tile = 0; tile < NT; ++tile) {
-                const int h = tile * (LUT_THREADS * CPL) + CPL * t;
-                if (h < (int)ldp) {
-                    double e[CPL];
-#pragma unroll
-                    for (int c = 0; c < CPL; ++c) e[c] = exp(vals[tile][c] - shift);    // columns past H hold -inf: exp gives the pad's 0
-                    if (vec_ok && h + CPL <= (int)ldp) {
-#pragma unroll
-                        for (int c = 0; c < CPL; c += 2)
-                            __builtin_nontemporal_store(d2{e[c], e[c + 1]}, reinterpret_cast<d2 *>(prow + h) + c / 2);
-                    } else {
-#pragma unroll
-                        for (int c = 0; c < CPL; ++c)
-                            if (h + c < (int)ldp) prow[h + c] = e[c];
-                    }
-                }
-            }
-        }
     }
 }
 

@@ -31,15 +31,22 @@ static int fail(int code, const char *fmt, const char *a = "", long long b = 0, 
         if (e_ != hipSuccess) return fail(-2, "HIP error: %s (line %lld)", hipGetErrorString(e_), __LINE__); \
     } while (0)
 
-static int g_num_cu = 0;
+// CUs of the calling thread's CURRENT device, cached per device (one host thread per GPU may share the process).
+#define MXM_MAX_DEVICES 64
+static std::atomic<int> g_num_cu[MXM_MAX_DEVICES];
 static int num_cu() {
-    if (g_num_cu == 0) {
-        int dev = 0;
-        hipDeviceProp_t prop;
-        if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
-        g_num_cu = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return 256;
+    const bool cached = dev >= 0 && dev < MXM_MAX_DEVICES;
+    if (cached) {
+        const int have = g_num_cu[dev].load(std::memory_order_relaxed);
+        if (have > 0) return have;
     }
-    return g_num_cu;
+    hipDeviceProp_t prop;
+    if (hipGetDeviceProperties(&prop, dev) != hipSuccess) return 256;
+    const int n = prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
+    if (cached) g_num_cu[dev].store(n, std::memory_order_relaxed);
+    return n;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -13,8 +13,8 @@
 // One translation unit; the kernels live in headers beside this file
 // (DESIGN.md section 4 has the roofline of each):
 //   common.hpp          error plumbing, reductions
-//   build_kernels.hpp   build_em_matrix_kernel (byte table, L2/MALL), build_tile_kernel (LDS-staged 4-bit table)
-//   build_lut_kernels.hpp  build_lut_kernel (hit/miss by LDS lookup; optionally emits the linearised matrix too)
+//   build_kernels.hpp   build_em_matrix_kernel (byte table, L2/MALL: any alphabet, any width)
+//   build_lut_kernels.hpp  build_lut_kernel (hit/miss by LDS lookup)
 //   build_sparse_kernels.hpp  build_sparse_kernel (the row from the haplogroups' markers: one in-order sum per distinct cell value)
 //   em_kernels.hpp      linearize, em_iter_wide_kernel (THE hot kernel: R*H*8 B read per EM iteration,
 //                       1-4 restarts per pass), em_iter_wide_f32_kernel (opt-in storage variant),
@@ -31,6 +31,7 @@
 #include <string.h>
 #include <math.h>
 #include <algorithm>
+#include <atomic>
 #include <mutex>
 #include <type_traits>
 #include <utility>
@@ -49,6 +50,46 @@
 #include "aux_kernels.hpp"
 #include "fused_kernels.hpp"
 #include "fused_cols_kernels.hpp"
+
+
+// ------------------------------------------------------------------------------------------
+// Tuning / measurement state (include/mixemt_hip_tuning.h).  ONE struct, guarded by a mutex: the setters
+// lock it, and every entry point of the ABI takes a private snapshot into thread-local storage when
+// it starts (MXM_ENTER), so a call sees one consistent set of knobs from beginning to end whatever
+// other host threads (one per GPU) set in the meantime.  Results never depend on any of it beyond the
+// rounding of a different summation order.
+// ------------------------------------------------------------------------------------------
+struct mxm_em_state;
+typedef void (*mxm_progress_fn)(const mxm_em_state *state_host, int32_t B, void *user);
+struct mxm_tuning {
+    int sparse_maxd = -1;           // distinct non-zero masks a row of the marker build may have (-1: the kernel's limit)
+    int min_rows_per_wg = 8;        // measured: 1000 x 5408 31 us/step (vs 39 at 2); no effect from 10^4 rows up
+    int compact_restarts = 2;       // mxm_em_loop: 1 packs the running restarts, 2 also keeps ONE full tile of them iterating
+    int max_bt = 4;                 // restarts per matrix pass (1..MXM_MAX_BT)
+    int loop_graph = -1;            // -1 auto (graph when R*H*B is small), 0 never, 1 always
+    int loop_fused = -1;            // -1 auto (by size), 0 never, 1 whenever the shape allows
+    int fused_chunk = 0;            // iterations per launch of the one-launch loop (0 = run to the end)
+    int fused_cols = 1;             // matrices of up to 1536 rows take the transposed form (columns split)
+    int coded_batch = 2;            // restarts per pass of the row-dictionary kernel (1 or 2)
+    double fused_cells = 1.0e8;     // ~18 000 rows at H = 5408: measured break-even is ~30 000 rows (profiles/r02/small_runs.txt)
+    hipEvent_t ev_start = nullptr, ev_stop = nullptr;     // timing hook around the dominant kernel
+    mxm_progress_fn progress = nullptr;
+    void *progress_user = nullptr;
+    int progress_every = 10;
+};
+static std::mutex g_tune_mu;
+static mxm_tuning g_tune;
+static thread_local mxm_tuning T;   // the calling thread's snapshot for the entry point it is in
+#define MXM_ENTER() do { std::lock_guard<std::mutex> lk_(g_tune_mu); T = g_tune; } while (0)
+template <typename F>
+static int tune_set(F f) {
+    std::lock_guard<std::mutex> lk(g_tune_mu);
+    f(g_tune);
+    return 0;
+}
+extern "C" int mxm_reset_tuning(void) {
+    return tune_set([](mxm_tuning &t) { t = mxm_tuning(); });
+}
 
 // ------------------------------------------------------------------------------------------
 // host side of the C ABI
@@ -140,13 +181,12 @@ extern "C" int mxm_build_em_matrix(const uint8_t *E, int64_t lde, const double *
     return 0;
 }
 
-template <bool FUSE_P>
 static int launch_build_lut(int nt, int grid, hipStream_t s, const uint8_t *E, int64_t lde, int64_t e_bytes,
                             const double *lhit, const double *lmiss, const uint8_t *obsmap, const int64_t *row_ptr,
                             const uint16_t *site, const uint8_t *obs, const int64_t *order, int64_t R, int H, double *M,
-                            int64_t ldm, double *P, int64_t ldp, double *rowmax, int vec_ok) {
+                            int64_t ldm, int vec_ok) {
     switch (nt) {
-#define BL_CASE(n) case n: hipLaunchKernelGGL((build_lut_kernel<FUSE_P, n, LUT_CPL>), dim3(grid), dim3(LUT_THREADS), 0, s, E, lde, e_bytes, lhit, lmiss, obsmap, row_ptr, site, obs, order, R, H, M, ldm, P, ldp, rowmax, vec_ok); break;
+#define BL_CASE(n) case n: hipLaunchKernelGGL((build_lut_kernel<n, LUT_CPL>), dim3(grid), dim3(LUT_THREADS), 0, s, E, lde, e_bytes, lhit, lmiss, obsmap, row_ptr, site, obs, order, R, H, M, ldm, vec_ok); break;
         BL_CASE(1) BL_CASE(2) BL_CASE(3) BL_CASE(4) BL_CASE(5) BL_CASE(6) BL_CASE(7) BL_CASE(8)
 #undef BL_CASE
         default: return 1;
@@ -157,7 +197,7 @@ static int launch_build_lut(int nt, int grid, hipStream_t s, const uint8_t *E, i
 extern "C" int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const double *lhit, const double *lmiss,
                                        const uint8_t *obsmap, const int64_t *row_ptr, const uint16_t *site,
                                        const uint8_t *obs, const int64_t *order, int64_t R, int32_t H, int32_t S,
-                                       double *M, int64_t ldm, double *P, int64_t ldp, double *rowmax, void *stream) {
+                                       double *M, int64_t ldm, void *stream) {
     if (R < 0 || H <= 0 || S <= 0) return fail(-1, "mxm_build_em_matrix_lut: bad shape R=%s%lld H=%lld", "", R, H);
     if (H > 8192) return fail(-1, "mxm_build_em_matrix_lut: more than 8192 haplogroups%s (H=%lld): use mxm_build_em_matrix", "", H);
     if (lde < (((int64_t)H + 7) & ~(int64_t)7) || (lde & 7) != 0 || (reinterpret_cast<uintptr_t>(Ecode) & 7) != 0)
@@ -165,33 +205,19 @@ extern "C" int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const 
     if (ldm < H) return fail(-1, "mxm_build_em_matrix_lut: ldm < H%s", "");
     if (S > 65536 || (int64_t)S * lde >= ((int64_t)1 << 31))
         return fail(-1, "mxm_build_em_matrix_lut: table of %s%lld x %lld bytes exceeds one buffer descriptor", "", S, lde);
-    if (P != nullptr && (ldp < H || (ldp & 1) || rowmax == nullptr))
-        return fail(-1, "mxm_build_em_matrix_lut: P needs an even ldp >= H and rowmax%s", "");
     if (R == 0) return 0;
     const int grid = clamp_grid(R, num_cu() * 8);
     const int nt = (H + LUT_THREADS * LUT_CPL - 1) / (LUT_THREADS * LUT_CPL);
-    int vec_ok = ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
-    if (P != nullptr) vec_ok = vec_ok && ((reinterpret_cast<uintptr_t>(P) & 15) == 0);
-    const int rc = (P != nullptr)
-                       ? launch_build_lut<true>(nt, grid, (hipStream_t)stream, Ecode, lde, (int64_t)S * lde, lhit, lmiss, obsmap,
-                                                row_ptr, site, obs, order, R, (int)H, M, ldm, P, ldp, rowmax, vec_ok)
-                       : launch_build_lut<false>(nt, grid, (hipStream_t)stream, Ecode, lde, (int64_t)S * lde, lhit, lmiss, obsmap,
-                                                 row_ptr, site, obs, order, R, (int)H, M, ldm, P, ldp, rowmax, vec_ok);
-    if (rc != 0) return fail(-1, "mxm_build_em_matrix_lut: H=%s%lld outside the kernel's range", "", H);
+    const int vec_ok = ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
+    if (launch_build_lut(nt, grid, (hipStream_t)stream, Ecode, lde, (int64_t)S * lde, lhit, lmiss, obsmap, row_ptr, site, obs,
+                         order, R, (int)H, M, ldm, vec_ok) != 0)
+        return fail(-1, "mxm_build_em_matrix_lut: H=%s%lld outside the kernel's range", "", H);
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-static int g_sparse_passes = 2;        // column ranges per row of the marker kernel (1, 2 or 4): LDS per workgroup
-static int g_sparse_maxd = SPB_MAXD;   // distinct non-zero masks a row may have before it is handed to the fallback
 extern "C" int mxm_set_sparse_max_distinct(int32_t n) {
-    g_sparse_maxd = n < 0 ? 0 : (n > SPB_MAXD ? SPB_MAXD : n);
-    return 0;
-}
-extern "C" int mxm_set_sparse_passes(int32_t passes) {
-    if (passes != 1 && passes != 2 && passes != 4) return fail(-1, "mxm_set_sparse_passes: 1, 2 or 4%s", "");
-    g_sparse_passes = passes;
-    return 0;
+    return tune_set([n](mxm_tuning &t) { t.sparse_maxd = n < 0 ? -1 : n; });
 }
 
 static inline int coded_ld(int H) { return (H + 7) & ~7; }
@@ -213,7 +239,8 @@ static int build_sparse_impl(const char *who, const uint8_t *maj, const double *
     const int hpad = (H + 1) & ~1;
     const int nch = (hpad / 2 + SPB_THREADS - 1) / SPB_THREADS;
     const int vec_ok = (M != nullptr) && ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
-    const int passes = g_sparse_passes;
+    const int passes = 2;          // column ranges per row (measured: 1 / 2 / 4 ranges 22.5 / 16.4 / 21.3 ms at 10^6 x 5408)
+    const int maxd = (T.sparse_maxd < 0 || T.sparse_maxd > SPB_MAXD) ? SPB_MAXD : T.sparse_maxd;
     const int kpp = (nch + passes - 1) / passes;
     const size_t lds = (size_t)kpp * 2 * SPB_THREADS * 8 + 14 * 1024;      // mask array + the kernel's other LDS
     int per_cu = (int)((160 * 1024) / lds);
@@ -222,8 +249,8 @@ static int build_sparse_impl(const char *who, const uint8_t *maj, const double *
     const int grid = clamp_grid(R, num_cu() * per_cu * 2);
     spb_records none = {};
     const spb_records rec = out != nullptr ? *out : none;
-#define SPB_LAUNCH(n, p) do { if (out != nullptr) hipLaunchKernelGGL((build_sparse_kernel<n, p, true>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), g_sparse_maxd, rec); \
-                          else hipLaunchKernelGGL((build_sparse_kernel<n, p, false>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), g_sparse_maxd, rec); } while (0)
+#define SPB_LAUNCH(n, p) do { if (out != nullptr) hipLaunchKernelGGL((build_sparse_kernel<n, p, true>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), maxd, rec); \
+                          else hipLaunchKernelGGL((build_sparse_kernel<n, p, false>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), maxd, rec); } while (0)
 #define SPB_CASE(n) case n: if (passes == 1) { if constexpr (n <= 7) SPB_LAUNCH(n, 1); else return fail(-1, "%s: one pass covers H <= 3584", who); } else if (passes == 2) SPB_LAUNCH(n, 2); else SPB_LAUNCH(n, 4); break;
     switch (nch) {
         SPB_CASE(1) SPB_CASE(2) SPB_CASE(3) SPB_CASE(4) SPB_CASE(5) SPB_CASE(6) SPB_CASE(7) SPB_CASE(8)
@@ -241,6 +268,7 @@ extern "C" int mxm_build_em_matrix_sparse(const uint8_t *maj, const double *lhit
                                           const int64_t *row_ptr, const uint16_t *site, const uint8_t *obs,
                                           const int64_t *order, int64_t R, int32_t H, int32_t S, double *M, int64_t ldm,
                                           int64_t *fallback, int64_t *n_fallback, void *stream) {
+    MXM_ENTER();
     if (M == nullptr) return fail(-1, "mxm_build_em_matrix_sparse: M required%s", "");
     return build_sparse_impl("mxm_build_em_matrix_sparse", maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs,
                              order, R, H, S, M, ldm, nullptr, fallback, n_fallback, (hipStream_t)stream);
@@ -257,6 +285,7 @@ extern "C" int mxm_build_em_records(const uint8_t *maj, const double *lhit, cons
                                     const int64_t *order, int64_t R, int32_t H, int32_t S, double *M, int64_t ldm,
                                     uint8_t *rec, size_t rec_bytes, int64_t *rec_off, int32_t *ndist, double *rowmax,
                                     int64_t *stats, int64_t *fallback, int64_t *n_fallback, void *stream) {
+    MXM_ENTER();
     if (!mxm_linear_supported(H) || (H & 1))
         return fail(-1, "mxm_build_em_records: records need an even H in [66, 8192]%s (H=%lld)", "", H);
     if (rec == nullptr || (reinterpret_cast<uintptr_t>(rec) & 15) || rec_bytes < (size_t)coded_ld(H) + 16 * ENC_MAX_CODES ||
@@ -272,40 +301,6 @@ extern "C" int mxm_build_em_records(const uint8_t *maj, const double *lhit, cons
     out.ldc = coded_ld(H);
     return build_sparse_impl("mxm_build_em_records", maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order,
                              R, H, S, M, ldm, &out, fallback, n_fallback, (hipStream_t)stream);
-}
-
-extern "C" size_t mxm_build_packed_lds_bytes(int32_t S, int32_t n_mu) {
-    return ((size_t)S + 1) * 32 + ((size_t)n_mu + 1) * 16 + 256 + (((size_t)S + 4) & ~(size_t)3);
-}
-
-extern "C" int mxm_build_em_matrix_packed(const uint32_t *Epk, const uint8_t *muidx, const double *pairs,
-                                          int32_t n_mu, const uint8_t *obsmap, const int64_t *row_ptr,
-                                          const uint16_t *site, const uint8_t *obs, int64_t R, int32_t H,
-                                          int32_t S, double *M, int64_t ldm, void *stream) {
-    if (R < 0 || H <= 0 || S <= 0 || n_mu <= 0 || n_mu > 255)
-        return fail(-1, "mxm_build_em_matrix_packed: bad shape R=%s%lld H=%lld", "", R, H);
-    if (ldm < H) return fail(-1, "mxm_build_em_matrix_packed: ldm < H%s", "");
-    if (S > 65536) return fail(-1, "mxm_build_em_matrix_packed: more than 65536 variant sites%s", "");
-    const size_t lds = mxm_build_packed_lds_bytes(S, n_mu);
-    if (lds > 158 * 1024) return fail(-1, "mxm_build_em_matrix_packed: tables need %s%lld B of LDS (> 158 KiB); use mxm_build_em_matrix", "", (long long)lds);
-    if (R == 0) return 0;
-    if (raise_dynamic_lds(reinterpret_cast<const void *>(&build_tile_kernel), 160 * 1024, "build_tile_kernel") != hipSuccess)
-        return -2;
-    const int ntiles = (H + TILE_COLS - 1) / TILE_COLS;
-    // one workgroup per CU (the table slice fills the LDS): aim at ~2 waves of workgroups
-    int nchunks = (2 * num_cu() + ntiles - 1) / ntiles;
-    if (nchunks < 1) nchunks = 1;
-    const int64_t max_chunks = (R + 127) / 128;
-    if (nchunks > max_chunks) nchunks = (int)max_chunks;
-    int64_t rows_per_chunk = (R + nchunks - 1) / nchunks;
-    rows_per_chunk = (rows_per_chunk + 127) / 128 * 128;
-    nchunks = (int)((R + rows_per_chunk - 1) / rows_per_chunk);
-    const int vec_ok = ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
-    hipLaunchKernelGGL(build_tile_kernel, dim3(ntiles, nchunks), dim3(TILE_THREADS), lds, (hipStream_t)stream,
-                       Epk, muidx, pairs, (int)n_mu, obsmap, row_ptr, site, obs, R, (int)H, (int)S, M, ldm,
-                       rows_per_chunk, vec_ok);
-    HIP_TRY(hipGetLastError());
-    return 0;
 }
 
 template <typename ST>
@@ -346,40 +341,27 @@ extern "C" int mxm_linearize(const double *M, int64_t ldm, int64_t R, int32_t H,
 }
 
 // ---- optional timing hook (bench.py): events recorded right around the dominant kernel --------
-static hipEvent_t g_ev_start = nullptr, g_ev_stop = nullptr;
-static int g_min_rows_per_wg = 8;     // measured: 1000 x 5408 31 us/step (vs 39 at 2); no effect from 10^4 rows up
-static int g_v1_shape = 1;            // 0: 256 threads x 2 WG/CU, ring 2;  1: 512 threads x 1 WG/CU, ring 3
-                                      // (in-process A/B, profiles/r01/tune_sweep.txt: 6.43 vs 6.50 ms median)
-static int g_compact_restarts = 2;    // mxm_em_loop: 1 packs the running restarts into the leading slots, 2 also
-                                      // keeps only one full tile of them iterating (slot refill)
-static int g_max_bt = 4;              // restarts per matrix pass (1..MXM_MAX_BT); see mxm_set_batch_tile
 extern "C" int mxm_set_timing_events(void *ev_start, void *ev_stop) {
-    g_ev_start = (hipEvent_t)ev_start;
-    g_ev_stop = (hipEvent_t)ev_stop;
-    return 0;
+    return tune_set([=](mxm_tuning &t) { t.ev_start = (hipEvent_t)ev_start; t.ev_stop = (hipEvent_t)ev_stop; });
 }
 
 extern "C" int mxm_set_min_rows_per_wg(int32_t n) {
     if (n < 1) return fail(-1, "mxm_set_min_rows_per_wg: n < 1%s", "");
-    g_min_rows_per_wg = n;
-    return 0;
-}
-
-extern "C" int mxm_set_v1_shape(int32_t shape) {
-    if (shape < 0 || shape > 1) return fail(-1, "mxm_set_v1_shape: shape must be 0 or 1%s", "");
-    g_v1_shape = shape;
-    return 0;
+    return tune_set([n](mxm_tuning &t) { t.min_rows_per_wg = n; });
 }
 
 extern "C" int mxm_set_compact_restarts(int32_t mode) {
-    g_compact_restarts = mode < 0 ? 0 : (mode > 2 ? 2 : mode);
-    return 0;
+    return tune_set([mode](mxm_tuning &t) { t.compact_restarts = mode < 0 ? 0 : (mode > 2 ? 2 : mode); });
 }
 
 extern "C" int mxm_set_batch_tile(int32_t bt) {
     if (bt < 1 || bt > 4) return fail(-1, "mxm_set_batch_tile: tile must be 1..4%s", "");
-    g_max_bt = bt;
-    return 0;
+    return tune_set([bt](mxm_tuning &t) { t.max_bt = bt; });
+}
+
+extern "C" int mxm_set_coded_batch(int32_t nb) {
+    if (nb < 1 || nb > 2) return fail(-1, "mxm_set_coded_batch: 1 or 2 restarts per pass%s", "");
+    return tune_set([nb](mxm_tuning &t) { t.coded_batch = nb; });
 }
 
 // ---- wide-kernel dispatch over NCH ------------------------------------------------------------
@@ -423,7 +405,8 @@ extern "C" int mxm_set_batch_tile(int32_t bt) {
 #ifndef MXM_V4_PREG
 #define MXM_V4_PREG 2
 #endif
-// second single-restart shape, selectable at run time (mxm_set_v1_shape) for in-process A/B runs
+// the single-restart shape of the dense matrix (512 threads, one workgroup per CU, ring 3: in-process A/B 6.43 vs 6.50 ms
+// median, profiles/r01/tune_sweep.txt); the 256-thread shape above runs the dense leftover rows of a row-dictionary plan
 #ifndef MXM_V1B_THREADS
 #define MXM_V1B_THREADS 512
 #endif
@@ -504,7 +487,7 @@ static int stream_linear_tile(const double *P, int64_t ldp, const double *w, con
                               int v1_shape = -1) {
     const int64_t ldpart = part_ld(H);
     const int ncol2 = (H + 1) / 2;
-    if (v1_shape < 0) v1_shape = g_v1_shape;
+    if (v1_shape < 0) v1_shape = 1;
     const bool alt = (nb == 1) && (v1_shape == 1);          // the second single-restart shape
     const int threads = alt ? MXM_V1B_THREADS : variant_threads(nb);
     const int wg_per_cu = alt ? 1 : ((nb == 1) ? MXM_V1_WG_PER_CU : 1);
@@ -514,9 +497,9 @@ static int stream_linear_tile(const double *P, int64_t ldp, const double *w, con
     // rows are dealt round-robin over the workgroups (row_deal, common.hpp).  Small matrices:
     // fewer workgroups with more rows each (every workgroup pays 2 x H x 8 bytes of proportion
     // loads and partial stores, which colreduce then reads back)
-    const int nwg = clamp_grid((R + g_min_rows_per_wg - 1) / g_min_rows_per_wg, cap);
+    const int nwg = clamp_grid((R + T.min_rows_per_wg - 1) / T.min_rows_per_wg, cap);
     for (int i = nb; i < MXM_MAX_BT; ++i) slots.s[i] = slots.s[0];          // unused entries stay in range
-    if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
+    if (timed && T.ev_start != nullptr) HIP_TRY(hipEventRecord(T.ev_start, stream));
     int rc;
     if (alt)
         rc = dispatch_wide<MXM_V1B_THREADS, 1, MXM_V1B_NBUF, 1>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, slots, stream);
@@ -530,8 +513,21 @@ static int stream_linear_tile(const double *P, int64_t ldp, const double *w, con
         rc = dispatch_wide<MXM_V4_THREADS, 4, MXM_V4_NBUF, MXM_V4_PREG>(nch, P, ldp, w, props, R, H, nwg, partial, ldpart, state, slots, stream);
     if (rc != 0) return rc;
     HIP_TRY(hipGetLastError());
-    if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
+    if (timed && T.ev_stop != nullptr) HIP_TRY(hipEventRecord(T.ev_stop, stream));
     *nwg_out = nwg;
+    return 0;
+}
+
+// The template instance stream_linear_tile launches for a tile of nb restarts at width H, as a profiler prints it
+// ("em_iter_wide_kernel<512, 6, 1, 3, 1>"): bench.py matches its committed counter files by this name.
+extern "C" int mxm_describe_stream_kernel(int32_t H, int32_t nb, char *buf, size_t len) {
+    if (buf == nullptr || len == 0 || H <= 0 || nb < 1 || nb > MXM_MAX_BT) return fail(-1, "mxm_describe_stream_kernel: bad arguments%s", "");
+    const int ncol2 = (H + 1) / 2;
+    const bool alt = nb == 1;
+    const int threads = alt ? MXM_V1B_THREADS : variant_threads(nb);
+    const int nbuf = alt ? MXM_V1B_NBUF : (nb == 2 ? MXM_V2_NBUF : (nb == 3 ? MXM_V3_NBUF : MXM_V4_NBUF));
+    snprintf(buf, len, "em_iter_wide_kernel<%d, %d, %d, %d, %d>", threads, (ncol2 + threads - 1) / threads, nb, nbuf,
+             variant_preg(nb));
     return 0;
 }
 
@@ -580,7 +576,7 @@ static int em_iter_f32_one(const float *P, int64_t ldp, const double *w, const d
     int cap = num_cu() * MXM_F32_WG_PER_CU;
     if (cap > MXM_MAX_WG) cap = MXM_MAX_WG;
     const int nwg = clamp_grid((R + nbuf - 1) / nbuf, cap);
-    if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
+    if (timed && T.ev_start != nullptr) HIP_TRY(hipEventRecord(T.ev_start, stream));
     switch (nch) {
 #define F32_CASE(n) case n: { const int lrc = launch_wide_f32<n>(P, ldp, w, props, R, H, nwg, partial, ldpart, state, stream); if (lrc != 0) return lrc; } break;
         F32_CASE(1) F32_CASE(2) F32_CASE(3) F32_CASE(4) F32_CASE(5) F32_CASE(6) F32_CASE(7) F32_CASE(8)
@@ -588,7 +584,7 @@ static int em_iter_f32_one(const float *P, int64_t ldp, const double *w, const d
         default: return fail(-1, "mxm_em_iter_f32: H=%s%lld outside the kernel's range", "", H);
     }
     HIP_TRY(hipGetLastError());
-    if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
+    if (timed && T.ev_stop != nullptr) HIP_TRY(hipEventRecord(T.ev_stop, stream));
     hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg,
                        1, H, (const double *)nullptr, colsum, state, slots_from(0));
     HIP_TRY(hipGetLastError());
@@ -646,15 +642,16 @@ static int em_iter_log_one(const double *M, int64_t ldm, const double *w, const 
 extern "C" int mxm_em_iter(const double *M, int64_t ldm, const double *P, int64_t ldp, const double *w,
                            const double *props, const double *ln_props, int64_t R, int32_t H, int32_t B,
                            const mxm_em_state *state, double *colsum, void *ws, size_t ws_bytes, void *stream) {
+    MXM_ENTER();
     if (R <= 0 || H <= 0 || B <= 0) return fail(-1, "mxm_em_iter: bad shape R=%s%lld H=%lld", "", R, H);
     if (ws == nullptr || ws_bytes < mxm_workspace_bytes(R, H, B)) return fail(-1, "mxm_em_iter: workspace too small%s", "");
     if (P != nullptr && ((ldp & 1) || ldp < H)) return fail(-1, "mxm_em_iter: ldp must be even and >= H%s", "");
     if (M != nullptr && ldm < H) return fail(-1, "mxm_em_iter: ldm < H%s", "");
     const bool linear = (P != nullptr) && mxm_linear_supported(H);
-    // restarts are taken in tiles of up to g_max_bt that share one pass over the matrix; the
+    // restarts are taken in tiles of up to T.max_bt that share one pass over the matrix; the
     // scratch is reused tile after tile (same stream, so the passes are ordered)
     // a batch keeps (most of) its proportion vectors in LDS: the largest tile that fits
-    int max_bt = linear ? g_max_bt : 1;
+    int max_bt = linear ? T.max_bt : 1;
     while (max_bt > 1 && !batch_fits((int)H, max_bt)) --max_bt;
     for (int b = 0; b < B;) {
         // the fewest passes that cover what is left, restarts spread evenly over them (a pass
@@ -697,6 +694,7 @@ extern "C" int mxm_linearize_f32(const double *M, int64_t ldm, int64_t R, int32_
 extern "C" int mxm_em_iter_f32(const float *P, int64_t ldp, const double *w, const double *props, int64_t R,
                                int32_t H, int32_t B, const mxm_em_state *state, double *colsum, void *ws,
                                size_t ws_bytes, void *stream) {
+    MXM_ENTER();
     if (R <= 0 || H <= 0 || B <= 0) return fail(-1, "mxm_em_iter_f32: bad shape R=%s%lld H=%lld", "", R, H);
     if (!mxm_linear_supported(H)) return fail(-1, "mxm_em_iter_f32: H=%s%lld outside the linear kernel's range", "", H);
     if (P == nullptr || (ldp & 3) || ldp < H) return fail(-1, "mxm_em_iter_f32: ldp must be a multiple of 4 and >= H%s", "");
@@ -790,17 +788,11 @@ extern "C" int mxm_gather_columns_coded(const mxm_coded *c, int32_t H, const int
     return 0;
 }
 
-// Shapes of em_iter_coded_kernel (mxm_set_coded_shape; measured in profiles/r02/coded_shapes.txt)
+// Shape of em_iter_coded_kernel {threads, rows in flight, workgroups per CU}: 256 x 4 x 2 measured best of five
+// (profiles/r02/coded_shapes.txt)
 struct coded_shape { int threads, nbuf, wg_per_cu; };
-static const coded_shape g_coded_shapes[] = {{256, 4, 2}, {256, 3, 2}, {512, 4, 2}, {256, 6, 2}, {512, 3, 2}};
-static int g_coded_shape = 0;
-extern "C" int mxm_set_coded_shape(int32_t shape) {
-    if (shape < 0 || shape >= (int)(sizeof(g_coded_shapes) / sizeof(g_coded_shapes[0])))
-        return fail(-1, "mxm_set_coded_shape: unknown shape%s", "");
-    g_coded_shape = shape;
-    return 0;
-}
-
+static const coded_shape g_coded_shapes[] = {{256, 4, 2}};
+static const int g_coded_shape = 0;
 template <int THREADS, int NBUF, int MINWG>
 static int launch_coded(int nch, int nwg, hipStream_t stream, const mxm_coded *c, int ldc, const double *w, const double *props,
                         int H, double *partial, int64_t ldpart, const mxm_em_state *state, int run) {
@@ -825,18 +817,12 @@ static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *
     if (cap > MXM_MAX_WG - num_cu()) cap = MXM_MAX_WG - num_cu();             // the dense rest's rows come behind
     if (cap < 1) cap = 1;
     const int nwg = clamp_grid((c->R + sh.nbuf - 1) / sh.nbuf, cap);
-    if (timed && g_ev_start != nullptr) HIP_TRY(hipEventRecord(g_ev_start, stream));
+    if (timed && T.ev_start != nullptr) HIP_TRY(hipEventRecord(T.ev_start, stream));
     int lrc;
-    switch (g_coded_shape) {
-        case 0: lrc = launch_coded<256, 4, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
-        case 1: lrc = launch_coded<256, 3, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
-        case 2: lrc = launch_coded<512, 4, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
-        case 3: lrc = launch_coded<256, 6, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
-        default: lrc = launch_coded<512, 3, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run); break;
-    }
+    lrc = launch_coded<256, 4, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run);
     if (lrc != 0) return lrc;
     HIP_TRY(hipGetLastError());
-    if (timed && g_ev_stop != nullptr) HIP_TRY(hipEventRecord(g_ev_stop, stream));
+    if (timed && T.ev_stop != nullptr) HIP_TRY(hipEventRecord(T.ev_stop, stream));
     int nwg_rest = 0;
     mxm_slots sl;
     for (int i = 0; i < MXM_MAX_BT; ++i) sl.s[i] = run;
@@ -855,6 +841,7 @@ static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *
 
 extern "C" int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, int32_t H, int32_t B,
                                  const mxm_em_state *state, double *colsum, void *ws, size_t ws_bytes, void *stream) {
+    MXM_ENTER();
     const int rc = coded_check(c, H, "mxm_em_iter_coded");
     if (rc != 0) return rc;
     if (B <= 0 || props == nullptr || colsum == nullptr) return fail(-1, "mxm_em_iter_coded: bad arguments%s", "");
@@ -867,8 +854,9 @@ extern "C" int mxm_em_iter_coded(const mxm_coded *c, const double *w, const doub
 }
 
 extern "C" int mxm_restart_tile(int32_t H) {
+    MXM_ENTER();
     if (!mxm_linear_supported(H)) return 1;
-    int bt = g_max_bt;
+    int bt = T.max_bt;
     while (bt > 1 && !batch_fits((int)H, bt)) --bt;
     return bt;
 }
@@ -887,42 +875,29 @@ extern "C" int mxm_m_finalize(const double *colsum, double *ln_cur, double *ln_n
 // hipGraph and replayed (the loop is launch-bound there: 3 kernels of a few microseconds each),
 // for large ones plain launches already run ahead of the GPU.  Either way the kernels of a
 // finished restart are no-ops, so the state freezes on the iteration the reference stops on.
-static int g_loop_graph = -1;          // -1 auto (graph when R*H*B is small), 0 never, 1 always
 extern "C" int mxm_set_loop_graph(int32_t mode) {
-    g_loop_graph = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
-    return 0;
+    return tune_set([mode](mxm_tuning &t) { t.loop_graph = mode < 0 ? -1 : (mode > 0 ? 1 : 0); });
 }
 
 // ---- progress hook: called on the host thread inside mxm_em_loop after every state read-back ------
-typedef void (*mxm_progress_fn)(const mxm_em_state *state_host, int32_t B, void *user);
-static mxm_progress_fn g_progress = nullptr;
-static void *g_progress_user = nullptr;
-static int g_progress_every = 10;
 extern "C" int mxm_set_progress_callback(mxm_progress_fn fn, void *user, int32_t every) {
-    g_progress = fn;
-    g_progress_user = user;
-    g_progress_every = every > 0 ? every : 10;
-    return 0;
+    return tune_set([=](mxm_tuning &t) { t.progress = fn; t.progress_user = user; t.progress_every = every > 0 ? every : 10; });
 }
 
 // ---- one-launch loop for cache-resident matrices (fused_kernels.hpp) ---------------------------
-static int g_loop_fused = -1;          // -1 auto (R * H below g_fused_cells), 0 never, 1 whenever the shape allows
-static int g_fused_chunk = 0;          // iterations per launch (0 = run to the end in one launch)
-static int g_fused_cols = 1;           // matrices of up to 1536 rows take the transposed form (columns split)
-static double g_fused_cells = 1.0e8;   // ~18 000 rows at H = 5408 (800 MB of fp64): measured break-even against the
-                                       // per-iteration kernels is ~30 000 rows (profiles/r02/small_runs.txt)
 extern "C" int mxm_set_loop_fused(int32_t mode, int32_t chunk) {
-    g_loop_fused = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
-    g_fused_cols = (mode == 2) ? 0 : 1;                // mode 2: one launch, rows split (A/B against the transposed form)
-    g_fused_chunk = chunk > 0 ? chunk : 0;
-    return 0;
+    return tune_set([=](mxm_tuning &t) {
+        t.loop_fused = mode < 0 ? -1 : (mode > 0 ? 1 : 0);
+        t.fused_cols = (mode == 2) ? 0 : 1;            // mode 2: one launch, rows split (A/B against the transposed form)
+        t.fused_chunk = chunk > 0 ? chunk : 0;
+    });
 }
 
 static size_t fused_sync_bytes() { return (sizeof(fused_sync) + 255) & ~(size_t)255; }
 
 // The transposed one-launch loop (fused_cols_kernels.hpp): up to 1536 rows, a 256-CU grid.
 static bool fused_cols_eligible(int64_t R, int H, int nwg) {
-    if (!g_fused_cols || nwg != 256) return false;          // the Z reduce is laid out for 256 partials per row
+    if (!T.fused_cols || nwg != 256) return false;          // the Z reduce is laid out for 256 partials per row
     if (R > (int64_t)FCOLS_MAX_RPT * FCOLS_THREADS || (R + nwg - 1) / nwg > 2 * FCOLS_NQ) return false;
     const int cp = (H + nwg - 1) / nwg;
     if (cp > FCOLS_MAX_CP) return false;
@@ -936,7 +911,7 @@ static bool fused_cols_eligible(int64_t R, int H, int nwg) {
 // 10 000 rows), while the per-iteration kernels share each pass between up to four of them (11 / 15 / 27 us
 // from three restarts on; profiles/r02/small_runs_restarts.txt).
 static bool fused_eligible(const double *P, int64_t ldp, int64_t R, int H, size_t ws_bytes, bool p_is_f32, int running) {
-    if (g_loop_fused == 0 || p_is_f32 || P == nullptr || !mxm_linear_supported(H)) return false;
+    if (T.loop_fused == 0 || p_is_f32 || P == nullptr || !mxm_linear_supported(H)) return false;
     if ((ldp & 1) || (reinterpret_cast<uintptr_t>(P) & 15)) return false;
     int nwg = num_cu() < MXM_MAX_WG ? num_cu() : MXM_MAX_WG;
     const int ncol2 = (H + 1) / 2;
@@ -944,11 +919,11 @@ static bool fused_eligible(const double *P, int64_t ldp, int64_t R, int H, size_
     if ((ncol2 + FUSED_THREADS - 1) / FUSED_THREADS > FUSED_MAX_NCH) return false;   // spill-free instances only
     if ((int64_t)nwg * part_ld(H) * 8 >= ((int64_t)1 << 31)) return false;  // one buffer descriptor over the partials
     if (ws_bytes < fused_sync_bytes() + (size_t)(nwg + 2) * part_ld(H) * sizeof(double)) return false;
-    if (g_loop_fused == 1) return true;
+    if (T.loop_fused == 1) return true;
     // the transposed form runs a restart-iteration in 12 us at 600 rows whatever the number of restarts; the
     // batched kernels need 18 / 13 / 11 us with 2 / 3 / 4 restarts per pass: up to three restarts stay here
     if (running <= 3 && fused_cols_eligible(R, H, nwg)) return true;
-    return running <= 1 && (double)R * (double)H <= g_fused_cells;
+    return running <= 1 && (double)R * (double)H <= T.fused_cells;
 }
 
 // Diagnostic (-DFUSED_STAMPS builds): the per-phase clock sums of the last one-launch loop, from the
@@ -1006,7 +981,7 @@ static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t 
                                 "workgroups resident?  mxm_set_loop_fused(0) selects the per-iteration kernels", "", b, nwg);
             all_done = all_done && state_host[b].done != 0;
         }
-        if (g_progress != nullptr) g_progress(state_host, B, g_progress_user);
+        if (T.progress != nullptr) T.progress(state_host, B, T.progress_user);
         if (all_done) return 0;
         HIP_TRY(hipMemsetAsync(sync, 0, fused_sync_bytes(), s));       // every polled word, before EVERY launch
         if (fused_cols_eligible(R, (int)H, nwg)) {
@@ -1090,7 +1065,7 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     if (R <= 0 || H <= 0 || B <= 0) return fail(-1, "mxm_em_loop: bad shape R=%s%lld H=%lld", "", R, H);
     if (ws == nullptr || ws_bytes < mxm_workspace_bytes(R, H, B)) return fail(-1, "mxm_em_loop: workspace too small%s", "");
     if (check_every < 1) check_every = 1;
-    if (g_progress != nullptr && check_every > g_progress_every) check_every = g_progress_every;
+    if (T.progress != nullptr && check_every > T.progress_every) check_every = T.progress_every;
     hipStream_t caller = (hipStream_t)stream;
     (void)num_cu();                                    // device query outside any capture
     HIP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, caller));
@@ -1100,14 +1075,14 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     if (fused_eligible(P, ldp, R, (int)H, ws_bytes, p_is_f32, running)) {
         // cache-resident matrix: the whole loop in one persistent launch on the caller's stream
         // (the host only waits for it; nothing is decided between iterations)
-        int chunk = g_fused_chunk > 0 ? g_fused_chunk : max_iter;
-        if (g_progress != nullptr && chunk > g_progress_every) chunk = g_progress_every;     // someone is watching
+        int chunk = T.fused_chunk > 0 ? T.fused_chunk : max_iter;
+        if (T.progress != nullptr && chunk > T.progress_every) chunk = T.progress_every;     // someone is watching
         return em_loop_fused(P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, state, tol, max_iter, chunk, ws, caller,
                              state_host);
     }
-    const bool want_graph = g_loop_graph == 1 ||
-                            (g_loop_graph == -1 && (double)R * (double)H * (double)B < 6.4e7);
-    int window = g_max_bt;                             // the largest restart tile that fits (mxm_em_iter)
+    const bool want_graph = T.loop_graph == 1 ||
+                            (T.loop_graph == -1 && (double)R * (double)H * (double)B < 6.4e7);
+    int window = T.max_bt;                             // the largest restart tile that fits (mxm_em_iter)
     if (p_is_f32 || P == nullptr || !mxm_linear_supported(H)) window = 1;
     while (window > 1 && !batch_fits((int)H, window)) --window;
 
@@ -1148,14 +1123,14 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
         std::vector<int> members, sizes;
         // (with one restart per pass every schedule costs the same: no rotation, the tile list then only
         // changes when a restart stops and a captured graph stays valid in between)
-        const bool rotating = g_compact_restarts == 2 && window > 1 && (int)order.size() > window;
+        const bool rotating = T.compact_restarts == 2 && window > 1 && (int)order.size() > window;
         if (rotating) {
             members.assign(order.begin(), order.begin() + window);
             sizes.push_back(window);
             std::rotate(order.begin(), order.begin() + window, order.end());       // they go to the back of the queue
         } else {
             std::vector<int> all;
-            if (g_compact_restarts == 0) { for (int b = 0; b < B; ++b) all.push_back(b); }
+            if (T.compact_restarts == 0) { for (int b = 0; b < B; ++b) all.push_back(b); }
             else all = order;
             for (size_t at = 0; at < all.size();) {
                 // the fewest passes that cover what is left, restarts spread evenly over them
@@ -1213,7 +1188,7 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
         }
         LOOP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
         LOOP_TRY(hipStreamSynchronize(s));
-        if (g_progress != nullptr) g_progress(state_host, B, g_progress_user);
+        if (T.progress != nullptr) T.progress(state_host, B, T.progress_user);
         std::vector<int> still;
         for (int b : order)
             if (state_host[b].done == 0) still.push_back(b);
@@ -1236,6 +1211,7 @@ extern "C" int mxm_em_loop(const double *M, int64_t ldm, const double *P, int64_
                            double *colsum, mxm_em_state *state, double tol, int32_t max_iter,
                            int32_t check_every, void *ws, size_t ws_bytes, void *stream,
                            mxm_em_state *state_host) {
+    MXM_ENTER();
     return em_loop_impl(M, ldm, P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, colsum, state, tol, max_iter,
                         check_every, ws, ws_bytes, stream, state_host, false);
 }
@@ -1244,6 +1220,7 @@ extern "C" int mxm_em_loop_coded(const mxm_coded *c, const double *w, int32_t H,
                                  double *ln_cur, double *ln_new, double *colsum, mxm_em_state *state, double tol,
                                  int32_t max_iter, int32_t check_every, void *ws, size_t ws_bytes, void *stream,
                                  mxm_em_state *state_host) {
+    MXM_ENTER();
     const int rc = coded_check(c, H, "mxm_em_loop_coded");
     if (rc != 0) return rc;
     return em_loop_impl(nullptr, 0, nullptr, 0, w, c->R, H, B, props_cur, ln_cur, ln_new, colsum, state, tol, max_iter,
@@ -1254,6 +1231,7 @@ extern "C" int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int
                                double *props_cur, double *ln_cur, double *ln_new, double *colsum,
                                mxm_em_state *state, double tol, int32_t max_iter, int32_t check_every, void *ws,
                                size_t ws_bytes, void *stream, mxm_em_state *state_host) {
+    MXM_ENTER();
     return em_loop_impl(nullptr, 0, reinterpret_cast<const double *>(P), ldp, w, R, H, B, props_cur, ln_cur, ln_new,
                         colsum, state, tol, max_iter, check_every, ws, ws_bytes, stream, state_host, true);
 }

@@ -117,8 +117,7 @@ class EmPlan(object):
     the log matrix, fp64 weights, the linearised copy and scratch.
     """
 
-    def __init__(self, read_hap_mat, weights, n_runs=1, keep_log_matrix=True, storage="f64", linear=None,
-                 records=None):
+    def __init__(self, read_hap_mat, weights, n_runs=1, keep_log_matrix=True, storage="f64", records=None):
         """
         storage: element type of the linearised matrix the loop streams.
         "f64" (default) is the reference's arithmetic type end to end; "f32" is
@@ -134,8 +133,6 @@ class EmPlan(object):
         (below that the one-launch loops over the dense matrix are faster) and at
         most a quarter of the rows left dense by the encoder; otherwise "f64".
         `plan.storage` says what the plan iterates.
-        linear = (P, rowmax): the linearised matrix already made by the matrix build
-        (preprocess.build_em_matrix_device(..., linear=...)): nothing is recomputed here.
         records = preprocess.build_em_records_device(...)'s CodedMatrix: the matrix arrives in dictionary
         form straight from the build (no encode pass); read_hap_mat may then be None -- the posterior
         pass (em.posterior) then reads the records' log tables (mxm_em_step_coded).
@@ -162,11 +159,9 @@ class EmPlan(object):
         self.coded = None
         auto = storage == "auto"
         if auto:
-            storage = "coded" if (linear is None and float(self.n_rows) * self.n_haps > AUTO_CODED_MIN_CELLS) else "f64"
+            storage = "coded" if (float(self.n_rows) * self.n_haps > AUTO_CODED_MIN_CELLS) else "f64"
             self.storage = storage
         if storage == "coded":
-            if linear is not None:
-                raise ValueError("linear = (P, rowmax) is the dense fp64 plan's input")
             if (self.n_rows > 0 and self.lib.mxm_linear_supported(self.n_haps) and self.n_haps % 2 == 0
                     and self.mat.stride(1) == 1 and self.mat.stride(0) % 2 == 0 and self.mat.data_ptr() % 16 == 0):
                 self.encode()
@@ -177,13 +172,6 @@ class EmPlan(object):
                 self.storage = storage = "f64"
         if self.coded is not None:
             pass
-        elif linear is not None:
-            lin, rowmax = linear
-            if (storage != "f64" or not self.lib.mxm_linear_supported(self.n_haps) or lin.dtype != torch.float64
-                    or lin.shape[0] != self.n_rows or lin.stride(0) < self.n_haps or lin.stride(0) % 2
-                    or lin.stride(1) != 1 or rowmax.numel() != self.n_rows):
-                raise ValueError("linear = (P [R][ldp even >= H] float64, rowmax [R]) for an fp64 plan of a wide matrix")
-            self.lin, self.rowmax = lin, rowmax
         elif self.lib.mxm_linear_supported(self.n_haps) and self.n_rows > 0:
             self.rowmax = torch.empty(self.n_rows, dtype=torch.float64, device=self.dev)
             if storage == "f32":

@@ -59,8 +59,6 @@ class HapVarTables(object):
             if int(p) >= 0:
                 self.site_of_pos[int(p)] = k
         self._dev = None
-        self._packed = None          # None = not tried, False = does not qualify
-        self._packed_dev = None
         self._lut = None
         self._lut_dev = None
         self._sparse = None
@@ -93,47 +91,6 @@ class HapVarTables(object):
             lhit[k] = math.log(1.0 - mu)
             lmiss[k] = math.log(mu / 3.0)
         return cls(sites, expected, lhit, lmiss, list(haplogroups), n_haps)
-
-    def packed(self):
-        """
-        The LDS-staged kernel's encoding of the same tables (include/mixemt_hip.h,
-        mxm_build_em_matrix_packed), or None if they do not qualify (more than 14
-        distinct expected bases, more than 256 distinct mutation probabilities,
-        or a site count whose 64-column slice does not fit a CU's LDS):
-            epk[ntiles][S][8] uint32  4-bit codes, 8 columns per dword (permuted, see header)
-            muidx[S] uint8, pairs[n_mu][2] f64 (lhit, lmiss), obsmap[256] uint8
-        """
-        if self._packed is not None:
-            return self._packed or None
-        n_sites, n_haps = len(self.sites), self.n_haps
-        body = self.expected[:, :n_haps]
-        alphabet = numpy.unique(body)
-        alphabet = alphabet[alphabet != 0]
-        keys = numpy.stack([self.lhit, self.lmiss], axis=1)
-        uniq, inverse = numpy.unique(keys, axis=0, return_inverse=True)
-        lds = (n_sites + 1) * 32 + (len(uniq) + 1) * 16 + 256 + (n_sites + 4) // 4 * 4
-        if len(alphabet) > 14 or len(uniq) > 255 or lds > 158 * 1024 or n_sites == 0:
-            self._packed = False
-            return None
-        code_of = numpy.zeros(256, dtype=numpy.uint8)
-        code_of[alphabet] = numpy.arange(1, len(alphabet) + 1, dtype=numpy.uint8)
-        obsmap = numpy.full(256, 15, dtype=numpy.uint8)
-        obsmap[alphabet] = code_of[alphabet]
-        ntiles = (n_haps + 63) // 64
-        codes = numpy.zeros((n_sites, ntiles * 64), dtype=numpy.uint8)
-        codes[:, :n_haps] = code_of[body]
-        # tile-local column c -> dword (c % 16) // 2, nibble 2 * (c // 16) + c % 2
-        c = numpy.arange(64)
-        slot = ((c % 16) // 2) * 8 + 2 * (c // 16) + (c % 2)      # nibble slot 0..63 in the tile
-        by_slot = numpy.empty_like(codes).reshape(n_sites, ntiles, 64)
-        by_slot[:, :, slot] = codes.reshape(n_sites, ntiles, 64)
-        nibbles = (by_slot[:, :, 0::2] | (by_slot[:, :, 1::2] << 4)).astype(numpy.uint8)  # [S][ntiles][32]
-        epk = numpy.ascontiguousarray(nibbles.transpose(1, 0, 2)).view(numpy.uint32)
-        self._packed = {"epk": epk.reshape(ntiles, n_sites, 8),
-                        "muidx": inverse.reshape(-1).astype(numpy.uint8),
-                        "pairs": numpy.ascontiguousarray(uniq, dtype=numpy.float64),
-                        "obsmap": obsmap}
-        return self._packed
 
     def lut(self):
         """
@@ -206,20 +163,6 @@ class HapVarTables(object):
                              "obsmap": torch.from_numpy(enc["obsmap"]).to(dev),
                              "lhit": lhit_d, "lmiss": lmiss_d}
         return self._lut_dev
-
-    def packed_device(self):
-        """Device copies of packed(), uploaded once; None if the tables do not qualify."""
-        pk = self.packed()
-        if pk is None:
-            return None
-        if self._packed_dev is None:
-            dev = require_gpu()
-            self._packed_dev = {
-                "epk": torch.from_numpy(pk["epk"].view(numpy.int32)).to(dev),
-                "muidx": torch.from_numpy(pk["muidx"]).to(dev),
-                "pairs": torch.from_numpy(pk["pairs"]).to(dev),
-                "obsmap": torch.from_numpy(pk["obsmap"]).to(dev)}
-        return self._packed_dev
 
     def device(self):
         """Upload once; returns (expected, lhit, lmiss) as device tensors."""
@@ -316,35 +259,25 @@ def row_order_by_position(row_ptr_d, site_d):
     return torch.argsort(keys, stable=True)
 
 
-def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto", linear=None,
-                           sort_rows="auto"):
+def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto", sort_rows="auto"):
     """
     CSR observations (numpy or device tensors) -> device tensor M[R][H] float64.
     `out` may supply a preallocated [R][>=H] tensor.  kernel:
-      "lut"    hit / miss by LDS lookup (mxm_build_em_matrix_lut): the fastest, and the only one
-               that can also emit the loop's linearised matrix (see `linear`)
+      "lut"    hit / miss by LDS lookup (mxm_build_em_matrix_lut): the fastest cell-by-cell kernel
       "bytes"  the byte-table kernel (mxm_build_em_matrix), any alphabet, any width
-      "packed" the LDS-staged 4-bit-table kernel (mxm_build_em_matrix_packed)
       "sparse" the marker kernel (mxm_build_em_matrix_sparse): one in-order sum per distinct cell value of a
                row instead of one per cell; rows with more than 64 observations go through "lut"
-      "auto"   "sparse" where the tables qualify for "lut" (at most 14 distinct bases, H <= 8192; "lut" itself when
-               `linear` is asked for), else "bytes"
+      "auto"   "sparse" where the tables qualify for "lut" (at most 14 distinct bases, H <= 8192), else "bytes"
     All give the same bits (profiles/r02/build_kernels.txt has the timings).
-    linear = (P, rowmax): preallocated [R][ldp] float64 (ldp even, >= H) and [R] float64 tensors
-    that receive mxm_linearize's output in the same pass ("lut" only) -- hand them to
-    em.EmPlan(..., linear=(P, rowmax)) and the EM loop starts without re-reading M.
     sort_rows: take the rows in position order ("lut" only; True / False / "auto" = from
     SORT_ROWS_FROM rows); results do not depend on it.
     """
     lib = _lib.load()
     dev = require_gpu()
     if kernel == "auto":
-        if tables.lut() is None:
-            kernel = "bytes"
-        else:
-            kernel = "lut" if linear is not None else "sparse"
-    if linear is not None and kernel != "lut":
-        raise ValueError("the linearised matrix is a by-product of the lookup-table kernel only")
+        kernel = "bytes" if tables.lut() is None else "sparse"
+    if kernel not in ("sparse", "lut", "bytes"):
+        raise ValueError("kernel must be 'auto', 'sparse', 'lut' or 'bytes'")
     if kernel == "sparse":
         if tables.lut() is None or tables.n_haps > 8192:
             raise ValueError("tables do not qualify for the marker kernel (its leftover rows need the lookup-table kernel)")
@@ -374,7 +307,7 @@ def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto", 
             _lib.check(lib.mxm_build_em_matrix_lut(
                 lut["ecode"].data_ptr(), lut["ecode"].stride(0), lut["lhit"].data_ptr(), lut["lmiss"].data_ptr(),
                 lut["obsmap"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(),
-                rows.data_ptr(), left, n_haps, len(tables.sites), out.data_ptr(), out.stride(0), 0, 0, 0,
+                rows.data_ptr(), left, n_haps, len(tables.sites), out.data_ptr(), out.stride(0),
                 current_stream()), "mxm_build_em_matrix_lut")
         return out
     if kernel == "lut":
@@ -393,36 +326,11 @@ def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto", 
         order = None
         if sort_rows is True or (sort_rows == "auto" and n_rows >= SORT_ROWS_FROM):
             order = row_order_by_position(row_ptr_d, site_d)
-        p_ptr = ldp = rm_ptr = 0
-        if linear is not None:
-            lin, rowmax = linear
-            if (lin.dtype != torch.float64 or lin.shape[0] != n_rows or lin.stride(1) != 1
-                    or rowmax.dtype != torch.float64 or rowmax.numel() != n_rows):
-                raise ValueError("linear = (P [R][ldp] float64, rowmax [R] float64)")
-            p_ptr, ldp, rm_ptr = lin.data_ptr(), lin.stride(0), rowmax.data_ptr()
         _lib.check(lib.mxm_build_em_matrix_lut(
             enc["ecode"].data_ptr(), enc["ecode"].stride(0), enc["lhit"].data_ptr(), enc["lmiss"].data_ptr(),
             enc["obsmap"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(),
             0 if order is None else order.data_ptr(), n_rows, n_haps, len(tables.sites),
-            out.data_ptr(), out.stride(0), p_ptr, ldp, rm_ptr, current_stream()), "mxm_build_em_matrix_lut")
-        return out
-    packed = tables.packed_device() if kernel == "packed" else None
-    if kernel == "packed" and packed is None:
-        raise ValueError("tables do not qualify for the packed-table kernel")
-    if packed is not None:
-        row_ptr_d = as_device(row_ptr, torch.int64, dev)
-        site_d = as_device(site, torch.uint16, dev)
-        obs_d = as_device(obs, torch.uint8, dev)
-        n_rows = row_ptr_d.numel() - 1
-        if out is None:
-            out = device_empty((n_rows, tables.n_haps), torch.float64, dev, "the EM input matrix")
-        if n_rows == 0:
-            return out
-        _lib.check(lib.mxm_build_em_matrix_packed(
-            packed["epk"].data_ptr(), packed["muidx"].data_ptr(), packed["pairs"].data_ptr(),
-            packed["pairs"].shape[0], packed["obsmap"].data_ptr(), row_ptr_d.data_ptr(),
-            site_d.data_ptr(), obs_d.data_ptr(), n_rows, tables.n_haps, len(tables.sites),
-            out.data_ptr(), out.stride(0), current_stream()), "mxm_build_em_matrix_packed")
+            out.data_ptr(), out.stride(0), current_stream()), "mxm_build_em_matrix_lut")
         return out
     exp_d, lhit_d, lmiss_d = tables.device()
     row_ptr_d = as_device(row_ptr, torch.int64, dev)
@@ -594,7 +502,7 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False):
         _lib.check(lib.mxm_build_em_matrix_lut(
             lut["ecode"].data_ptr(), lut["ecode"].stride(0), lut["lhit"].data_ptr(), lut["lmiss"].data_ptr(),
             lut["obsmap"].data_ptr(), rp.data_ptr(), si.data_ptr(), ob.data_ptr(), order, count, n_haps, n_sites,
-            out.data_ptr(), out.stride(0), 0, 0, 0, current_stream()), "mxm_build_em_matrix_lut")
+            out.data_ptr(), out.stride(0), current_stream()), "mxm_build_em_matrix_lut")
 
     m_rest = None
     if dense:

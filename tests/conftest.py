@@ -51,6 +51,16 @@ def built_library():
     return build.build()
 
 
+@pytest.fixture(autouse=True)
+def default_tuning(built_library):
+    """Every tuning / measurement knob of the library (include/mixemt_hip_tuning.h: process-wide state) is back at
+    its default after each test, whatever the test set and however it ended -- so that e.g. config 3 at 10^6 rows
+    runs the restart schedule the product ships, not the one an earlier test selected."""
+    yield
+    from mixemt_amd import _lib
+    _lib.load().mxm_reset_tuning()
+
+
 @pytest.fixture(scope="session")
 def b17():
     """(refseq, phylo, sorted haplogroups, HapVarTables) for Build 17 + RSRS."""

@@ -50,11 +50,36 @@ def test_binding_table_matches_header(lib_path):
     from mixemt_amd import _lib
     assert sorted(_lib.SIGNATURES) == _declared()
     lib = _lib.load()
-    assert lib.mxm_version() == 100
+    header = open(os.path.join(ROOT, "include", "mixemt_hip.h")).read()
+    declared = int(re.search(r"#define\s+MXM_VERSION\s+(\d+)", header).group(1))
+    assert lib.mxm_version() == declared == _lib.ABI_VERSION          # header, library and binding agree
     assert ctypes.sizeof(_lib.EmState) == 16
     assert lib.mxm_linear_supported(5408) == 1 and lib.mxm_linear_supported(3) == 0
     assert lib.mxm_linear_supported(8192) == 1 and lib.mxm_linear_supported(8193) == 0
     assert lib.mxm_workspace_bytes(1000000, 5408, 1) >= 1024 * 5408 * 8
+
+
+def test_binding_refuses_a_library_of_another_abi_version(lib_path, monkeypatch):
+    """mxm_version() is what a binding has to detect an incompatible library with: load() compares."""
+    from mixemt_amd import _lib
+    monkeypatch.setattr(_lib, "_lib", None)
+    monkeypatch.setattr(_lib, "ABI_VERSION", _lib.ABI_VERSION + 1)
+    with pytest.raises(_lib.MixemtHipError, match="ABI version"):
+        _lib.load()
+
+
+def test_tuning_knobs_reset_and_take_their_ranges(lib_path):
+    """Setters validate their argument; mxm_reset_tuning restores the shipped defaults (host-side state only)."""
+    from mixemt_amd import _lib
+    lib = _lib.load()
+    assert lib.mxm_set_batch_tile(7) < 0 and lib.mxm_set_batch_tile(2) == 0
+    assert lib.mxm_restart_tile(5408) == 2
+    assert lib.mxm_set_coded_batch(3) < 0 and lib.mxm_set_coded_batch(1) == 0
+    assert lib.mxm_reset_tuning() == 0
+    assert lib.mxm_restart_tile(5408) == 4
+    buf = ctypes.create_string_buffer(96)
+    assert lib.mxm_describe_stream_kernel(5408, 1, buf, len(buf)) == 0
+    assert buf.value == b"em_iter_wide_kernel<512, 6, 1, 3, 1>"
 
 
 def test_code_object_is_gfx950(lib_path):

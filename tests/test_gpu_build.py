@@ -135,10 +135,9 @@ def test_reference_phylotree_object_is_accepted(toy):
     assert numpy.array_equal(preprocess.build_em_matrix(ref, bare, reads, haps, em_args()), g["mat"])
 
 
-@pytest.mark.parametrize("kernel", ["packed", "bytes", "lut", "sparse"])
+@pytest.mark.parametrize("kernel", ["bytes", "lut", "sparse"])
 def test_all_kernels_give_reference_bits(b17, kernel):
-    """The lookup-table kernel, the LDS-staged packed-table kernel and the byte-table kernel are
-    interchangeable."""
+    """The marker kernel, the lookup-table kernel and the byte-table kernel are interchangeable."""
     from mixemt_amd import preprocess
     refseq, phy, haps, tables = b17
     g = golden("g2_build_b17")
@@ -148,54 +147,18 @@ def test_all_kernels_give_reference_bits(b17, kernel):
     assert _sha(mat) == str(g["mat_sha256"])
 
 
-@pytest.mark.parametrize("n_cols", [1, 7, 63, 64, 65, 129, 1000])
-def test_packed_kernel_ragged_tiles_and_rows(b17, n_cols):
-    """Column counts around the 64-column tile, row counts around the 8-row / 128-row steps."""
-    from mixemt_amd import preprocess, synth
-    refseq, phy, haps, tables = b17
-    sub = haps[100:100 + n_cols]
-    sub_tables = preprocess.HapVarTables.build(refseq, phy, sub)
-    assert sub_tables.packed() is not None
-    for n_rows, seed in ((1, 1), (9, 2), (127, 3), (130, 4), (1000, 5)):
-        row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=seed)
-        got = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="packed").cpu().numpy()
-        want = c_oracle.build_em_matrix(sub_tables.expected, sub_tables.lhit, sub_tables.lmiss, row_ptr,
-                                        site, obs, n_cols)
-        assert numpy.array_equal(got, want), (n_cols, n_rows)
-
-
-def test_packed_kernel_long_reads_unusual_bases_and_strided_output(b17):
-    import torch
-    from mixemt_amd import preprocess, synth
-    refseq, phy, haps, tables = b17
-    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 5, seed=9, read_len=3000)
-    obs = obs.copy()
-    obs[::17] = ord("N")                 # never matches an expected base
-    obs[5::29] = ord("a")                # lower case is a different string in the reference
-    obs[3::31] = 0                       # multi-character observation (encoded as 0)
-    want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, row_ptr, site, obs,
-                                    len(haps))
-    got = preprocess.build_em_matrix_device(tables, row_ptr, site, obs, kernel="packed").cpu().numpy()
-    assert numpy.array_equal(got, want)
-    # odd leading dimension: the kernel must fall back to 8-byte stores
-    out = torch.full((5, len(haps) + 3), -1.0, dtype=torch.float64, device="cuda")
-    preprocess.build_em_matrix_device(tables, row_ptr, site, obs, out=out, kernel="packed")
-    host = out.cpu().numpy()
-    assert numpy.array_equal(host[:, :len(haps)], want) and (host[:, len(haps):] == -1.0).all()
-
-
 def test_tables_that_do_not_qualify_fall_back(b17, toy):
     from mixemt_amd import preprocess
     ref, phy, haps = toy
     tables = preprocess.HapVarTables.build(ref, phy, haps)
-    tables._packed = False               # as if the alphabet / LDS budget check had failed
+    tables._lut = False                  # as if the alphabet check had failed: "auto" must take the byte-table kernel
     g = golden("g1_toy")
     reads = str(g["reads"]).split("\n")
     rp, si, ob = preprocess.encode_signatures(reads, tables)
     got = preprocess.build_em_matrix_device(tables, rp, si, ob).cpu().numpy()
     assert numpy.array_equal(got, g["mat"])
     with pytest.raises(ValueError):
-        preprocess.build_em_matrix_device(tables, rp, si, ob, kernel="packed")
+        preprocess.build_em_matrix_device(tables, rp, si, ob, kernel="lut")
 
 
 def test_prob_for_vars_closed_forms(toy):
@@ -255,40 +218,6 @@ def test_lut_kernel_long_reads_unusual_bases_and_strided_output(b17):
     assert numpy.array_equal(host[:, :len(haps)], want) and (host[:, len(haps):] == -1.0).all()
 
 
-@pytest.mark.parametrize("n_cols,n_rows,read_len", [(5408, 700, 150), (777, 90, 150), (66, 33, 150),
-                                                    (5408, 4, 3000), (1024, 257, 150)])
-def test_lut_kernel_emits_the_linearised_matrix(b17, n_cols, n_rows, read_len):
-    """
-    linear = (P, rowmax): the build's by-product equals mxm_linearize's output on the same matrix bit
-    for bit (rowmax = max_h M, P = exp(M - rowmax), pad column of an odd width zero), and a plan made
-    from it runs the same EM.
-    """
-    import torch
-    from conftest import em_args as mk
-    from mixemt_amd import em, preprocess, synth
-    refseq, phy, haps, tables = b17
-    sub_tables = tables if n_cols == len(haps) else preprocess.HapVarTables.build(refseq, phy, haps[:n_cols])
-    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=21, read_len=read_len)
-    ldp = (n_cols + 1) // 2 * 2
-    lin = torch.full((n_rows, ldp), -7.0, dtype=torch.float64, device="cuda")
-    rowmax = torch.full((n_rows,), -7.0, dtype=torch.float64, device="cuda")
-    mat = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="lut", linear=(lin, rowmax))
-    want = c_oracle.build_em_matrix(sub_tables.expected, sub_tables.lhit, sub_tables.lmiss, row_ptr, site, obs,
-                                    n_cols)
-    assert numpy.array_equal(mat.cpu().numpy(), want)
-    wts = torch.ones(n_rows, dtype=torch.float64, device="cuda")
-    plain = em.EmPlan(mat, wts)                               # mxm_linearize on the same matrix
-    assert torch.equal(plain.rowmax, rowmax)
-    assert torch.equal(plain.lin, lin)
-    assert numpy.array_equal(rowmax.cpu().numpy(), want.max(axis=1))
-    fused = em.EmPlan(mat, wts, linear=(lin, rowmax))
-    numpy.random.seed(3)
-    init = em.init_props(n_cols, 1.0)[None, :]
-    a = em.em_loop(plain, init, 1e-4, 40)
-    b = em.em_loop(fused, init, 1e-4, 40)
-    assert a[2] == b[2] and torch.equal(a[1], b[1])
-
-
 @pytest.mark.parametrize("n_cols", [1, 2, 3, 255, 1024, 1025, 2050, 5408])
 def test_sparse_kernel_ragged_widths_and_rows(b17, n_cols):
     """The marker kernel (one in-order sum per distinct cell value of a row): the oracle's bits at every width,
@@ -331,26 +260,20 @@ def test_sparse_kernel_unusual_bases_strided_output_and_golden(b17):
     assert hashlib.sha256(mat.cpu().numpy().tobytes()).hexdigest() == str(g["mat_sha256"])
 
 
-@pytest.mark.parametrize("passes", [1, 2, 4])
-def test_sparse_kernel_column_ranges_and_full_table_fallback(b17, passes):
-    """Every number of column ranges gives the same bits; rows with more distinct values than the dedup table
-    is allowed to hold (limit lowered to 6 here, so a third of ordinary rows qualify) go through the fallback."""
+@pytest.mark.parametrize("n_cols", [3000, 5408])
+def test_sparse_kernel_full_table_fallback(b17, n_cols):
+    """Rows with more distinct values than the dedup table is allowed to hold (limit lowered to 6 here, so a
+    third of ordinary rows qualify) go through the fallback list and come out with the same bits."""
     from mixemt_amd import _lib, preprocess, synth
     refseq, phy, haps, tables = b17
     lib = _lib.load()
-    sub_tables = preprocess.HapVarTables.build(refseq, phy, haps[:3000]) if passes == 1 else tables
-    n_cols = 3000 if passes == 1 else len(haps)
+    sub_tables = preprocess.HapVarTables.build(refseq, phy, haps[:n_cols]) if n_cols < len(haps) else tables
     row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 700, seed=31)
     want = c_oracle.build_em_matrix(sub_tables.expected, sub_tables.lhit, sub_tables.lmiss, row_ptr, site, obs, n_cols)
-    try:
-        lib.mxm_set_sparse_passes(passes)
-        got = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="sparse").cpu().numpy()
-        assert numpy.array_equal(got, want)
-        plain = preprocess.build_em_matrix_device.last_fallback
-        lib.mxm_set_sparse_max_distinct(6)
-        got = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="sparse").cpu().numpy()
-        assert numpy.array_equal(got, want)
-        assert plain + 50 < preprocess.build_em_matrix_device.last_fallback < 700      # both paths, many rows each
-    finally:
-        lib.mxm_set_sparse_passes(2)
-        lib.mxm_set_sparse_max_distinct(704)
+    got = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="sparse").cpu().numpy()
+    assert numpy.array_equal(got, want)
+    plain = preprocess.build_em_matrix_device.last_fallback
+    lib.mxm_set_sparse_max_distinct(6)                   # (conftest resets every knob after the test)
+    got = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="sparse").cpu().numpy()
+    assert numpy.array_equal(got, want)
+    assert plain + 50 < preprocess.build_em_matrix_device.last_fallback < 700      # both paths, many rows each

@@ -496,12 +496,9 @@ def test_running_restarts_are_packed_without_changing_results(n_rows, n_haps, n_
     inits = rng.dirichlet([0.3] * n_haps, size=n_runs)
     args = em_args(n_multi=n_runs, max_iter=300, tolerance=1e-5)
     out = {}
-    try:
-        for on in (1, 0):
-            lib.mxm_set_compact_restarts(on)
-            out[on] = em.run_em_ex(mat, wts, args, inits=inits, want_read_mix=True)
-    finally:
-        lib.mxm_set_compact_restarts(1)
+    for on in (1, 0):                        # (the library default is 2; conftest resets every knob after the test)
+        lib.mxm_set_compact_restarts(on)
+        out[on] = em.run_em_ex(mat, wts, args, inits=inits, want_read_mix=True)
     assert len(set(out[0]["iters"])) > 1, "the case must have restarts stopping on different iterations"
     assert out[1]["iters"] == out[0]["iters"]
     assert numpy.abs(out[1]["run_props"] - out[0]["run_props"]).max() < 1e-13

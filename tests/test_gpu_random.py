@@ -55,7 +55,7 @@ def test_random_tables_build_bitwise(seed):
     assert numpy.array_equal(got, want)
     tables = preprocess.HapVarTables.build(phy.refseq, phy, haps)
     rp, si, ob = preprocess.encode_signatures(reads, tables)
-    for kernel, ok in (("bytes", True), ("packed", tables.packed() is not None), ("lut", tables.lut() is not None)):
+    for kernel, ok in (("bytes", True), ("lut", tables.lut() is not None), ("sparse", tables.lut() is not None)):
         if ok:
             alt = preprocess.build_em_matrix_device(tables, rp, si, ob, kernel=kernel).cpu().numpy()
             assert numpy.array_equal(alt, want), kernel

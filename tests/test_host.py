@@ -255,3 +255,31 @@ def test_gather_csr_of_a_row_subset():
     want_site = numpy.concatenate([site[row_ptr[r]:row_ptr[r + 1]] for r in rows])
     want_obs = numpy.concatenate([obs[row_ptr[r]:row_ptr[r + 1]] for r in rows])
     assert numpy.array_equal(sub_site.numpy(), want_site) and numpy.array_equal(sub_obs.numpy(), want_obs)
+
+
+def test_bench_quotes_counter_traffic_of_the_kernel_it_ran(tmp_path):
+    """bench.pmc_traffic: the committed counter file of the SAME workload, storage and kernel instance;
+    for the headline (10^6 x 5408, dense fp64, one restart) that is 43.4 GB +- 2 % per launch -- never the
+    0.97 GB of the dense leftover rows that a row-dictionary run sends through the same kernel template."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    algo = 1e6 * 5408 * 8
+    name = "em_iter_wide_kernel<512, 6, 1, 3, 1>"
+    got = bench.pmc_traffic(10 ** 6, 5408, "f64", name, algo)
+    assert got is not None and abs(got[0] - 43.4e9) < 0.02 * 43.4e9, got
+    assert "coded" not in got[1]
+    # the leftover-rows instance of a coded run is never taken for the dense matrix's kernel
+    assert bench.pmc_traffic(10 ** 6, 5408, "f64", "em_iter_wide_kernel<256, 11, 1, 2, 1>", algo) is None
+    # another workload has no figure
+    assert bench.pmc_traffic(123456, 5408, "f64", name, 123456 * 5408 * 8.0) is None
+    # selection rules on a scratch tree: storage must match, the later round wins, out-of-range figures are refused
+    for rnd, fname, storage, val in (("r01", "pmc_traffic_a.json", "f64", 1.01 * algo), ("r07", "pmc_traffic_a.json", "f64", 1.02 * algo),
+                                     ("r09", "pmc_traffic_coded_a.json", "coded", 1.0 * algo), ("r10", "pmc_traffic_b.json", "f64", 0.02 * algo)):
+        os.makedirs(tmp_path / "profiles" / rnd, exist_ok=True)
+        with open(tmp_path / "profiles" / rnd / fname, "w") as fout:
+            json.dump({name: {"hbm_bytes_per_launch": val},
+                       "_workload": {"rows_per_gpu": 10 ** 6, "haps": 5408, "storage": storage}}, fout)
+    val, path = bench.pmc_traffic(10 ** 6, 5408, "f64", name, algo, root=str(tmp_path))
+    assert val == 1.02 * algo and path == os.path.join("profiles", "r07", "pmc_traffic_a.json")

@@ -20,6 +20,14 @@ Fixtures (SURVEY.md section 8 c):
     g7  config 1: 1000 x 100
     g8  consumers of the result on the g4 run: contributor votes, read assignment, refinement
     g9  run_em on 2400 x 5408 with de-duplication-style weights (repeats up to 400), n_multi = 1
+    g10 build_em_matrix + run_em on 20 000 x 5408 (Zipf weights): the size at which the product
+        leaves the one-launch loops / takes the row-dictionary branch of storage="auto".
+        The reference's build runs in row blocks over worker processes (rows are independent,
+        preprocess.py:188-191); its run_em is one process (hours).  --g10-rows N overrides.
+    g11 front end: the reference's process_reads / reduce_reads / build_em_input
+        (preprocess.py:99-139,163-174,201-227) on a few hundred synthetic alignments
+        (tests/_fake_aln.py objects: mates, conflicting overlaps, low MQ / BQ, missing qualities,
+        indels, soft clips, lower-case bases)
 """
 
 import argparse
@@ -78,10 +86,20 @@ def ref_run_em(ref, mat, wts, seed, **kw):
     return props, read_mix, numpy.array(iters), inits
 
 
+_G10 = None
+
+
+def _g10_block(span):
+    ref, refseq, phy, sigs, haps, quiet = _G10
+    return ref.preprocess.build_em_matrix(refseq, phy, sigs[span[0]:span[1]], haps, quiet)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
     ap.add_argument("--out", default=os.path.join(ROOT, "tests", "golden"))
+    ap.add_argument("--g10-rows", type=int, default=20000)
+    ap.add_argument("--workers", type=int, default=6)
     opts = ap.parse_args()
     only = set(x for x in opts.only.split(",") if x)
     os.makedirs(opts.out, exist_ok=True)
@@ -318,6 +336,41 @@ def main():
              mix_argmax=best, mix_argmax_sha256=numpy.array(sha(best)), votes=votes,
              mix_rowmax=mix.max(axis=1), mix_row_lse_abs_max=numpy.array(
                  numpy.abs(numpy.log(numpy.exp(mix).sum(axis=1))).max()),
+             contributors=numpy.flatnonzero(votes >= 10).astype(numpy.int32))
+
+
+    if want("g10"):
+        n10 = opts.g10_rows
+        row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), n10, seed=10)
+        sigs = synth.signatures(tables, row_ptr, site, obs)
+        t0 = time.time()
+        import multiprocessing
+        step = 250
+        blocks = [(a, min(a + step, n10)) for a in range(0, n10, step)]
+        global _G10
+        _G10 = (ref, refseq, phy, sigs, haps, quiet)
+        with multiprocessing.get_context("fork").Pool(opts.workers) as pool:
+            parts = pool.map(_g10_block, blocks)
+        mat = numpy.concatenate(parts, axis=0)
+        del parts
+        print("g10: reference built %d x %d in %.0f s (%d workers)"
+              % (n10, len(haps), time.time() - t0, opts.workers), flush=True)
+        rng = numpy.random.default_rng(1010)
+        wts = numpy.minimum(rng.zipf(1.6, size=n10), 400).astype(numpy.int64)
+        mat_sha = sha(mat)
+        numpy.save("/tmp/g10_mat.npy", mat)           # scratch: lets a rerun skip the build
+        t0 = time.time()
+        props, mix, iters, inits = ref_run_em(ref, mat, wts, 23)
+        print("g10: reference run_em %d iterations in %.0f s" % (iters[0], time.time() - t0), flush=True)
+        best, votes = votes_of(mix, wts, len(haps))
+        pick = numpy.arange(0, n10, max(n10 // 8, 1))[:8]
+        save("g10_run_em_20k", n_rows=numpy.array(n10), synth_seed=numpy.array(10),
+             csr_sha256=numpy.array(sha(row_ptr) + sha(site) + sha(obs)),
+             wts=wts.astype(numpy.int16), mat_sha256=numpy.array(mat_sha),
+             mat_row_sum=mat.sum(axis=1), props=props, iters=iters, inits=inits,
+             mix_pick=pick, mix_rows=mix[pick].copy(),
+             mix_argmax=best.astype(numpy.int16), mix_argmax_sha256=numpy.array(sha(best)), votes=votes,
+             mix_rowmax=mix.max(axis=1),
              contributors=numpy.flatnonzero(votes >= 10).astype(numpy.int32))
 
     if want("g7"):

@@ -3,10 +3,11 @@
 Summarise rocprofv3 --pmc passes (FETCH_SIZE / WRITE_SIZE, collected in
 separate runs as MI355X_MICROARCH.md prescribes) into per-kernel HBM traffic.
 
-    python tools/pmc_summary.py FETCH.csv WRITE.csv [ROWS HAPS] > profiles/rNN/pmc_traffic_<shape>.json
+    python tools/pmc_summary.py FETCH.csv WRITE.csv [ROWS HAPS [STORAGE]] > profiles/rNN/pmc_traffic_<shape>.json
 
-ROWS / HAPS (default 1000000 / 5408, bench.py's default workload) are recorded as "_workload";
-bench.py only quotes a traffic figure whose workload matches the one it runs.
+ROWS / HAPS / STORAGE (default 1000000 / 5408 / f64, bench.py's default workload) are recorded as
+"_workload"; bench.py only quotes a traffic figure whose workload AND storage match the run, from the
+kernel instance the run launched (mxm_describe_stream_kernel).
 
 Units and corrections (MI355X_MICROARCH.md, section HBM):
   * both counters count units of 1024 B;
@@ -49,7 +50,8 @@ def main():
                      "hbm_bytes_per_launch": f * 1024.0 * corr + w * 1024.0}
     rows = int(sys.argv[3]) if len(sys.argv) > 3 else 1000000
     haps = int(sys.argv[4]) if len(sys.argv) > 4 else 5408
-    out["_workload"] = {"rows_per_gpu": rows, "haps": haps,
+    storage = sys.argv[5] if len(sys.argv) > 5 else "f64"
+    out["_workload"] = {"rows_per_gpu": rows, "haps": haps, "storage": storage,
                         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py "
                                    "--steps 4 --warmup 1 --no-cpu-baseline (tools/profile_round.sh)"}
     json.dump(out, sys.stdout, indent=1)

@@ -26,7 +26,7 @@ python3 $repo/bench.py --storage coded > $out/bench_1m_coded.json 2> $out/bench_
 rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt_coded -o kt -- python3 $repo/bench.py --storage coded --no-cpu-baseline > $out/bench_1m_coded_under_rocprof.json 2> $out/kt_coded.log
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch_coded -o f -- python3 $repo/bench.py --storage coded --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_fetch_coded.log
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write_coded -o w -- python3 $repo/bench.py --storage coded --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_write_coded.log
-python3 $repo/tools/pmc_summary.py $out/pmc_fetch_coded/f_counter_collection.csv $out/pmc_write_coded/w_counter_collection.csv > $out/pmc_traffic_coded_1m.json
+python3 $repo/tools/pmc_summary.py $out/pmc_fetch_coded/f_counter_collection.csv $out/pmc_write_coded/w_counter_collection.csv 1000000 5408 coded > $out/pmc_traffic_coded_1m.json
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $out/pmc_sq_coded -o sq -- python3 $repo/bench.py --storage coded --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_sq_coded.log
 python3 $repo/tools/sq_summary.py $out/pmc_sq_coded/sq_counter_collection.csv > $out/coded_pmc_sq_summary.txt 2>&1
 python3 $repo/tools/time_coded.py > $out/coded_shapes.txt 2>&1
@@ -49,7 +49,7 @@ python3 $repo/bench.py --mode restarts --restarts 16 --no-cpu-baseline > $out/be
 # --- the one-launch loop (cache-resident matrices) and the matrix build kernels ------------------------
 rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt_small -o kt -- python3 $repo/tools/time_small_runs.py --rows 600,2400,10000 > $out/small_runs_under_rocprof.txt 2> $out/kt_small.log
 python3 $repo/tools/time_small_runs.py > $out/small_runs.txt 2>&1
-rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt_build -o kt -- python3 $repo/tools/run_build_only.py 1000000 sparse bytes lut lut+sort lut+sort+P linearize > $out/build_under_rocprof.txt 2> $out/kt_build.log
+rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt_build -o kt -- python3 $repo/tools/run_build_only.py 1000000 sparse records bytes lut lut+sort linearize > $out/build_under_rocprof.txt 2> $out/kt_build.log
 rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch_build -o f -- python3 $repo/tools/run_build_only.py 1000000 sparse bytes lut+sort > /dev/null 2> $out/pmc_fetch_build.log
 rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write_build -o w -- python3 $repo/tools/run_build_only.py 1000000 sparse bytes lut+sort > /dev/null 2> $out/pmc_write_build.log
 rocprofv3 --output-format csv --kernel-trace --pmc TCC_HIT_sum TCC_MISS_sum -d $out/pmc_l2_build -o l2 -- python3 $repo/tools/run_build_only.py 1000000 bytes lut+sort > /dev/null 2> $out/pmc_l2_build.log

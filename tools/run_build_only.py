@@ -2,8 +2,8 @@
 """
 Build the synth-v1 matrix once per kernel variant (timing / profiling target):
     python tools/run_build_only.py [rows] [variant ...]
-variants: bytes, packed, sparse (marker kernel), lut (rows in given order), lut+sort (position-sorted row order),
-          lut+P (also emits the linearised matrix), lut+sort+P; "linearize" times mxm_linearize alone.
+variants: bytes, sparse (marker kernel), records (marker kernel -> row-dictionary records, no dense matrix),
+          lut (rows in given order), lut+sort (position-sorted row order); "linearize" times mxm_linearize alone.
 """
 import os
 import sys
@@ -15,7 +15,7 @@ import torch
 from mixemt_amd import _lib, phylotree, preprocess, synth
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
-variants = sys.argv[2:] or ["sparse", "sparse4", "bytes", "lut", "lut+sort", "lut+P", "lut+sort+P", "linearize"]
+variants = sys.argv[2:] or ["sparse", "records", "bytes", "lut", "lut+sort", "linearize"]
 refseq = phylotree.load_rsrs()
 phy = phylotree.load_build17(refseq)
 haps = sorted(phy.hap_var)
@@ -28,7 +28,7 @@ ob = torch.from_numpy(obs).to(dev)
 out = torch.empty((rows, len(haps)), dtype=torch.float64, device=dev)
 lin = torch.empty((rows, len(haps)), dtype=torch.float64, device=dev)
 rowmax = torch.empty(rows, dtype=torch.float64, device=dev)
-tables.device(); tables.packed_device(); tables.lut_device(); tables.sparse_device()
+tables.device(); tables.lut_device(); tables.sparse_device()
 lib = _lib.load()
 cells = rows * len(haps)
 print("one MI355X; %d synth-v1 reads x %d haplogroups (%.1f observed sites per read); wall time per call, "
@@ -41,14 +41,14 @@ for var in variants:
                                          rowmax.data_ptr(), torch.cuda.current_stream().cuda_stream), "mxm_linearize")
         else:
             parts = var.split("+")
-            if parts[0].startswith("sparse"):           # sparse, sparse1, sparse2, sparse4: column ranges per row
-                lib.mxm_set_sparse_passes(int(parts[0][6:] or 2))
-                parts[0] = "sparse"
-            preprocess.build_em_matrix_device(tables, rp, si, ob, out=out, kernel=parts[0],
-                                              sort_rows=("sort" in parts) if parts[0] == "lut" else "auto",
-                                              linear=(lin, rowmax) if "P" in parts else None)
+            if parts[0] == "records":
+                cm = preprocess.build_em_records_device(tables, rp, si, ob)
+                del cm
+            else:
+                preprocess.build_em_matrix_device(tables, rp, si, ob, out=out, kernel=parts[0],
+                                                  sort_rows=("sort" in parts) if parts[0] == "lut" else "auto")
         torch.cuda.synchronize(); dt = time.perf_counter() - t0
-        nbytes = cells * 8 * (2 if ("P" in var or var == "linearize") else 1)
+        nbytes = cells * 8 * (2 if var == "linearize" else 1)
         print("%-11s rep %d: %7.2f ms  (%.3g cells/s, %.0f GB/s %s)"
               % (var, rep, dt * 1e3, cells / dt, nbytes / dt / 1e9,
                  "read + written" if var == "linearize" else "written"))

@@ -114,9 +114,7 @@ for case in range(20):
     want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, row_ptr, site, obs, n_cols)
     line = "build %2d: %5d rows x %4d columns, read length %4d (up to %d sites per row):" % (
         case, n_rows, n_cols, read_len, int(numpy.diff(row_ptr).max()))
-    for kernel in ("lut", "bytes", "packed", "sparse"):
-        if kernel == "packed" and tables.packed() is None:
-            continue
+    for kernel in ("lut", "bytes", "sparse"):
         if kernel == "sparse" and tables.lut() is None:
             continue
         for sort_rows in ((False, True) if kernel == "lut" else (False,)):

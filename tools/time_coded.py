@@ -104,17 +104,10 @@ def coded_iter():
 
 
 t_dense = timed(dense_iter)
-shapes = ["256 threads, 4 rows in flight, 2 workgroups per CU", "256, 3, 2", "512, 4, 2", "256, 6, 2", "512, 3, 2"]
-best = None
-for shape, label in enumerate(shapes):
-    if only is not None and shape not in only:
-        continue
-    lib.mxm_set_coded_shape(shape)
-    t = timed(coded_iter)
-    print("  shape %d (%s): %.3f ms" % (shape, label, t * 1e3))
-    if best is None or t < best[0]:
-        best = (t, shape)
-lib.mxm_set_coded_shape(best[1])
+for nb in (1, 2):
+    lib.mxm_set_coded_batch(nb)
+    print("  restarts per pass %d: %.3f ms for ONE restart" % (nb, timed(coded_iter) * 1e3))
+lib.mxm_reset_tuning()
 t_coded = timed(coded_iter)
 rel = ((cs_coded - cs_dense).abs() / cs_dense.abs().clamp_min(1e-300)).max().item()
 print("one EM iteration (pass + column reduce): dense fp64 %.3f ms, row dictionaries %.3f ms (x%.2f); "
