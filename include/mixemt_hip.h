@@ -261,11 +261,12 @@ int mxm_em_loop_coded(const mxm_coded *c, const double *w, int32_t H, int32_t B,
  * {mxm_em_iter; mxm_m_finalize} on `stream` until every restart is done.
  * A single restart on a matrix of up to 1e8 cells (H <= 6144) runs its whole loop in ONE persistent launch instead (one
  * workgroup per CU, grid barriers; same results up to rounding of the summation order).  That grid needs
- * the device to itself while it runs: calls from several threads of one process are serialised by the
- * library; a second PROCESS running such a loop on the same GPU at the same moment can starve both
- * grids, which then give up after a few seconds with status -3 (never a hang, never a wrong result) --
- * processes that share a GPU select the per-iteration kernels with mxm_set_loop_fused(0)
- * (mixemt_hip_tuning.h).
+ * the device to itself while it runs: the library checks with the runtime that the grid can be co-resident,
+ * serialises calls from several threads of one process, and bounds every spin; if a second PROCESS holding CUs
+ * starves the grid it gives up after a few seconds, the launch is undone (loop vectors restored from a snapshot in
+ * `ws`) and the same call finishes through the per-iteration kernels (never a hang, never a wrong result).
+ * Processes that share a GPU avoid the wait with mxm_set_loop_fused(0) (mixemt_hip_tuning.h); only
+ * mxm_set_loop_fused(1) turns giving up into an error (-3).
  * Iterations are enqueued in chunks of `check_every`; kernels of a finished
  * restart are no-ops, so the state freezes on exactly the iteration the
  * reference would stop on.  Blocks the calling thread (stream sync per chunk).

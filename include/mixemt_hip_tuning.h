@@ -70,13 +70,21 @@ int mxm_set_loop_graph(int32_t mode);
  * the kernels' own break-even is ~1.6e8; several restarts share the per-iteration kernels' passes, which
  * is faster from two restarts on) in ONE persistent launch (em_fused_loop_kernel: grid barriers instead of kernel
  * boundaries): mode -1 = automatic by size, 0 = never (per-iteration kernels), 1 = whenever the
- * shape allows, 2 = as 1 but always with the rows split over the workgroups (matrices of up to 1536
+ * shape allows (a launch that cannot run to its end -- grid not co-resident, grid barrier timed out -- is then an error, -3;
+ * in automatic mode the call undoes that launch and goes on through the per-iteration kernels), 2 = as 1 but always with the rows split over the workgroups (matrices of up to 1536
  * rows normally take the transposed form, em_fused_cols_kernel: columns split, matrix in registers).  chunk > 0 splits the loop into launches of that many iterations per restart
  * (same bits: a resumed restart continues from its saved proportions); 0 = one launch.
  * Against the per-iteration kernels the results differ by rounding only (another summation
  * order; the linear proportions are carried as p T / tot instead of exp(ln p')).
  */
 int mxm_set_loop_fused(int32_t mode, int32_t chunk);
+
+/*
+ * Test hook: the next one-launch loops start with their abort flag already raised, i.e. behave as if a workgroup had
+ * waited in vain at the first grid barrier (the situation a second process holding CUs creates).  mxm_em_loop must then
+ * undo the launch and finish through the per-iteration kernels (mode -1), or return -3 (mode 1).
+ */
+int mxm_diag_fused_force_abort(int32_t on);
 
 /*
  * Diagnostic: per-phase clock sums (100 MHz ticks) of the last one-launch loop that used workspace

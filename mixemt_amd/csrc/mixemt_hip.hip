@@ -71,6 +71,7 @@ struct mxm_tuning {
     int fused_chunk = 0;            // iterations per launch of the one-launch loop (0 = run to the end)
     int fused_cols = 1;             // matrices of up to 1536 rows take the transposed form (columns split)
     int coded_batch = 2;            // restarts per pass of the row-dictionary kernel (1 or 2)
+    int fused_force_abort = 0;      // test hook: the one-launch loop starts with its abort flag raised (as if starved)
     double fused_cells = 1.0e8;     // ~18 000 rows at H = 5408: measured break-even is ~30 000 rows (profiles/r02/small_runs.txt)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;     // timing hook around the dominant kernel
     mxm_progress_fn progress = nullptr;
@@ -357,6 +358,10 @@ extern "C" int mxm_set_compact_restarts(int32_t mode) {
 extern "C" int mxm_set_batch_tile(int32_t bt) {
     if (bt < 1 || bt > 4) return fail(-1, "mxm_set_batch_tile: tile must be 1..4%s", "");
     return tune_set([bt](mxm_tuning &t) { t.max_bt = bt; });
+}
+
+extern "C" int mxm_diag_fused_force_abort(int32_t on) {
+    return tune_set([on](mxm_tuning &t) { t.fused_force_abort = on ? 1 : 0; });
 }
 
 extern "C" int mxm_set_coded_batch(int32_t nb) {
@@ -894,6 +899,11 @@ extern "C" int mxm_set_loop_fused(int32_t mode, int32_t chunk) {
 }
 
 static size_t fused_sync_bytes() { return (sizeof(fused_sync) + 255) & ~(size_t)255; }
+// The loop vectors of the restarts in flight are saved at the TAIL of the workspace before every launch of a
+// one-launch loop (3 x [B][H] doubles + B states), so that a launch that gives up (status -3) can be undone.
+static size_t fused_snapshot_bytes(int H, int B) {
+    return ((size_t)3 * B * H * sizeof(double) + (size_t)B * sizeof(mxm_em_state) + 255) & ~(size_t)255;
+}
 
 // The transposed one-launch loop (fused_cols_kernels.hpp): up to 1536 rows, a 256-CU grid.
 static bool fused_cols_eligible(int64_t R, int H, int nwg) {
@@ -910,7 +920,7 @@ static bool fused_cols_eligible(int64_t R, int H, int nwg) {
 // restart only: it runs restarts one after another (17 / 26 / 80 us per restart-iteration at 600 / 2400 /
 // 10 000 rows), while the per-iteration kernels share each pass between up to four of them (11 / 15 / 27 us
 // from three restarts on; profiles/r02/small_runs_restarts.txt).
-static bool fused_eligible(const double *P, int64_t ldp, int64_t R, int H, size_t ws_bytes, bool p_is_f32, int running) {
+static bool fused_eligible(const double *P, int64_t ldp, int64_t R, int H, int B, size_t ws_bytes, bool p_is_f32, int running) {
     if (T.loop_fused == 0 || p_is_f32 || P == nullptr || !mxm_linear_supported(H)) return false;
     if ((ldp & 1) || (reinterpret_cast<uintptr_t>(P) & 15)) return false;
     int nwg = num_cu() < MXM_MAX_WG ? num_cu() : MXM_MAX_WG;
@@ -918,7 +928,7 @@ static bool fused_eligible(const double *P, int64_t ldp, int64_t R, int H, size_
     if ((ncol2 + nwg - 1) / nwg > 16 * FUSED_MAX_M) return false;           // slice wider than the column reduce covers
     if ((ncol2 + FUSED_THREADS - 1) / FUSED_THREADS > FUSED_MAX_NCH) return false;   // spill-free instances only
     if ((int64_t)nwg * part_ld(H) * 8 >= ((int64_t)1 << 31)) return false;  // one buffer descriptor over the partials
-    if (ws_bytes < fused_sync_bytes() + (size_t)(nwg + 2) * part_ld(H) * sizeof(double)) return false;
+    if (ws_bytes < fused_sync_bytes() + (size_t)(nwg + 2) * part_ld(H) * sizeof(double) + fused_snapshot_bytes(H, B) + 256) return false;
     if (T.loop_fused == 1) return true;
     // the transposed form runs a restart-iteration in 12 us at 600 rows whatever the number of restarts; the
     // batched kernels need 18 / 13 / 11 us with 2 / 3 / 4 restarts per pass: up to three restarts stay here
@@ -935,32 +945,54 @@ extern "C" int mxm_diag_fused_stamps(const void *ws, unsigned long long *out_hos
     return 0;
 }
 
+// A persistent grid with grid barriers must be co-resident: ask the runtime how many workgroups of the instance fit a
+// CU before launching (returns false -> the caller takes the per-iteration kernels instead).
+template <typename K>
+static bool grid_fits(K kernel, int threads, int nwg) {
+    int per_cu = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, threads, 0) != hipSuccess) {
+        (void)hipGetLastError();
+        return false;
+    }
+    return (long long)per_cu * num_cu() >= nwg;
+}
+
 template <int CP, int RPT>
-static void launch_fused_cols(int nwg, hipStream_t s, const double *P, int64_t ldp, const double *w, int64_t R, int H,
+static bool launch_fused_cols(int nwg, hipStream_t s, const double *P, int64_t ldp, const double *w, int64_t R, int H,
                               int B, double *ln_cur, double *ln_new, double *props_cur, mxm_em_state *state, double tol,
                               int max_iter, int chunk, double *zpart, int64_t ldz, double *cbuf, double *l1part,
                               fused_sync *sync) {
+    if (!grid_fits(em_fused_cols_kernel<CP, RPT>, FCOLS_THREADS, nwg)) return false;
     hipLaunchKernelGGL((em_fused_cols_kernel<CP, RPT>), dim3(nwg), dim3(FCOLS_THREADS), 0, s, P, ldp, w, R, H, B, ln_cur,
                        ln_new, props_cur, state, tol, max_iter, chunk, zpart, ldz, cbuf, l1part, sync);
+    return true;
 }
 
 template <int NCH>
-static void launch_fused(int nwg, hipStream_t s, const double *P, int64_t ldp, const double *w, int64_t R, int H, int B,
+static bool launch_fused(int nwg, hipStream_t s, const double *P, int64_t ldp, const double *w, int64_t R, int H, int B,
                          double *ln_cur, double *ln_new, double *props_cur, mxm_em_state *state, double tol,
                          int max_iter, int chunk, double *partial, int64_t ldpart, double *tbuf, fused_sync *sync) {
+    if (!grid_fits(em_fused_loop_kernel<NCH, FUSED_NBUF>, FUSED_THREADS, nwg)) return false;
     hipLaunchKernelGGL((em_fused_loop_kernel<NCH, FUSED_NBUF>), dim3(nwg), dim3(FUSED_THREADS), 0, s, P, ldp, w, R, H, B, ln_cur,
                        ln_new, props_cur, state, tol, max_iter, chunk, partial, ldpart, tbuf, sync);
+    return true;
 }
 
 // The loop of every restart in [0, B) that is not done yet, in launches of at most `chunk` iterations
 // per restart (one launch unless the caller wants to look at the state in between).
+// Returns 0 when every restart has stopped; MXM_FUSED_GAVE_UP when a launch could not run to its end -- the grid does
+// not fit the device, or its bounded grid barrier timed out because not all workgroups became resident (another
+// process or stream holding CUs): the loop vectors and states are then back at their values from before that launch
+// (snapshot at the tail of the workspace), so the caller can continue with the per-iteration kernels.
+#define MXM_FUSED_GAVE_UP 1
 static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t R, int32_t H, int32_t B,
                          double *props_cur, double *ln_cur, double *ln_new, mxm_em_state *state, double tol,
-                         int32_t max_iter, int32_t chunk, void *ws, hipStream_t s, mxm_em_state *state_host) {
+                         int32_t max_iter, int32_t chunk, void *ws, size_t ws_bytes, hipStream_t s,
+                         mxm_em_state *state_host) {
     // The persistent grid needs every workgroup resident, one per CU.  Two such grids in flight on one
     // device (two host threads, two streams) can each hold a part of the CUs and wait for the rest for
-    // ever -- the bounded spins would end both with an error after seconds.  Inside one process the
-    // launches are therefore serialised here; across processes sharing a GPU nothing can (see the header).
+    // ever -- the bounded spins would end both after seconds.  Inside one process the launches are
+    // therefore serialised here; across processes sharing a GPU nothing can (see the header).
     static std::mutex one_loop_at_a_time;
     std::lock_guard<std::mutex> guard(one_loop_at_a_time);
     const int nwg = num_cu() < MXM_MAX_WG ? num_cu() : MXM_MAX_WG;
@@ -970,20 +1002,44 @@ static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t 
     double *tbuf = reinterpret_cast<double *>(base + fused_sync_bytes());
     double *partial = tbuf + 2 * ldpart;
     const int nch = ((H + 1) / 2 + FUSED_THREADS - 1) / FUSED_THREADS;
+    const size_t vec = (size_t)B * H * sizeof(double);
+    char *snap = base + ((ws_bytes - fused_snapshot_bytes(H, B)) & ~(size_t)255);
+    auto snapshot = [&](bool save) -> hipError_t {
+        double *vecs[3] = {props_cur, ln_cur, ln_new};
+        for (int i = 0; i < 3; ++i) {
+            const hipError_t e = save ? hipMemcpyAsync(snap + i * vec, vecs[i], vec, hipMemcpyDeviceToDevice, s)
+                                      : hipMemcpyAsync(vecs[i], snap + i * vec, vec, hipMemcpyDeviceToDevice, s);
+            if (e != hipSuccess) return e;
+        }
+        return save ? hipMemcpyAsync(snap + 3 * vec, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToDevice, s)
+                    : hipMemcpyAsync(state, snap + 3 * vec, sizeof(mxm_em_state) * B, hipMemcpyDeviceToDevice, s);
+    };
     if (chunk < 1) chunk = 1;
+    bool launched_once = false;
     for (;;) {
         HIP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
-        bool all_done = true;
+        bool all_done = true, gave_up = false;
         for (int b = 0; b < B; ++b) {
-            if (state_host[b].done < 0)
-                return fail(-3, "mxm_em_loop: the one-launch loop's grid barrier timed out (restart %s%lld): are all %lld "
-                                "workgroups resident?  mxm_set_loop_fused(0) selects the per-iteration kernels", "", b, nwg);
+            gave_up = gave_up || state_host[b].done < 0;
             all_done = all_done && state_host[b].done != 0;
         }
-        if (T.progress != nullptr) T.progress(state_host, B, T.progress_user);
+        if (gave_up) {
+            // the grid barrier timed out: undo the launch (its vectors are mid-iteration) and hand back
+            HIP_TRY(snapshot(false));
+            HIP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            fail(-3, "mxm_em_loop: the one-launch loop's grid barrier timed out: not all %s%lld workgroups became resident "
+                     "(is another process or stream using the GPU?)", "", nwg);
+            return MXM_FUSED_GAVE_UP;
+        }
+        if (launched_once && T.progress != nullptr) T.progress(state_host, B, T.progress_user);
         if (all_done) return 0;
+        HIP_TRY(snapshot(true));
         HIP_TRY(hipMemsetAsync(sync, 0, fused_sync_bytes(), s));       // every polled word, before EVERY launch
+        if (T.fused_force_abort)                                       // test hook: as if a workgroup had given up
+            HIP_TRY(hipMemsetAsync(&sync->abort_[0], 1, sizeof(unsigned), s));
+        bool fits = true;
         if (fused_cols_eligible(R, (int)H, nwg)) {
             // smallest matrices: columns split over the workgroups, the matrix in registers (workspace:
             // [sync][z partials nwg x ldz][c ldz][l1 partials 2 x nwg], far inside what mxm_workspace_bytes reserves)
@@ -995,31 +1051,35 @@ static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t 
             const int rpt = (int)((R + FCOLS_THREADS - 1) / FCOLS_THREADS);
 #define FC_ARGS nwg, s, P, ldp, w, R, (int)H, (int)B, ln_cur, ln_new, props_cur, state, tol, (int)max_iter, (int)chunk, zpart, ldz, cbuf, l1part, sync
             if (cp <= 12) {
-                if (rpt <= 1) launch_fused_cols<12, 1>(FC_ARGS);
-                else if (rpt == 2) launch_fused_cols<12, 2>(FC_ARGS);
-                else launch_fused_cols<12, 3>(FC_ARGS);
+                if (rpt <= 1) fits = launch_fused_cols<12, 1>(FC_ARGS);
+                else if (rpt == 2) fits = launch_fused_cols<12, 2>(FC_ARGS);
+                else fits = launch_fused_cols<12, 3>(FC_ARGS);
             } else if (cp <= 22) {
-                if (rpt <= 1) launch_fused_cols<22, 1>(FC_ARGS);
-                else if (rpt == 2) launch_fused_cols<22, 2>(FC_ARGS);
-                else launch_fused_cols<22, 3>(FC_ARGS);
+                if (rpt <= 1) fits = launch_fused_cols<22, 1>(FC_ARGS);
+                else if (rpt == 2) fits = launch_fused_cols<22, 2>(FC_ARGS);
+                else fits = launch_fused_cols<22, 3>(FC_ARGS);
             } else {
-                if (rpt <= 1) launch_fused_cols<24, 1>(FC_ARGS);
-                else launch_fused_cols<24, 2>(FC_ARGS);
+                if (rpt <= 1) fits = launch_fused_cols<24, 1>(FC_ARGS);
+                else fits = launch_fused_cols<24, 2>(FC_ARGS);
             }
 #undef FC_ARGS
-            HIP_TRY(hipGetLastError());
-            continue;
-        }
-        switch (nch) {
-#define FU_CASE(n) case n: launch_fused<n>(nwg, s, P, ldp, w, R, (int)H, (int)B, ln_cur, ln_new, props_cur, state, tol, (int)max_iter, (int)chunk, partial, ldpart, tbuf, sync); break;
-            FU_CASE(1) FU_CASE(2) FU_CASE(3)
+        } else {
+            switch (nch) {
+#define FU_CASE(n) case n: fits = launch_fused<n>(nwg, s, P, ldp, w, R, (int)H, (int)B, ln_cur, ln_new, props_cur, state, tol, (int)max_iter, (int)chunk, partial, ldpart, tbuf, sync); break;
+                FU_CASE(1) FU_CASE(2) FU_CASE(3)
 #if FUSED_MAX_NCH > 3
-            FU_CASE(4) FU_CASE(5) FU_CASE(6)
+                FU_CASE(4) FU_CASE(5) FU_CASE(6)
 #endif
 #undef FU_CASE
-            default: return fail(-1, "mxm_em_loop: H=%s%lld outside the one-launch loop's range", "", H);
+                default: return fail(-1, "mxm_em_loop: H=%s%lld outside the one-launch loop's range", "", H);
+            }
+        }
+        if (!fits) {
+            fail(-3, "mxm_em_loop: the one-launch loop's %s%lld workgroups cannot be co-resident on this device", "", nwg);
+            return MXM_FUSED_GAVE_UP;                                  // nothing was launched, nothing to undo
         }
         HIP_TRY(hipGetLastError());
+        launched_once = true;
     }
 }
 
@@ -1072,13 +1132,18 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     HIP_TRY(hipStreamSynchronize(caller));
     int running = 0;
     for (int b = 0; b < B; ++b) running += (state_host[b].done == 0) ? 1 : 0;
-    if (fused_eligible(P, ldp, R, (int)H, ws_bytes, p_is_f32, running)) {
+    if (fused_eligible(P, ldp, R, (int)H, (int)B, ws_bytes, p_is_f32, running)) {
         // cache-resident matrix: the whole loop in one persistent launch on the caller's stream
         // (the host only waits for it; nothing is decided between iterations)
         int chunk = T.fused_chunk > 0 ? T.fused_chunk : max_iter;
         if (T.progress != nullptr && chunk > T.progress_every) chunk = T.progress_every;     // someone is watching
-        return em_loop_fused(P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, state, tol, max_iter, chunk, ws, caller,
-                             state_host);
+        const int frc = em_loop_fused(P, ldp, w, R, H, B, props_cur, ln_cur, ln_new, state, tol, max_iter, chunk, ws, ws_bytes,
+                                      caller, state_host);
+        // Gave up (grid not co-resident / starved): only mxm_set_loop_fused(1, ...) -- "whenever the shape allows" --
+        // makes that an error; by default the same call goes on through the per-iteration kernels from the restored
+        // state (another summation order: rounding-level differences, same stopping rule).
+        if (frc != MXM_FUSED_GAVE_UP) return frc;
+        if (T.loop_fused == 1) return -3;
     }
     const bool want_graph = T.loop_graph == 1 ||
                             (T.loop_graph == -1 && (double)R * (double)H * (double)B < 6.4e7);

@@ -89,3 +89,69 @@ def test_dump_and_load_roundtrip(tmp_path):
     os.remove(prefix + ".prop.npy")
     with pytest.raises(ValueError):
         mio.load_prev(prefix)
+
+
+# ---- g11: the reference's own front end RUN on synthetic alignments (tools/gen_golden.py) -------------------
+def _g11():
+    import json
+    from conftest import golden
+    g = golden("g11_frontend")
+    alns = [FakeAln(*rec) for rec in json.loads(str(g["alns"]))]
+    return g, alns
+
+
+def test_process_and_reduce_reads_equal_the_reference_run(b17):
+    """preprocess.py:99-139, :163-174 on 454 alignments: mates, conflicting overlaps ('N' -> dropped), low mapping /
+    base qualities, missing quality arrays, indels, soft clips, lower-case bases, duplicates, and one fragment
+    left with no site at all (empty signature)."""
+    import json
+    refseq, phy, haps, tables = b17
+    g, alns = _g11()
+    got = preprocess.process_reads(alns, phy.get_variant_pos(), int(g["min_mq"]), int(g["min_bq"]))
+    want = {name: {int(p): b for p, b in obs.items()} for name, obs in json.loads(str(g["read_obs"])).items()}
+    assert got == want
+    assert got[str(g["empty_name"])] == {}
+    sigs = preprocess.reduce_reads(got)
+    assert {k: list(v) for k, v in sigs.items()} == json.loads(str(g["read_sigs"]))
+    assert any(len(v) > 1 for v in sigs.values())                     # duplicates really collapse
+    # the fixture exercises what it claims to
+    assert any(a.query_qualities is None for a in alns) and any("I" in a.cigarstring for a in alns)
+    assert any("D" in a.cigarstring for a in alns) and any("S" in a.cigarstring for a in alns)
+    assert any(a.query_sequence.islower() for a in alns) and any(a.mapping_quality < 30 for a in alns)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("as_records", [False, True])
+def test_build_em_input_equals_the_reference_run(b17, as_records, capsys):
+    """preprocess.py:201-227 end to end: rows = sorted distinct signatures, weights, read-id lists, haplogroup order
+    and the matrix itself (sha256 of the reference's) -- dense and as row-dictionary records; the fragment the
+    reference dies on (recorded in the fixture) is skipped with a warning."""
+    import argparse
+    import hashlib
+    import json
+    import torch
+    from mixemt_amd import _lib
+    refseq, phy, haps, tables = b17
+    g, alns = _g11()
+    assert str(g["ref_died_with"]).startswith("ValueError")
+    args = argparse.Namespace(min_mq=int(g["min_mq"]), min_bq=int(g["min_bq"]), verbose=False)
+    mat, wts, hap_order, read_ids = preprocess.build_em_input(FakeBam(alns), refseq, phy, args, as_records=as_records)
+    assert preprocess.build_em_input.last_dropped == [str(g["empty_name"])]
+    assert "skipped 1 fragment" in capsys.readouterr().err
+    assert hashlib.sha256("\n".join(hap_order).encode()).hexdigest() == str(g["hap_sha256"])
+    assert numpy.array_equal(wts, g["weights"])
+    assert read_ids == json.loads(str(g["read_ids"]))
+    rows = str(g["signatures"]).split("\n")
+    if as_records:
+        # decode the records: P = exp(M - rowmax) bit for bit what mxm_linearize makes of the reference's matrix;
+        # the log tables give the matrix itself
+        cm = mat
+        assert cm.n_rows == len(rows) and cm.n_haps == len(hap_order)
+        cols = torch.arange(cm.n_haps, dtype=torch.int32, device="cuda")
+        dense, _ = preprocess.reduce_em_records(cm, hap_order, [[None, h, 0.0] for h in hap_order])
+        host = dense.cpu().numpy()
+    else:
+        host = mat
+    assert host.shape == (len(rows), len(hap_order))
+    assert hashlib.sha256(numpy.ascontiguousarray(host).tobytes()).hexdigest() == str(g["mat_sha256"])
+    assert numpy.array_equal(host[:3], g["mat_rows"])

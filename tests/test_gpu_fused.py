@@ -147,3 +147,38 @@ def test_auto_selection_by_size(b17, lib):
     numpy.random.seed(7)
     forced = em.run_em_ex(mat, g["wts"], em_args(), want_read_mix=False)
     assert numpy.array_equal(auto["props"], forced["props"]) and auto["iters"] == forced["iters"]
+
+
+@pytest.mark.parametrize("rows,chunk", [(600, 0), (600, 7), (2400, 0)])
+def test_a_one_launch_loop_that_gives_up_is_undone_and_finished_by_the_kernels(b17, lib, rows, chunk):
+    """
+    ADVICE r2: if the persistent grid cannot run to its end (not co-resident / starved at a grid barrier) the
+    call must not fail with the loop vectors left mid-run.  mxm_diag_fused_force_abort raises the abort flag
+    before the launch -- exactly what a workgroup that waited in vain does: in automatic mode the launch is
+    undone from the snapshot and the SAME call finishes through the per-iteration kernels with the reference's
+    result (g4: 600 rows -> transposed loop; g9: 2400 rows -> row-split loop); with mxm_set_loop_fused(1) it is
+    the documented error -3, and the loop vectors are intact even then.
+    """
+    from mixemt_amd import em
+    refseq, phy, haps, tables = b17
+    g = golden("g4_run_em" if rows == 600 else "g9_run_em_2400")
+    seed = 7 if rows == 600 else 17
+    mat = _b17_matrix(tables, g, len(haps))
+    lib.mxm_set_loop_fused(0, 0)
+    numpy.random.seed(seed)
+    want = em.run_em_ex(mat, g["wts"], em_args())                  # the per-iteration kernels, undisturbed
+    lib.mxm_set_loop_fused(-1, chunk)
+    lib.mxm_diag_fused_force_abort(1)
+    numpy.random.seed(seed)
+    got = em.run_em_ex(mat, g["wts"], em_args())
+    assert got["iters"] == list(g["iters"]) == want["iters"] and got["done"] == [1]
+    assert numpy.array_equal(got["run_props"], want["run_props"])   # the very same kernels ran from the very same state
+    assert numpy.abs(got["props"] - g["props"]).max() < PROPS_ATOL
+    # forced mode: the error is reported, nothing is left half-done
+    lib.mxm_set_loop_fused(1, chunk)
+    plan = em.EmPlan(mat, g["wts"])
+    with pytest.raises(ValueError, match="one-launch loop"):
+        em.em_loop(plan, g["inits"], 1e-4, 10000)
+    lib.mxm_diag_fused_force_abort(0)
+    ln_cur, ln_new, states = em.em_loop(plan, g["inits"], 1e-4, 10000)
+    assert [s[1] for s in states] == list(g["iters"])

@@ -94,6 +94,105 @@ def _g10_block(span):
     return ref.preprocess.build_em_matrix(refseq, phy, sigs[span[0]:span[1]], haps, quiet)
 
 
+def make_g11_alignments(refseq, tables, n_frag=320, seed=1111):
+    """
+    Seeded alignments for g11: fragments of three contributors' sequences (the reference sequence with the
+    contributor's expected base at every variant site), read length 80-150, with sequencing errors, indels, soft
+    clips, lower-case bases, low mapping / base qualities, missing quality arrays, mates that overlap (some with a
+    conflicting high-quality base at a variant site -> 'N' -> dropped, some whose conflict is a low-quality base),
+    PCR-style duplicates (equal signatures -> weights > 1), and one fragment whose only site is conflicted away
+    (empty signature).  -> (list of FakeAln, name of that fragment)
+    """
+    from _fake_aln import FakeAln
+    rng = numpy.random.default_rng(seed)
+    sites = numpy.asarray(tables.sites)
+    seqs = []
+    for col in (10, 2000, 4000):
+        seq = numpy.frombuffer(refseq.encode(), dtype=numpy.uint8).copy()
+        seq[sites] = tables.expected[:, col]
+        seqs.append(seq)
+    letters = numpy.frombuffer(b"ACGT", dtype=numpy.uint8)
+    ref_len = len(refseq)
+
+    def one(name, start, length, who, cigar_kind, mq, qual_kind, lower):
+        src = seqs[who]
+        if cigar_kind == "ins":
+            a = int(rng.integers(10, length - 10)); k = int(rng.integers(1, 4))
+            q = numpy.concatenate([src[start:start + a], rng.choice(letters, k), src[start + a:start + length - k]])
+            cigar = "%dM%dI%dM" % (a, k, length - a - k)
+        elif cigar_kind == "del":
+            a = int(rng.integers(10, length - 10)); k = int(rng.integers(1, 6))
+            q = numpy.concatenate([src[start:start + a], src[start + a + k:start + length + k]])
+            cigar = "%dM%dD%dM" % (a, k, length - a)
+        elif cigar_kind == "clip":
+            k = int(rng.integers(2, 9))
+            q = numpy.concatenate([rng.choice(letters, k), src[start:start + length - k]])
+            cigar = "%dS%dM" % (k, length - k)
+        else:
+            q = src[start:start + length].copy()
+            cigar = "%dM" % length
+        q = q.copy()
+        err = rng.random(q.size) < 0.004                          # sequencing errors
+        q[err] = rng.choice(letters, int(err.sum()))
+        text = q.tobytes().decode()
+        if lower:
+            text = text.lower()
+        if qual_kind == "none":
+            quals = None
+        else:
+            quals = rng.integers(31, 41, size=len(text)).tolist()
+            if qual_kind == "low":
+                for at in rng.choice(len(text), size=max(1, len(text) // 10), replace=False):
+                    quals[int(at)] = int(rng.integers(2, 30))
+        return FakeAln(name, int(start), int(mq), text, quals, cigar)
+
+    alns = []
+    for f in range(n_frag):
+        name = "frag%04d" % f
+        who = int(rng.choice(3, p=[0.6, 0.3, 0.1]))
+        length = int(rng.integers(80, 151))
+        # a third of the fragments start at one of a few fixed positions: equal signatures, weights > 1
+        start = int(rng.choice([310, 2700, 7020, 11710, 16120])) if rng.random() < 0.33 else int(rng.integers(0, ref_len - 400))
+        if rng.random() < 0.33:
+            length = 120
+        cigar_kind = str(rng.choice(["plain", "plain", "plain", "ins", "del", "clip"]))
+        mq = int(rng.choice([60, 60, 60, 60, 42, 30, 29, 10, 0]))
+        qual_kind = str(rng.choice(["ok", "ok", "ok", "low", "none"]))
+        alns.append(one(name, start, length, who, cigar_kind, mq, qual_kind, rng.random() < 0.1))
+        if rng.random() < 0.4:                                    # the mate, overlapping by 20-60 bases
+            shift = length - int(rng.integers(20, 61))
+            mate = one(name, start + shift, int(rng.integers(80, 151)), who, "plain", int(rng.choice([60, 60, 35, 12])),
+                       str(rng.choice(["ok", "ok", "none"])), False)
+            lo, hi = start + shift, start + length                # overlap on the reference
+            inside = sites[(sites >= lo) & (sites < min(hi, lo + len(mate.query_sequence)))]
+            if inside.size and rng.random() < 0.6:
+                pos = int(inside[0]); at = pos - mate.reference_start
+                was = mate.query_sequence[at]
+                other = [c for c in "ACGT" if c != was.upper()][int(rng.integers(0, 3))]
+                mate.query_sequence = mate.query_sequence[:at] + other + mate.query_sequence[at + 1:]
+                if mate.query_qualities is not None:
+                    # half of these conflicts are low-quality bases, which do not count (preprocess.py:122-123)
+                    mate.query_qualities[at] = 5 if rng.random() < 0.5 else 38
+            alns.append(mate)
+    # one fragment whose only variant site is seen with two different high-quality bases: two 30-base mates
+    # around the most isolated site of the tree (its neighbours are more than 20 bases away on both sides)
+    gap = numpy.diff(sites)
+    iso = numpy.minimum(gap[:-1], gap[1:])
+    lone = int(sites[1:-1][int(iso.argmax())])
+    assert iso.max() > 20
+    first = one("lonely", lone - 15, 30, 0, "plain", 60, "ok", False)
+    first.query_sequence = seqs[0][lone - 15:lone + 15].tobytes().decode()        # no sequencing error here
+    first.query_qualities = [38] * 30
+    base = first.query_sequence[15]
+    flip = [c for c in "ACGT" if c != base][0]
+    seq2 = seqs[0][lone - 10:lone + 20].tobytes().decode()
+    second = FakeAln("lonely", lone - 10, 60, seq2[:10] + flip + seq2[11:], [38] * 30, "30M")
+    alns.insert(len(alns) // 2, first)
+    alns.append(second)
+    order = rng.permutation(len(alns))                            # file order is not fragment order
+    return [alns[i] for i in order], "lonely"
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--only", default="")
@@ -372,6 +471,47 @@ def main():
              mix_argmax=best.astype(numpy.int16), mix_argmax_sha256=numpy.array(sha(best)), votes=votes,
              mix_rowmax=mix.max(axis=1),
              contributors=numpy.flatnonzero(votes >= 10).astype(numpy.int32))
+
+    if want("g11"):
+        # front end (row f-4) by a reference RUN: process_reads / reduce_reads / build_em_input on duck-typed
+        # alignments (tests/_fake_aln.py implements the pysam attributes preprocess.py:99-139 touches)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        import json
+        from _fake_aln import FakeAln, FakeBam
+        alns, empty_name = make_g11_alignments(refseq, tables)
+        var_pos = phy.get_variant_pos()
+        fe_args = ns(min_mq=30, min_bq=30)
+        obs_all = ref.preprocess.process_reads(alns, var_pos, fe_args.min_mq, fe_args.min_bq)
+        sigs_all = ref.preprocess.reduce_reads(obs_all)
+        assert "" in sigs_all and sigs_all[""] == [empty_name], sigs_all.get("")
+        # the reference itself dies on the fragment whose every site was conflicted away (int('') at :156-160) ...
+        try:
+            ref.preprocess.build_em_input(FakeBam(alns), refseq, phy, fe_args)
+            died = ""
+        except ValueError as exc:
+            died = "ValueError: %s" % exc
+        assert died, "the reference was expected to stop on the empty signature"
+        # ... so the full comparison runs on the same alignments without that fragment
+        kept = [a for a in alns if a.query_name != empty_name]
+        t0 = time.time()
+        mat, wts, hap_order, read_ids = ref.preprocess.build_em_input(FakeBam(kept), refseq, phy, fe_args)
+        print("g11: reference build_em_input on %d alignments -> %d x %d in %.0f s"
+              % (len(kept), mat.shape[0], mat.shape[1], time.time() - t0), flush=True)
+        obs_kept = ref.preprocess.process_reads(kept, var_pos, fe_args.min_mq, fe_args.min_bq)
+        sig_kept = ref.preprocess.reduce_reads(obs_kept)
+        rows = sorted(sig_kept)
+        save("g11_frontend",
+             alns=numpy.array(json.dumps([[a.query_name, a.reference_start, a.mapping_quality, a.query_sequence,
+                                           a.query_qualities, a.cigarstring] for a in alns])),
+             empty_name=numpy.array(empty_name), min_mq=numpy.array(30), min_bq=numpy.array(30),
+             read_obs=numpy.array(json.dumps({name: {str(p): b for p, b in sorted(o.items())}
+                                              for name, o in sorted(obs_all.items())})),
+             read_sigs=numpy.array(json.dumps({sig: ids for sig, ids in sorted(sigs_all.items())})),
+             ref_died_with=numpy.array(died),
+             signatures=numpy.array("\n".join(rows)), weights=numpy.asarray(wts, dtype=numpy.int64),
+             read_ids=numpy.array(json.dumps(read_ids)), hap_sha256=numpy.array(
+                 hashlib.sha256("\n".join(hap_order).encode()).hexdigest()),
+             mat_sha256=numpy.array(sha(mat)), mat_row_sum=mat.sum(axis=1), mat_rows=mat[:3].copy())
 
     if want("g7"):
         cols = list(range(0, 5400, 54))
