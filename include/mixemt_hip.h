@@ -39,8 +39,8 @@ extern "C" {
  * header it was written against (mixemt_amd/_lib.py does).  History: 100 rounds 1-2 (mxm_row_argmax_votes gained
  * ws / ws_bytes and mxm_set_compact_restarts became 0/1/2 inside that number -- the reason for this rule);
  * 300 round 3: mxm_build_em_matrix_packed / mxm_build_packed_lds_bytes removed, mxm_build_em_matrix_lut lost its
- * P / ldp / rowmax outputs, the marker build takes rows of up to 128 observations, mxm_row_argmax_votes_coded,
- * mxm_em_loop_graph added. */
+ * P / ldp / rowmax outputs, the marker build takes rows of up to 128 observations, mxm_row_argmax_votes_coded replaces mxm_row_argmax_coded,
+ * mxm_em_step_coded / mxm_gather_columns_coded cover the rows without a record, mxm_iter_graph_* added. */
 #define MXM_VERSION 300
 
 /* per-restart loop state, written by mxm_m_finalize (16 bytes) */
@@ -237,17 +237,31 @@ size_t mxm_coded_bytes(int64_t R, int32_t H);
 int mxm_encode_rows(const double *M, int64_t ldm, int64_t R, int32_t H, uint8_t *rec, size_t rec_bytes,
                     int64_t *rec_off, int32_t *ndist, double *rowmax, int64_t *stats, void *stream);
 int mxm_decode_rows(const mxm_coded *c, int32_t H, double *P, int64_t ldp, void *stream);
-/* consumers that need the LOG values (the record's second table), coded rows only -- rows without a record
- * are left untouched, the caller has them dense:
- *   best[r] = first index of max_h (ln_props[h] + M[r][h])    assemble.py:115-123 (row argmax of the posterior)
- *   out[r][i] = M[r][cols[i]]                                  preprocess.py:247-251 (em_mat[:, indexes]) */
-int mxm_row_argmax_coded(const mxm_coded *c, int32_t H, const double *ln_props, int32_t *best, void *stream);
+/* The contributor vote straight from records -- assemble.py:115-123 / stats.py:39-40 over run_em's returned posterior
+ * (em.py:145-161), for ALL rows, without a dense matrix or a posterior matrix:
+ *   best[r] = first index of max_h  fold_k logaddexp( ln_props[k][h] + M[r][h] - lse_k[r] )     k = 0 .. n_runs-1 in run order
+ *   votes[h] = sum of w[r] over the rows with best[r] == h   (NULL = not wanted; no float atomics: reproducible)
+ * ln_props / props [n_runs][H]: each run's log theta_k and exp of it; rowmax[R] from the encoder.  With one run the
+ * row normaliser drops out (props / rowmax may be NULL); with several, each run's normaliser weighs that run's columns.
+ * Rows without a record (ndist[r] == 0) are read from M_rest[n_rest][ldm_rest] -- their LOG values, row i being row
+ * rest_rows[i] of the matrix.  n_runs <= 64.  ws / ws_bytes as for mxm_row_argmax_votes (only when votes != NULL). */
+int mxm_row_argmax_votes_coded(const mxm_coded *c, int32_t H, int32_t n_runs, const double *ln_props,
+                               const double *props, const double *rowmax, const double *M_rest, int64_t ldm_rest,
+                               const int64_t *rest_rows, int64_t n_rest, const double *w, int32_t *best,
+                               double *votes, void *ws, size_t ws_bytes, void *stream);
 /* mxm_em_step for coded rows -- em.py:80-83 (mode 0 store) and :156 (mode 1 logaddexp fold):
  *   out[r][h] = (ln_props[h] + M[r][h]) - (rowmax[r] + log(sum_h props[h] * P[r][h]))
- * the row's log-sum-exp taken in the loop's own linear variables (props = exp(ln_props), rowmax from the encoder). */
+ * the row's log-sum-exp taken in the loop's own linear variables (props = exp(ln_props), rowmax from the encoder);
+ * a row whose linear sum is 0 or not finite (every supported haplogroup underflowed) is redone in log space with a
+ * max shift, so the result is finite exactly where mxm_em_step's is.
+ * The rows without a record (ndist[r] == 0) come from M_rest[n_rest][ldm_rest], their LOG values, row i of it being
+ * row rest_rows[i] of the matrix (n_rest = 0: none; they are then left untouched): the reference's E-step in log
+ * space (mxm_em_step's generic kernel) / a plain gather, written to their own rows of `out`. */
 int mxm_em_step_coded(const mxm_coded *c, int32_t H, const double *ln_props, const double *props,
-                      const double *rowmax, double *out, int64_t ldo, int32_t mode, void *stream);
+                      const double *rowmax, const double *M_rest, int64_t ldm_rest, const int64_t *rest_rows,
+                      int64_t n_rest, double *out, int64_t ldo, int32_t mode, void *stream);
 int mxm_gather_columns_coded(const mxm_coded *c, int32_t H, const int32_t *cols, int32_t nC,
+                             const double *M_rest, int64_t ldm_rest, const int64_t *rest_rows, int64_t n_rest,
                              double *out, int64_t ldo, void *stream);
 int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, int32_t H, int32_t B,
                       const mxm_em_state *state, double *colsum, void *ws, size_t ws_bytes, void *stream);

@@ -62,9 +62,12 @@ SIGNATURES = {
     "mxm_coded_bytes": (c_size, [c_i64, c_i32]),
     "mxm_encode_rows": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_size, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mxm_decode_rows": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_ptr, c_i64, c_ptr]),
-    "mxm_row_argmax_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_ptr, c_ptr, c_ptr]),
-    "mxm_em_step_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_i32, c_ptr]),
-    "mxm_gather_columns_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),
+    "mxm_row_argmax_votes_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
+                                                  c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
+    "mxm_em_step_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_i64,
+                                         c_ptr, c_i64, c_i32, c_ptr]),
+    "mxm_gather_columns_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_ptr, c_i32, c_ptr, c_i64, c_ptr, c_i64,
+                                                c_ptr, c_i64, c_ptr]),
     "mxm_em_iter_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_ptr, c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr,
                                          c_size, c_ptr]),
     "mxm_em_loop_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_ptr, c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr,

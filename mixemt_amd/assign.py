@@ -45,35 +45,46 @@ def row_argmax_votes(read_hap_mat, wts=None):
     return best.cpu().numpy(), votes.cpu().numpy()
 
 
-def row_argmax_votes_records(cm, ln_theta, wts=None, chunk=32768):
+def row_argmax_votes_records(cm, ln_theta_k, wts=None):
     """
-    row_argmax_votes for a matrix that exists only as records (preprocess.CodedMatrix): the posterior's row
-    argmax under log-proportions ln_theta is argmax_h (ln_theta[h] + M[r][h]) -- the row's normaliser shifts
-    every column alike -- taken from the records' log tables (mxm_row_argmax_coded); rows without a record
-    from their dense copies.  Votes are exact sums for integer weights (the reference's weights are counts,
-    preprocess.py:220).  Returns (best int32[R], votes float64[H]) as numpy arrays.
+    row_argmax_votes of run_em's returned posterior for a matrix that exists only as records
+    (preprocess.CodedMatrix) -- neither the dense matrix nor the posterior matrix is made
+    (mxm_row_argmax_votes_coded).  ln_theta_k: the log theta_k of the run ([H]) or of every run of a multi-run
+    ([n_multi][H], em.run_em_ex's "ln_theta_k"): the reference votes on the logaddexp fold of the runs' posteriors
+    (em.py:156 -> assemble.py:115-123), in which each run's row normaliser weighs that run's columns -- with one
+    run it drops out and best = argmax_h (ln_theta[h] + M[r][h]).  Rows without a record are read from their
+    dense copies by the same entry point; votes are summed without float atomics.
+    Returns (best int32[R], votes float64[H]) as numpy arrays.
     """
     import ctypes
     lib = _lib.load()
     dev = cm.rec.device
-    lnp = as_device(ln_theta, torch.float64, dev).reshape(-1)
-    if lnp.numel() != cm.n_haps:
-        raise ValueError("ln_theta does not match the matrix width")
+    lnp = as_device(ln_theta_k, torch.float64, dev)
+    lnp = lnp.reshape(1, -1) if lnp.dim() == 1 else lnp
+    lnp = lnp.contiguous()
+    n_runs = lnp.shape[0]
+    if lnp.dim() != 2 or lnp.shape[1] != cm.n_haps:
+        raise ValueError("ln_theta_k does not match the matrix width")
+    props = torch.exp(lnp)
     best = torch.zeros(cm.n_rows, dtype=torch.int32, device=dev)
+    votes = torch.zeros(cm.n_haps, dtype=torch.float64, device=dev)
+    w_d = None if wts is None else as_device(wts, torch.float64, dev)
+    nbytes = lib.mxm_workspace_bytes(cm.n_rows, cm.n_haps, 1)
+    ws = torch.empty(nbytes // 8 + 1, dtype=torch.float64, device=dev)
     coded = cm.struct()
-    _lib.check(lib.mxm_row_argmax_coded(ctypes.byref(coded), cm.n_haps, lnp.data_ptr(), best.data_ptr(),
-                                        current_stream()), "mxm_row_argmax_coded")
-    for lo in range(0, int(cm.rest_rows.numel()), chunk):        # dense rows: first maximum, like numpy.argmax
-        rows = cm.rest_rows[lo:lo + chunk]
-        best[rows] = (cm.m_rest[lo:lo + chunk] + lnp).argmax(dim=1).to(torch.int32)
-    w_d = torch.ones(cm.n_rows, dtype=torch.float64, device=dev) if wts is None else as_device(wts, torch.float64, dev)
-    votes = torch.bincount(best.to(torch.int64), weights=w_d, minlength=cm.n_haps)
+    n_rest = int(cm.rest_rows.numel())
+    _lib.check(lib.mxm_row_argmax_votes_coded(
+        ctypes.byref(coded), cm.n_haps, n_runs, lnp.data_ptr(), props.data_ptr(), cm.rowmax.data_ptr(),
+        cm.m_rest.data_ptr() if n_rest else 0, cm.m_rest.stride(0) if n_rest else 0,
+        cm.rest_rows.data_ptr() if n_rest else 0, n_rest, ptr(w_d), best.data_ptr(), votes.data_ptr(),
+        ws.data_ptr(), nbytes, current_stream()), "mxm_row_argmax_votes_coded")
     return best.cpu().numpy(), votes.cpu().numpy()
 
 
-def find_contribs_from_records(cm, ln_theta, wts, args):
-    """find_contribs_from_reads (assemble.py:103-123) from records and the EM's log theta_k."""
-    best, votes = row_argmax_votes_records(cm, ln_theta, wts)
+def find_contribs_from_records(cm, ln_theta_k, wts, args):
+    """find_contribs_from_reads (assemble.py:103-123) from records and the EM's log theta_k ([H], or [n_multi][H]
+    for a multi-run: see row_argmax_votes_records)."""
+    best, votes = row_argmax_votes_records(cm, ln_theta_k, wts)
     return [int(h) for h in _first_seen_order(best) if votes[h] >= args.min_reads]
 
 

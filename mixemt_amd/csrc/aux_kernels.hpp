@@ -247,12 +247,13 @@ __global__ __launch_bounds__(256) void assign_reads_kernel(const double *__restr
 // capped at 64), so the writes of a wave are contiguous; the reads touch nC sectors per row.
 __global__ __launch_bounds__(256) void gather_columns_kernel(const double *__restrict__ M, int64_t ldm, int64_t R,
                                                              const int32_t *__restrict__ cols, int nC,
-                                                             double *__restrict__ out, int64_t ldo) {
+                                                             double *__restrict__ out, int64_t ldo,
+                                                             const int64_t *__restrict__ out_rows = nullptr) {
     const int64_t n = R * (int64_t)nC;
     for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
         const int64_t r = i / nC;
         const int c = (int)(i - r * nC);
-        out[r * ldo + c] = M[r * ldm + cols[c]];
+        out[(out_rows != nullptr ? out_rows[r] : r) * ldo + c] = M[r * ldm + cols[c]];
     }
 }
 

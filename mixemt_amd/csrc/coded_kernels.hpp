@@ -369,68 +369,48 @@ __global__ __launch_bounds__(256) void decode_rows_kernel(const uint8_t *__restr
 
 // ------------------------------------------------------------------------------------------
 // Consumers of a coded matrix that need the LOG values (the record's second table):
-//   best[r] = first index of max_h (ln_props[h] + M[r][h])   -- the row argmax of the posterior under theta_k
-//             (assemble.py:115-123; the row's log-sum-exp shifts every column alike, so it drops out)
+//   (the row argmax of the posterior lives in records_kernels.hpp: posterior_argmax_kernel)
 //   out[r][i] = M[r][cols[i]]                                 -- preprocess.py:247-251 (em_mat[:, indexes])
 // One workgroup per row; rows without a record are left untouched (the caller has them dense).
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void coded_argmax_kernel(const uint8_t *__restrict__ rec,
-                                                          const int64_t *__restrict__ rec_off,
-                                                          const int32_t *__restrict__ ndist, int ldc, int64_t R, int H,
-                                                          const double *__restrict__ ln_props,
-                                                          int32_t *__restrict__ best) {
-    __shared__ double s_m[ENC_MAX_CODES];
-    __shared__ double s_val[4];
-    __shared__ int s_idx[4];
+// Log-sum-exp of a coded row under one proportion vector, lse_r = logsumexp_h(ln_props[h] + M[r][h]) (em.py:82), for a
+// workgroup of 256 that holds the row's tables in LDS (s_p = P table, s_m = log table).  Fast form, in the loop's own
+// variables: rowmax_r + log(sum_h props[h] P[r][h]) -- one lookup and one FMA per cell, one logarithm per row.  Where
+// that sum is 0 or not finite (every supported haplogroup's proportion or P underflowed, or a NaN proportion) the
+// row is redone in log space with a max shift, as the dense pass (mxm_em_step) and the reference do, so the records
+// posterior stays finite exactly where theirs does.  Uniform result; contains barriers.
+__device__ __forceinline__ double coded_row_lse(const uint8_t *codes, const double *s_p, const double *s_m,
+                                                const double *__restrict__ props, const double *__restrict__ ln_props,
+                                                double rowmax_r, int H, double *s_red) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
-    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
-        const int nd = ndist[r];
-        if (nd <= 0) continue;                               // uniform
-        const uint8_t *codes = rec + rec_off[r];
-        const double *mtab = reinterpret_cast<const double *>(codes + ldc) + nd;
-        if (t < nd) s_m[t] = mtab[t];
-        __syncthreads();
-        double bv = -INFINITY;
-        int bi = 0x7fffffff;
-        for (int h = t; h < H; h += 256) {                   // increasing h per thread: '>' keeps the first maximum
-            const double x = ln_props[h] + s_m[codes[h]];
-            if (x > bv || bi == 0x7fffffff) {
-                bv = x;
-                bi = h;
-            }
-        }
-#pragma unroll
-        for (int off = 32; off > 0; off >>= 1) {
-            const double ov = __shfl_xor(bv, off, 64);
-            const int oi = __shfl_xor(bi, off, 64);
-            if (ov > bv || (ov == bv && oi < bi)) {
-                bv = ov;
-                bi = oi;
-            }
-        }
-        if (lane == 0) {
-            s_val[wv] = bv;
-            s_idx[wv] = bi;
-        }
-        __syncthreads();
-        if (t == 0) {
-            double v = s_val[0];
-            int i0 = s_idx[0];
-            for (int q = 1; q < 4; ++q)
-                if (s_val[q] > v || (s_val[q] == v && s_idx[q] < i0)) {
-                    v = s_val[q];
-                    i0 = s_idx[q];
-                }
-            best[r] = i0;
-        }
-        __syncthreads();
-    }
+    double z = 0.0;
+    for (int h = t; h < H; h += 256) z = fma(props[h], s_p[codes[h]], z);
+    z = wave_sum(z);
+    __syncthreads();                                        // s_red free
+    if (lane == 0) s_red[wv] = z;
+    __syncthreads();
+    z = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    if (z > 0.0 && z < INFINITY) return rowmax_r + log(z);  // uniform branch
+    double m = -INFINITY;
+    for (int h = t; h < H; h += 256) m = fmax(m, ln_props[h] + s_m[codes[h]]);
+    m = wave_max(m);
+    __syncthreads();
+    if (lane == 0) s_red[wv] = m;
+    __syncthreads();
+    m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    const double shift = (m > -INFINITY && m < INFINITY) ? m : 0.0;         // as the dense pass (estep_kernels.hpp)
+    double sacc = 0.0;
+    for (int h = t; h < H; h += 256) sacc += exp((ln_props[h] + s_m[codes[h]]) - shift);
+    sacc = wave_sum(sacc);
+    __syncthreads();
+    if (lane == 0) s_red[wv] = sacc;
+    __syncthreads();
+    sacc = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+    return log(sacc) + m;                                   // m, not shift: -inf rows stay -inf, as scipy does
 }
 
-// Posterior pass from records (em.py:80-83, :156): out[r][h] = ln_props[h] + M[r][h] - lse_r, where the row's
-// log-sum-exp is taken in the loop's own variables, lse_r = rowmax_r + log(sum_h props[h] P[r][h]) -- one table
-// lookup and one FMA per cell, one logarithm per row, no exponential.  mode 1 folds with logaddexp (multi-run).
-// (Same limit as the loop: a row whose every supported haplogroup has an underflowed proportion has Z = 0.)
+// Posterior pass from records (em.py:80-83, :156): out[r][h] = ln_props[h] + M[r][h] - lse_r (coded_row_lse).
+// mode 1 folds with logaddexp (multi-run).
 __global__ __launch_bounds__(256) void coded_posterior_kernel(const uint8_t *__restrict__ rec,
                                                              const int64_t *__restrict__ rec_off,
                                                              const int32_t *__restrict__ ndist, int ldc, int64_t R, int H,
@@ -440,7 +420,7 @@ __global__ __launch_bounds__(256) void coded_posterior_kernel(const uint8_t *__r
                                                              double *__restrict__ out, int64_t ldo, int mode) {
     __shared__ double s_p[ENC_MAX_CODES], s_m[ENC_MAX_CODES];
     __shared__ double s_red[4];
-    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int t = threadIdx.x;
     for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
         const int nd = ndist[r];
         if (nd <= 0) continue;                               // uniform
@@ -451,13 +431,7 @@ __global__ __launch_bounds__(256) void coded_posterior_kernel(const uint8_t *__r
             s_m[t] = ptab[nd + t];
         }
         __syncthreads();
-        double z = 0.0;
-        for (int h = t; h < H; h += 256) z = fma(props[h], s_p[codes[h]], z);
-        z = wave_sum(z);
-        if (lane == 0) s_red[wv] = z;
-        __syncthreads();
-        z = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
-        const double lse = rowmax[r] + log(z);
+        const double lse = coded_row_lse(codes, s_p, s_m, props, ln_props, rowmax[r], H, s_red);
         double *dst = out + r * ldo;
         for (int h = t; h < H; h += 256) {
             const double v = (ln_props[h] + s_m[codes[h]]) - lse;

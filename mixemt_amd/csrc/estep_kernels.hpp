@@ -15,7 +15,9 @@ __global__ __launch_bounds__(ROW_THREADS) void estep_log_kernel(
     const double *__restrict__ M, int64_t ldm, const double *__restrict__ w,
     const double *__restrict__ ln_props, int64_t R, int H, double *__restrict__ out, int64_t ldo,
     int mode, double *__restrict__ partial, int64_t ldpart,
-    const mxm_em_state *__restrict__ state) {
+    const mxm_em_state *__restrict__ state, const int64_t *__restrict__ out_rows = nullptr) {
+    // out_rows (nullable): row r's posterior goes to row out_rows[r] of `out` (a compact side matrix whose rows
+    // belong at scattered places of the result: the dense leftover rows of a matrix in record form).
     // ITER = false: the reference's E-step verbatim (posterior written / folded; `partial` gets the
     //               M-step sums  sum_r w_r exp(posterior)).
     // ITER = true:  one loop iteration for narrow matrices, nothing written but `partial`, which
@@ -58,7 +60,7 @@ __global__ __launch_bounds__(ROW_THREADS) void estep_log_kernel(
             for (int h = t; h < H; h += ROW_THREADS) {
                 const double v = (lnp[h] + src[h]) - lse;
                 if (out != nullptr) {
-                    double *o = out + r * ldo + h;
+                    double *o = out + (out_rows != nullptr ? out_rows[r] : r) * ldo + h;
                     *o = (mode == 1) ? logaddexp_f64(*o, v) : v;
                 }
                 if (partial != nullptr && wr != 0.0) acc[h] += wr * exp(v);   // scipy drops zero-weight rows, NaN or not

@@ -20,6 +20,7 @@
 //                       1-4 restarts per pass), em_iter_wide_f32_kernel (opt-in storage variant),
 //                       colreduce_kernel, finalize_kernel
 //   estep_kernels.hpp   estep_log_kernel (any H), estep_wide_kernel (register-resident posterior pass)
+//   records_kernels.hpp posterior_argmax_kernel (row argmax of the folded posterior from records), votes_from_best_kernel
 //   aux_kernels.hpp     log_normalize, l1_exp_diff, add_scalar, row_argmax_votes, assign_reads, gather, fold, diag_stream_read
 //   fused_kernels.hpp   em_fused_loop_kernel (the whole EM loop of a cache-resident matrix in one persistent launch)
 //   fused_cols_kernels.hpp  em_fused_cols_kernel (the same for up to 1536 rows, columns split over the workgroups, matrix in registers)
@@ -48,6 +49,7 @@
 #include "em_kernels.hpp"
 #include "estep_kernels.hpp"
 #include "aux_kernels.hpp"
+#include "records_kernels.hpp"
 #include "fused_kernels.hpp"
 #include "fused_cols_kernels.hpp"
 
@@ -759,37 +761,91 @@ extern "C" int mxm_decode_rows(const mxm_coded *c, int32_t H, double *P, int64_t
     return 0;
 }
 
-extern "C" int mxm_row_argmax_coded(const mxm_coded *c, int32_t H, const double *ln_props, int32_t *best, void *stream) {
-    const int rc = coded_check(c, H, "mxm_row_argmax_coded");
+extern "C" int mxm_row_argmax_votes_coded(const mxm_coded *c, int32_t H, int32_t n_runs, const double *ln_props,
+                                          const double *props, const double *rowmax, const double *M_rest, int64_t ldm_rest,
+                                          const int64_t *rest_rows, int64_t n_rest, const double *w, int32_t *best,
+                                          double *votes, void *ws, size_t ws_bytes, void *stream) {
+    const int rc = coded_check(c, H, "mxm_row_argmax_votes_coded");
     if (rc != 0) return rc;
-    if (ln_props == nullptr || best == nullptr) return fail(-1, "mxm_row_argmax_coded: ln_props and best required%s", "");
-    hipLaunchKernelGGL(coded_argmax_kernel, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(256), 0, (hipStream_t)stream, c->rec,
-                       c->rec_off, c->ndist, coded_ld(H), c->R, (int)H, ln_props, best);
+    if (ln_props == nullptr || best == nullptr || n_runs < 1 || n_runs > RECK_MAX_RUNS)
+        return fail(-1, "mxm_row_argmax_votes_coded: ln_props, best and 1..%s%lld runs required", "", (long long)RECK_MAX_RUNS);
+    if (n_runs > 1 && (props == nullptr || rowmax == nullptr))
+        return fail(-1, "mxm_row_argmax_votes_coded: several runs need props and rowmax (each run's row normaliser)%s", "");
+    if (n_rest < 0 || (n_rest > 0 && (M_rest == nullptr || rest_rows == nullptr || ldm_rest < H)))
+        return fail(-1, "mxm_row_argmax_votes_coded: the rows without a record need M_rest, rest_rows and ldm_rest >= H%s", "");
+    if (votes != nullptr && (ws == nullptr || ws_bytes < mxm_workspace_bytes(c->R, H, 1)))
+        return fail(-1, "mxm_row_argmax_votes_coded: workspace too small%s", "");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(posterior_argmax_kernel<true>, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(256), 0, s, c->rec, c->rec_off,
+                       c->ndist, coded_ld(H), (const double *)nullptr, (int64_t)0, (const int64_t *)nullptr, c->R, (int)H,
+                       (int)n_runs, ln_props, props, rowmax, best);
     HIP_TRY(hipGetLastError());
+    if (n_rest > 0) {
+        hipLaunchKernelGGL(posterior_argmax_kernel<false>, dim3(clamp_grid(n_rest, num_cu() * 8)), dim3(256), 0, s,
+                           (const uint8_t *)nullptr, (const int64_t *)nullptr, (const int32_t *)nullptr, 0, M_rest, ldm_rest,
+                           rest_rows, n_rest, (int)H, (int)n_runs, ln_props, props, rowmax, best);
+        HIP_TRY(hipGetLastError());
+    }
+    if (votes != nullptr) {
+        const int64_t ldpart = part_ld(H);
+        const int nwg = clamp_grid((c->R + 255) / 256, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
+        hipLaunchKernelGGL(votes_from_best_kernel, dim3(nwg), dim3(256), 0, s, best, w, c->R, (int)H, (double *)ws, ldpart);
+        HIP_TRY(hipGetLastError());
+        hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, s, (const double *)ws, ldpart, nwg,
+                           1, (int)H, (const double *)nullptr, votes, (const mxm_em_state *)nullptr, slots_from(0));
+        HIP_TRY(hipGetLastError());
+    }
+    return 0;
+}
+
+static int rest_check(const char *who, int32_t H, const double *M_rest, int64_t ldm_rest, const int64_t *rest_rows, int64_t n_rest) {
+    if (n_rest < 0 || (n_rest > 0 && (M_rest == nullptr || rest_rows == nullptr || ldm_rest < H)))
+        return fail(-1, "%s: the rows without a record need M_rest, rest_rows and ldm_rest >= H", who);
     return 0;
 }
 
 extern "C" int mxm_em_step_coded(const mxm_coded *c, int32_t H, const double *ln_props, const double *props,
-                                 const double *rowmax, double *out, int64_t ldo, int32_t mode, void *stream) {
-    const int rc = coded_check(c, H, "mxm_em_step_coded");
+                                 const double *rowmax, const double *M_rest, int64_t ldm_rest, const int64_t *rest_rows,
+                                 int64_t n_rest, double *out, int64_t ldo, int32_t mode, void *stream) {
+    int rc = coded_check(c, H, "mxm_em_step_coded");
     if (rc != 0) return rc;
     if (ln_props == nullptr || props == nullptr || rowmax == nullptr || out == nullptr || ldo < H)
         return fail(-1, "mxm_em_step_coded: bad arguments%s", "");
+    if ((rc = rest_check("mxm_em_step_coded", H, M_rest, ldm_rest, rest_rows, n_rest)) != 0) return rc;
     hipLaunchKernelGGL(coded_posterior_kernel, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(256), 0, (hipStream_t)stream, c->rec,
                        c->rec_off, c->ndist, coded_ld(H), c->R, (int)H, ln_props, props, rowmax, out, ldo, (int)mode);
     HIP_TRY(hipGetLastError());
+    if (n_rest > 0) {
+        // the rows without a record: the reference's E-step in log space on their dense copies, each written to its
+        // own row of `out`
+        const size_t lds = 2 * (size_t)H * sizeof(double);
+        if (lds > 150 * 1024) return fail(-1, "mxm_em_step_coded: H=%s%lld too large", "", H);
+        if (lds > 60 * 1024 && raise_dynamic_lds(reinterpret_cast<const void *>(&estep_log_kernel<false>), lds, "estep_log_kernel") != hipSuccess)
+            return -2;
+        hipLaunchKernelGGL((estep_log_kernel<false>), dim3(clamp_grid(n_rest, num_cu() * 2)), dim3(ROW_THREADS), lds,
+                           (hipStream_t)stream, M_rest, ldm_rest, (const double *)nullptr, ln_props, n_rest, (int)H, out, ldo,
+                           (int)mode, (double *)nullptr, (int64_t)0, (const mxm_em_state *)nullptr, rest_rows);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
-extern "C" int mxm_gather_columns_coded(const mxm_coded *c, int32_t H, const int32_t *cols, int32_t nC, double *out,
+extern "C" int mxm_gather_columns_coded(const mxm_coded *c, int32_t H, const int32_t *cols, int32_t nC, const double *M_rest,
+                                        int64_t ldm_rest, const int64_t *rest_rows, int64_t n_rest, double *out,
                                         int64_t ldo, void *stream) {
-    const int rc = coded_check(c, H, "mxm_gather_columns_coded");
+    int rc = coded_check(c, H, "mxm_gather_columns_coded");
     if (rc != 0) return rc;
     if (cols == nullptr || out == nullptr || nC <= 0 || ldo < nC) return fail(-1, "mxm_gather_columns_coded: bad arguments%s", "");
+    if ((rc = rest_check("mxm_gather_columns_coded", H, M_rest, ldm_rest, rest_rows, n_rest)) != 0) return rc;
     const int64_t blocks = (c->R * nC + 255) / 256;
     hipLaunchKernelGGL(coded_gather_columns_kernel, dim3(clamp_grid(blocks, num_cu() * 16)), dim3(256), 0, (hipStream_t)stream,
                        c->rec, c->rec_off, c->ndist, coded_ld(H), c->R, cols, (int)nC, out, ldo);
     HIP_TRY(hipGetLastError());
+    if (n_rest > 0) {
+        hipLaunchKernelGGL(gather_columns_kernel, dim3(clamp_grid((n_rest * nC + 255) / 256, num_cu() * 16)), dim3(256), 0,
+                           (hipStream_t)stream, M_rest, ldm_rest, n_rest, cols, (int)nC, out, ldo, rest_rows);
+        HIP_TRY(hipGetLastError());
+    }
     return 0;
 }
 
@@ -1349,7 +1405,7 @@ extern "C" int mxm_em_step(const double *M, int64_t ldm, const double *w, const 
         if (lds > 150 * 1024) return fail(-1, "mxm_em_step: H=%s%lld too large", "", H);
         nwg = clamp_grid(R, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
         hipLaunchKernelGGL((estep_log_kernel<false>), dim3(nwg), dim3(ROW_THREADS), lds, s, M, ldm, w, ln_props, R,
-                           (int)H, out, ldo, (int)mode, partial, ldpart, (const mxm_em_state *)nullptr);
+                           (int)H, out, ldo, (int)mode, partial, ldpart, (const mxm_em_state *)nullptr, (const int64_t *)nullptr);
     }
     HIP_TRY(hipGetLastError());
     if (colsum != nullptr) {
@@ -1461,7 +1517,7 @@ extern "C" int mxm_gather_columns(const double *M, int64_t ldm, int64_t R, int32
     if (R == 0) return 0;
     const int64_t want = (R * (int64_t)nC + 255) / 256;
     hipLaunchKernelGGL(gather_columns_kernel, dim3(clamp_grid(want, num_cu() * 16)), dim3(256), 0, (hipStream_t)stream,
-                       M, ldm, R, cols, (int)nC, out, ldo);
+                       M, ldm, R, cols, (int)nC, out, ldo, (const int64_t *)nullptr);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -419,17 +419,13 @@ def posterior(plan, ln_theta, out=None, fold=False):
         lnp = lnp.reshape(-1).contiguous()
         coded = cm.struct()
         props_d = torch.exp(lnp)
-        _lib.check(plan.lib.mxm_em_step_coded(ctypes.byref(coded), plan.n_haps, lnp.data_ptr(), props_d.data_ptr(),
-                                              cm.rowmax.data_ptr(), out.data_ptr(), out.stride(0), 1 if fold else 0,
-                                              current_stream()), "mxm_em_step_coded")
         n_rest = int(cm.rest_rows.numel())
-        if n_rest:
-            tmp = out.index_select(0, cm.rest_rows) if fold else torch.empty((n_rest, plan.n_haps), dtype=torch.float64,
-                                                                             device=plan.dev)
-            _lib.check(plan.lib.mxm_em_step(cm.m_rest.data_ptr(), cm.m_rest.stride(0), 0, lnp.data_ptr(), n_rest,
-                                            plan.n_haps, tmp.data_ptr(), tmp.stride(0), 1 if fold else 0, 0, 0, 0,
-                                            current_stream()), "mxm_em_step")
-            out.index_copy_(0, cm.rest_rows, tmp)
+        _lib.check(plan.lib.mxm_em_step_coded(ctypes.byref(coded), plan.n_haps, lnp.data_ptr(), props_d.data_ptr(),
+                                              cm.rowmax.data_ptr(), cm.m_rest.data_ptr() if n_rest else 0,
+                                              cm.m_rest.stride(0) if n_rest else 0,
+                                              cm.rest_rows.data_ptr() if n_rest else 0, n_rest,
+                                              out.data_ptr(), out.stride(0), 1 if fold else 0,
+                                              current_stream()), "mxm_em_step_coded")
         return out
     if plan.mat is None:
         raise ValueError("posterior pass needs the log matrix (keep_log_matrix=True)")

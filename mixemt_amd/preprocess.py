@@ -615,11 +615,12 @@ def reduce_em_records(cm, haplogroups, contrib_props):
     if cm.n_rows and idx:
         cols_d = torch.tensor(idx, dtype=torch.int32, device=dev)
         coded = cm.struct()
+        n_rest = int(cm.rest_rows.numel())
         _lib.check(lib.mxm_gather_columns_coded(ctypes.byref(coded), cm.n_haps, cols_d.data_ptr(), len(idx),
+                                                cm.m_rest.data_ptr() if n_rest else 0, cm.m_rest.stride(0) if n_rest else 0,
+                                                cm.rest_rows.data_ptr() if n_rest else 0, n_rest,
                                                 out.data_ptr(), out.stride(0), current_stream()),
                    "mxm_gather_columns_coded")
-        if cm.rest_rows.numel():
-            out[cm.rest_rows] = cm.m_rest.index_select(1, cols_d.to(torch.int64))
     return out, names
 
 

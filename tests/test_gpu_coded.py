@@ -348,3 +348,65 @@ def test_consumers_from_records_match_the_dense_pipeline(b17):
     sub_r, names_r = preprocess.reduce_em_records(cm_only, haps, contribs)
     assert names_r == names_d
     assert numpy.array_equal(sub_r.cpu().numpy(), sub_d.cpu().numpy())           # the log values, bit for bit
+
+
+def test_votes_from_records_of_a_multi_run_follow_the_fold(b17):
+    """
+    ADVICE r2: with n_multi > 1 the reference votes on the logaddexp fold of the runs' posteriors (em.py:156 ->
+    assemble.py:115-123); each run's row normaliser weighs its columns, so argmax_h(ln theta_0 + M) is NOT it.
+    g5 (three restarts, reference run): calls and votes from records alone, all three log theta_k handed over,
+    equal the reference's; fractional weights reproduce bit for bit; rows without a record are covered.
+    """
+    from mixemt_amd import _lib, assign, em, preprocess
+    refseq, phy, haps, tables = b17
+    g5 = golden("g5_run_em_multi")
+    cm = preprocess.build_em_records_device(tables, g5["row_ptr"], g5["site"], g5["obs"])
+    numpy.random.seed(11)
+    res = em.run_em_ex(None, g5["wts"], em_args(n_multi=3), want_read_mix=False, records=cm)
+    assert res["iters"] == list(g5["iters"]) and res["ln_theta_k"].shape == (3, len(haps))
+    best, votes = assign.row_argmax_votes_records(cm, res["ln_theta_k"], g5["wts"])
+    assert numpy.array_equal(best, g5["mix_argmax"])
+    assert numpy.array_equal(votes, g5["votes"])
+    # the same through the dense pipeline's posterior
+    numpy.random.seed(11)
+    cm2, mat = preprocess.build_em_records_device(tables, g5["row_ptr"], g5["site"], g5["obs"], dense=True)
+    full = em.run_em_ex(mat, g5["wts"], em_args(n_multi=3))
+    best_d, votes_d = assign.row_argmax_votes(full["read_mix"], g5["wts"])
+    assert numpy.array_equal(best, best_d) and numpy.array_equal(votes, votes_d)
+    frac = numpy.random.default_rng(5).random(len(best))
+    v1 = assign.row_argmax_votes_records(cm, res["ln_theta_k"], frac)[1]
+    v2 = assign.row_argmax_votes_records(cm, res["ln_theta_k"], frac)[1]
+    assert numpy.array_equal(v1, v2) and abs(v1.sum() - frac.sum()) < 1e-9
+    # every row dense-leftover (the marker kernel hands every row to the fallback list, whose rows are coded from
+    # their dense form only up to 256 values): long reads give rows that stay dense
+    from mixemt_amd import synth
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 300, seed=77, read_len=2500)
+    cm3, mat3 = preprocess.build_em_records_device(tables, row_ptr, site, obs, dense=True)
+    assert int(cm3.rest_rows.numel()) > 100
+    wts3 = numpy.ones(300)
+    numpy.random.seed(3)
+    r3 = em.run_em_ex(mat3, wts3, em_args(n_multi=2, max_iter=60))
+    b_rec, v_rec = assign.row_argmax_votes_records(cm3, r3["ln_theta_k"], wts3)
+    b_den, v_den = assign.row_argmax_votes(r3["read_mix"], wts3)
+    assert numpy.array_equal(b_rec, b_den) and numpy.array_equal(v_rec, v_den)
+
+
+def test_records_posterior_stays_finite_where_the_dense_pass_does(b17):
+    """a row whose every supported haplogroup has an underflowed proportion has a zero linear row sum; the
+    records posterior then redoes that row in log space and returns the dense pass's finite values."""
+    import torch
+    from mixemt_amd import em, preprocess
+    refseq, phy, haps, tables = b17
+    g = golden("g4_run_em")
+    cm, mat = preprocess.build_em_records_device(tables, g["row_ptr"], g["site"], g["obs"], dense=True)
+    lnp = numpy.full(len(haps), -900.0)                    # exp() underflows to 0 everywhere
+    lnp[5] = -1200.0
+    rec_plan = em.EmPlan(None, g["wts"], records=cm)
+    dense_plan = em.EmPlan(mat, g["wts"])
+    a = em.posterior(rec_plan, lnp).cpu().numpy()
+    b = em.posterior(dense_plan, lnp).cpu().numpy()
+    assert numpy.isfinite(b).all() and numpy.isfinite(a).all()
+    assert numpy.abs(a - b).max() < 1e-9
+    fold_a = em.posterior(rec_plan, lnp + 1.0, out=torch.from_numpy(a.copy()).cuda(), fold=True).cpu().numpy()
+    fold_b = em.posterior(dense_plan, lnp + 1.0, out=torch.from_numpy(b.copy()).cuda(), fold=True).cpu().numpy()
+    assert numpy.abs(fold_a - fold_b).max() < 1e-9
