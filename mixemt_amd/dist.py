@@ -86,7 +86,8 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     any object with its em_iter / finalize / alloc / read_state surface -- the
     CPU tests pass a numpy-backed double).  Returns
     (ln_cur = log theta_k, ln_new = log theta_{k+1}, [(done, iters, l1)]) --
-    identical on every rank.
+    identical on every rank.  The plan's finalize() must mark a restart done (1 converged, 2 at max_iter) -- as
+    mxm_m_finalize does; the loop raises instead of spinning if it never does.
 
     compact: restarts stop on different iterations; the unfinished ones are
     kept packed in the leading slots of the loop vectors.  window: at most that
@@ -117,10 +118,19 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     if max_iter <= 0:
         return ln_cur, ln_new, states
     first = True
+    # The loop ends when `finalize` has marked every restart done (converged, or at its own max_iter).  A plan whose
+    # finalize never does that must not spin for ever: a restart needs at most ceil(max_iter / check_every) bursts, and
+    # at most ceil(n_runs / window) groups of restarts take turns.
+    bursts_left = -(-n_runs // window) * (-(-int(max_iter) // int(check_every)) + 1) + 1
     while True:
         running = [s for s in range(n_runs) if states[s][0] == 0]        # slot order = round-robin order
         if not running:
             break
+        bursts_left -= 1
+        if bursts_left < 0:
+            raise RuntimeError("sharded EM loop: restarts %s are still running after every burst max_iter=%d allows "
+                               "(the plan's finalize() must stop a restart at its max_iter)"
+                               % ([slot_run[s] for s in running], max_iter))
         lead = min(len(running), window) if compact else n_runs
         if compact:
             # one full tile per iteration, dealt round-robin chunk by chunk: the tile that just ran goes
@@ -269,7 +279,11 @@ def exchange_fold_blocks(fold, has_fold, n_rows, n_haps, delta, dev, group=None,
                 a = bounds[p][0] + c * chunk_rows
                 b = min(a + chunk_rows, bounds[p][1])
                 if b > a:
-                    src = fold[a:b] if direct else fold[a:b].cpu()
+                    src = fold[a:b]
+                    if direct and not src.is_contiguous():
+                        src = src.contiguous()          # RCCL sends a flat buffer: rows with a padded stride are staged
+                    elif not direct:
+                        src = src.cpu()
                     keep.append(src)
                     ops.append(dist.P2POp(dist.isend, src, _global_rank(group, p), group))
         a = lo + c * chunk_rows
@@ -328,6 +342,7 @@ def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_rea
     ln_sum = torch.zeros(n_haps, dtype=torch.float64, device=dev)
     counts = torch.zeros((n_multi, 2), dtype=torch.int64, device=dev)       # iters, done
     run_props = torch.zeros((n_multi, n_haps), dtype=torch.float64, device=dev)
+    theta_k = torch.zeros((n_multi, n_haps), dtype=torch.float64, device=dev)    # each run's log theta_k (exp'ed: additive)
     fold = None
 
     def sync():
@@ -347,6 +362,7 @@ def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_rea
             counts[run, 0] = states[j][1]
             counts[run, 1] = states[j][0]
             run_props[run] = torch.exp(ln_new[j])
+            theta_k[run] = ln_cur[j]
     sync()
     t1 = time.perf_counter()
     if mine and want_read_mix:
@@ -359,6 +375,7 @@ def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_rea
         dist.all_reduce(ln_sum, group=group)
         dist.all_reduce(counts, group=group)
         dist.all_reduce(run_props, group=group)
+        dist.all_reduce(theta_k, group=group)          # every run lives on exactly one rank, the others hold zeros
     read_mix = None
     lo, hi = shard_bounds(n_rows, rank, world)
     if want_read_mix:
@@ -374,4 +391,5 @@ def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_rea
     props = torch.exp(ln_sum / n_multi).cpu().numpy() if n_multi > 1 else run_props[0].cpu().numpy()
     counts = counts.cpu().numpy()
     return {"props": props, "read_mix": read_mix, "rows": (lo, hi), "iters": [int(x) for x in counts[:, 0]],
-            "done": [int(x) for x in counts[:, 1]], "run_props": run_props.cpu().numpy(), "inits": inits}
+            "done": [int(x) for x in counts[:, 1]], "run_props": run_props.cpu().numpy(), "inits": inits,
+            "ln_theta_k": theta_k.cpu().numpy()}

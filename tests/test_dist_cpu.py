@@ -195,3 +195,25 @@ def test_row_block_exchange_is_a_log_space_reduce_scatter(tmp_path, world, n_wit
         got = numpy.load(str(tmp_path / ("block%d.npy" % r)))
         assert got.shape == (hi - lo, n_haps)
         assert numpy.allclose(got, want[lo:hi], rtol=0, atol=1e-12)
+
+
+def test_sharded_loop_raises_instead_of_spinning_when_finalize_never_stops_a_restart():
+    """sharded_em_loop bounds its bursts; a plan whose finalize ignores max_iter is an error, not a hang."""
+    from _cpu_plan import CpuPlan
+    from mixemt_amd import dist as mdist
+
+    class NeverStops(CpuPlan):
+        def finalize(self, colsum, ln_cur, ln_new, props_cur, state, tol, max_iter):
+            CpuPlan.finalize(self, colsum, ln_cur, ln_new, props_cur, state, -1.0, 1 << 30)   # never converged, never capped
+
+    rng = numpy.random.default_rng(3)
+    mat = rng.normal(-20.0, 5.0, size=(30, 12))
+    inits = rng.dirichlet([1.0] * 12, size=3)
+    plan = NeverStops(mat, numpy.ones(30))
+    with pytest.raises(RuntimeError, match="still running"):
+        mdist.sharded_em_loop(plan, inits, 1e-4, 20, check_every=4, window=2)
+    assert plan.calls <= (2 * (5 + 1) + 1) * 4
+    # and the cap never bites a well-behaved plan: three restarts, window 1, per-restart max_iter
+    good = CpuPlan(mat, numpy.ones(30))
+    _, _, states = mdist.sharded_em_loop(good, inits, 0.0, 9, check_every=4, window=1)
+    assert [s[:2] for s in states] == [(2, 9)] * 3

@@ -36,8 +36,15 @@ def full(b17):
     plan = em.EmPlan(mat, wts, n_runs=N_RESTARTS)
     numpy.random.seed(7)
     inits = numpy.stack([em.init_props(len(haps), 1.0) for _ in range(N_RESTARTS)])   # sequential draws
-    return dict(tables=tables, row_ptr=row_ptr, site=site, obs=obs, who=who, mat=mat, wts=wts, plan=plan,
+    held = dict(tables=tables, row_ptr=row_ptr, site=site, obs=obs, who=who, mat=mat, wts=wts, plan=plan,
                 inits=inits, n_haps=len(haps))
+    yield held
+    # 87 GB back to the device before the next module (configs 4 and 5 at size) starts its own processes
+    held.clear()
+    del mat, wts, plan
+    import gc
+    gc.collect()
+    torch.cuda.empty_cache()
 
 
 def _sample_csr(row_ptr, site, obs, rows):
