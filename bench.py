@@ -548,11 +548,17 @@ def bench_rows(opts, env):
         st = em.read_state(state)[0]
         total_ok = st[1] == total
     kernel_ms_per_rank = [float(kernel_ms.mean())]
+    all_reduce_us_per_rank = None
     if use_dist:
-        mine = torch.tensor([float(kernel_ms.mean())], dtype=torch.float64, device=dev)
+        # per-rank view of a step, so that a scaling result explains itself: streaming kernel, the exchange as this
+        # rank's stream saw it (colreduce done -> all-reduced sums visible: includes waiting for the slowest rank)
+        mine = torch.tensor([float(kernel_ms.mean()), all_reduce_us if all_reduce_us is not None else -1.0],
+                            dtype=torch.float64, device=dev)
         every = [torch.zeros_like(mine) for _ in range(world)]
         dist.all_gather(every, mine)
-        kernel_ms_per_rank = [float(x.item()) for x in every]
+        kernel_ms_per_rank = [float(x[0].item()) for x in every]
+        if all_reduce_us is not None:
+            all_reduce_us_per_rank = [float(x[1].item()) for x in every]
     # sanity (untimed): one more E+M pass; the M-step sums  sum_h p_h T_h  must add up to the
     # total weight of all ranks' rows, once per restart
     plan.em_iter(props_cur, ln_cur, state, colsum)
@@ -676,7 +682,16 @@ def bench_rows(opts, env):
         "parity_in_run": parity,
         "coded_storage": coded_info,
         "all_reduce_us": all_reduce_us,
+        "all_reduce_us_per_rank": all_reduce_us_per_rank,
+        "all_reduce_us_min_mean_max": (None if not all_reduce_us_per_rank else
+                                       [min(all_reduce_us_per_rank), sum(all_reduce_us_per_rank) / len(all_reduce_us_per_rank),
+                                        max(all_reduce_us_per_rank)]),
         "kernel_ms_per_rank": kernel_ms_per_rank,
+        # what a step spends outside the streaming kernel and the exchange on the slowest rank: column reduce, finalize,
+        # launch gaps, host (one restart per step only: with several the passes of a step are not one kernel)
+        "step_remainder_us": (None if batched else
+                              (elapsed / opts.steps * 1e3 - max(kernel_ms_per_rank)) * 1e3
+                              - (max(all_reduce_us_per_rank) if all_reduce_us_per_rank else 0.0)),
         "matrix_build_cells_per_s": float(n_rows) * n_haps / build_s,
         "linearize_ms": linearize_s * 1e3,
         "posterior_pass_ms": posterior_ms,

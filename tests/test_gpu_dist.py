@@ -202,6 +202,33 @@ def test_bench_starts_its_own_ranks_and_reports_the_world_it_ran():
     assert line["steps"] == 4 and line["roofline"]["kernel_ms"] > 0
 
 
+def test_bench_four_ranks_on_the_metrics_own_problem():
+    """
+    Dry run of what the driver's scaling bench does (`bench.py --gpus N`, strong scaling of the 10^6-row problem):
+    four rank processes started by bench.py itself share this box's GPU over gloo -- 250 000 rows each, the
+    per-iteration kernels, the all-reduce between mxm_em_iter and mxm_m_finalize -- and rank 0 prints ONE line that
+    carries every rank's kernel time, the exchange time per rank and the step's non-kernel remainder.
+    (RCCL refuses several ranks on one device; 4 ranks + this process stay inside the box's limit of GPU processes.)
+    """
+    import torch
+    if torch.cuda.mem_get_info()[0] < 100e9:
+        pytest.skip("needs 100 GB of free HBM for four quarter shards")
+    torch.cuda.empty_cache()
+    proc, line = _run_bench(["--gpus", "4", "--backend", "gloo", "--total-rows", "1000000", "--steps", "6",
+                             "--warmup", "2", "--no-cpu-baseline"])
+    assert proc.returncode == 0, proc.stderr[-3000:]
+    assert len([ln for ln in proc.stdout.splitlines() if ln.strip()]) == 1
+    assert line["n_gpus"] == 4 and line["scaling"] == "strong" and line["sanity_ok"]
+    assert line["config"]["total_rows"] == 1000000 and line["config"]["rows_per_gpu"] == 250000
+    assert line["steps"] == 6 and line["warmup"] == 2
+    assert len(line["kernel_ms_per_rank"]) == 4 and min(line["kernel_ms_per_rank"]) > 0
+    assert len(line["all_reduce_us_per_rank"]) == 4 and min(line["all_reduce_us_per_rank"]) > 0
+    lo, mean, hi = line["all_reduce_us_min_mean_max"]
+    assert lo <= mean <= hi and line["all_reduce_us"] > 0
+    assert line["step_remainder_us"] is not None
+    assert line["value"] > 0 and abs(line["value"] - 1e6 * 5408 * 6 / (line["ms_per_step"] * 6e-3)) < 1e-3 * line["value"]
+
+
 def test_bench_line_carries_parity_observables():
     """N = 1: cpu_baseline and parity_in_run come from the same oracle leg, and sanity_ok needs them."""
     proc, line = _run_bench(["--total-rows", "20000", "--steps", "3", "--warmup", "1", "--cpu-rows", "512",
