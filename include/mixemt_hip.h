@@ -39,7 +39,7 @@ extern "C" {
  * header it was written against (mixemt_amd/_lib.py does).  History: 100 rounds 1-2 (mxm_row_argmax_votes gained
  * ws / ws_bytes and mxm_set_compact_restarts became 0/1/2 inside that number -- the reason for this rule);
  * 300 round 3: mxm_build_em_matrix_packed / mxm_build_packed_lds_bytes removed, mxm_build_em_matrix_lut lost its
- * P / ldp / rowmax outputs, the marker build takes its tables as mxm_markers (light lists + heavy bitmaps), mxm_row_argmax_votes_coded replaces mxm_row_argmax_coded,
+ * P / ldp / rowmax outputs, mxm_row_argmax_votes_coded replaces mxm_row_argmax_coded,
  * mxm_em_step_coded / mxm_gather_columns_coded cover the rows without a record, mxm_iter_graph_* added. */
 #define MXM_VERSION 300
 
@@ -103,37 +103,22 @@ int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const double *lhi
 
 /*
  * build_em_matrix from the haplogroups' MARKERS -- preprocess.py:177-198, the same bits as the kernels
- * above, formed once per distinct cell value of a row instead of once per cell.  At a site nearly every haplogroup
- * expects the same base maj[s]; a haplogroup's cell is decided by the SET of the row's sites where its term differs
- * from the majority's (a 64-bit mask); the row's distinct masks are deduplicated and each one's sum is formed in
- * signature order from 0.0, as prob_for_vars does (preprocess.py:86-96).  Where the differing (site, haplogroup)
- * pairs come from (host encoder: preprocess.HapVarTables.markers()):
- *   LIGHT sites   mk_ptr[S+1], mk_hap[], mk_base[]: CSR over sites of the (haplogroup, expected base) pairs that
- *                 differ from maj[s] -- for the sites where few haplogroups do (an empty range for a heavy site)
- *   HEAVY sites   heavy_id[s] >= 0 (else -1): a whole clade deviates.  heavy_alt[id][1..3] are the bases deviating
- *                 haplogroups expect there (0 = unused), heavy_bits[id][a][ldw] bitmaps over the haplogroups
- *                 (bit h & 31 of word h >> 5): [0] = h deviates at all, [a] = h expects heavy_alt[id][a].
- *                 ldw >= 16 * ceil(H / 512) words, pad bits 0.
- *   obs[]         the observation's byte itself (it hits where it equals the expected base's byte)
- * Which sites are heavy is the encoder's choice (any split gives the same bits; more than ~48 deviating haplogroups
- * is where a bitmap test beats the scatter).
- * Rows with more than 64 observations, more than 1024 light entries or more than 704 distinct values are NOT
+ * above, formed once per distinct cell value of a row instead of once per cell:
+ *   maj[S]            the base most haplogroups expect at site s
+ *   mk_ptr[S+1], mk_hap[], mk_base[]   CSR over sites of the (haplogroup, expected base) pairs that
+ *                     differ from maj[s]  (Build 17: 113 027 entries)
+ *   obs[]             the observation's byte itself (it hits where it equals the expected base's byte)
+ * A haplogroup's cell is decided by the set of the row's sites where its term differs from the
+ * majority's (a 64-bit mask OR-ed together from the marker lists); the row's distinct masks are
+ * deduplicated and each one's sum is formed in signature order from 0.0, as prob_for_vars does
+ * (preprocess.py:86-96).  Rows with more than 64 observations (or more than 704 distinct values) are NOT
  * written: their indices are appended to fallback[] (device int64[R], *n_fallback = how many, device) and
  * the caller builds them with mxm_build_em_matrix_lut (order = fallback, R = *n_fallback; any order of the list).
  */
-typedef struct mxm_markers {
-    const uint8_t  *maj;            /* [S] */
-    const double   *lhit, *lmiss;   /* [S] */
-    const int32_t  *mk_ptr;         /* [S+1] */
-    const uint16_t *mk_hap;
-    const uint8_t  *mk_base;
-    const int32_t  *heavy_id;       /* [S] */
-    const uint8_t  *heavy_alt;      /* [n_heavy][4] */
-    const uint32_t *heavy_bits;     /* [n_heavy][4][ldw] */
-    int32_t         ldw, n_heavy;
-} mxm_markers;
-int mxm_build_em_matrix_sparse(const mxm_markers *markers, const int64_t *row_ptr, const uint16_t *site,
-                               const uint8_t *obs, const int64_t *order, int64_t R, int32_t H, int32_t S,
+int mxm_build_em_matrix_sparse(const uint8_t *maj, const double *lhit, const double *lmiss,
+                               const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
+                               const int64_t *row_ptr, const uint16_t *site, const uint8_t *obs,
+                               const int64_t *order, int64_t R, int32_t H, int32_t S,
                                double *M, int64_t ldm, int64_t *fallback, int64_t *n_fallback, void *stream);
 
 /*
@@ -143,13 +128,15 @@ int mxm_build_em_matrix_sparse(const mxm_markers *markers, const int64_t *row_pt
  *     record = codes[ldc] ++ P table[ndist] ++ table of the log sums themselves [ndist]
  * (P = exp(sum - rowmax[r]); code 0 = the value of a haplogroup without a deviating marker in the window).
  * Rows that get no record have ndist[r] = 0: with M given, rows of more than 256 distinct values (their dense
- * row is written); rows on the fallback list (see above, and -- when M is NULL -- more than 256 values), which
- * the caller builds densely.  stats[0] = bytes used,
+ * row is written); rows on the fallback list (more than 64 observations, more than 704 distinct masks, and --
+ * when M is NULL -- more than 256 values), which the caller builds densely.  stats[0] = bytes used,
  * stats[1] = rows without a record (device int64[2]); rec_bytes >= mxm_record_bytes(R, H) never overflows.
  */
 size_t mxm_record_bytes(int64_t R, int32_t H);
-int mxm_build_em_records(const mxm_markers *markers, const int64_t *row_ptr, const uint16_t *site,
-                         const uint8_t *obs, const int64_t *order, int64_t R, int32_t H, int32_t S, double *M, int64_t ldm,
+int mxm_build_em_records(const uint8_t *maj, const double *lhit, const double *lmiss,
+                         const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
+                         const int64_t *row_ptr, const uint16_t *site, const uint8_t *obs,
+                         const int64_t *order, int64_t R, int32_t H, int32_t S, double *M, int64_t ldm,
                          uint8_t *rec, size_t rec_bytes, int64_t *rec_off, int32_t *ndist, double *rowmax,
                          int64_t *stats, int64_t *fallback, int64_t *n_fallback, void *stream);
 

@@ -121,8 +121,6 @@ int mxm_set_min_rows_per_wg(int32_t n);
  * formed in the single kernel's order. */
 int mxm_set_coded_batch(int32_t nb);
 
-/* Tuning knob: workgroups per CU of the marker build's persistent grid (0 = what the runtime says fits, at most 8). */
-int mxm_set_markers_wg_per_cu(int32_t n);
 /* Test knob: distinct non-zero masks a row of the marker build kernel may have before it goes to the
  * fallback list (negative = the kernel's own limit, the default); lowering it drives ordinary rows through the fallback path. */
 int mxm_set_sparse_max_distinct(int32_t n);

@@ -21,13 +21,6 @@ class EmState(ctypes.Structure):
     _fields_ = [("done", c_i32), ("iters", c_i32), ("l1", c_f64)]
 
 
-class Markers(ctypes.Structure):
-    """mxm_markers (include/mixemt_hip.h): the marker build's tables."""
-    _fields_ = [("maj", c_ptr), ("lhit", c_ptr), ("lmiss", c_ptr), ("mk_ptr", c_ptr), ("mk_hap", c_ptr),
-                ("mk_base", c_ptr), ("heavy_id", c_ptr), ("heavy_alt", c_ptr), ("heavy_bits", c_ptr),
-                ("ldw", c_i32), ("n_heavy", c_i32)]
-
-
 class Coded(ctypes.Structure):
     """mxm_coded (include/mixemt_hip.h): a matrix in row-dictionary storage."""
     _fields_ = [("rec", c_ptr), ("rec_off", c_ptr), ("ndist", c_ptr), ("R", c_i64),
@@ -46,10 +39,10 @@ SIGNATURES = {
                                            c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     "mxm_build_em_matrix_lut": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                                c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
-    "mxm_build_em_matrix_sparse": (ctypes.c_int, [ctypes.POINTER(Markers), c_ptr, c_ptr, c_ptr, c_ptr,
+    "mxm_build_em_matrix_sparse": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                                   c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
     "mxm_record_bytes": (c_size, [c_i64, c_i32]),
-    "mxm_build_em_records": (ctypes.c_int, [ctypes.POINTER(Markers), c_ptr, c_ptr, c_ptr, c_ptr,
+    "mxm_build_em_records": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                             c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_size, c_ptr, c_ptr, c_ptr,
                                             c_ptr, c_ptr, c_ptr, c_ptr]),
     "mxm_linearize": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i64, c_ptr, c_ptr]),
@@ -99,7 +92,6 @@ SIGNATURES = {
     "mxm_set_progress_callback": (ctypes.c_int, [c_ptr, c_ptr, c_i32]),
     "mxm_set_min_rows_per_wg": (ctypes.c_int, [c_i32]),
     "mxm_set_coded_batch": (ctypes.c_int, [c_i32]),
-    "mxm_set_markers_wg_per_cu": (ctypes.c_int, [c_i32]),
     "mxm_reset_tuning": (ctypes.c_int, []),
     "mxm_describe_stream_kernel": (ctypes.c_int, [c_i32, c_i32, ctypes.c_char_p, c_size]),
     "mxm_set_sparse_max_distinct": (ctypes.c_int, [c_i32]),

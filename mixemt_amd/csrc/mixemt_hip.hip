@@ -15,7 +15,7 @@
 //   common.hpp          error plumbing, reductions
 //   build_kernels.hpp   build_em_matrix_kernel (byte table, L2/MALL: any alphabet, any width)
 //   build_lut_kernels.hpp  build_lut_kernel (hit/miss by LDS lookup)
-//   build_markers_kernels.hpp  build_markers_kernel (the row from the haplogroups' markers: one in-order sum per distinct cell value)
+//   build_sparse_kernels.hpp  build_sparse_kernel (the row from the haplogroups' markers: one in-order sum per distinct cell value)
 //   em_kernels.hpp      linearize, em_iter_wide_kernel (THE hot kernel: R*H*8 B read per EM iteration,
 //                       1-4 restarts per pass), em_iter_wide_f32_kernel (opt-in storage variant),
 //                       colreduce_kernel, finalize_kernel
@@ -45,7 +45,7 @@
 #include "coded_kernels.hpp"
 #include "build_kernels.hpp"
 #include "build_lut_kernels.hpp"
-#include "build_markers_kernels.hpp"
+#include "build_sparse_kernels.hpp"
 #include "em_kernels.hpp"
 #include "estep_kernels.hpp"
 #include "aux_kernels.hpp"
@@ -73,7 +73,6 @@ struct mxm_tuning {
     int fused_chunk = 0;            // iterations per launch of the one-launch loop (0 = run to the end)
     int fused_cols = 1;             // matrices of up to 1536 rows take the transposed form (columns split)
     int coded_batch = 2;            // restarts per pass of the row-dictionary kernel (1 or 2)
-    int markers_wg_per_cu = 0;      // marker build: workgroups per CU of its persistent grid (0: what the runtime says fits, at most 8)
     int fused_force_abort = 0;      // test hook: the one-launch loop starts with its abort flag raised (as if starved)
     double fused_cells = 1.0e8;     // ~18 000 rows at H = 5408: measured break-even is ~30 000 rows (profiles/r02/small_runs.txt)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;     // timing hook around the dominant kernel
@@ -227,72 +226,55 @@ extern "C" int mxm_set_sparse_max_distinct(int32_t n) {
 static inline int coded_ld(int H) { return (H + 7) & ~7; }
 
 // marker build: dense rows (M != nullptr) and / or row-dictionary records (out != nullptr)
-#ifndef MKB_KPS
-#define MKB_KPS 2                      // rounds of 128 haplogroups per wave and sub-pass (its mask array: MKB_KPS KB per wave)
-#endif
-template <int NCH, bool EMIT>
-static int launch_build_markers(int per_cu_cap, hipStream_t s, const mkb_tables &tb, const int64_t *row_ptr, const uint16_t *site,
-                                const uint8_t *obs, const int64_t *order, int64_t R, int H, double *M, int64_t ldm, int vec_ok,
-                                int64_t *fallback, int64_t *n_fallback, int maxd, const spb_records &rec) {
-    constexpr int KPS = NCH < MKB_KPS ? NCH : MKB_KPS;
-    // a persistent grid: every workgroup resident, rows dealt round-robin (each workgroup pipelines its rows' loads)
-    int per_cu = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, build_markers_kernel<NCH, KPS, EMIT>, MKB_THREADS, 0) != hipSuccess ||
-        per_cu < 1) {
-        (void)hipGetLastError();
-        per_cu = 4;
-    }
-    if (per_cu > per_cu_cap) per_cu = per_cu_cap;
-    const int grid = clamp_grid(R, num_cu() * per_cu);
-    hipLaunchKernelGGL((build_markers_kernel<NCH, KPS, EMIT>), dim3(grid), dim3(MKB_THREADS), 0, s, tb, row_ptr, site, obs, order,
-                       R, H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), maxd, rec);
-    return 0;
-}
-
-static int build_sparse_impl(const char *who, const mxm_markers *mk, const int64_t *row_ptr, const uint16_t *site,
-                             const uint8_t *obs, const int64_t *order, int64_t R, int32_t H, int32_t S, double *M,
-                             int64_t ldm, const spb_records *out, int64_t *fallback, int64_t *n_fallback, hipStream_t s) {
+static int build_sparse_impl(const char *who, const uint8_t *maj, const double *lhit, const double *lmiss,
+                             const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
+                             const int64_t *row_ptr, const uint16_t *site, const uint8_t *obs, const int64_t *order,
+                             int64_t R, int32_t H, int32_t S, double *M, int64_t ldm, const spb_records *out,
+                             int64_t *fallback, int64_t *n_fallback, hipStream_t s) {
     if (R < 0 || H <= 0 || S <= 0) return fail(-1, "%s: bad shape R=%lld H=%lld", who, R, H);
     if (H > 8192) return fail(-1, "%s: more than 8192 haplogroups (H=%lld): use mxm_build_em_matrix", who, H);
     if (M != nullptr && ldm < H) return fail(-1, "%s: ldm < H", who);
-    if (mk == nullptr || mk->maj == nullptr || mk->lhit == nullptr || mk->lmiss == nullptr || mk->mk_ptr == nullptr ||
-        mk->mk_hap == nullptr || mk->mk_base == nullptr || mk->heavy_id == nullptr || fallback == nullptr || n_fallback == nullptr)
+    if (maj == nullptr || mk_ptr == nullptr || fallback == nullptr || n_fallback == nullptr)
         return fail(-1, "%s: marker tables and the fallback list are required", who);
-    const int nch = (H + 511) / 512;                        // rounds of 128 haplogroups per wave
-    if (mk->n_heavy < 0 || (mk->n_heavy > 0 && (mk->heavy_alt == nullptr || mk->heavy_bits == nullptr || mk->ldw < 16 * nch)))
-        return fail(-1, "%s: heavy-site bitmaps need ldw >= 16 * ceil(H / 512) words (ldw=%lld)", who, mk->ldw);
-    if ((int64_t)mk->n_heavy * 16 * mk->ldw >= ((int64_t)1 << 31)) return fail(-1, "%s: heavy-site bitmaps exceed one buffer descriptor", who);
     HIP_TRY(hipMemsetAsync(n_fallback, 0, sizeof(int64_t), s));
     if (out != nullptr) HIP_TRY(hipMemsetAsync(out->stats, 0, 2 * sizeof(int64_t), s));
     if (R == 0) return 0;
+    const int hpad = (H + 1) & ~1;
+    const int nch = (hpad / 2 + SPB_THREADS - 1) / SPB_THREADS;
     const int vec_ok = (M != nullptr) && ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
-    const int maxd = (T.sparse_maxd < 0 || T.sparse_maxd > MKB_MAXD) ? MKB_MAXD : T.sparse_maxd;
-    mkb_tables tb;
-    tb.maj = mk->maj; tb.lhit = mk->lhit; tb.lmiss = mk->lmiss;
-    tb.mk_ptr = mk->mk_ptr; tb.mk_hap = mk->mk_hap; tb.mk_base = mk->mk_base;
-    tb.heavy_id = mk->heavy_id; tb.heavy_alt = mk->heavy_alt; tb.heavy_bits = mk->heavy_bits; tb.ldw = mk->ldw; tb.n_heavy = mk->n_heavy;
+    const int passes = 2;          // column ranges per row (measured: 1 / 2 / 4 ranges 22.5 / 16.4 / 21.3 ms at 10^6 x 5408)
+    const int maxd = (T.sparse_maxd < 0 || T.sparse_maxd > SPB_MAXD) ? SPB_MAXD : T.sparse_maxd;
+    const int kpp = (nch + passes - 1) / passes;
+    const size_t lds = (size_t)kpp * 2 * SPB_THREADS * 8 + 14 * 1024;      // mask array + the kernel's other LDS
+    int per_cu = (int)((160 * 1024) / lds);
+    if (per_cu > 8) per_cu = 8;
+    if (per_cu < 1) per_cu = 1;
+    const int grid = clamp_grid(R, num_cu() * per_cu * 2);
     spb_records none = {};
     const spb_records rec = out != nullptr ? *out : none;
-    const int cap = T.markers_wg_per_cu > 0 ? T.markers_wg_per_cu : 8;
-#define MKB_CASE(n) case n: if (out != nullptr) launch_build_markers<n, true>(cap, s, tb, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, n_fallback, maxd, rec); \
-                            else launch_build_markers<n, false>(cap, s, tb, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, n_fallback, maxd, rec); break;
+#define SPB_LAUNCH(n, p) do { if (out != nullptr) hipLaunchKernelGGL((build_sparse_kernel<n, p, true>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), maxd, rec); \
+                          else hipLaunchKernelGGL((build_sparse_kernel<n, p, false>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), maxd, rec); } while (0)
+#define SPB_CASE(n) case n: if (passes == 1) { if constexpr (n <= 7) SPB_LAUNCH(n, 1); else return fail(-1, "%s: one pass covers H <= 3584", who); } else if (passes == 2) SPB_LAUNCH(n, 2); else SPB_LAUNCH(n, 4); break;
     switch (nch) {
-        MKB_CASE(1) MKB_CASE(2) MKB_CASE(3) MKB_CASE(4) MKB_CASE(5) MKB_CASE(6) MKB_CASE(7) MKB_CASE(8)
-        MKB_CASE(9) MKB_CASE(10) MKB_CASE(11) MKB_CASE(12) MKB_CASE(13) MKB_CASE(14) MKB_CASE(15) MKB_CASE(16)
+        SPB_CASE(1) SPB_CASE(2) SPB_CASE(3) SPB_CASE(4) SPB_CASE(5) SPB_CASE(6) SPB_CASE(7) SPB_CASE(8)
+        SPB_CASE(9) SPB_CASE(10) SPB_CASE(11) SPB_CASE(12) SPB_CASE(13) SPB_CASE(14) SPB_CASE(15) SPB_CASE(16)
         default: return fail(-1, "%s: H=%lld outside the kernel's range", who, H);
     }
-#undef MKB_CASE
+#undef SPB_CASE
+#undef SPB_LAUNCH
     HIP_TRY(hipGetLastError());
     return 0;
 }
 
-extern "C" int mxm_build_em_matrix_sparse(const mxm_markers *markers, const int64_t *row_ptr, const uint16_t *site,
-                                          const uint8_t *obs, const int64_t *order, int64_t R, int32_t H, int32_t S,
-                                          double *M, int64_t ldm, int64_t *fallback, int64_t *n_fallback, void *stream) {
+extern "C" int mxm_build_em_matrix_sparse(const uint8_t *maj, const double *lhit, const double *lmiss,
+                                          const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
+                                          const int64_t *row_ptr, const uint16_t *site, const uint8_t *obs,
+                                          const int64_t *order, int64_t R, int32_t H, int32_t S, double *M, int64_t ldm,
+                                          int64_t *fallback, int64_t *n_fallback, void *stream) {
     MXM_ENTER();
     if (M == nullptr) return fail(-1, "mxm_build_em_matrix_sparse: M required%s", "");
-    return build_sparse_impl("mxm_build_em_matrix_sparse", markers, row_ptr, site, obs, order, R, H, S, M, ldm, nullptr, fallback,
-                             n_fallback, (hipStream_t)stream);
+    return build_sparse_impl("mxm_build_em_matrix_sparse", maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs,
+                             order, R, H, S, M, ldm, nullptr, fallback, n_fallback, (hipStream_t)stream);
 }
 
 extern "C" size_t mxm_record_bytes(int64_t R, int32_t H) {
@@ -300,10 +282,12 @@ extern "C" size_t mxm_record_bytes(int64_t R, int32_t H) {
     return (size_t)(R > 0 ? R : 1) * ((size_t)coded_ld(H) + 16 * ENC_MAX_CODES);
 }
 
-extern "C" int mxm_build_em_records(const mxm_markers *markers, const int64_t *row_ptr, const uint16_t *site,
-                                    const uint8_t *obs, const int64_t *order, int64_t R, int32_t H, int32_t S, double *M,
-                                    int64_t ldm, uint8_t *rec, size_t rec_bytes, int64_t *rec_off, int32_t *ndist,
-                                    double *rowmax, int64_t *stats, int64_t *fallback, int64_t *n_fallback, void *stream) {
+extern "C" int mxm_build_em_records(const uint8_t *maj, const double *lhit, const double *lmiss,
+                                    const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
+                                    const int64_t *row_ptr, const uint16_t *site, const uint8_t *obs,
+                                    const int64_t *order, int64_t R, int32_t H, int32_t S, double *M, int64_t ldm,
+                                    uint8_t *rec, size_t rec_bytes, int64_t *rec_off, int32_t *ndist, double *rowmax,
+                                    int64_t *stats, int64_t *fallback, int64_t *n_fallback, void *stream) {
     MXM_ENTER();
     if (!mxm_linear_supported(H) || (H & 1))
         return fail(-1, "mxm_build_em_records: records need an even H in [66, 8192]%s (H=%lld)", "", H);
@@ -318,8 +302,8 @@ extern "C" int mxm_build_em_records(const mxm_markers *markers, const int64_t *r
     out.rowmax = rowmax;
     out.stats = reinterpret_cast<unsigned long long *>(stats);
     out.ldc = coded_ld(H);
-    return build_sparse_impl("mxm_build_em_records", markers, row_ptr, site, obs, order, R, H, S, M, ldm, &out, fallback,
-                             n_fallback, (hipStream_t)stream);
+    return build_sparse_impl("mxm_build_em_records", maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order,
+                             R, H, S, M, ldm, &out, fallback, n_fallback, (hipStream_t)stream);
 }
 
 template <typename ST>
@@ -380,10 +364,6 @@ extern "C" int mxm_set_batch_tile(int32_t bt) {
 
 extern "C" int mxm_diag_fused_force_abort(int32_t on) {
     return tune_set([on](mxm_tuning &t) { t.fused_force_abort = on ? 1 : 0; });
-}
-
-extern "C" int mxm_set_markers_wg_per_cu(int32_t n) {
-    return tune_set([n](mxm_tuning &t) { t.markers_wg_per_cu = n < 0 ? 0 : n; });
 }
 
 extern "C" int mxm_set_coded_batch(int32_t nb) {

@@ -62,8 +62,7 @@ class HapVarTables(object):
         self._lut = None
         self._lut_dev = None
         self._sparse = None
-        self._markers = None
-        self._markers_dev = None
+        self._sparse_dev = None
 
     @classmethod
     def build(cls, refseq, phylo, haplogroups, mut_wt=MUT_WT, mut_max=MUT_MAX):
@@ -139,76 +138,18 @@ class HapVarTables(object):
                             "mk_base": numpy.ascontiguousarray(exp[site_i, hap_i])}
         return self._sparse
 
-    HEAVY_FROM = 48      # deviating haplogroups from which a site's list becomes bitmaps (markers())
-
-    def markers(self, heavy_from=None):
-        """
-        The marker build's tables (include/mixemt_hip.h, mxm_markers), from sparse():
-          light sites   keep their (haplogroup, base) lists: mk_ptr[S+1], mk_hap[], mk_base[] (an empty range at a heavy site)
-          heavy sites   (more than `heavy_from` deviating haplogroups -- a whole clade; Build 17: 382 of 4070 sites hold
-                        87 000 of the 113 000 entries) get bitmaps over the haplogroups instead:
-                        heavy_id[S] (-1 / index), heavy_alt[n][4] (the bases deviating haplogroups expect there, [0] unused),
-                        heavy_bits[n][4][ldw] uint32: [0] = deviates at all, [a] = expects heavy_alt[a]
-        A row of synth-v1 reads then has ~230 list entries to scatter instead of ~1000, the rest are bit tests by the
-        lanes that own the haplogroups.  Any split gives the same matrix.
-        """
-        heavy_from = self.HEAVY_FROM if heavy_from is None else int(heavy_from)
-        cached = getattr(self, "_markers", None)
-        if cached is not None and cached[0] == heavy_from:
-            return cached[1]
-        sp = self.sparse()
-        n_sites, n_haps = len(self.sites), self.n_haps
-        lens = numpy.diff(sp["mk_ptr"])
-        heavy = numpy.flatnonzero(lens > heavy_from)
-        heavy_id = numpy.full(n_sites, -1, dtype=numpy.int32)
-        heavy_id[heavy] = numpy.arange(len(heavy), dtype=numpy.int32)
-        ldw = 16 * ((n_haps + 511) // 512)
-        alt = numpy.zeros((max(len(heavy), 1), 4), dtype=numpy.uint8)
-        bits = numpy.zeros((max(len(heavy), 1), 4, ldw * 32), dtype=bool)
-        site_of_entry = numpy.repeat(numpy.arange(n_sites), lens)
-        keep = heavy_id[site_of_entry] < 0
-        for k, s in enumerate(heavy):
-            a, b = int(sp["mk_ptr"][s]), int(sp["mk_ptr"][s + 1])
-            haps, bases = sp["mk_hap"][a:b].astype(numpy.int64), sp["mk_base"][a:b]
-            bits[k, 0, haps] = True
-            kinds = numpy.unique(bases)
-            if len(kinds) > 3:
-                # more than three deviating bases at one site (no such site in any shipped tree): leave it a list
-                heavy_id[s] = -1
-                keep[a:b] = True
-                bits[k] = False
-                continue
-            for i, base in enumerate(kinds):
-                alt[k, i + 1] = base
-                bits[k, i + 1, haps[bases == base]] = True
-        light_lens = numpy.where(heavy_id < 0, lens, 0)
-        mk_ptr = numpy.zeros(n_sites + 1, dtype=numpy.int32)
-        numpy.cumsum(light_lens, out=mk_ptr[1:])
-        words = numpy.packbits(bits.reshape(-1, 32)[:, ::-1], axis=1).view(">u4").astype(numpy.uint32).reshape(bits.shape[0], 4, ldw)
-        enc = {"maj": sp["maj"], "mk_ptr": mk_ptr, "mk_hap": numpy.ascontiguousarray(sp["mk_hap"][keep]),
-               "mk_base": numpy.ascontiguousarray(sp["mk_base"][keep]), "heavy_id": heavy_id, "heavy_alt": alt,
-               "heavy_bits": numpy.ascontiguousarray(words), "ldw": ldw, "n_heavy": int(len(heavy))}
-        self._markers = (heavy_from, enc)
-        self._markers_dev = None
-        return enc
-
     def sparse_device(self):
-        """Device copies of markers() (plus lhit / lmiss) and the mxm_markers struct over them, uploaded once:
-        {"struct": _lib.Markers, ...tensors (kept alive)...}."""
-        enc = self.markers()
-        if getattr(self, "_markers_dev", None) is None:
+        """Device copies of sparse() (plus lhit / lmiss), uploaded once."""
+        if self._sparse_dev is None:
             dev = require_gpu()
+            enc = self.sparse()
             _, lhit_d, lmiss_d = self.device()
-            ten = {key: torch.from_numpy(val).to(dev) for key, val in enc.items() if isinstance(val, numpy.ndarray)}
-            if ten["mk_hap"].numel() == 0:                               # keep the pointers valid
-                ten["mk_hap"] = torch.zeros(1, dtype=torch.uint16, device=dev)
-                ten["mk_base"] = torch.zeros(1, dtype=torch.uint8, device=dev)
-            ten["lhit"], ten["lmiss"] = lhit_d, lmiss_d
-            ten["struct"] = _lib.Markers(ten["maj"].data_ptr(), lhit_d.data_ptr(), lmiss_d.data_ptr(), ten["mk_ptr"].data_ptr(),
-                                         ten["mk_hap"].data_ptr(), ten["mk_base"].data_ptr(), ten["heavy_id"].data_ptr(),
-                                         ten["heavy_alt"].data_ptr(), ten["heavy_bits"].data_ptr(), enc["ldw"], enc["n_heavy"])
-            self._markers_dev = ten
-        return self._markers_dev
+            self._sparse_dev = {key: torch.from_numpy(val).to(dev) for key, val in enc.items()}
+            if self._sparse_dev["mk_hap"].numel() == 0:                  # keep the pointers valid
+                self._sparse_dev["mk_hap"] = torch.zeros(1, dtype=torch.uint16, device=dev)
+                self._sparse_dev["mk_base"] = torch.zeros(1, dtype=torch.uint8, device=dev)
+            self._sparse_dev["lhit"], self._sparse_dev["lmiss"] = lhit_d, lmiss_d
+        return self._sparse_dev
 
     def lut_device(self):
         """Device copies of lut() (plus lhit / lmiss), uploaded once; None if the tables do not qualify."""
@@ -352,9 +293,9 @@ def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto", 
             return out
         fallback = torch.empty(n_rows, dtype=torch.int64, device=dev)
         n_fallback = torch.zeros(1, dtype=torch.int64, device=dev)
-        import ctypes
         _lib.check(lib.mxm_build_em_matrix_sparse(
-            ctypes.byref(enc["struct"]), row_ptr_d.data_ptr(), site_d.data_ptr(),
+            enc["maj"].data_ptr(), enc["lhit"].data_ptr(), enc["lmiss"].data_ptr(), enc["mk_ptr"].data_ptr(),
+            enc["mk_hap"].data_ptr(), enc["mk_base"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(),
             obs_d.data_ptr(), 0, n_rows, n_haps, len(tables.sites), out.data_ptr(), out.stride(0),
             fallback.data_ptr(), n_fallback.data_ptr(), current_stream()), "mxm_build_em_matrix_sparse")
         left = int(n_fallback.item())
@@ -546,9 +487,9 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False):
     stats = torch.zeros(2, dtype=torch.int64, device=dev)
     fallback = torch.empty(n_rows, dtype=torch.int64, device=dev)
     n_fallback = torch.zeros(1, dtype=torch.int64, device=dev)
-    import ctypes
     _lib.check(lib.mxm_build_em_records(
-        ctypes.byref(enc["struct"]), row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(),
+        enc["maj"].data_ptr(), enc["lhit"].data_ptr(), enc["lmiss"].data_ptr(), enc["mk_ptr"].data_ptr(),
+        enc["mk_hap"].data_ptr(), enc["mk_base"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(),
         0, n_rows, n_haps, n_sites, mat.data_ptr() if dense else 0, mat.stride(0) if dense else 0,
         rec.data_ptr(), cap, rec_off.data_ptr(), ndist.data_ptr(), rowmax.data_ptr(), stats.data_ptr(),
         fallback.data_ptr(), n_fallback.data_ptr(), current_stream()), "mxm_build_em_records")

@@ -283,35 +283,3 @@ def test_bench_quotes_counter_traffic_of_the_kernel_it_ran(tmp_path):
                        "_workload": {"rows_per_gpu": 10 ** 6, "haps": 5408, "storage": storage}}, fout)
     val, path = bench.pmc_traffic(10 ** 6, 5408, "f64", name, algo, root=str(tmp_path))
     assert val == 1.02 * algo and path == os.path.join("profiles", "r07", "pmc_traffic_a.json")
-
-
-@pytest.mark.parametrize("heavy_from", [0, 48, 10 ** 6])
-def test_marker_tables_light_lists_and_heavy_bitmaps_are_the_dense_table(b17, heavy_from):
-    """HapVarTables.markers(): whatever the light / heavy split (every site a bitmap, the default, every site a
-    list), lists + bitmaps describe exactly the cells of the expected-base table that differ from the site's
-    majority base, and which base they hold."""
-    refseq, phy, haps, tables = b17
-    m = tables.markers(heavy_from)
-    exp = tables.expected[:, :tables.n_haps]
-    assert m["ldw"] >= 16 * ((tables.n_haps + 511) // 512)
-    n_heavy_sites = int((m["heavy_id"] >= 0).sum())
-    assert (n_heavy_sites == 0) == (heavy_from == 10 ** 6)
-    for s in range(0, len(tables.sites), 5):
-        dev = numpy.flatnonzero(exp[s] != m["maj"][s])
-        k = int(m["heavy_id"][s])
-        a, b = int(m["mk_ptr"][s]), int(m["mk_ptr"][s + 1])
-        if k < 0:
-            assert numpy.array_equal(m["mk_hap"][a:b], dev) and numpy.array_equal(m["mk_base"][a:b], exp[s][dev])
-            continue
-        assert a == b and len(dev) > heavy_from
-        words = m["heavy_bits"][k]
-        bits = ((words[:, :, None] >> numpy.arange(32, dtype=numpy.uint32)[None, None, :]) & 1).reshape(4, -1).astype(bool)
-        assert not bits[:, tables.n_haps:].any()
-        assert numpy.array_equal(numpy.flatnonzero(bits[0]), dev)
-        seen = numpy.zeros(tables.n_haps, dtype=bool)
-        for alt in (1, 2, 3):
-            base = int(m["heavy_alt"][k, alt])
-            want = (exp[s] == base) & (exp[s] != m["maj"][s]) if base else numpy.zeros(tables.n_haps, dtype=bool)
-            assert numpy.array_equal(bits[alt][:tables.n_haps], want)
-            seen |= want
-        assert numpy.array_equal(numpy.flatnonzero(seen), dev)         # every deviating haplogroup is in exactly one
