@@ -222,3 +222,19 @@ def test_g9_matrix_bits_from_the_c_oracle(b17):
                                    len(haps))
     assert _sha(mat) == str(g["mat_sha256"])
     assert numpy.array_equal(mat.sum(axis=1), g["mat_row_sum"])
+
+
+def test_g10_oracle_build_equals_the_reference_matrix_at_20000_rows(b17):
+    """g10 (reference run at 20 000 x 5408): the C restatement of build_em_matrix gives the reference's bits on every
+    one of its 1.08e8 cells (sha256), from the generator's seed (its CSR digest is pinned too)."""
+    import hashlib
+    from mixemt_amd import synth
+    from oracle import c_oracle
+    refseq, phy, haps, tables = b17
+    g = golden("g10_run_em_20k")
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), int(g["n_rows"]), seed=int(g["synth_seed"]))
+    sha = lambda a: hashlib.sha256(numpy.ascontiguousarray(a).tobytes()).hexdigest()
+    assert sha(row_ptr) + sha(site) + sha(obs) == str(g["csr_sha256"])
+    mat = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, row_ptr, site, obs, len(haps))
+    assert sha(mat) == str(g["mat_sha256"])
+    assert numpy.array_equal(mat.sum(axis=1), g["mat_row_sum"])
