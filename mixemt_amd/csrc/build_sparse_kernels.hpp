@@ -25,8 +25,11 @@
 // ------------------------------------------------------------------------------------------
 #define SPB_THREADS 256
 #define SPB_MAXN 64
-#define SPB_SLOTS 1024                // hash slots for the row's distinct non-zero masks (8 bytes of LDS each)
-#define SPB_MAXD 704                  // ... of which at most this many may fill up (load factor < 0.7); beyond: fallback
+#ifndef SPB_SLOTS
+#define SPB_SLOTS 512                 // hash slots for the row's distinct non-zero masks (8 bytes of LDS each)
+#endif
+#define SPB_MAXD (SPB_SLOTS * 11 / 16) // ... of which at most this many may fill up (load factor < 0.7); beyond: fallback
+                                      // (rows of up to 64 observations: median 25 distinct values, 0.2 % above 256, 0.17 % above 352)
 #ifndef SPB_GATHER
 #define SPB_GATHER 4                  // marker entries a thread has in flight during the scatter (2 / 4 / 8: 16.4 / 16.5 / 17.2 ms)
 #endif
@@ -50,8 +53,11 @@ struct spb_records {
 
 // (the record variant asks for 4 waves per SIMD: its exponentials would otherwise take 164 VGPRs and the fourth row
 // per CU -- 21.9 against 15 ms; the dense variant gets there by itself, and ran 5 % slower with the hint)
+#ifndef SPB_WAVES
+#define SPB_WAVES 6                   // waves per SIMD the dense variant is compiled for (80 VGPRs, 100 bytes of scratch): with three
+#endif                                // column ranges and a 512-slot table 6 rows fit a CU (round 2: 4) -- 13.7 against 14.7 ms
 template <int NCH, int PASSES, bool EMIT>
-__global__ __launch_bounds__(SPB_THREADS, (EMIT ? 4 : 1)) void build_sparse_kernel(
+__global__ __launch_bounds__(SPB_THREADS, (EMIT ? 4 : SPB_WAVES)) void build_sparse_kernel(
     const uint8_t *__restrict__ maj, const double *__restrict__ lhit, const double *__restrict__ lmiss,
     const int32_t *__restrict__ mk_ptr, const uint16_t *__restrict__ mk_hap, const uint8_t *__restrict__ mk_base,
     const int64_t *__restrict__ row_ptr, const uint16_t *__restrict__ site, const uint8_t *__restrict__ obs,

@@ -242,10 +242,16 @@ static int build_sparse_impl(const char *who, const uint8_t *maj, const double *
     const int hpad = (H + 1) & ~1;
     const int nch = (hpad / 2 + SPB_THREADS - 1) / SPB_THREADS;
     const int vec_ok = (M != nullptr) && ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M) & 15) == 0);
-    const int passes = 2;          // column ranges per row (measured: 1 / 2 / 4 ranges 22.5 / 16.4 / 21.3 ms at 10^6 x 5408)
+#ifndef SPB_PASSES
+#define SPB_PASSES 3
+#endif
+    // column ranges per row: the mask array is 1 / passes of a row, which (with the table) decides how many rows a CU holds;
+    // every range walks the marker lists again.  10^6 x 5408, kernel alone: 2 ranges 14.7 ms (4-5 rows per CU), 3 ranges 13.7 ms
+    // (6 rows), 4 ranges 14.7-17.4 ms (profiles/r03/build_kernel_experiments.txt)
+    const int passes = SPB_PASSES;
     const int maxd = (T.sparse_maxd < 0 || T.sparse_maxd > SPB_MAXD) ? SPB_MAXD : T.sparse_maxd;
     const int kpp = (nch + passes - 1) / passes;
-    const size_t lds = (size_t)kpp * 2 * SPB_THREADS * 8 + 14 * 1024;      // mask array + the kernel's other LDS
+    const size_t lds = (size_t)kpp * 2 * SPB_THREADS * 8 + SPB_SLOTS * 8 + 6 * 1024;      // mask array + table + the kernel's other LDS
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
@@ -254,7 +260,7 @@ static int build_sparse_impl(const char *who, const uint8_t *maj, const double *
     const spb_records rec = out != nullptr ? *out : none;
 #define SPB_LAUNCH(n, p) do { if (out != nullptr) hipLaunchKernelGGL((build_sparse_kernel<n, p, true>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), maxd, rec); \
                           else hipLaunchKernelGGL((build_sparse_kernel<n, p, false>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), maxd, rec); } while (0)
-#define SPB_CASE(n) case n: if (passes == 1) { if constexpr (n <= 7) SPB_LAUNCH(n, 1); else return fail(-1, "%s: one pass covers H <= 3584", who); } else if (passes == 2) SPB_LAUNCH(n, 2); else SPB_LAUNCH(n, 4); break;
+#define SPB_CASE(n) case n: if (passes == 1) { if constexpr (n <= 7) SPB_LAUNCH(n, 1); else return fail(-1, "%s: one pass covers H <= 3584", who); } else if (passes == 2) SPB_LAUNCH(n, 2); else if (passes == 3) SPB_LAUNCH(n, 3); else SPB_LAUNCH(n, 4); break;
     switch (nch) {
         SPB_CASE(1) SPB_CASE(2) SPB_CASE(3) SPB_CASE(4) SPB_CASE(5) SPB_CASE(6) SPB_CASE(7) SPB_CASE(8)
         SPB_CASE(9) SPB_CASE(10) SPB_CASE(11) SPB_CASE(12) SPB_CASE(13) SPB_CASE(14) SPB_CASE(15) SPB_CASE(16)

@@ -191,7 +191,7 @@ def run_em_sharded(local_mat, local_weights, args, inits=None, group=None, want_
     """
     n_multi = int(args.n_multi)
     plan = _em.EmPlan(local_mat, local_weights, n_runs=n_multi,
-                      storage=storage or getattr(args, "storage", "f64"), records=records)
+                      storage=storage or getattr(args, "storage", "auto"), records=records)
     if inits is None:
         inits = broadcast_inits(n_multi, plan.n_haps, args.init_alpha, plan.dev, group)
     inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)

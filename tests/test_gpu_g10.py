@@ -71,7 +71,7 @@ def test_dense_per_iteration_kernels_reproduce_the_reference_run(g10):
     from mixemt_amd import assign, em
     g = g10["g"]
     numpy.random.seed(23)
-    res = em.run_em_ex(g10["mat"], g10["wts"], em_args())
+    res = em.run_em_ex(g10["mat"], g10["wts"], em_args(), storage="f64")
     assert res["storage"] == "f64"
     _check(res, g, mix=res["read_mix"])
     best, votes = assign.row_argmax_votes(res["read_mix"], g10["wts"])
@@ -82,7 +82,7 @@ def test_storage_auto_takes_the_row_dictionaries_and_reproduces_it(g10):
     from mixemt_amd import em
     g = g10["g"]
     numpy.random.seed(23)
-    res = em.run_em_ex(g10["mat"], g10["wts"], em_args(), storage="auto")
+    res = em.run_em_ex(g10["mat"], g10["wts"], em_args())            # the default
     assert res["storage"] == "coded"                                 # 1.08e8 cells > 5e7: the coded branch
     _check(res, g, mix=res["read_mix"])
 

@@ -6,7 +6,11 @@ synthetic reads, device-resident end to end:
     CSR observations -> build_em_matrix_device -> run_em -> contributors from read votes
     -> refinement EM on the contributor columns -> read assignment -> contributor table
 
-    python tools/run_pipeline.py [--reads N] [--seed S] [--multi M] [--storage f64|coded] [--records]
+    python tools/run_pipeline.py [--reads N] [--seed S] [--multi M] [--dense [--storage f64|f32|coded|auto]]
+
+Default (round 3): the build leaves the matrix as row-dictionary records -- no dense matrix, no posterior matrix; the
+contributors, the vote table and the reduced matrix for the refinement come from the records.  --dense takes the
+reference's own data flow (dense matrix -> run_em -> posterior matrix -> votes) on the device.
 """
 import argparse
 import os
@@ -26,12 +30,14 @@ def main():
     ap.add_argument("--reads", type=int, default=20000)
     ap.add_argument("--seed", type=int, default=7)
     ap.add_argument("--multi", type=int, default=1)
-    ap.add_argument("--records", action="store_true",
-                    help="the build leaves the matrix as row-dictionary records and NO dense matrix or posterior is "
-                         "ever made: contributors, vote table and the reduced matrix come from the records")
-    ap.add_argument("--storage", default="f64", choices=["f64", "f32", "coded", "auto"],
-                    help="form of the matrix the EM loop streams (EmPlan): coded = lossless row dictionaries")
+    ap.add_argument("--dense", action="store_true",
+                    help="build the dense matrix and the posterior matrix (the reference's data flow); default: records only")
+    ap.add_argument("--records", action="store_true", help="(the default since round 3; kept for old command lines)")
+    ap.add_argument("--storage", default="auto", choices=["f64", "f32", "coded", "auto"],
+                    help="with --dense: form of the matrix the EM loop streams (EmPlan): coded = lossless row dictionaries, "
+                         "auto = coded from 5e7 cells on")
     opts = ap.parse_args()
+    opts.records = not opts.dense
     args = argparse.Namespace(init_alpha=1.0, tolerance=1e-4, max_iter=10000, n_multi=opts.multi,
                               verbose=True, min_reads=10, min_fold=2.0, storage=opts.storage)
     numpy.random.seed(opts.seed)                       # bin/mixemt:507-508
