@@ -507,6 +507,7 @@ def bench_rows(opts, env):
         return sts
 
     batched = n_runs > 1
+    issue_s = None
     if batched:
         if opts.warmup > 0:
             run_loop(opts.warmup)
@@ -522,6 +523,7 @@ def bench_rows(opts, env):
         t0 = time.perf_counter()
         for i in range(opts.steps):
             step(evs[i])
+        issue_s = time.perf_counter() - t0           # the host has ENQUEUED every step by now (nothing waited for yet)
         fence()
         elapsed = time.perf_counter() - t0
     if use_dist:
@@ -689,6 +691,9 @@ def bench_rows(opts, env):
         "kernel_ms_per_rank": kernel_ms_per_rank,
         # what a step spends outside the streaming kernel and the exchange on the slowest rank: column reduce, finalize,
         # launch gaps, host (one restart per step only: with several the passes of a step are not one kernel)
+        # host time to enqueue one step (library calls + the collective's launch): while it stays well below ms_per_step the
+        # host runs ahead of the GPU and is not what a step waits for (no graph capture needed at this step size)
+        "host_issue_us_per_step": None if issue_s is None else issue_s / opts.steps * 1e6,
         "step_remainder_us": (None if batched else
                               (elapsed / opts.steps * 1e3 - max(kernel_ms_per_rank)) * 1e3
                               - (max(all_reduce_us_per_rank) if all_reduce_us_per_rank else 0.0)),

@@ -111,7 +111,7 @@ int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const double *lhi
  * A haplogroup's cell is decided by the set of the row's sites where its term differs from the
  * majority's (a 64-bit mask OR-ed together from the marker lists); the row's distinct masks are
  * deduplicated and each one's sum is formed in signature order from 0.0, as prob_for_vars does
- * (preprocess.py:86-96).  Rows with more than 64 observations (or more than 704 distinct values) are NOT
+ * (preprocess.py:86-96).  Rows with more than 64 observations (or more than 352 distinct values) are NOT
  * written: their indices are appended to fallback[] (device int64[R], *n_fallback = how many, device) and
  * the caller builds them with mxm_build_em_matrix_lut (order = fallback, R = *n_fallback; any order of the list).
  */
@@ -128,7 +128,7 @@ int mxm_build_em_matrix_sparse(const uint8_t *maj, const double *lhit, const dou
  *     record = codes[ldc] ++ P table[ndist] ++ table of the log sums themselves [ndist]
  * (P = exp(sum - rowmax[r]); code 0 = the value of a haplogroup without a deviating marker in the window).
  * Rows that get no record have ndist[r] = 0: with M given, rows of more than 256 distinct values (their dense
- * row is written); rows on the fallback list (more than 64 observations, more than 704 distinct masks, and --
+ * row is written); rows on the fallback list (more than 64 observations, more than 352 distinct masks, and --
  * when M is NULL -- more than 256 values), which the caller builds densely.  stats[0] = bytes used,
  * stats[1] = rows without a record (device int64[2]); rec_bytes >= mxm_record_bytes(R, H) never overflows.
  */

@@ -116,11 +116,6 @@ int mxm_set_compact_restarts(int32_t mode);
 /* Tuning knob: rows a workgroup of the streaming kernel handles at least (grid = min(cap, R / n)). */
 int mxm_set_min_rows_per_wg(int32_t n);
 
-/* Tuning knob: restarts that share one pass of the row-dictionary streaming kernel (1 or 2; default 2: the pass is
- * bound by its LDS lookups, which two restarts share).  Same results up to nothing: each restart's sums are
- * formed in the single kernel's order. */
-int mxm_set_coded_batch(int32_t nb);
-
 /* Test knob: distinct non-zero masks a row of the marker build kernel may have before it goes to the
  * fallback list (negative = the kernel's own limit, the default); lowering it drives ordinary rows through the fallback path. */
 int mxm_set_sparse_max_distinct(int32_t n);

@@ -91,7 +91,6 @@ SIGNATURES = {
     "mxm_set_loop_fused": (ctypes.c_int, [c_i32, c_i32]),
     "mxm_set_progress_callback": (ctypes.c_int, [c_ptr, c_ptr, c_i32]),
     "mxm_set_min_rows_per_wg": (ctypes.c_int, [c_i32]),
-    "mxm_set_coded_batch": (ctypes.c_int, [c_i32]),
     "mxm_reset_tuning": (ctypes.c_int, []),
     "mxm_describe_stream_kernel": (ctypes.c_int, [c_i32, c_i32, ctypes.c_char_p, c_size]),
     "mxm_set_sparse_max_distinct": (ctypes.c_int, [c_i32]),

@@ -72,7 +72,6 @@ struct mxm_tuning {
     int loop_fused = -1;            // -1 auto (by size), 0 never, 1 whenever the shape allows
     int fused_chunk = 0;            // iterations per launch of the one-launch loop (0 = run to the end)
     int fused_cols = 1;             // matrices of up to 1536 rows take the transposed form (columns split)
-    int coded_batch = 2;            // restarts per pass of the row-dictionary kernel (1 or 2)
     int fused_force_abort = 0;      // test hook: the one-launch loop starts with its abort flag raised (as if starved)
     double fused_cells = 1.0e8;     // ~18 000 rows at H = 5408: measured break-even is ~30 000 rows (profiles/r02/small_runs.txt)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;     // timing hook around the dominant kernel
@@ -370,11 +369,6 @@ extern "C" int mxm_set_batch_tile(int32_t bt) {
 
 extern "C" int mxm_diag_fused_force_abort(int32_t on) {
     return tune_set([on](mxm_tuning &t) { t.fused_force_abort = on ? 1 : 0; });
-}
-
-extern "C" int mxm_set_coded_batch(int32_t nb) {
-    if (nb < 1 || nb > 2) return fail(-1, "mxm_set_coded_batch: 1 or 2 restarts per pass%s", "");
-    return tune_set([nb](mxm_tuning &t) { t.coded_batch = nb; });
 }
 
 // ---- wide-kernel dispatch over NCH ------------------------------------------------------------

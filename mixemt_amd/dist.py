@@ -80,7 +80,7 @@ def broadcast_inits(n_runs, n_haps, alpha, device, group=None, src=0):
 
 
 def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8, compact=True,
-                    window=None, verify=True):
+                    window=None, verify=True, graph=False):
     """
     The EM loop over a row-sharded matrix.  `plan` is the rank-local EmPlan (or
     any object with its em_iter / finalize / alloc / read_state surface -- the
@@ -100,6 +100,13 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     verify: at every state check the ranks compare (done, iters) of all restarts
     (two tiny all-reduces, MIN and MAX) and fail loudly if they ever disagree --
     the loop's correctness rests on bit-identical all-reduce results on all ranks.
+    graph (opt-in): replay each burst of `check_every` iterations -- streaming kernel, column reduce, all-reduce,
+    finalize -- from ONE captured hipGraph instead of enqueueing 4 x check_every operations from Python, for shards so
+    small that the host would otherwise be what a step waits for (bench.py reports host_issue_us_per_step: ~60 us
+    against 0.85 ms at 125 000 rows per GPU, so the default path does not need it).  The first burst always runs
+    eagerly; a burst whose set of iterating restarts changed is re-captured; whenever capture is not possible (gloo,
+    CPU tensors, a backend that refuses collectives under capture) the loop silently stays eager.  Results are
+    bit-identical either way (same kernels, same order).
     """
     exchange = _collective(group)
     ln0, p0 = _em.log_inits(inits)
@@ -118,6 +125,8 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     if max_iter <= 0:
         return ln_cur, ln_new, states
     first = True
+    captured = None                                    # None: nothing captured yet; False: capture refused; (lead, graph)
+    graph_bursts = 0
     # The loop ends when `finalize` has marked every restart done (converged, or at its own max_iter).  A plan whose
     # finalize never does that must not spin for ever: a restart needs at most ceil(max_iter / check_every) bursts, and
     # at most ceil(n_runs / window) groups of restarts take turns.
@@ -147,13 +156,33 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
                     vec.copy_(vec[idx])
                 slot_run = [slot_run[s] for s in order]
                 states = [states[s] for s in order]
+        def burst():
+            for _ in range(check_every):
+                plan.em_iter(props_cur[:lead], ln_cur[:lead], state[:lead], colsum[:lead])
+                if exchange:
+                    dist.all_reduce(colsum[:lead], op=dist.ReduceOp.SUM, group=group)
+                plan.finalize(colsum[:lead], ln_cur[:lead], ln_new[:lead], props_cur[:lead], state[:lead],
+                              tolerance, max_iter)
+
+        use_graph = (graph and not first and captured is not False and props_cur.is_cuda
+                     and (not exchange or dist.get_backend(group) == "nccl"))
+        if use_graph and (captured is None or captured[0] != lead):
+            # (re)capture: the burst's launches are recorded, not run; a failure leaves the loop eager for good
+            try:
+                torch.cuda.synchronize()
+                cg = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(cg, capture_error_mode="thread_local"):
+                    burst()
+                captured = (lead, cg)
+            except Exception:                         # noqa: BLE001 -- any refusal means "not capturable here"
+                captured = False
+                torch.cuda.synchronize()
         first = False
-        for _ in range(check_every):
-            plan.em_iter(props_cur[:lead], ln_cur[:lead], state[:lead], colsum[:lead])
-            if exchange:
-                dist.all_reduce(colsum[:lead], op=dist.ReduceOp.SUM, group=group)
-            plan.finalize(colsum[:lead], ln_cur[:lead], ln_new[:lead], props_cur[:lead], state[:lead],
-                          tolerance, max_iter)
+        if use_graph and captured:
+            captured[1].replay()
+            graph_bursts += 1
+        else:
+            burst()
         states = plan.read_state(state)
         if exchange and verify:
             _assert_ranks_agree(states, props_cur.device, group)
@@ -165,7 +194,11 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
         for vec in vectors:
             vec.copy_(vec[idx])
         states = [states[s] for s in back]
+    sharded_em_loop.last_graph_bursts = graph_bursts
     return ln_cur, ln_new, states
+
+
+sharded_em_loop.last_graph_bursts = 0        # bursts the last call replayed from a captured graph (diagnostic)
 
 
 def _assert_ranks_agree(states, device, group):

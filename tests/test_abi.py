@@ -74,7 +74,6 @@ def test_tuning_knobs_reset_and_take_their_ranges(lib_path):
     lib = _lib.load()
     assert lib.mxm_set_batch_tile(7) < 0 and lib.mxm_set_batch_tile(2) == 0
     assert lib.mxm_restart_tile(5408) == 2
-    assert lib.mxm_set_coded_batch(3) < 0 and lib.mxm_set_coded_batch(1) == 0
     assert lib.mxm_reset_tuning() == 0
     assert lib.mxm_restart_tile(5408) == 4
     buf = ctypes.create_string_buffer(96)

@@ -62,10 +62,8 @@ def test_encoded_rows_decode_to_the_linearised_matrix_bit_for_bit(b17, name):
     assert coded.coded_bytes < 0.25 * mat.size * 8    # ~8x smaller on these matrices
 
 
-@pytest.mark.parametrize("batch", [1, 2])
-def test_one_iteration_equals_the_dense_pass(b17, batch):
-    """Same proportions in -> same column sums out (summation order differs: 1e-13 relative), one and two
-    restarts per pass of the row-dictionary kernel."""
+def test_one_iteration_equals_the_dense_pass(b17):
+    """Same proportions in -> same column sums out (summation order differs: 1e-13 relative), three restarts."""
     import torch
     from mixemt_amd import em
     refseq, phy, haps, tables = b17
@@ -73,14 +71,13 @@ def test_one_iteration_equals_the_dense_pass(b17, batch):
     mat = _b17_matrix(tables, g, len(haps))
     dense = em.EmPlan(mat, g["wts"])
     coded = em.EmPlan(mat, g["wts"], storage="coded")
-    rng = numpy.random.default_rng(batch)
+    rng = numpy.random.default_rng(1)
     init = rng.dirichlet([1.0] * len(haps), size=3)
     props = torch.from_numpy(init).to(dense.dev)
     lnp = torch.log(props)
     state = em.new_state(3, dense.dev)
     a, b = torch.zeros_like(props), torch.zeros_like(props)
     dense.em_iter(props, lnp, state, a)
-    assert coded.lib.mxm_set_coded_batch(batch) == 0      # (conftest resets every knob after the test)
     coded.em_iter(props, lnp, state, b)
     assert float(((a - b).abs() / a.abs()).max()) < 1e-12
     # and against the oracle's M-step: sum_r w_r posterior = p_h T_h

@@ -334,3 +334,56 @@ def _worker_multi_gpu(rank, world, port, out_dir, mode):
                     best=mix.argmax(axis=1), lo=lo, hi=hi, rowmax=mix.max(axis=1))
     finally:
         dist.destroy_process_group()
+
+
+def _graph_worker(rank, port, out_path):
+    import sys
+    here = os.path.dirname(os.path.abspath(__file__))
+    sys.path.insert(0, here)
+    sys.path.insert(0, os.path.dirname(here))
+    import torch
+    import torch.distributed as dist
+    from mixemt_amd import dist as mdist, em, phylotree, preprocess
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    torch.cuda.set_device(0)
+    g = numpy.load(os.path.join(here, "golden", "g5_run_em_multi.npz"))
+    refseq = phylotree.load_rsrs()
+    phy = phylotree.load_build17(refseq)
+    tables = preprocess.HapVarTables.build(refseq, phy, sorted(phy.hap_var))
+    mat = preprocess.build_em_matrix_device(tables, g["row_ptr"], g["site"], g["obs"])
+    plan = em.EmPlan(mat, torch.from_numpy(g["wts"]).cuda(), n_runs=3)
+    out = {}
+    # no process group: the burst is kernels only
+    eager = mdist.sharded_em_loop(plan, g["inits"], 1e-4, 10000, check_every=8)
+    graphed = mdist.sharded_em_loop(plan, g["inits"], 1e-4, 10000, check_every=8, graph=True)
+    out["local_bursts"] = mdist.sharded_em_loop.last_graph_bursts
+    out["local_equal"] = int(torch.equal(eager[1], graphed[1]) and eager[2] == graphed[2])
+    # one-rank RCCL group: the all-reduce is inside the captured burst (if the backend allows it)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+    try:
+        with_group = mdist.sharded_em_loop(plan, g["inits"], 1e-4, 10000, check_every=8, graph=True)
+        out["rccl_bursts"] = mdist.sharded_em_loop.last_graph_bursts
+        out["rccl_equal"] = int(torch.equal(eager[1], with_group[1]) and eager[2] == with_group[2])
+        out["iters"] = numpy.array([s[1] for s in with_group[2]])
+    finally:
+        dist.destroy_process_group()
+    numpy.savez(out_path, **out)
+
+
+def test_sharded_loop_bursts_replayed_from_a_captured_graph(tmp_path):
+    """sharded_em_loop(graph=True): bursts of iterations replayed from one captured hipGraph -- bit-identical to the
+    eager loop (g5, three restarts stopping on different iterations: the graph is re-captured when the set of running
+    restarts changes); with a process group the RCCL all-reduce sits inside the capture where the backend allows it,
+    and the loop stays eager (same results) where it does not."""
+    import torch
+    import torch.multiprocessing as mp
+    torch.cuda.empty_cache()
+    out_path = str(tmp_path / "graph.npz")
+    mp.spawn(_graph_worker, args=(_free_port(), out_path), nprocs=1, join=True)
+    r = numpy.load(out_path)
+    g = golden("g5_run_em_multi")
+    assert int(r["local_equal"]) == 1 and int(r["local_bursts"]) > 10          # really replayed, really identical
+    assert int(r["rccl_equal"]) == 1 and list(r["iters"]) == list(g["iters"])
+    print("bursts replayed with the RCCL all-reduce inside the graph: %d" % int(r["rccl_bursts"]))

@@ -590,3 +590,60 @@ def test_verbose_progress_text_is_the_references(capsys, fused):
     assert res["iters"] == [n]
     assert capsys.readouterr().err == "Starting EM run 1...\n" + "." * (n // 10) + "\nConverged! (%d)\n" % n
     assert numpy.abs(res["props"] - g["props"]).max() < PROPS_ATOL
+
+
+def test_two_host_threads_on_two_streams_while_a_third_turns_the_knobs(b17):
+    """
+    VERDICT r2 #9: the library's tuning state is process-wide but guarded -- setters lock, every entry point works on
+    the snapshot it took when it started.  Two host threads run EM (one-launch loop and per-iteration kernels,
+    each on a stream of its own) while a third keeps changing knobs: every run ends on the reference's iteration
+    with the reference's proportions (goldens g4 and g9), and nothing deadlocks.
+    """
+    import threading
+    import torch
+    from mixemt_amd import _lib, em
+    refseq, phy, haps, tables = b17
+    lib = _lib.load()
+    jobs = []
+    for name, seed in (("g4_run_em", 7), ("g9_run_em_2400", 17)):
+        g = golden(name)
+        mat = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, g["row_ptr"], g["site"], g["obs"], len(haps))
+        jobs.append((g, torch.from_numpy(mat).cuda(), torch.from_numpy(g["wts"].astype(numpy.float64)).cuda()))
+    torch.cuda.synchronize()
+    out, errors, stop = {}, [], threading.Event()
+
+    def worker(k):
+        try:
+            g, mat, wts = jobs[k]
+            with torch.cuda.stream(torch.cuda.Stream()):
+                for rep in range(3):
+                    res = em.run_em_ex(mat, wts, em_args(), inits=g["inits"], want_read_mix=False)
+                    out[(k, rep)] = (res["iters"], res["props"])
+        except Exception as exc:                      # pragma: no cover
+            errors.append(repr(exc))
+
+    def fiddler():
+        i = 0
+        while not stop.is_set():
+            lib.mxm_set_batch_tile(1 + i % 4)
+            lib.mxm_set_compact_restarts(i % 3)
+            lib.mxm_set_loop_graph(i % 2)
+            lib.mxm_set_min_rows_per_wg(1 + i % 8)
+            i += 1
+        lib.mxm_reset_tuning()
+
+    threads = [threading.Thread(target=worker, args=(k,)) for k in (0, 1)] + [threading.Thread(target=fiddler)]
+    for th in threads:
+        th.start()
+    for th in threads[:2]:
+        th.join(timeout=300)
+    stop.set()
+    threads[2].join(timeout=30)
+    assert not errors, errors
+    assert not any(th.is_alive() for th in threads)
+    for k in (0, 1):
+        g = jobs[k][0]
+        for rep in range(3):
+            iters, props = out[(k, rep)]
+            assert iters == list(g["iters"])
+            assert numpy.abs(props - g["props"]).max() < 1e-9

@@ -104,10 +104,6 @@ def coded_iter():
 
 
 t_dense = timed(dense_iter)
-for nb in (1, 2):
-    lib.mxm_set_coded_batch(nb)
-    print("  restarts per pass %d: %.3f ms for ONE restart" % (nb, timed(coded_iter) * 1e3))
-lib.mxm_reset_tuning()
 t_coded = timed(coded_iter)
 rel = ((cs_coded - cs_dense).abs() / cs_dense.abs().clamp_min(1e-300)).max().item()
 print("one EM iteration (pass + column reduce): dense fp64 %.3f ms, row dictionaries %.3f ms (x%.2f); "
