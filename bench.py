@@ -679,6 +679,7 @@ def bench_rows(opts, env):
                      "traffic_source": traffic[1] if traffic else None,
                      "kernel": kernel_name,
                      "kernel_ms": float(kernel_ms.mean()),
+                     "kernel_ms_min": float(kernel_ms.min()), "kernel_ms_max": float(kernel_ms.max()),
                      "algorithmic_bytes_per_launch": algo_bytes},
         "cpu_baseline": cpu,
         "parity_in_run": parity,

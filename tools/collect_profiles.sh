@@ -2,17 +2,17 @@
 # Copy the summaries of a tools/profile_round.sh run from gpurun_out/<round>/ (scratch) into
 # profiles/<round>/ (tracked).  usage: bash tools/collect_profiles.sh r02
 set -u
-round=${1:-r02}
+round=${1:-r03}
 src=gpurun_out/$round
 dst=profiles/$round
 mkdir -p $dst
 for f in bench_1m.json bench_1m_under_rocprof.json bench_1m_10restarts.json bench_100k.json \
          bench_restarts10_run.json bench_restarts16_run.json pmc_traffic_1m.json pmc_traffic_build_1m.json \
          pmc_sq_summary.txt small_runs.txt small_runs_under_rocprof.txt build_kernels.txt build_under_rocprof.txt \
-         restart_schedules.txt dropin_build.txt lut_variants.txt barrier_variants.txt \
+         restart_schedules.txt dropin_build.txt build_kernel_alone.txt \
          bench_1m_coded.json bench_1m_coded_under_rocprof.json bench_1m_coded_10restarts.json \
          bench_125k_coded_one_rank_rccl.json bench_125k_one_rank_rccl.json bench_1250k_per_gpu.json \
-         pmc_traffic_coded_1m.json coded_pmc_sq_summary.txt coded_shapes.txt pipeline_1m.txt pipeline_1m_coded.txt \
+         pmc_traffic_coded_1m.json coded_pmc_sq_summary.txt coded_storage_1m.txt pipeline_1m.txt pipeline_1m_coded.txt \
          bench_1m_records.json bench_10m_records_one_gpu.json bench_10m_records_one_gpu.log \
          bench_125k_records_one_rank_rccl.json pipeline_1m_records.txt pipeline_10m_records_one_gpu.txt; do
   [ -f $src/$f ] && cp $src/$f $dst/$f
