@@ -51,6 +51,14 @@ def main():
     sys.stderr.write("Using %d variant sites from %d haplogroups; %d synthetic fragments (%.1f s)\n"
                      % (len(tables.sites), len(haps), opts.reads, time.perf_counter() - t0))
 
+    # one-time table set-up (the reference's HapVarBaseMatrix.__init__, preprocess.py:39-67): marker lists and lookup
+    # tables encoded on the host and uploaded; the first HIP call also loads the code object
+    t0 = time.perf_counter()
+    tables.sparse_device()
+    tables.lut_device()
+    torch.cuda.synchronize()
+    sys.stderr.write("haplogroup tables encoded and uploaded: %.1f ms\n" % ((time.perf_counter() - t0) * 1e3))
+
     t0 = time.perf_counter()
     wts = torch.ones(opts.reads, dtype=torch.float64, device="cuda")
     if opts.records:
