@@ -40,7 +40,7 @@ extern "C" {
  * ws / ws_bytes and mxm_set_compact_restarts became 0/1/2 inside that number -- the reason for this rule);
  * 300 round 3: mxm_build_em_matrix_packed / mxm_build_packed_lds_bytes removed, mxm_build_em_matrix_lut lost its
  * P / ldp / rowmax outputs, mxm_row_argmax_votes_coded replaces mxm_row_argmax_coded,
- * mxm_em_step_coded / mxm_gather_columns_coded cover the rows without a record, mxm_iter_graph_* added. */
+ * mxm_em_step_coded / mxm_gather_columns_coded cover the rows without a record. */
 #define MXM_VERSION 300
 
 /* per-restart loop state, written by mxm_m_finalize (16 bytes) */
