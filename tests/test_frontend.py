@@ -155,3 +155,56 @@ def test_build_em_input_equals_the_reference_run(b17, as_records, capsys):
     assert host.shape == (len(rows), len(hap_order))
     assert hashlib.sha256(numpy.ascontiguousarray(host).tobytes()).hexdigest() == str(g["mat_sha256"])
     assert numpy.array_equal(host[:3], g["mat_rows"])
+
+
+# ---- g12: the -s / -l files as the reference's own dump_all writes them and its load_prev reads them ----------------
+def _g12():
+    import json
+    from conftest import golden
+    g = golden("g12_io_formats")
+    return g, str(g["haps"]).split("\n"), json.loads(str(g["reads"]))
+
+
+def _files(prefix):
+    out = {}
+    for ext in ("haps", "reads", "em.npy", "mat.npy", "prop.npy"):
+        with open("%s.%s" % (prefix, ext), "rb") as fin:
+            out["file_" + ext.replace(".", "_")] = numpy.frombuffer(fin.read(), dtype=numpy.uint8)
+    return out
+
+
+def test_dump_all_writes_the_reference_bytes_and_load_prev_reads_them(tmp_path):
+    """bin/mixemt:168-245 run by the reference itself (tools/gen_golden.py, g12): our dump_all writes the same five
+    files byte for byte (numpy's .npy header included), our load_prev returns what the reference's returns from the
+    reference's files -- either tool can resume the other's run."""
+    g, haps, reads = _g12()
+    prefix = str(tmp_path / "ours")
+    mio.dump_all(prefix, haps, reads, g["em"], (g["props"], g["mix"]))
+    for key, mine in _files(prefix).items():
+        assert numpy.array_equal(mine, g[key]), key
+    ref_prefix = str(tmp_path / "theirs")
+    for key in ("haps", "reads", "em.npy", "mat.npy", "prop.npy"):
+        with open("%s.%s" % (ref_prefix, key), "wb") as fout:
+            fout.write(g["file_" + key.replace(".", "_")].tobytes())
+    import json
+    h2, r2, wts, init, (props, mat) = mio.load_prev(ref_prefix)
+    assert h2 == str(g["loaded_haps"]).split("\n") and r2 == json.loads(str(g["loaded_reads"]))
+    assert numpy.array_equal(wts, g["loaded_wts"]) and numpy.array_equal(init, g["loaded_init"])
+    assert numpy.array_equal(props, g["loaded_props"]) and numpy.array_equal(mat, g["loaded_mat"])
+
+
+@pytest.mark.gpu
+def test_dump_all_from_device_tensors_writes_the_reference_bytes(tmp_path):
+    """The same files streamed from matrices that live on the GPU (row slabs through a memory map): same bytes."""
+    import torch
+    g, haps, reads = _g12()
+    prefix = str(tmp_path / "dev")
+    old = mio.SLAB_BYTES
+    mio.SLAB_BYTES = 64                       # two rows per slab: the slab loop really loops
+    try:
+        mio.dump_all(prefix, haps, reads, torch.from_numpy(g["em"]).cuda(),
+                     (torch.from_numpy(g["props"]).cuda(), torch.from_numpy(g["mix"]).cuda()))
+    finally:
+        mio.SLAB_BYTES = old
+    for key, mine in _files(prefix).items():
+        assert numpy.array_equal(mine, g[key]), key

@@ -28,6 +28,8 @@ Fixtures (SURVEY.md section 8 c):
         (preprocess.py:99-139,163-174,201-227) on a few hundred synthetic alignments
         (tests/_fake_aln.py objects: mates, conflicting overlaps, low MQ / BQ, missing qualities,
         indels, soft clips, lower-case bases)
+    g12 on-disk formats: the bytes the reference's own dump_all writes (bin/mixemt:214-245) for a small run and what its
+        load_prev (bin/mixemt:168-211) reads back from them
 """
 
 import argparse
@@ -512,6 +514,37 @@ def main():
              read_ids=numpy.array(json.dumps(read_ids)), hap_sha256=numpy.array(
                  hashlib.sha256("\n".join(hap_order).encode()).hexdigest()),
              mat_sha256=numpy.array(sha(mat)), mat_row_sum=mat.sum(axis=1), mat_rows=mat[:3].copy())
+
+    if want("g12"):
+        # the -s / -l files, written and read back by the reference's own functions (bin/mixemt is a script: loaded as a
+        # module; its main() sits behind the __main__ guard)
+        import importlib.machinery
+        import tempfile
+        for name in ("pysam", "Bio", "Bio.Seq", "Bio.SeqRecord", "Bio.SeqIO", "pkg_resources"):
+            sys.modules.setdefault(name, types.ModuleType(name))
+        sys.modules["Bio"].SeqIO = sys.modules["Bio.SeqIO"]
+        sys.modules["Bio.Seq"].Seq = object
+        sys.modules["Bio.SeqRecord"].SeqRecord = object
+        cli = importlib.machinery.SourceFileLoader("mixemt_cli", os.path.join(REF, "bin", "mixemt")).load_module()
+        rng = numpy.random.default_rng(1212)
+        io_haps = ["A12a", "B4'5", "H2a2a1", "L3e1a1a", "M9a'b", "R0", "U5b2a1a1"]
+        io_reads = [["frag0001"], ["frag0002", "frag0007", "frag0100"], ["r/1", "r/2"], ["x"], ["y y", "z"]]
+        io_em = rng.normal(-20.0, 7.0, size=(5, 7))
+        io_mix = io_em - numpy.log(numpy.exp(io_em).sum(axis=1, keepdims=True))
+        io_props = rng.dirichlet([1.0] * 7)
+        out = {}
+        with tempfile.TemporaryDirectory() as tmp:
+            prefix = os.path.join(tmp, "run")
+            cli.dump_all(prefix, io_haps, io_reads, io_em, (io_props, io_mix))
+            for ext in ("haps", "reads", "em.npy", "mat.npy", "prop.npy"):
+                with open("%s.%s" % (prefix, ext), "rb") as fin:
+                    out["file_" + ext.replace(".", "_")] = numpy.frombuffer(fin.read(), dtype=numpy.uint8)
+            haps2, reads2, wts2, init2, (props2, mat2) = cli.load_prev(prefix)
+        import json
+        save("g12_io_formats", haps=numpy.array("\n".join(io_haps)), reads=numpy.array(json.dumps(io_reads)),
+             em=io_em, mix=io_mix, props=io_props, loaded_haps=numpy.array("\n".join(haps2)),
+             loaded_reads=numpy.array(json.dumps(reads2)), loaded_wts=numpy.asarray(wts2), loaded_init=init2,
+             loaded_props=props2, loaded_mat=mat2, **out)
 
     if want("g7"):
         cols = list(range(0, 5400, 54))
