@@ -214,3 +214,46 @@ def test_row_argmax_votes_shapes_ties_and_nans(n_rows, n_haps, seed):
     want_votes = numpy.zeros(n_haps)
     numpy.add.at(want_votes, want, wts)
     assert numpy.array_equal(votes, want_votes)
+
+
+def test_multi_run_consumers_equal_the_reference_run(b17):
+    """
+    g13: the reference's own consumers on its own n_multi = 3 run (the logaddexp fold of three posteriors, em.py:156):
+    `_find_contribs_from_reads` (assemble.py:103-123: columns AND order), the vote text (stats.py:34-45),
+    `get_contributors`' table and `assign_read_indexes` (assemble.py:284-334) -- from the dense posterior, and the
+    contributors once more from records alone with all three log theta_k (mxm_row_argmax_votes_coded).
+    """
+    import hashlib
+    import torch
+    from mixemt_amd import assign, em, preprocess
+    refseq, phy, haps, tables = b17
+    g13, g5 = golden("g13_consumers_multi"), golden("g5_run_em_multi")
+    cm, mat = preprocess.build_em_records_device(tables, g5["row_ptr"], g5["site"], g5["obs"], dense=True)
+    assert hashlib.sha256(mat.cpu().numpy().tobytes()).hexdigest() == str(g13["mat_sha256"])
+    wts = g5["wts"]
+    args = em_args(n_multi=3, min_reads=10, min_fold=2.0)
+    numpy.random.seed(11)
+    res = em.run_em_ex(mat, torch.from_numpy(wts).cuda(), args)
+    assert numpy.array_equal(res["inits"], g13["inits"]) and res["iters"] == list(g13["iters"])
+    assert numpy.abs(res["props"] - g13["props"]).max() < 1e-9
+    want = list(g13["contributors"])
+    assert assign.find_contribs_from_reads(res["read_mix"], wts, args) == want
+    assert assign.find_contribs_from_records(cm, res["ln_theta_k"], wts, args) == want
+    err, sys.stderr = sys.stderr, io.StringIO()
+    try:
+        assign.report_read_votes(haps, res["read_mix"], 10)
+        text = sys.stderr.getvalue()
+    finally:
+        sys.stderr = err
+    assert text == str(g13["vote_text"])
+    # get_contributors' table (assemble.py:126-170 without the variant check): hap#, haplogroup, proportion by descending proportion
+    table = sorted(([haps[c], res["props"][c]] for c in want), key=lambda c: c[1], reverse=True)
+    names = str(g13["contrib_names"]).split("\n")
+    assert [c[0] for c in table] == str(g13["contrib_haps"]).split("\n")
+    assert numpy.abs(numpy.array([c[1] for c in table]) - g13["contrib_props"]).max() < 1e-9
+    contribs = [[n, h, p] for n, (h, p) in zip(names, table)]
+    got_table = assign.assign_read_indexes(contribs, (res["props"], res["read_mix"]), haps, [[str(i)] for i in range(600)], 2.0)
+    got = numpy.full(600, -2, dtype=numpy.int32)
+    for key, idxs in got_table.items():
+        got[sorted(idxs)] = -1 if key == "unassigned" else names.index(key)
+    assert numpy.array_equal(got, g13["assigned"])

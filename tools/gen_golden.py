@@ -28,6 +28,8 @@ Fixtures (SURVEY.md section 8 c):
         (preprocess.py:99-139,163-174,201-227) on a few hundred synthetic alignments
         (tests/_fake_aln.py objects: mates, conflicting overlaps, low MQ / BQ, missing qualities,
         indels, soft clips, lower-case bases)
+    g13 consumers of a MULTI-RUN result: the reference's _find_contribs_from_reads / get_contributors / assign_read_indexes
+        (assemble.py:103-123, :284-334) on its own n_multi = 3 run of the g5 matrix (the logaddexp fold of three posteriors)
     g12 on-disk formats: the bytes the reference's own dump_all writes (bin/mixemt:214-245) for a small run and what its
         load_prev (bin/mixemt:168-211) reads back from them
 """
@@ -545,6 +547,41 @@ def main():
              em=io_em, mix=io_mix, props=io_props, loaded_haps=numpy.array("\n".join(haps2)),
              loaded_reads=numpy.array(json.dumps(reads2)), loaded_wts=numpy.asarray(wts2), loaded_init=init2,
              loaded_props=props2, loaded_mat=mat2, **out)
+
+    if want("g13"):
+        for name in ("pysam", "Bio", "Bio.Seq", "Bio.SeqRecord", "Bio.SeqIO"):
+            sys.modules.setdefault(name, types.ModuleType(name))
+        sys.modules["Bio"].SeqIO = sys.modules["Bio.SeqIO"]
+        sys.modules["Bio.Seq"].Seq = object
+        sys.modules["Bio.SeqRecord"].SeqRecord = object
+        import mixemt.assemble
+        import mixemt.stats
+        row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), 600, seed=4)
+        sigs = synth.signatures(tables, row_ptr, site, obs)
+        mat = ref.preprocess.build_em_matrix(refseq, phy, sigs, haps, quiet)
+        wts = numpy.random.default_rng(44).integers(1, 4, size=600).astype(numpy.int64)
+        t0 = time.time()
+        props, mix, iters, inits = ref_run_em(ref, mat, wts, 11, n_multi=3)
+        print("g13: reference run_em x3 %s iterations in %.0f s" % (iters, time.time() - t0), flush=True)
+        asm_args = ns(min_reads=10, contributors=None, var_check=False, min_fold=2.0)
+        cons = ref.assemble._find_contribs_from_reads(mix, wts, asm_args)
+        contribs = ref.assemble.get_contributors(phy, None, haps, wts, (props, mix), asm_args)
+        reads_stub = [[str(i)] for i in range(600)]
+        table = ref.assemble.assign_read_indexes(contribs, (props, mix), haps, reads_stub, 2.0)
+        names = [c[0] for c in contribs]
+        assigned = numpy.full(600, -2, dtype=numpy.int32)
+        for key, idxs in table.items():
+            assigned[sorted(idxs)] = -1 if key == "unassigned" else names.index(key)
+        err, sys.stderr = sys.stderr, io.StringIO()
+        try:
+            ref.stats.report_read_votes(haps, mix, 10)
+            vote_text = sys.stderr.getvalue()
+        finally:
+            sys.stderr = err
+        save("g13_consumers_multi", contributors=numpy.array(cons, dtype=numpy.int32),
+             contrib_names=numpy.array("\n".join(names)), contrib_haps=numpy.array("\n".join(c[1] for c in contribs)),
+             contrib_props=numpy.array([c[2] for c in contribs]), assigned=assigned, vote_text=numpy.array(vote_text),
+             props=props, iters=iters, inits=inits, mat_sha256=numpy.array(sha(mat)))
 
     if want("g7"):
         cols = list(range(0, 5400, 54))
