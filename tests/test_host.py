@@ -283,3 +283,34 @@ def test_bench_quotes_counter_traffic_of_the_kernel_it_ran(tmp_path):
                        "_workload": {"rows_per_gpu": 10 ** 6, "haps": 5408, "storage": storage}}, fout)
     val, path = bench.pmc_traffic(10 ** 6, 5408, "f64", name, algo, root=str(tmp_path))
     assert val == 1.02 * algo and path == os.path.join("profiles", "r07", "pmc_traffic_a.json")
+
+
+def test_committed_profiles_name_the_kernel_instances_this_source_builds():
+    """profile files must come from the binary that ships.  The latest round's rocprofv3 kernel statistics
+    and counter summary name exactly the template instances this source tree launches for the benchmark's workload
+    (streaming kernel shape from the library itself, the build kernel's column ranges and the lookup-table / coded
+    shapes from the source's defaults)."""
+    import ctypes
+    import glob
+    import json
+    import re
+    from mixemt_amd import _lib
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    rounds = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9]*")), key=lambda p: int(re.search(r"r(\d+)$", p).group(1)))
+    latest = rounds[-1]
+    stats = open(os.path.join(latest, "bench_1m_kernel_stats.csv")).read()
+    traffic = json.load(open(os.path.join(latest, "pmc_traffic_1m.json")))
+    lib = _lib.load()
+    buf = ctypes.create_string_buffer(96)
+    assert lib.mxm_describe_stream_kernel(5408, 1, buf, len(buf)) == 0
+    stream_kernel = buf.value.decode()
+    src = open(os.path.join(root, "mixemt_amd", "csrc", "mixemt_hip.hip")).read()
+    passes = int(re.search(r"#define SPB_PASSES (\d+)", src).group(1))
+    lut = open(os.path.join(root, "mixemt_amd", "csrc", "build_lut_kernels.hpp")).read()
+    cpl = int(re.search(r"#define LUT_CPL (\d+)", lut).group(1))
+    expected = [stream_kernel, "build_sparse_kernel<11, %d, false>" % passes, "build_lut_kernel<6, %d>" % cpl,
+                "em_iter_coded_kernel<256, 6, 4, 2>", "em_iter_wide_kernel<256, 11, 1, 2, 1>"]
+    for name in expected:
+        assert name in stats, "%s: not in %s/bench_1m_kernel_stats.csv -- regenerate the profiles from this binary" % (name, latest)
+    assert stream_kernel in traffic and traffic["_workload"]["storage"] == "f64"
+    assert abs(traffic[stream_kernel]["hbm_bytes_per_launch"] / (1e6 * 5408 * 8) - 1.0) < 0.02
