@@ -205,7 +205,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
 // between its dot product and the accumulation, column partials in registers for the whole launch),
 // but a row arrives as 4 code bytes per thread and chunk plus its table (<= 2 KB), which the first 256
 // threads park in LDS one row ahead (double buffered; the same barrier that publishes the wave sums
-// publishes it).  Per cell: one shift-by-3 of a code byte, one ds_read_b64, two fp64 FMAs.
+// publishes it).  Per cell: one shift-by-3 of a code byte, one ds_read_b64 (issued one row ahead), two fp64 FMAs.
 // 8x fewer HBM bytes per row make the per-row chain (reduce -> barrier -> divide) the bound, so two or
 // three workgroups share a CU and overlap each other's chains.
 // ------------------------------------------------------------------------------------------
@@ -223,6 +223,15 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
 // (profiles/r02/coded_reduce_division_variants.txt): the wave sum as an xor butterfly on the LDS crossbar (6 VALU
 // ops instead of 22, but six dependent ds_bpermute round trips) 2.07 ms; reciprocal + two Newton steps instead of
 // the IEEE division 1.73 ms (-2 %, not taken: it would change the quotient's last bit against the dense kernel).
+// Round 3 (profiles/r03/coded_variants.txt; same column sums bit for bit): timing builds with one stage knocked out
+// each put 0.11 ms on the DPP ladder, 0.09 on the barrier, 0.16 on what follows it (partials + division), 0.01 on the
+// LDS lookups once they are issued a step ahead, and 1.17 ms on everything else -- the step is a latency chain, not
+// an instruction count.  Kept: lookups one step ahead, interleaved with the accumulation FMAs (-4 %); the wave sums
+// after the barrier as two broadcast 16-byte LDS reads instead of a read and two DPP steps; s_setprio 1 from the
+// ladder to the coefficient, so the chain does not queue behind the other workgroup's bulk FMAs (-6 %): 1.63 ->
+// 1.47-1.52 ms.  Lost: the wave sum on the matrix pipe (two v_mfma_f64_16x16x4 with B = 1 + three adds instead of the
+// 22-instruction ladder: +8 %, the MFMA's result latency is longer than the ladder it replaces), a branch-free
+// quotient, 5 or 6 rows in flight, 16-byte code loads (a thread owning 24 consecutive bytes): all within noise.
 template <int THREADS, int NCH, int NBUF, int MINWG>
 __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_kernel(
     const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off, const int32_t *__restrict__ ndist, int ldc,
@@ -231,7 +240,7 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
     static_assert(NBUF >= 3, "codes NBUF - 1 rows ahead, tables NBUF - 2");
     constexpr int NW = THREADS / 64;
     __shared__ double s_tbl[NBUF][ENC_MAX_CODES];
-    __shared__ double red[NBUF][NW];
+    __shared__ __attribute__((aligned(16))) double red[NBUF][NW];
     if (state != nullptr && state[run].done != 0) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int nword = ldc >> 2;
@@ -291,41 +300,83 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
         }
     };
 
+    // byte e of a code word x 8 = the byte offset of its table entry.  One SDWA shift per cell; written out because
+    // the compiler takes byte 0 as shift + and.
+    const unsigned int three = 3;
+    auto entry_off = [&](unsigned int word, auto E) -> unsigned int {
+        constexpr int e = decltype(E)::value;
+        unsigned int r;
+        if constexpr (e == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(word));
+        else if constexpr (e == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(three), "v"(word));
+        else if constexpr (e == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(three), "v"(word));
+        else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(three), "v"(word));
+        return r;
+    };
+    auto lookup = [&](const char *tb, unsigned int word, auto E) -> double {
+        return *reinterpret_cast<const double *>(tb + entry_off(word, E));
+    };
+    using E0 = std::integral_constant<int, 0>;
+    using E1 = std::integral_constant<int, 1>;
+    using E2 = std::integral_constant<int, 2>;
+    using E3 = std::integral_constant<int, 3>;
+
+    // v = the row's values, looked up ONE STEP AHEAD: row q + 1's lookups are issued between the accumulation FMAs
+    // of row q (each into the register that FMA just released), so their LDS latency runs under those FMAs instead
+    // of in front of the next dot product.
+    double v[NCH][4];
+    auto lookup_row = [&](const char *tb, const unsigned int(&cws)[NCH]) {
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            v[k][0] = lookup(tb, cws[k], E0{});
+            v[k][1] = lookup(tb, cws[k], E1{});
+            v[k][2] = lookup(tb, cws[k], E2{});
+            v[k][3] = lookup(tb, cws[k], E3{});
+        }
+    };
+
     auto step = [&](auto J, int64_t q) {
         constexpr int j = decltype(J)::value;
         constexpr int jn = (j + 1) % NBUF, jl = (j + NBUF - 1) % NBUF;
         if ((q % THREADS) == 0) fetch_meta((int)((q / THREADS + 1) & 1), q + THREADS);   // the block after this one
         load_row(cw[jl], tring[jl], q + NBUF - 1);       // slot jl held row q - 1: consumed
         const double wr = s_wr[(q / THREADS) & 1][q % THREADS];
-        const char *tb = reinterpret_cast<const char *>(&s_tbl[j][0]);
-        double v[NCH][4];
-#pragma unroll
-        for (int k = 0; k < NCH; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e)
-                v[k][e] = *reinterpret_cast<const double *>(tb + (((cw[j][k] >> (8 * e)) & 0xffu) << 3));
         double s4[4] = {0.0, 0.0, 0.0, 0.0};             // four independent chains (a dependent fp64 FMA stalls its wave)
 #pragma unroll
         for (int k = 0; k < NCH; ++k)
 #pragma unroll
             for (int e = 0; e < 4; ++e) s4[e] = fma(v[k][e], p[k][e], s4[e]);
         double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        // From here to the row's coefficient the wave runs a chain of dependent instructions (DPP ladder, LDS exchange,
+        // barrier, division) that the whole workgroup waits for; the other workgroup's wave on this SIMD is mostly in
+        // its FMA / lookup bulk.  Issue priority for the chain: 1.58 -> 1.47 ms (profiles/r03/coded_variants.txt).
+        __builtin_amdgcn_s_setprio(1);
         s = wave_sum_lane63(s);
         if (lane == 63) red[j][wv] = s;
         if (tbl_thread) s_tbl[jn][tslot] = tring[jn];    // row q + 1's table, published by the same barrier
         __syncthreads();
-        double cs[1];
-        group_ratio_to_sgpr<NW, 1>(&red[j][0], lane, wr, cs);
-        const double cf = cs[0];
+        // the four wave sums at a uniform address (two broadcast 16-byte reads) and two additions, in the order of the
+        // DPP form it replaces, (r0 + r1) + (r2 + r3): no cross-lane step after the barrier
+        static_assert(NW == 4, "four wave sums");
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        const d2v ra = *reinterpret_cast<const d2v *>(&red[j][0]), rb = *reinterpret_cast<const d2v *>(&red[j][2]);
+        const double cf = readlane_f64(weight_over_norm(wr, (ra.x + ra.y) + (rb.x + rb.y)), 0);
+        __builtin_amdgcn_s_setprio(0);
+        const char *tbn = reinterpret_cast<const char *>(&s_tbl[jn][0]);
+        auto upd = [&](int k, auto E) {
+            constexpr int e = decltype(E)::value;
+            acc[k][e] = fma(cf, v[k][e], acc[k][e]);
+            // pin the update here: left alone, the compiler sinks all NBUF steps' updates to the end of
+            // the unrolled loop body and keeps (spills) every step's row values until then
+            asm volatile("" : "+v"(acc[k][e]));
+            v[k][e] = lookup(tbn, cw[jn][k], E);
+        };
 #pragma unroll
-        for (int k = 0; k < NCH; ++k)
-#pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                acc[k][e] = fma(cf, v[k][e], acc[k][e]);
-                // pin the update here: left alone, the compiler sinks all NBUF steps' updates to the end of
-                // the unrolled loop body and keeps (spills) every step's row values until then
-                asm volatile("" : "+v"(acc[k][e]));
-            }
+        for (int k = 0; k < NCH; ++k) {
+            upd(k, E0{});
+            upd(k, E1{});
+            upd(k, E2{});
+            upd(k, E3{});
+        }
     };
 
     fetch_meta(0, 0);
@@ -334,6 +385,7 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
     for (int j = 0; j < NBUF - 1; ++j) load_row(cw[j], tring[j], j);
     if (tbl_thread) s_tbl[0][tslot] = tring[0];
     __syncthreads();
+    lookup_row(reinterpret_cast<const char *>(&s_tbl[0][0]), cw[0]);
     for (int64_t q = 0; q < deal.nq; q += NBUF) {
         step(std::integral_constant<int, 0>{}, q);
         step(std::integral_constant<int, 1>{}, q + 1);
