@@ -228,10 +228,13 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
 // LDS lookups once they are issued a step ahead, and 1.17 ms on everything else -- the step is a latency chain, not
 // an instruction count.  Kept: lookups one step ahead, interleaved with the accumulation FMAs (-4 %); the wave sums
 // after the barrier as two broadcast 16-byte LDS reads instead of a read and two DPP steps; s_setprio 1 from the
-// ladder to the coefficient, so the chain does not queue behind the other workgroup's bulk FMAs (-6 %): 1.63 ->
-// 1.47-1.52 ms.  Lost: the wave sum on the matrix pipe (two v_mfma_f64_16x16x4 with B = 1 + three adds instead of the
+// ladder to the coefficient, so the chain does not queue behind the other workgroup's bulk FMAs (-6 %); the next
+// step's metadata read from LDS ahead of the lookups (-3 %): 1.63 -> 1.45-1.48 ms.  Lost: the wave sum on the matrix pipe (two v_mfma_f64_16x16x4 with B = 1 + three adds instead of the
 // 22-instruction ladder: +8 %, the MFMA's result latency is longer than the ladder it replaces), a branch-free
-// quotient, 5 or 6 rows in flight, 16-byte code loads (a thread owning 24 consecutive bytes): all within noise.
+// quotient, 5 or 6 rows in flight, 16-byte code loads (a thread owning 24 consecutive bytes), other cache policies
+// on the record loads: all within noise.  With the chain knocked out the kernel takes 1.19 ms, of which the record
+// loads are 0.40 (0.79 without them) and the 48 FMAs per thread 0.08: what is left is neither arithmetic nor HBM
+// bandwidth (5 of 8 TB/s) but two waves per SIMD overlapping their loads, LDS traffic and issue imperfectly.
 template <int THREADS, int NCH, int NBUF, int MINWG>
 __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_kernel(
     const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off, const int32_t *__restrict__ ndist, int ldc,
@@ -282,13 +285,24 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
 
     unsigned int cw[NBUF][NCH];
     double tring[NBUF];
-    // row q's record: codes into cws, entry t of its table into tbl_entry (lanes past the table read 0)
-    auto load_row = [&](unsigned int(&cws)[NCH], double &tbl_entry, int64_t q) {
-        const int half = (int)((q / THREADS) & 1), idx = (int)(q % THREADS);
+    // The metadata a step needs -- the record of the row whose loads it issues, the weight of the row it reduces --
+    // is read from LDS during the step BEFORE, after that step's barrier and ahead of the table lookups: LDS returns in
+    // order, so read at the top of the step it waited for the 24 lookups queued in front of it, with the wave's global
+    // loads and dot product stuck behind that wait (-3 %).
+    int pre_off_lo, pre_off_hi, pre_nd;                  // uniform (SGPRs)
+    double pre_wr;
+    auto read_meta = [&](int64_t q_load, int64_t q_weight) {
+        const int half = (int)((q_load / THREADS) & 1), idx = (int)(q_load % THREADS);
         const long long off = s_off[half][idx];
-        const int nd = __builtin_amdgcn_readfirstlane(s_nd[half][idx]);
-        const uint8_t *base = rec + (((long long)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
-                                     (unsigned int)__builtin_amdgcn_readfirstlane((int)off));
+        pre_nd = __builtin_amdgcn_readfirstlane(s_nd[half][idx]);
+        pre_off_hi = __builtin_amdgcn_readfirstlane((int)(off >> 32));
+        pre_off_lo = __builtin_amdgcn_readfirstlane((int)off);
+        pre_wr = s_wr[(q_weight / THREADS) & 1][q_weight % THREADS];
+    };
+    // a row's record: codes into cws, entry t of its table into tbl_entry (lanes past the table read 0)
+    auto load_row = [&](unsigned int(&cws)[NCH], double &tbl_entry) {
+        const int nd = pre_nd;
+        const uint8_t *base = rec + (((long long)pre_off_hi << 32) | (unsigned int)pre_off_lo);
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, ldc, 0x00020000);
 #pragma unroll
         for (int k = 0; k < NCH - 1; ++k) cws[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, k * THREADS * 4, 2);
@@ -338,8 +352,8 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
         constexpr int j = decltype(J)::value;
         constexpr int jn = (j + 1) % NBUF, jl = (j + NBUF - 1) % NBUF;
         if ((q % THREADS) == 0) fetch_meta((int)((q / THREADS + 1) & 1), q + THREADS);   // the block after this one
-        load_row(cw[jl], tring[jl], q + NBUF - 1);       // slot jl held row q - 1: consumed
-        const double wr = s_wr[(q / THREADS) & 1][q % THREADS];
+        load_row(cw[jl], tring[jl]);                     // row q + NBUF - 1; slot jl held row q - 1: consumed
+        const double wr = pre_wr;
         double s4[4] = {0.0, 0.0, 0.0, 0.0};             // four independent chains (a dependent fp64 FMA stalls its wave)
 #pragma unroll
         for (int k = 0; k < NCH; ++k)
@@ -354,6 +368,7 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
         if (lane == 63) red[j][wv] = s;
         if (tbl_thread) s_tbl[jn][tslot] = tring[jn];    // row q + 1's table, published by the same barrier
         __syncthreads();
+        read_meta(q + NBUF, q + 1);                      // for the next step; returns under the division
         // the four wave sums at a uniform address (two broadcast 16-byte reads) and two additions, in the order of the
         // DPP form it replaces, (r0 + r1) + (r2 + r3): no cross-lane step after the barrier
         static_assert(NW == 4, "four wave sums");
@@ -382,9 +397,13 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
     fetch_meta(0, 0);
     __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NBUF - 1; ++j) load_row(cw[j], tring[j], j);
+    for (int j = 0; j < NBUF - 1; ++j) {
+        read_meta(j, 0);
+        load_row(cw[j], tring[j]);
+    }
     if (tbl_thread) s_tbl[0][tslot] = tring[0];
     __syncthreads();
+    read_meta(NBUF - 1, 0);
     lookup_row(reinterpret_cast<const char *>(&s_tbl[0][0]), cw[0]);
     for (int64_t q = 0; q < deal.nq; q += NBUF) {
         step(std::integral_constant<int, 0>{}, q);
