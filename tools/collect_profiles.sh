@@ -22,6 +22,8 @@ cp $src/kt/kt_kernel_stats.csv $dst/bench_1m_kernel_stats.csv 2>/dev/null
 cp $src/kt_small/kt_kernel_stats.csv $dst/small_runs_kernel_stats.csv 2>/dev/null
 cp $src/kt_coded/kt_kernel_stats.csv $dst/coded_kernel_stats.csv 2>/dev/null
 cp $src/pmc_fetch_coded/f_counter_collection.csv $dst/pmc_fetch_size_coded.csv 2>/dev/null
+cp $src/pmc_sq_coded/sq_counter_collection.csv $dst/pmc_sq_coded.csv 2>/dev/null
+[ -f $src/bench_1m_coded.log ] && cp $src/bench_1m_coded.log $dst/bench_1m_coded.log
 cp $src/kt_build/kt_kernel_stats.csv $dst/build_kernel_stats.csv 2>/dev/null
 cp $src/pmc_fetch/f_counter_collection.csv $dst/pmc_fetch_size.csv 2>/dev/null
 cp $src/pmc_write/w_counter_collection.csv $dst/pmc_write_size.csv 2>/dev/null
