@@ -22,6 +22,15 @@
 // Rows with more than 64 observations, or more than 704 distinct non-zero masks, are appended to
 // `fallback` for the cell-by-cell kernel (3 % of synth-v1 rows).  Between rows both LDS arrays are zero: a mask
 // is cleared by the thread that reads it, a table slot through the compacted list of occupied slots.
+// What bounds it is the LDS unit, shared by the six rows a CU works on: ~750 LDS wave-instructions per row in round
+// 2's form, a third of them atomics or 8-byte gathers, with the data FIFO full 40 % of the time
+// (profiles/r03/build_sparse_pmc_lds.txt) -- hiding latency (more rows per CU, prefetching the next row's lists, issue
+// priority) and cheaper arithmetic (the hash) all measured as noise, while every cut in LDS traffic showed: the marker
+// entries looked up once per row instead of once per column range (-8 %), a thread's two neighbouring masks read and
+// cleared as one 16-byte access and the second one reusing the first one's slot when equal (-5 %), the two prefix
+// sums by DPP instead of ds_bpermute (-5 %), both term lists in one 16-byte read per observation (-4 %), a thread
+// taking CONSECUTIVE entries so that one search serves four (-3 %): 13.7 -> 10.5 ms, bit-exact throughout
+// (profiles/r03/build_kernel_experiments.txt, G).
 // ------------------------------------------------------------------------------------------
 #define SPB_THREADS 256
 #define SPB_MAXN 64
@@ -31,7 +40,7 @@
 #define SPB_MAXD (SPB_SLOTS * 11 / 16) // ... of which at most this many may fill up (load factor < 0.7); beyond: fallback
                                       // (rows of up to 64 observations: median 25 distinct values, 0.2 % above 256, 0.17 % above 352)
 #ifndef SPB_GATHER
-#define SPB_GATHER 4                  // marker entries a thread has in flight during the scatter (2 / 4 / 8: 16.4 / 16.5 / 17.2 ms)
+#define SPB_GATHER 4                  // marker entries a thread looks up and keeps (x 256 threads = the 1024 entries that 79 % of the rows stay below; 8: no gain)
 #endif
 
 // NCH column pairs per thread (ceil(H / 2 / 256)); the haplogroups are taken in PASSES column ranges so that the
@@ -66,10 +75,10 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? 4 : SPB_WAVES)) void build_spa
     constexpr int NW = SPB_THREADS / 64, SPT = SPB_SLOTS / SPB_THREADS;      // slots scanned per thread
     constexpr int KPP = (NCH + PASSES - 1) / PASSES;       // column-pair chunks per pass
     constexpr int SPAN = KPP * 2 * SPB_THREADS;            // haplogroups per pass
-    __shared__ unsigned long long s_dev[SPAN];             // flip mask of the pass's haplogroups (zero between passes)
+    __shared__ __attribute__((aligned(16))) unsigned long long s_dev[SPAN];   // flip mask of the pass's haplogroups (zero between passes)
     __shared__ unsigned long long s_key[SPB_SLOTS];        // distinct masks, then their sums (zero between rows)
     __shared__ unsigned short s_list[SPB_MAXD + SPB_THREADS];   // occupied slots, compacted
-    __shared__ double s_tref[SPB_MAXN], s_talt[SPB_MAXN];
+    __shared__ d2 s_t2[SPB_MAXN];                          // {majority term, flipped term} of observation j: one 16-byte read
     __shared__ int s_beg[SPB_MAXN], s_cum[SPB_MAXN + 1];
     __shared__ unsigned char s_obs[SPB_MAXN], s_hit[SPB_MAXN];
     __shared__ int s_wcnt[NW];
@@ -113,26 +122,63 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? 4 : SPB_WAVES)) void build_spa
                 const unsigned char o = obs[beg + t];
                 const bool hit = (o == maj[s0]);
                 const double lh = lhit[s0], lm = lmiss[s0];
-                s_tref[t] = hit ? lh : lm;
-                s_talt[t] = hit ? lm : lh;
+                s_t2[t] = hit ? d2{lh, lm} : d2{lm, lh};
                 s_obs[t] = o;
                 s_hit[t] = hit ? 1 : 0;
                 const int b = mk_ptr[s0];
                 s_beg[t] = b;
                 len = mk_ptr[s0 + 1] - b;
             }
-            int incl = len;                                  // prefix sums of the marker-list lengths
-#pragma unroll
-            for (int off = 1; off < 64; off <<= 1) {
-                const int up = __shfl_up(incl, off, 64);
-                if (lane >= off) incl += up;
-            }
+            const int incl = wave_inclusive_scan_i32(len);   // prefix sums of the marker-list lengths
             s_cum[t + 1] = incl;
             if (t == 0) s_cum[0] = 0;
         }
         __syncthreads();
         const int total = s_cum[n];
         int slot[NCH][2];
+        // ---- 2a. the row's first SPB_GATHER * 256 marker entries are looked up ONCE (site by a search in the prefix
+        // sums, haplogroup and base from the global lists, flip against the majority term) and kept packed in
+        // registers {haplogroup: 13 bits, observation index: 6 bits}, ~0 = no flip; every column range then only
+        // filters and ORs them.  79 % of the rows have no more entries than that; the rest of a longer row's entries
+        // are walked per range as before.
+        unsigned int cached[SPB_GATHER];
+        {
+            int jj[SPB_GATHER];
+            unsigned int hap[SPB_GATHER], base[SPB_GATHER];
+            // thread t takes entries SPB_GATHER * t ..: one search for the first, the others a few steps further on
+            const int tot_c = total < SPB_GATHER * SPB_THREADS ? total : SPB_GATHER * SPB_THREADS;
+            int lo = 0;
+            {
+                const int e = SPB_GATHER * t;
+                int hi = n;
+                if (e < tot_c) {
+                    while (hi - lo > 1) {
+                        const int mid = (lo + hi) >> 1;
+                        if (s_cum[mid] <= e) lo = mid;
+                        else hi = mid;
+                    }
+                }
+            }
+#pragma unroll
+            for (int u = 0; u < SPB_GATHER; ++u) {
+                const int e = SPB_GATHER * t + u;
+                if (e < tot_c) {
+                    while (s_cum[lo + 1] <= e) ++lo;        // e < total = s_cum[n]: stops at lo < n
+                }
+                jj[u] = (e < tot_c) ? lo : -1;
+                const int idx = (e < tot_c) ? s_beg[lo] + (e - s_cum[lo]) : 0;
+                hap[u] = mk_hap[idx];
+                base[u] = mk_base[idx];
+            }
+#pragma unroll
+            for (int u = 0; u < SPB_GATHER; ++u) {
+                cached[u] = 0xffffffffu;
+                if (jj[u] >= 0) {
+                    const bool hit = (s_obs[jj[u]] == base[u]);
+                    if ((hit ? 1 : 0) != s_hit[jj[u]]) cached[u] = hap[u] | ((unsigned int)jj[u] << 13);
+                }
+            }
+        }
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
             const int h_lo = pass * SPAN;
@@ -141,11 +187,16 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? 4 : SPB_WAVES)) void build_spa
                 for (int k = pass * KPP; k < NCH && k < (pass + 1) * KPP; ++k) slot[k][0] = slot[k][1] = -1;
                 continue;
             }
-            // ---- 2. OR the flips into the masks of this pass's haplogroups.  The row's marker lists are walked as
-            // ONE flat range (entry e -> its site by a search in the prefix sums), SPB_GATHER entries per thread in
-            // flight: a wave per site with its lanes on the list measured slower (22.4 against 16.4 ms at 10^6 rows),
-            // the per-site table loads then queue up behind each other
-            for (int e0 = t; e0 < total; e0 += SPB_THREADS * SPB_GATHER) {
+            // ---- 2. OR the flips into the masks of this pass's haplogroups: the kept entries first, then what a long
+            // row has beyond them.  The row's marker lists are ONE flat range (entry e -> its site by a search in the
+            // prefix sums): a wave per site with its lanes on the list measured slower (22.4 against 16.4 ms at 10^6
+            // rows), the per-site table loads then queue up behind each other
+#pragma unroll
+            for (int u = 0; u < SPB_GATHER; ++u) {
+                const unsigned int local = (cached[u] & 0x1fffu) - (unsigned int)h_lo;
+                if (cached[u] != 0xffffffffu && local < (unsigned int)SPAN) atomicOr(&s_dev[local], 1ull << (cached[u] >> 13));
+            }
+            for (int e0 = t + SPB_THREADS * SPB_GATHER; e0 < total; e0 += SPB_THREADS * SPB_GATHER) {
                 int jj[SPB_GATHER];
                 unsigned int hap[SPB_GATHER], base[SPB_GATHER];
 #pragma unroll
@@ -177,14 +228,25 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? 4 : SPB_WAVES)) void build_spa
             // ---- 3. distinct non-zero masks -> table slots; the masks are zeroed again on the way -------
 #pragma unroll
             for (int k = pass * KPP; k < NCH && k < (pass + 1) * KPP; ++k) {
+                // the thread's two haplogroups are neighbours: both masks in one 16-byte read, zeroed by one write;
+                // the second one takes the first one's slot when they are equal (haplogroups of one clade)
+                typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
+                const int h0 = 2 * (t + k * SPB_THREADS);
+                ull2 both = {0ull, 0ull};
+                if (h0 < H) {
+                    both = *reinterpret_cast<const ull2 *>(&s_dev[h0 - h_lo]);
+                    if (h0 + 1 >= H) both.y = 0ull;
+                    if ((both.x | both.y) != 0ull) *reinterpret_cast<ull2 *>(&s_dev[h0 - h_lo]) = ull2{0ull, 0ull};
+                }
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int h = 2 * (t + k * SPB_THREADS) + e;
                     int sl = -1;
                     if (h < H) {
-                        const unsigned long long mask = s_dev[h - h_lo];
-                        if (mask != 0ull) {
-                            s_dev[h - h_lo] = 0ull;
+                        const unsigned long long mask = e == 0 ? both.x : both.y;
+                        if (e == 1 && mask != 0ull && mask == both.x) {
+                            sl = slot[k][0];
+                        } else if (mask != 0ull) {
                             unsigned int hs = (unsigned int)((mask ^ (mask >> 29)) * 0x9E3779B97F4A7C15ull >> 40) & (SPB_SLOTS - 1);
                             for (int probes = 0;; ++probes) {
                                 const unsigned long long old = atomicCAS(&s_key[hs], 0ull, mask);
@@ -211,12 +273,7 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? 4 : SPB_WAVES)) void build_spa
             kk[q] = s_key[SPT * t + q];
             cnt += (kk[q] != 0ull) ? 1 : 0;
         }
-        int incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += up;
-        }
+        const int incl = wave_inclusive_scan_i32(cnt);
         if (lane == 63) s_wcnt[wv] = incl;
         __syncthreads();
         int base_d = 0, D = 0;
@@ -252,6 +309,7 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? 4 : SPB_WAVES)) void build_spa
             continue;
         }
         double mine[(SPB_MAXD + SPB_THREADS - 1) / SPB_THREADS];
+        double wmax = -INFINITY;
 #pragma unroll
         for (int q = 0; q < (SPB_MAXD + SPB_THREADS - 1) / SPB_THREADS; ++q) {
             const int d = t + q * SPB_THREADS;
@@ -259,15 +317,17 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? 4 : SPB_WAVES)) void build_spa
             if (d < D) {
                 const unsigned long long mask = s_key[s_list[d]];
 #pragma unroll 4
-                for (int j = 0; j < n; ++j) a += ((mask >> j) & 1ull) ? s_talt[j] : s_tref[j];
+                for (int j = 0; j < n; ++j) {
+                    const d2 tt = s_t2[j];
+                    a += ((mask >> j) & 1ull) ? tt.y : tt.x;
+                }
             }
             mine[q] = a;
         }
-        double wmax = -INFINITY;
         if (t == SPB_THREADS - 1) {
             double a = 0.0;
 #pragma unroll 4
-            for (int j = 0; j < n; ++j) a += s_tref[j];
+            for (int j = 0; j < n; ++j) a += s_t2[j].x;
             s_sum0 = a;
             wmax = a;
         }

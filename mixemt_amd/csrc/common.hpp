@@ -128,6 +128,18 @@ __device__ __forceinline__ double wave_max_lane63(double v) {
     return v;
 }
 
+// Inclusive prefix sum over the wave's 64 lanes by DPP only (row_shr 1 / 2 / 4 / 8 inside the rows of 16, row_bcast
+// 15 / 31 across them): six VALU steps instead of six ds_bpermute round trips on the LDS pipe.
+__device__ __forceinline__ int wave_inclusive_scan_i32(int v) {
+    v += __builtin_amdgcn_update_dpp(0, v, 0x111, 0xf, 0xf, false);     // row_shr:1
+    v += __builtin_amdgcn_update_dpp(0, v, 0x112, 0xf, 0xf, false);     // row_shr:2
+    v += __builtin_amdgcn_update_dpp(0, v, 0x114, 0xf, 0xf, false);     // row_shr:4
+    v += __builtin_amdgcn_update_dpp(0, v, 0x118, 0xf, 0xf, false);     // row_shr:8
+    v += __builtin_amdgcn_update_dpp(0, v, 0x142, 0xa, 0xf, false);     // row_bcast:15 into rows 1 and 3
+    v += __builtin_amdgcn_update_dpp(0, v, 0x143, 0xc, 0xf, false);     // row_bcast:31 into rows 2 and 3
+    return v;
+}
+
 // w_r / Z_r of a row.  Z_r == 0 means the row is -inf everywhere (no haplogroup can have produced
 // the read): the reference's E-step forms -inf - (-inf) = NaN there (em.py:81-83) and its weighted
 // column logsumexp (em.py:87) carries the NaN into every proportion -- unless the row's weight is 0,
