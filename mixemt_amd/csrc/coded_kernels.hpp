@@ -79,6 +79,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
         int prev_slot = 0;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
+            const bool give_up = *(volatile int *)&s_flag != 0;   // the row is already known to stay dense (looked at once per four columns)
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const bool valid = 4 * (t + k * ENC_THREADS) + e < H;
@@ -93,7 +94,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
                     sl = prev_slot;
                     need = false;
                 }
-                if (*(volatile int *)&s_flag) need = false; // the row is already known to stay dense
+                if (give_up) need = false;
                 // every lane that still needs a slot probes for itself: after the same-as-previous-column filter the
                 // lanes of a wave mostly hold DIFFERENT keys, whose compare-and-swaps go through the LDS side by side
                 // (a leader lane serving one distinct key per round -- the first form -- took 27.6 ms at 10^6 rows, this 16.8)
@@ -132,12 +133,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
             kk[j] = s_key[4 * t + j];
             cnt += (kk[j] != ENC_EMPTY) ? 1 : 0;
         }
-        int incl = cnt;
-#pragma unroll
-        for (int off = 1; off < 64; off <<= 1) {
-            const int up = __shfl_up(incl, off, 64);
-            if (lane >= off) incl += up;
-        }
+        const int incl = wave_inclusive_scan_i32(cnt);      // DPP: no ds_bpermute round trips on the LDS pipe
         if (lane == 63) s_wcnt[wv] = incl;
         __syncthreads();                                    // wave totals in place; s_flag read by everyone
         int base = 0, D = 0;

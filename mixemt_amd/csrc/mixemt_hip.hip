@@ -244,9 +244,9 @@ static int build_sparse_impl(const char *who, const uint8_t *maj, const double *
 #ifndef SPB_PASSES
 #define SPB_PASSES 3
 #endif
-    // column ranges per row: the mask array is 1 / passes of a row, which (with the table) decides how many rows a CU holds;
-    // every range walks the marker lists again.  10^6 x 5408, kernel alone: 2 ranges 14.7 ms (4-5 rows per CU), 3 ranges 13.7 ms
-    // (6 rows), 4 ranges 14.7-17.4 ms (profiles/r03/build_kernel_experiments.txt)
+    // column ranges per row: the mask array is 1 / passes of a row, which (with the table) decides how many rows a CU holds.
+    // 10^6 x 5408, kernel alone, since the marker entries are looked up once per row: 2 ranges 12.0-12.3 ms (4-5 rows per CU),
+    // 3 ranges 10.5 ms (6 rows; 12.4 when compiled for 5), 4 ranges 11.2-12.4 ms (profiles/r03/build_kernel_experiments.txt)
     const int passes = SPB_PASSES;
     const int maxd = (T.sparse_maxd < 0 || T.sparse_maxd > SPB_MAXD) ? SPB_MAXD : T.sparse_maxd;
     const int kpp = (nch + passes - 1) / passes;
