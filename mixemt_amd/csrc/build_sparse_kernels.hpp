@@ -60,13 +60,16 @@ struct spb_records {
     int ldc;
 };
 
-// (the record variant asks for 4 waves per SIMD: its exponentials would otherwise take 164 VGPRs and the fourth row
-// per CU -- 21.9 against 15 ms; the dense variant gets there by itself, and ran 5 % slower with the hint)
+// (left alone the record variant takes 164 VGPRs for its exponentials -- 3 rows per CU, 21.9 against 15 ms in round 2;
+// compiled for 4 / 5 / 6 waves per SIMD the build -> records call takes 18.3 / 18.3 / 16.9 ms at 10^6 rows)
 #ifndef SPB_WAVES
 #define SPB_WAVES 6                   // waves per SIMD the dense variant is compiled for (80 VGPRs, 100 bytes of scratch): with three
 #endif                                // column ranges and a 512-slot table 6 rows fit a CU (round 2: 4) -- 13.7 against 14.7 ms
+#ifndef SPB_WAVES_EMIT
+#define SPB_WAVES_EMIT 6
+#endif
 template <int NCH, int PASSES, bool EMIT>
-__global__ __launch_bounds__(SPB_THREADS, (EMIT ? 4 : SPB_WAVES)) void build_sparse_kernel(
+__global__ __launch_bounds__(SPB_THREADS, (EMIT ? SPB_WAVES_EMIT : SPB_WAVES)) void build_sparse_kernel(
     const uint8_t *__restrict__ maj, const double *__restrict__ lhit, const double *__restrict__ lmiss,
     const int32_t *__restrict__ mk_ptr, const uint16_t *__restrict__ mk_hap, const uint8_t *__restrict__ mk_base,
     const int64_t *__restrict__ row_ptr, const uint16_t *__restrict__ site, const uint8_t *__restrict__ obs,
