@@ -18,7 +18,7 @@
 //   * the row holds a few dozen DISTINCT masks (median 25): they are deduplicated in an LDS hash table and
 //     each one's sum is formed exactly as the reference forms it -- start at 0.0, add the n terms in order --
 //     so every cell carries the bits the cell-by-cell kernels produce;
-//   * the row is written from that table: the kernel is bound by the 43 KB store per row, not by 2e11 adds.
+//   * the row is written from that table: 43 KB of stores per row instead of 2e11 additions per 10^6 rows.
 // Rows with more than 64 observations, or more than 704 distinct non-zero masks, are appended to
 // `fallback` for the cell-by-cell kernel (3 % of synth-v1 rows).  Between rows both LDS arrays are zero: a mask
 // is cleared by the thread that reads it, a table slot through the compacted list of occupied slots.
