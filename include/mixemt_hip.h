@@ -34,14 +34,16 @@
 extern "C" {
 #endif
 
-/* 0.3.0.  Bumped whenever a signature or a documented default of this header changes; mxm_version() returns
+/* 0.4.0.  Bumped whenever a signature or a documented default of this header changes; mxm_version() returns
  * the value the loaded library was built with, and a binding must refuse a library whose value differs from the
  * header it was written against (mixemt_amd/_lib.py does).  History: 100 rounds 1-2 (mxm_row_argmax_votes gained
  * ws / ws_bytes and mxm_set_compact_restarts became 0/1/2 inside that number -- the reason for this rule);
  * 300 round 3: mxm_build_em_matrix_packed / mxm_build_packed_lds_bytes removed, mxm_build_em_matrix_lut lost its
  * P / ldp / rowmax outputs, mxm_row_argmax_votes_coded replaces mxm_row_argmax_coded,
- * mxm_em_step_coded / mxm_gather_columns_coded cover the rows without a record. */
-#define MXM_VERSION 300
+ * mxm_em_step_coded / mxm_gather_columns_coded cover the rows without a record;
+ * 400 round 4: mxm_coded gained wide_rows / n_wide (records with 16-bit codes for rows of 257..1024 distinct values),
+ * mxm_record_bytes / mxm_coded_bytes grew with them, mxm_workspace_bytes covers the one-launch loops' layouts. */
+#define MXM_VERSION 400
 
 /* per-restart loop state, written by mxm_m_finalize (16 bytes) */
 typedef struct mxm_em_state {
@@ -210,14 +212,18 @@ int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int64_t R, int
  * ROW-DICTIONARY storage of the linearised matrix (lossless; opt-in like the fp32 variant, but it keeps
  * every bit).  A row of build_em_matrix's output (preprocess.py:177-198) is a sum of per-site terms with
  * two possible values each, so its H cells hold few DISTINCT doubles.  Row r is stored as one record
- *     codes[ldc] (uint8 per column, ldc = H rounded up to 8)  ++  table[ndist[r]] (doubles)  ++  mtable[ndist[r]],
+ *     codes[ldc] (one per column, ldc = H rounded up to 8)  ++  table[ndist[r]] (doubles)  ++  mtable[ndist[r]],
  *     P[r][h] = exp(M[r][h] - rowmax[r]) = table[codes[h]]          -- the bits mxm_linearize writes
  *     M[r][h] = mtable[codes[h]]                                    -- the log value itself
- * at rec + rec_off[r]: ~5.9 KB instead of 43 KB at H = 5408.  Rows with more than 256 distinct values
- * get ndist[r] = 0; the caller keeps those dense (P_rest / w_rest: their mxm_linearize rows and
- * weights, in any fixed order) and both parts are summed by one column reduce.
- *   mxm_coded_bytes(R, H)   record buffer size that can never overflow (R * (ldc + 4096))
- *   mxm_encode_rows         M -> records; stats[0] = bytes used, stats[1] = rows left dense (device int64[2]);
+ * at rec + rec_off[r]: ~5.9 KB instead of 43 KB at H = 5408.  Codes are uint8 for rows of at most 256 distinct
+ * values and uint16 for 257..1024 ("wide" records, 2 * ldc bytes of codes; round 4 -- these rows used to stay
+ * dense).  Rows with more than 1024 distinct values get ndist[r] = 0; the caller keeps those dense (P_rest / w_rest:
+ * their mxm_linearize rows and weights, in any fixed order) and both parts are summed by one column reduce.
+ *   mxm_coded_bytes(R, H)   record buffer size that can never overflow (R * (2 ldc + 16384)).  A smaller buffer is
+ *                           allowed: rows that no longer fit get no record, and stats[0] > rec_bytes afterwards says so
+ *                           (and is the size that would have sufficed) -- the caller repeats the call with that much
+ *   mxm_encode_rows         M -> records (byte-coded pass over all rows, then a 16-bit pass over what it left);
+ *                           stats[0] = bytes asked for, stats[1] = rows left dense (device int64[2]);
  *                           needs an even H in [66, 8192], even ldm, 16-byte aligned M and rec
  *   mxm_decode_rows         P[r][:] = row r decoded, coded rows only (tests; posterior passes)
  *   mxm_em_iter_coded / mxm_em_loop_coded   = mxm_em_iter / mxm_em_loop over a coded matrix
@@ -226,12 +232,16 @@ int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int64_t R, int
 typedef struct mxm_coded {
     const uint8_t *rec;          /* records */
     const int64_t *rec_off;      /* [R] byte offset of row r's record */
-    const int32_t *ndist;        /* [R] table entries of row r; 0 = row r is one of the dense rest */
+    const int32_t *ndist;        /* [R] table entries of row r: 1..256 byte codes, 257..1024 16-bit codes ("wide"),
+                                    0 = row r is one of the dense rest */
     int64_t        R;            /* rows, coded or not */
     const double  *P_rest;       /* [R_rest][ldp_rest] linearised rows that did not code (NULL if none) */
     int64_t        ldp_rest;
     const double  *w_rest;       /* their weights (NULL = 1) */
     int64_t        R_rest;
+    const int64_t *wide_rows;    /* [n_wide] the rows with ndist > 256, in any FIXED order (it is the order their terms
+                                    are added in: sorted = the same sums on every run); only the EM iteration reads it */
+    int64_t        n_wide;
 } mxm_coded;
 size_t mxm_coded_bytes(int64_t R, int32_t H);
 int mxm_encode_rows(const double *M, int64_t ldm, int64_t R, int32_t H, uint8_t *rec, size_t rec_bytes,
@@ -244,7 +254,8 @@ int mxm_decode_rows(const mxm_coded *c, int32_t H, double *P, int64_t ldp, void 
  * ln_props / props [n_runs][H]: each run's log theta_k and exp of it; rowmax[R] from the encoder.  With one run the
  * row normaliser drops out (props / rowmax may be NULL); with several, each run's normaliser weighs that run's columns.
  * Rows without a record (ndist[r] == 0) are read from M_rest[n_rest][ldm_rest] -- their LOG values, row i being row
- * rest_rows[i] of the matrix.  n_runs <= 64.  ws / ws_bytes as for mxm_row_argmax_votes (only when votes != NULL). */
+ * rest_rows[i] of the matrix; a row without a record that is not among them gets best[r] = -1 and no vote.
+ * n_runs <= 4096.  ws / ws_bytes as for mxm_row_argmax_votes (only when votes != NULL). */
 int mxm_row_argmax_votes_coded(const mxm_coded *c, int32_t H, int32_t n_runs, const double *ln_props,
                                const double *props, const double *rowmax, const double *M_rest, int64_t ldm_rest,
                                const int64_t *rest_rows, int64_t n_rest, const double *w, int32_t *best,

@@ -24,7 +24,8 @@ class EmState(ctypes.Structure):
 class Coded(ctypes.Structure):
     """mxm_coded (include/mixemt_hip.h): a matrix in row-dictionary storage."""
     _fields_ = [("rec", c_ptr), ("rec_off", c_ptr), ("ndist", c_ptr), ("R", c_i64),
-                ("P_rest", c_ptr), ("ldp_rest", c_i64), ("w_rest", c_ptr), ("R_rest", c_i64)]
+                ("P_rest", c_ptr), ("ldp_rest", c_i64), ("w_rest", c_ptr), ("R_rest", c_i64),
+                ("wide_rows", c_ptr), ("n_wide", c_i64)]
 
 
 # name -> (restype, argtypes); must list every symbol the two headers declare
@@ -102,7 +103,7 @@ SIGNATURES = {
 }
 
 # the MXM_VERSION of include/mixemt_hip.h these signatures were written for; load() refuses any other
-ABI_VERSION = 300
+ABI_VERSION = 400
 
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.POINTER(EmState), c_i32, c_ptr)
 
@@ -127,14 +128,24 @@ def load():
     # interchangeable.  Loading order matters; a second runtime must not appear.
     from . import _dev  # noqa: F401
     lib = ctypes.CDLL(LIB_PATH)
+    # the version first: a stale library lacks newer symbols, and the useful message is "rebuild", not AttributeError
+    try:
+        lib.mxm_version.restype = ctypes.c_int
+        lib.mxm_version.argtypes = []
+        have = lib.mxm_version()
+    except AttributeError:
+        have = None
+    if have != ABI_VERSION:
+        raise MixemtHipError("%s reports ABI version %s, this binding was written for %d: rebuild with "
+                             "`python -m mixemt_amd.build --force`" % (LIB_PATH, have, ABI_VERSION))
     for name, (restype, argtypes) in SIGNATURES.items():
-        fn = getattr(lib, name)          # AttributeError if the symbol is absent
+        try:
+            fn = getattr(lib, name)
+        except AttributeError:
+            raise MixemtHipError("%s has ABI version %d but lacks %s: rebuild with "
+                                 "`python -m mixemt_amd.build --force`" % (LIB_PATH, have, name))
         fn.restype = restype
         fn.argtypes = argtypes
-    have = lib.mxm_version()
-    if have != ABI_VERSION:
-        raise MixemtHipError("%s reports ABI version %d, this binding was written for %d: rebuild with "
-                             "`python -m mixemt_amd.build --force`" % (LIB_PATH, have, ABI_VERSION))
     _lib = lib
     return lib
 

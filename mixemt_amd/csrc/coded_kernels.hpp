@@ -6,191 +6,252 @@
 // ------------------------------------------------------------------------------------------
 // A row of build_em_matrix's output (preprocess.py:177-198) is a sum of per-site terms that take one
 // of two values each, so the 5408 cells of a row hold only a few DISTINCT doubles (one per pattern of
-// mismatching sites among the haplogroups: median 25, 98 % of synth-v1 rows at most 256).  The
+// mismatching sites among the haplogroups: median 25, 98 % of synth-v1 rows at most 256, all at most ~900).  The
 // dictionary form of row r of P = exp(M - rowmax) (mxm_linearize's output) is
-//     record(r) = codes[ldc] (one byte per column, pad columns 0)  ++  table[D_r] (doubles)  ++  mtable[D_r]
+//     record(r) = codes[ldc] (one code per column, pad columns 0)  ++  table[D_r] (doubles)  ++  mtable[D_r]
 //     P[r][h]   = table[codes[h]]                       -- the SAME bits as the dense P
 //     M[r][h]   = mtable[codes[h]]                      -- the log matrix itself (posterior / argmax / column gathers)
-// 5.4 KB + 16 D bytes instead of 43 KB per row.  Rows with more than 256 distinct values stay dense
-// (ndist[r] = 0) and go through em_iter_wide_kernel; the two kernels' column partials are summed by one
-// colreduce.  Every cell still gets its own two FMAs: nothing is skipped, only the bytes shrink.
+// with BYTE codes for D_r <= 256 (5.4 KB + 16 D bytes instead of 43 KB per row) and 16-BIT codes for
+// 256 < D_r <= 1024 ("wide" records, round 4: 10.8 KB + 16 D; 2 % of the rows, which used to stay dense and cost a
+// launch of their own every iteration).  Rows with more than 1024 distinct values (random matrices; none from
+// build_em_matrix) stay dense (ndist[r] = 0) and go through em_iter_wide_kernel; the kernels' column partials are
+// summed by one colreduce.  Every cell still gets its own two FMAs: nothing is skipped, only the bytes shrink.
 // ------------------------------------------------------------------------------------------
 #define ENC_THREADS 256
 #define ENC_SLOTS 1024                 // hash slots per row (>= 4 x the 256 codes a row may use)
-#define ENC_MAX_CODES 256
+#define ENC_MAX_CODES 256              // distinct values of a row with byte codes
+#define ENC_MAX_WIDE 1024              // ... with 16-bit codes
+#define ENC_WIDE_SLOTS 4096            // hash slots of the wide encoder (>= 4 x ENC_MAX_WIDE)
 #define ENC_EMPTY 0xFFFFFFFFFFFFFFFFull
 
-// K7  encode_rows: one workgroup per row (strided).  Thread t holds the columns 4 (t + 256 k) .. + 3.
+// geometry of a record: bytes of its code array (the tables follow), and the code of column h
+__host__ __device__ __forceinline__ int rec_code_bytes(int nd, int ldc) { return nd > ENC_MAX_CODES ? 2 * ldc : ldc; }
+__device__ __forceinline__ int rec_code_at(const uint8_t *codes, int h, bool wide) {
+    return wide ? (int)reinterpret_cast<const uint16_t *>(codes)[h] : (int)codes[h];
+}
+
+// K7  encode_rows: one workgroup per row.  Thread t holds the columns 4 (t + 256 k) .. + 3.
 //   1. row maximum (mxm_linearize's shift);
 //   2. the row's distinct bit patterns go into an LDS hash table (64-bit compare-and-swap, linear
 //      probing); a thread skips the probe when its column repeats the previous one's value (85 % of a
 //      row is one value), the lanes that are left mostly hold different keys and probe side by side;
-//   3. occupied slots are numbered by a workgroup scan -> codes; more than 256 -> the row stays dense;
+//   3. occupied slots are numbered by a workgroup scan -> codes; more than MAXC -> the row gets no record here;
 //   4. the record is bump-allocated (one atomic per row; the order of records is irrelevant, every row
-//      carries its offset) and written: table[code] = exp(key - shift), one code byte per column.
-template <int NCH>
-__global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
-    const double *__restrict__ M, int64_t ldm, int64_t R, int H, int ldc, uint8_t *__restrict__ rec, int64_t rec_cap,
-    int64_t *__restrict__ rec_off, int32_t *__restrict__ ndist, double *__restrict__ rowmax,
-    unsigned long long *__restrict__ stats) {
+//      carries its offset) and written: table[code] = exp(key - shift), one code per column.
+// WIDE = false: the first pass over ALL rows (strided), byte codes, at most 256 values, 1024 slots.
+// WIDE = true: the second pass over the rows the first left without a record (ndist[r] == 0, found by a scan of
+// ndist in chunks of 256): 16-bit codes, at most 1024 values, 4096 slots; stats[1] (rows without a record) goes
+// down by one for every row it codes.
+template <int NCH, bool WIDE>
+__device__ __forceinline__ void encode_one_row(int64_t r, const double *__restrict__ M, int64_t ldm, int H, int ldc,
+                                               uint8_t *__restrict__ rec, int64_t rec_cap, int64_t *__restrict__ rec_off,
+                                               int32_t *__restrict__ ndist, double *__restrict__ rowmax,
+                                               unsigned long long *__restrict__ stats) {
     constexpr int NW = ENC_THREADS / 64;
-    __shared__ unsigned long long s_key[ENC_SLOTS];
-    __shared__ unsigned short s_code[ENC_SLOTS];
+    constexpr int SLOTS = WIDE ? ENC_WIDE_SLOTS : ENC_SLOTS;
+    constexpr int MAXC = WIDE ? ENC_MAX_WIDE : ENC_MAX_CODES;
+    constexpr int SPT = SLOTS / ENC_THREADS;                 // slots numbered per thread
+    __shared__ unsigned long long s_key[SLOTS];
+    __shared__ unsigned short s_code[SLOTS];
     __shared__ double s_red[NW];
     __shared__ int s_wcnt[NW];
     __shared__ int s_flag, s_n;
     __shared__ long long s_off;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     typedef unsigned int u4 __attribute__((ext_vector_type(4)));
+    typedef unsigned int u2 __attribute__((ext_vector_type(2)));
 
-    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
-        const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(M + r * ldm), 0, H * 8, 0x00020000);
-        double x[NCH][4];
+    const auto rsrc = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(M + r * ldm), 0, H * 8, 0x00020000);
+    double x[NCH][4];
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int off = (t + k * ENC_THREADS) * 32;     // past the row: the descriptor returns 0 (masked below)
-            const d2 a = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2));
-            const d2 b = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 16, 2));
-            x[k][0] = a.x;
-            x[k][1] = a.y;
-            x[k][2] = b.x;
-            x[k][3] = b.y;
-        }
+    for (int k = 0; k < NCH; ++k) {
+        const int off = (t + k * ENC_THREADS) * 32;     // past the row: the descriptor returns 0 (masked below)
+        const d2 a = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 0, 2));
+        const d2 b = __builtin_bit_cast(d2, (u4)__builtin_amdgcn_raw_buffer_load_b128(rsrc, off, 16, 2));
+        x[k][0] = a.x;
+        x[k][1] = a.y;
+        x[k][2] = b.x;
+        x[k][3] = b.y;
+    }
 #pragma unroll
-        for (int q = 0; q < ENC_SLOTS / ENC_THREADS; ++q) s_key[t + q * ENC_THREADS] = ENC_EMPTY;
-        if (t == 0) {
-            s_flag = 0;
-            s_n = 0;
-        }
-        double m = -INFINITY;
+    for (int q = 0; q < SPT; ++q) s_key[t + q * ENC_THREADS] = ENC_EMPTY;
+    if (t == 0) {
+        s_flag = 0;
+        s_n = 0;
+    }
+    double m = -INFINITY;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k)
+    for (int k = 0; k < NCH; ++k)
 #pragma unroll
-            for (int e = 0; e < 4; ++e)
-                if (4 * (t + k * ENC_THREADS) + e < H) m = fmax(m, x[k][e]);
-        m = wave_max(m);
-        if (lane == 0) s_red[wv] = m;
-        __syncthreads();                                    // table cleared, wave maxima in place
-        m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
-        const double shift = isfinite(m) ? m : 0.0;
+        for (int e = 0; e < 4; ++e)
+            if (4 * (t + k * ENC_THREADS) + e < H) m = fmax(m, x[k][e]);
+    m = wave_max(m);
+    if (lane == 0) s_red[wv] = m;
+    __syncthreads();                                    // table cleared, wave maxima in place
+    m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+    const double shift = isfinite(m) ? m : 0.0;
 
-        int slot[NCH][4];
-        unsigned long long prev_key = ENC_EMPTY;
-        int prev_slot = 0;
+    int slot[NCH][4];
+    unsigned long long prev_key = ENC_EMPTY;
+    int prev_slot = 0;
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const bool give_up = *(volatile int *)&s_flag != 0;   // the row is already known to stay dense (looked at once per four columns)
+    for (int k = 0; k < NCH; ++k) {
+        const bool give_up = *(volatile int *)&s_flag != 0;   // the row is already known to get no record (looked at once per four columns)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) {
-                const bool valid = 4 * (t + k * ENC_THREADS) + e < H;
-                const unsigned long long key = (unsigned long long)__double_as_longlong(x[k][e]);
-                int sl = 0;
-                bool need = valid;
-                if (valid && key == ENC_EMPTY) {            // the one pattern the table cannot hold
-                    s_flag = 1;
-                    need = false;
-                }
-                if (need && key == prev_key) {              // same value as the thread's previous column
-                    sl = prev_slot;
-                    need = false;
-                }
-                if (give_up) need = false;
-                // every lane that still needs a slot probes for itself: after the same-as-previous-column filter the
-                // lanes of a wave mostly hold DIFFERENT keys, whose compare-and-swaps go through the LDS side by side
-                // (a leader lane serving one distinct key per round -- the first form -- took 27.6 ms at 10^6 rows, this 16.8)
-                if (need) {
-                    unsigned int h = (unsigned int)((key ^ (key >> 29)) * 0x9E3779B97F4A7C15ull >> 40) & (ENC_SLOTS - 1);
-                    for (int probes = 0;; ++probes) {
-                        const unsigned long long old = atomicCAS(&s_key[h], ENC_EMPTY, key);
-                        if (old == ENC_EMPTY) {
-                            if (atomicAdd(&s_n, 1) >= ENC_MAX_CODES) s_flag = 1;
-                            break;
-                        }
-                        if (old == key) break;
-                        h = (h + 1) & (ENC_SLOTS - 1);
-                        if (probes >= ENC_SLOTS) {
-                            s_flag = 1;
-                            break;
-                        }
+        for (int e = 0; e < 4; ++e) {
+            const bool valid = 4 * (t + k * ENC_THREADS) + e < H;
+            const unsigned long long key = (unsigned long long)__double_as_longlong(x[k][e]);
+            int sl = 0;
+            bool need = valid;
+            if (valid && key == ENC_EMPTY) {            // the one pattern the table cannot hold
+                s_flag = 1;
+                need = false;
+            }
+            if (need && key == prev_key) {              // same value as the thread's previous column
+                sl = prev_slot;
+                need = false;
+            }
+            if (give_up) need = false;
+            // every lane that still needs a slot probes for itself: after the same-as-previous-column filter the
+            // lanes of a wave mostly hold DIFFERENT keys, whose compare-and-swaps go through the LDS side by side
+            // (a leader lane serving one distinct key per round -- the first form -- took 27.6 ms at 10^6 rows, this 16.8)
+            if (need) {
+                unsigned int h = (unsigned int)((key ^ (key >> 29)) * 0x9E3779B97F4A7C15ull >> 40) & (SLOTS - 1);
+                for (int probes = 0;; ++probes) {
+                    const unsigned long long old = atomicCAS(&s_key[h], ENC_EMPTY, key);
+                    if (old == ENC_EMPTY) {
+                        if (atomicAdd(&s_n, 1) >= MAXC) s_flag = 1;
+                        break;
                     }
-                    sl = (int)h;
+                    if (old == key) break;
+                    h = (h + 1) & (SLOTS - 1);
+                    if (probes >= SLOTS) {
+                        s_flag = 1;
+                        break;
+                    }
                 }
-                slot[k][e] = sl;
-                if (valid) {
-                    prev_key = key;
-                    prev_slot = sl;
-                }
+                sl = (int)h;
+            }
+            slot[k][e] = sl;
+            if (valid) {
+                prev_key = key;
+                prev_slot = sl;
             }
         }
-        __syncthreads();                                    // every key is in the table
-        const bool dense = (s_flag != 0);
+    }
+    __syncthreads();                                    // every key is in the table
+    const bool dense = (s_flag != 0);
 
-        // number the occupied slots: thread t scans slots 4 t .. 4 t + 3
-        unsigned long long kk[4];
-        int cnt = 0;
+    // number the occupied slots: thread t scans slots SPT t .. SPT t + SPT - 1
+    int cnt = 0;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            kk[j] = s_key[4 * t + j];
-            cnt += (kk[j] != ENC_EMPTY) ? 1 : 0;
-        }
-        const int incl = wave_inclusive_scan_i32(cnt);      // DPP: no ds_bpermute round trips on the LDS pipe
-        if (lane == 63) s_wcnt[wv] = incl;
-        __syncthreads();                                    // wave totals in place; s_flag read by everyone
-        int base = 0, D = 0;
+    for (int j = 0; j < SPT; ++j) cnt += (s_key[SPT * t + j] != ENC_EMPTY) ? 1 : 0;
+    const int incl = wave_inclusive_scan_i32(cnt);      // DPP: no ds_bpermute round trips on the LDS pipe
+    if (lane == 63) s_wcnt[wv] = incl;
+    __syncthreads();                                    // wave totals in place; s_flag read by everyone
+    int base = 0, D = 0;
 #pragma unroll
-        for (int q = 0; q < NW; ++q) {
-            if (q < wv) base += s_wcnt[q];
-            D += s_wcnt[q];
+    for (int q = 0; q < NW; ++q) {
+        if (q < wv) base += s_wcnt[q];
+        D += s_wcnt[q];
+    }
+    const int cbytes = WIDE ? 2 * ldc : ldc;
+    const int64_t bytes = (int64_t)cbytes + 16 * (int64_t)D;        // codes ++ table of P ++ table of the log values
+    // the wide pass leaves a row that fits byte codes alone (the first pass gave it up for another reason -- it cannot
+    // happen today, and must not produce a 16-bit record that readers would take for a byte one)
+    const bool coded = !dense && D <= MAXC && (!WIDE || D > ENC_MAX_CODES);
+    if (t == 0) {
+        long long off = -1;
+        if (coded) {
+            off = (long long)atomicAdd(&stats[0], (unsigned long long)bytes);
+            if (off + bytes > rec_cap) off = -1;         // cannot happen with mxm_coded_bytes(R, H)
         }
-        const int64_t bytes = (int64_t)ldc + 16 * (int64_t)D;        // codes ++ table of P ++ table of the log values
-        const bool coded = !dense && D <= ENC_MAX_CODES;
-        if (t == 0) {
-            long long off = -1;
-            if (coded) {
-                off = (long long)atomicAdd(&stats[0], (unsigned long long)bytes);
-                if (off + bytes > rec_cap) off = -1;         // cannot happen with mxm_coded_bytes(R, H)
+        s_off = off;
+    }
+    int code = base + incl - cnt;
+#pragma unroll
+    for (int j = 0; j < SPT; ++j) {
+        if (s_key[SPT * t + j] != ENC_EMPTY) s_code[SPT * t + j] = (unsigned short)code++;
+    }
+    __syncthreads();                                    // codes of the slots and the record offset in place
+    const long long off = s_off;
+    if (off >= 0) {
+        double *tbl = reinterpret_cast<double *>(rec + off + cbytes);
+        code = base + incl - cnt;
+#pragma unroll
+        for (int j = 0; j < SPT; ++j) {
+            const unsigned long long kk = s_key[SPT * t + j];
+            if (kk != ENC_EMPTY) {
+                const double mval = __longlong_as_double((long long)kk);
+                tbl[code] = exp(mval - shift);
+                tbl[D + code] = mval;                   // the log value itself: posterior / argmax passes read it
+                ++code;
             }
-            s_off = off;
         }
-        int code = base + incl - cnt;
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            if (kk[j] != ENC_EMPTY) s_code[4 * t + j] = (unsigned short)code++;
-        }
-        __syncthreads();                                    // codes of the slots and the record offset in place
-        const long long off = s_off;
-        if (off >= 0) {
-            double *tbl = reinterpret_cast<double *>(rec + off + ldc);
-            code = base + incl - cnt;
+        for (int k = 0; k < NCH; ++k) {
+            const int c0 = 4 * (t + k * ENC_THREADS);
+            if (c0 < ldc) {
+                unsigned int cd[4];
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (kk[j] != ENC_EMPTY) {
-                    const double mval = __longlong_as_double((long long)kk[j]);
-                    tbl[code] = exp(mval - shift);
-                    tbl[D + code] = mval;                   // the log value itself: posterior / argmax passes read it
-                    ++code;
+                for (int e = 0; e < 4; ++e) cd[e] = (c0 + e < H) ? (unsigned int)s_code[slot[k][e]] : 0u;
+                if constexpr (WIDE) {
+                    u2 word;
+                    word.x = cd[0] | (cd[1] << 16);
+                    word.y = cd[2] | (cd[3] << 16);
+                    reinterpret_cast<u2 *>(rec + off)[t + k * ENC_THREADS] = word;
+                } else {
+                    reinterpret_cast<unsigned int *>(rec + off)[t + k * ENC_THREADS] =
+                        cd[0] | (cd[1] << 8) | (cd[2] << 16) | (cd[3] << 24);
                 }
             }
-            unsigned int *cw = reinterpret_cast<unsigned int *>(rec + off);
-#pragma unroll
-            for (int k = 0; k < NCH; ++k) {
-                const int c0 = 4 * (t + k * ENC_THREADS);
-                if (c0 < ldc) {
-                    unsigned int word = 0;
-#pragma unroll
-                    for (int e = 0; e < 4; ++e)
-                        if (c0 + e < H) word |= (unsigned int)s_code[slot[k][e]] << (8 * e);
-                    cw[t + k * ENC_THREADS] = word;
-                }
-            }
         }
-        if (t == 0) {
+    }
+    if (t == 0) {
+        if constexpr (WIDE) {
+            if (off >= 0) {                              // rowmax[r] is the first pass's (same shift)
+                ndist[r] = D;
+                rec_off[r] = off;
+                atomicAdd(&stats[1], ~0ull);             // one row less without a record
+            }
+        } else {
             rowmax[r] = shift;
             ndist[r] = (off >= 0) ? D : 0;
             rec_off[r] = (off >= 0) ? off : 0;
             if (off < 0) atomicAdd(&stats[1], 1ull);
         }
-        __syncthreads();                                    // the next row clears the table
+    }
+    __syncthreads();                                    // the next row clears the table
+}
+
+template <int NCH>
+__global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
+    const double *__restrict__ M, int64_t ldm, int64_t R, int H, int ldc, uint8_t *__restrict__ rec, int64_t rec_cap,
+    int64_t *__restrict__ rec_off, int32_t *__restrict__ ndist, double *__restrict__ rowmax,
+    unsigned long long *__restrict__ stats) {
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x)
+        encode_one_row<NCH, false>(r, M, ldm, H, ldc, rec, rec_cap, rec_off, ndist, rowmax, stats);
+}
+
+template <int NCH>
+__global__ __launch_bounds__(ENC_THREADS) void encode_wide_rows_kernel(
+    const double *__restrict__ M, int64_t ldm, int64_t R, int H, int ldc, uint8_t *__restrict__ rec, int64_t rec_cap,
+    int64_t *__restrict__ rec_off, int32_t *__restrict__ ndist, double *__restrict__ rowmax,
+    unsigned long long *__restrict__ stats) {
+    __shared__ int s_list[ENC_THREADS];
+    __shared__ int s_nlist;
+    const int t = threadIdx.x;
+    const int64_t nchunk = (R + ENC_THREADS - 1) / ENC_THREADS;
+    for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
+        if (t == 0) s_nlist = 0;
+        __syncthreads();
+        const int64_t r = c * ENC_THREADS + t;
+        if (r < R && ndist[r] == 0) s_list[atomicAdd(&s_nlist, 1)] = t;
+        __syncthreads();
+        const int n = s_nlist;                           // uniform
+        for (int i = 0; i < n; ++i)
+            encode_one_row<NCH, true>(c * ENC_THREADS + s_list[i], M, ldm, H, ldc, rec, rec_cap, rec_off, ndist, rowmax, stats);
+        __syncthreads();
     }
 }
 
@@ -231,30 +292,32 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_rows_kernel(
 // on the record loads: all within noise.  With the chain knocked out the kernel takes 1.19 ms, of which the record
 // loads are 0.40 (0.79 without them) and the 48 FMAs per thread 0.08: what is left is neither arithmetic nor HBM
 // bandwidth (5 of 8 TB/s) but two waves per SIMD overlapping their loads, LDS traffic and issue imperfectly.
-template <int THREADS, int NCH, int NBUF, int MINWG>
-__global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_kernel(
-    const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off, const int32_t *__restrict__ ndist, int ldc,
-    const double *__restrict__ w, const double *__restrict__ props, int64_t R, int H, double *__restrict__ partial,
-    int64_t ldpart, const mxm_em_state *__restrict__ state, int run) {
+// The row pass is a device function so that the per-iteration kernel (em_iter_coded_kernel) and the one-launch loop
+// (fused_coded_kernels.hpp) run the very same code: acc[k][e] += (w_r / Z_r) P[r][c] over this workgroup's dealt rows,
+// Z_r = sum_c p[c] P[r][c], thread t owning the columns c = 4 (t + THREADS k) + e.
+//   NT        cache policy of the record loads: true = non-temporal (a pass over records that do not fit the caches),
+//             false = default (the one-launch loop re-reads the same rows every iteration: L2 / Infinity Cache)
+//   RESIDENT  the one-launch loop on a matrix whose per-workgroup row count fits the LDS metadata blocks
+//             (nq <= THREADS, wide rows per workgroup <= THREADS): the metadata is fetched by the FIRST pass of a
+//             launch only (meta_ready says whether it is there) instead of once per pass -- two dependent gathers
+//             (~2 us) that a 15 us iteration would otherwise pay every time.
+// WIDE rows (16-bit codes, 256 < D <= 1024; `wide_rows` lists them) are skipped by the main loop (weight 0, empty
+// table) and taken by a second loop over the list, dealt round-robin like the rows: codes as 8 bytes per thread and
+// chunk, the table (<= 8 KB) through LDS, one row in flight ahead of the one being reduced.  They are 2 % of the rows
+// of a build_em_matrix matrix; as dense rows they cost a kernel launch of their own per iteration (0.147 ms at 10^6
+// rows, 9 % of the step).
+template <int THREADS, int NCH, int NBUF, bool NT, bool RESIDENT>
+__device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off,
+                                               const int32_t *__restrict__ ndist, int ldc, const double *__restrict__ w,
+                                               const int64_t *__restrict__ wide_rows, int64_t n_wide, int64_t R,
+                                               const double (&p)[NCH][4], double (&acc)[NCH][4], bool &meta_ready) {
     static_assert(NBUF >= 3, "codes NBUF - 1 rows ahead, tables NBUF - 2");
     constexpr int NW = THREADS / 64;
+    constexpr int AUX = NT ? 2 : 0;
     __shared__ double s_tbl[NBUF][ENC_MAX_CODES];
     __shared__ __attribute__((aligned(16))) double red[NBUF][NW];
-    if (state != nullptr && state[run].done != 0) return;
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int nword = ldc >> 2;
-    props += (int64_t)run * H;
-
-    double p[NCH][4], acc[NCH][4];
-#pragma unroll
-    for (int k = 0; k < NCH; ++k) {
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-            const int c = 4 * (t + k * THREADS) + e;
-            p[k][e] = (c < H) ? props[c] : 0.0;
-            acc[k][e] = 0.0;
-        }
-    }
     const row_deal deal(R);
     const int voff = t * 4;
     int last_w = t + (NCH - 1) * THREADS;               // words past the row are clamped: their columns have p = 0
@@ -273,7 +336,8 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
     auto fetch_meta = [&](int half, int64_t q0) {       // steps q0 .. q0 + THREADS - 1, thread t takes step q0 + t
         const int64_t q = q0 + t;
         const int64_t r = deal.row(q);
-        const int nd = ndist[r];
+        int nd = ndist[r];
+        if (nd > ENC_MAX_CODES) nd = 0;                  // a wide row: the second loop's (empty table here, weight 0)
         s_off[half][t] = rec_off[r];
         s_nd[half][t] = nd;
         s_wr[half][t] = (deal.live(q) && nd > 0) ? (w != nullptr ? w[r] : 1.0) : 0.0;   // dense rows are not ours
@@ -301,11 +365,11 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
         const uint8_t *base = rec + (((long long)pre_off_hi << 32) | (unsigned int)pre_off_lo);
         const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, ldc, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < NCH - 1; ++k) cws[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, k * THREADS * 4, 2);
-        cws[NCH - 1] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_last, 0, 2);
+        for (int k = 0; k < NCH - 1; ++k) cws[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, k * THREADS * 4, AUX);
+        cws[NCH - 1] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_last, 0, AUX);
         if (tbl_thread) {
             const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base + ldc), 0, nd * 8, 0x00020000);
-            const u2v v = __builtin_amdgcn_raw_buffer_load_b64(rt, tslot * 8, 0, 2);
+            const u2v v = __builtin_amdgcn_raw_buffer_load_b64(rt, tslot * 8, 0, AUX);
             tbl_entry = __hiloint2double((int)v.y, (int)v.x);
         }
     };
@@ -347,7 +411,9 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
     auto step = [&](auto J, int64_t q) {
         constexpr int j = decltype(J)::value;
         constexpr int jn = (j + 1) % NBUF, jl = (j + NBUF - 1) % NBUF;
-        if ((q % THREADS) == 0) fetch_meta((int)((q / THREADS + 1) & 1), q + THREADS);   // the block after this one
+        if constexpr (!RESIDENT) {
+            if ((q % THREADS) == 0) fetch_meta((int)((q / THREADS + 1) & 1), q + THREADS);   // the block after this one
+        }
         load_row(cw[jl], tring[jl]);                     // row q + NBUF - 1; slot jl held row q - 1: consumed
         const double wr = pre_wr;
         double s4[4] = {0.0, 0.0, 0.0, 0.0};             // four independent chains (a dependent fp64 FMA stalls its wave)
@@ -390,26 +456,135 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
         }
     };
 
-    fetch_meta(0, 0);
-    __syncthreads();
+    if (deal.nq > 0) {                                   // (a one-launch grid may be larger than a tiny matrix)
+        if (!RESIDENT || !meta_ready) {
+            __syncthreads();                             // the blocks may still be read by a slower wave of the pass before
+            fetch_meta(0, 0);
+            if constexpr (RESIDENT) fetch_meta(1, THREADS);  // steps past the last row read it too (clamped rows)
+        }
+        __syncthreads();
 #pragma unroll
-    for (int j = 0; j < NBUF - 1; ++j) {
-        read_meta(j, 0);
-        load_row(cw[j], tring[j]);
+        for (int j = 0; j < NBUF - 1; ++j) {
+            read_meta(j, 0);
+            load_row(cw[j], tring[j]);
+        }
+        if (tbl_thread) s_tbl[0][tslot] = tring[0];
+        __syncthreads();
+        read_meta(NBUF - 1, 0);
+        lookup_row(reinterpret_cast<const char *>(&s_tbl[0][0]), cw[0]);
+        for (int64_t q = 0; q < deal.nq; q += NBUF) {
+            step(std::integral_constant<int, 0>{}, q);
+            step(std::integral_constant<int, 1>{}, q + 1);
+            step(std::integral_constant<int, 2>{}, q + 2);
+            if constexpr (NBUF > 3) step(std::integral_constant<int, 3>{}, q + 3);
+            if constexpr (NBUF > 4) step(std::integral_constant<int, 4>{}, q + 4);
+            if constexpr (NBUF > 5) step(std::integral_constant<int, 5>{}, q + 5);
+            static_assert(NBUF <= 6, "unrolled by hand");
+        }
     }
-    if (tbl_thread) s_tbl[0][tslot] = tring[0];
-    __syncthreads();
-    read_meta(NBUF - 1, 0);
-    lookup_row(reinterpret_cast<const char *>(&s_tbl[0][0]), cw[0]);
-    for (int64_t q = 0; q < deal.nq; q += NBUF) {
-        step(std::integral_constant<int, 0>{}, q);
-        step(std::integral_constant<int, 1>{}, q + 1);
-        step(std::integral_constant<int, 2>{}, q + 2);
-        if constexpr (NBUF > 3) step(std::integral_constant<int, 3>{}, q + 3);
-        if constexpr (NBUF > 4) step(std::integral_constant<int, 4>{}, q + 4);
-        if constexpr (NBUF > 5) step(std::integral_constant<int, 5>{}, q + 5);
-        static_assert(NBUF <= 6, "unrolled by hand");
+
+    // ---- the wide rows of this workgroup: wide_rows[blockIdx.x + i * grid] ----------------------------------------
+    const int64_t nq_w = (n_wide > (int64_t)blockIdx.x) ? (n_wide - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    if (nq_w > 0) {                                      // workgroup uniform
+        __shared__ double s_wide[ENC_MAX_WIDE];
+        __shared__ long long s_woff[THREADS];
+        __shared__ double s_wwr[THREADS];
+        __shared__ int s_wnd[THREADS];
+        constexpr int TPT = ENC_MAX_WIDE / THREADS;      // table entries per thread
+        const int voff8 = t * 8;
+        const int voff8_last = last_w * 8;
+        for (int64_t q0 = 0; q0 < nq_w; q0 += THREADS) {
+            if (!RESIDENT || !meta_ready || nq_w > THREADS) {
+                __syncthreads();                         // the previous batch's entries have been read
+                const int64_t q = q0 + t;
+                if (q < nq_w) {
+                    const int64_t r = wide_rows[(int64_t)blockIdx.x + q * (int64_t)gridDim.x];
+                    s_woff[t] = rec_off[r];
+                    s_wnd[t] = ndist[r];
+                    s_wwr[t] = (w != nullptr) ? w[r] : 1.0;
+                }
+            }
+            __syncthreads();
+            const int n_here = (int)((nq_w - q0) < THREADS ? (nq_w - q0) : THREADS);
+            u2v cwn[NCH];                                // the row in flight: codes (four 16-bit codes per chunk) ...
+            double tn[TPT];                              // ... and this thread's entries of its table
+            auto fetch_wide = [&](int i) {
+                const long long off = s_woff[i];
+                const int nd = __builtin_amdgcn_readfirstlane(s_wnd[i]);
+                const uint8_t *base = rec + (((long long)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+                                             (unsigned int)__builtin_amdgcn_readfirstlane((int)off));
+                const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, 2 * ldc, 0x00020000);
+#pragma unroll
+                for (int k = 0; k < NCH - 1; ++k) cwn[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff8, k * THREADS * 8, AUX);
+                cwn[NCH - 1] = __builtin_amdgcn_raw_buffer_load_b64(rs, voff8_last, 0, AUX);
+                const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base + 2 * ldc), 0, nd * 8, 0x00020000);
+#pragma unroll
+                for (int j = 0; j < TPT; ++j) {
+                    const u2v x = __builtin_amdgcn_raw_buffer_load_b64(rt, (t + j * THREADS) * 8, 0, AUX);
+                    tn[j] = __hiloint2double((int)x.y, (int)x.x);
+                }
+            };
+            fetch_wide(0);
+            for (int i = 0; i < n_here; ++i) {
+                const double wr = s_wwr[i];
+                u2v cwc[NCH];
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) cwc[k] = cwn[k];
+#pragma unroll
+                for (int j = 0; j < TPT; ++j) s_wide[t + j * THREADS] = tn[j];
+                if (i + 1 < n_here) fetch_wide(i + 1);   // in flight under this row's reduction
+                __syncthreads();                         // the table is in LDS (and red[0] of the row before is read)
+                const char *tb = reinterpret_cast<const char *>(&s_wide[0]);
+                double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    v[k][0] = *reinterpret_cast<const double *>(tb + ((cwc[k].x & 0xffffu) << 3));
+                    v[k][1] = *reinterpret_cast<const double *>(tb + ((cwc[k].x >> 16) << 3));
+                    v[k][2] = *reinterpret_cast<const double *>(tb + ((cwc[k].y & 0xffffu) << 3));
+                    v[k][3] = *reinterpret_cast<const double *>(tb + ((cwc[k].y >> 16) << 3));
+                }
+#pragma unroll
+                for (int k = 0; k < NCH; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s4[e] = fma(v[k][e], p[k][e], s4[e]);
+                double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+                s = wave_sum_lane63(s);
+                if (lane == 63) red[0][wv] = s;
+                __syncthreads();                         // wave sums in place; every lookup of s_wide is done
+                static_assert(NW == 4, "four wave sums");
+                const double cf = readlane_f64(weight_over_norm(wr, (red[0][0] + red[0][1]) + (red[0][2] + red[0][3])), 0);
+#pragma unroll
+                for (int k = 0; k < NCH; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) acc[k][e] = fma(cf, v[k][e], acc[k][e]);
+            }
+        }
     }
+    meta_ready = true;
+}
+
+template <int THREADS, int NCH, int NBUF, int MINWG>
+__global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_kernel(
+    const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off, const int32_t *__restrict__ ndist, int ldc,
+    const double *__restrict__ w, const int64_t *__restrict__ wide_rows, int64_t n_wide,
+    const double *__restrict__ props, int64_t R, int H, double *__restrict__ partial,
+    int64_t ldpart, const mxm_em_state *__restrict__ state, int run) {
+    if (state != nullptr && state[run].done != 0) return;
+    const int t = threadIdx.x;
+    props += (int64_t)run * H;
+
+    double p[NCH][4], acc[NCH][4];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (t + k * THREADS) + e;
+            p[k][e] = (c < H) ? props[c] : 0.0;
+            acc[k][e] = 0.0;
+        }
+    }
+    bool meta_ready = false;
+    coded_row_pass<THREADS, NCH, NBUF, true, false>(rec, rec_off, ndist, ldc, w, wide_rows, n_wide, R, p, acc, meta_ready);
 
     double *dst = partial + (int64_t)blockIdx.x * ldpart;
 #pragma unroll
@@ -427,10 +602,12 @@ __global__ __launch_bounds__(256) void decode_rows_kernel(const uint8_t *__restr
                                                           const int32_t *__restrict__ ndist, int ldc, int64_t R, int H,
                                                           double *__restrict__ P, int64_t ldp) {
     for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
-        if (ndist[r] <= 0) continue;
+        const int nd = ndist[r];
+        if (nd <= 0) continue;
+        const bool wide = nd > ENC_MAX_CODES;
         const uint8_t *codes = rec + rec_off[r];
-        const double *tbl = reinterpret_cast<const double *>(codes + ldc);
-        for (int h = threadIdx.x; h < H; h += 256) P[r * ldp + h] = tbl[codes[h]];
+        const double *tbl = reinterpret_cast<const double *>(codes + rec_code_bytes(nd, ldc));
+        for (int h = threadIdx.x; h < H; h += 256) P[r * ldp + h] = tbl[rec_code_at(codes, h, wide)];
     }
 }
 
@@ -446,12 +623,12 @@ __global__ __launch_bounds__(256) void decode_rows_kernel(const uint8_t *__restr
 // that sum is 0 or not finite (every supported haplogroup's proportion or P underflowed, or a NaN proportion) the
 // row is redone in log space with a max shift, as the dense pass (mxm_em_step) and the reference do, so the records
 // posterior stays finite exactly where theirs does.  Uniform result; contains barriers.
-__device__ __forceinline__ double coded_row_lse(const uint8_t *codes, const double *s_p, const double *s_m,
+__device__ __forceinline__ double coded_row_lse(const uint8_t *codes, bool wide, const double *s_p, const double *s_m,
                                                 const double *__restrict__ props, const double *__restrict__ ln_props,
                                                 double rowmax_r, int H, double *s_red) {
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     double z = 0.0;
-    for (int h = t; h < H; h += 256) z = fma(props[h], s_p[codes[h]], z);
+    for (int h = t; h < H; h += 256) z = fma(props[h], s_p[rec_code_at(codes, h, wide)], z);
     z = wave_sum(z);
     __syncthreads();                                        // s_red free
     if (lane == 0) s_red[wv] = z;
@@ -459,7 +636,7 @@ __device__ __forceinline__ double coded_row_lse(const uint8_t *codes, const doub
     z = (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
     if (z > 0.0 && z < INFINITY) return rowmax_r + log(z);  // uniform branch
     double m = -INFINITY;
-    for (int h = t; h < H; h += 256) m = fmax(m, ln_props[h] + s_m[codes[h]]);
+    for (int h = t; h < H; h += 256) m = fmax(m, ln_props[h] + s_m[rec_code_at(codes, h, wide)]);
     m = wave_max(m);
     __syncthreads();
     if (lane == 0) s_red[wv] = m;
@@ -467,7 +644,7 @@ __device__ __forceinline__ double coded_row_lse(const uint8_t *codes, const doub
     m = fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
     const double shift = (m > -INFINITY && m < INFINITY) ? m : 0.0;         // as the dense pass (estep_kernels.hpp)
     double sacc = 0.0;
-    for (int h = t; h < H; h += 256) sacc += exp((ln_props[h] + s_m[codes[h]]) - shift);
+    for (int h = t; h < H; h += 256) sacc += exp((ln_props[h] + s_m[rec_code_at(codes, h, wide)]) - shift);
     sacc = wave_sum(sacc);
     __syncthreads();
     if (lane == 0) s_red[wv] = sacc;
@@ -485,23 +662,24 @@ __global__ __launch_bounds__(256) void coded_posterior_kernel(const uint8_t *__r
                                                              const double *__restrict__ props,
                                                              const double *__restrict__ rowmax,
                                                              double *__restrict__ out, int64_t ldo, int mode) {
-    __shared__ double s_p[ENC_MAX_CODES], s_m[ENC_MAX_CODES];
+    __shared__ double s_p[ENC_MAX_WIDE], s_m[ENC_MAX_WIDE];
     __shared__ double s_red[4];
     const int t = threadIdx.x;
     for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
         const int nd = ndist[r];
         if (nd <= 0) continue;                               // uniform
+        const bool wide = nd > ENC_MAX_CODES;
         const uint8_t *codes = rec + rec_off[r];
-        const double *ptab = reinterpret_cast<const double *>(codes + ldc);
-        if (t < nd) {
-            s_p[t] = ptab[t];
-            s_m[t] = ptab[nd + t];
+        const double *ptab = reinterpret_cast<const double *>(codes + rec_code_bytes(nd, ldc));
+        for (int i = t; i < nd; i += 256) {
+            s_p[i] = ptab[i];
+            s_m[i] = ptab[nd + i];
         }
         __syncthreads();
-        const double lse = coded_row_lse(codes, s_p, s_m, props, ln_props, rowmax[r], H, s_red);
+        const double lse = coded_row_lse(codes, wide, s_p, s_m, props, ln_props, rowmax[r], H, s_red);
         double *dst = out + r * ldo;
         for (int h = t; h < H; h += 256) {
-            const double v = (ln_props[h] + s_m[codes[h]]) - lse;
+            const double v = (ln_props[h] + s_m[rec_code_at(codes, h, wide)]) - lse;
             dst[h] = (mode == 1) ? logaddexp_f64(dst[h], v) : v;
         }
         __syncthreads();
@@ -520,8 +698,8 @@ __global__ __launch_bounds__(256) void coded_gather_columns_kernel(const uint8_t
         const int nd = ndist[r];
         if (nd <= 0) continue;
         const uint8_t *codes = rec + rec_off[r];
-        const double *mtab = reinterpret_cast<const double *>(codes + ldc) + nd;
-        out[r * ldo + i] = mtab[codes[cols[i]]];
+        const double *mtab = reinterpret_cast<const double *>(codes + rec_code_bytes(nd, ldc)) + nd;
+        out[r * ldo + i] = mtab[rec_code_at(codes, cols[i], nd > ENC_MAX_CODES)];
     }
 }
 

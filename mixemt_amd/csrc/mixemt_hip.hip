@@ -25,6 +25,7 @@
 //   fused_kernels.hpp   em_fused_loop_kernel (the whole EM loop of a cache-resident matrix in one persistent launch)
 //   fused_cols_kernels.hpp  em_fused_cols_kernel (the same for up to 1536 rows, columns split over the workgroups, matrix in registers)
 //   coded_kernels.hpp   encode_rows_kernel, em_iter_coded_kernel (row-dictionary storage: one byte per cell + the row's distinct values)
+//   fused_coded_kernels.hpp  em_fused_coded_kernel (the whole EM loop over records in one persistent launch)
 // This file: the host side of the C ABI (shape checks, grid sizing, dispatch, the loop driver).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -52,6 +53,7 @@
 #include "records_kernels.hpp"
 #include "fused_kernels.hpp"
 #include "fused_cols_kernels.hpp"
+#include "fused_coded_kernels.hpp"
 
 
 // ------------------------------------------------------------------------------------------
@@ -121,10 +123,31 @@ extern "C" int mxm_linear_supported(int32_t H) {
     return (H >= MXM_LINEAR_MIN_H && H <= 8192) ? 1 : 0;
 }
 
+// Scratch layouts of the one-launch loops (fused_kernels.hpp, fused_cols_kernels.hpp), all inside `ws`:
+//   [sync block][exchange buffers of the form in use][... free ...][snapshot of the loop vectors at the tail]
+static size_t fused_sync_bytes() { return (sizeof(fused_sync) + 255) & ~(size_t)255; }
+// The loop vectors of the restarts in flight are saved at the TAIL of the workspace before every launch of a
+// one-launch loop (3 x [B][H] doubles + B states), so that a launch that gives up (status -3) can be undone.
+static size_t fused_snapshot_bytes(int H, int B) {
+    return ((size_t)3 * B * H * sizeof(double) + (size_t)B * sizeof(mxm_em_state) + 255) & ~(size_t)255;
+}
+// rows split: T / ln T (2 rows) + one partial row per workgroup
+static size_t fused_rows_bytes(int H, int nwg) { return (size_t)(nwg + 2) * part_ld(H) * sizeof(double); }
+// columns split (R <= FCOLS_MAX_RPT * FCOLS_THREADS): z partials [nwg][ldz] + c [ldz] + L1 partials [2][nwg]
+static size_t fused_cols_bytes(int64_t R, int nwg) {
+    const size_t ldz = (size_t)((R + 1) & ~(int64_t)1);
+    return ((size_t)(nwg + 1) * ldz + 2 * (size_t)nwg) * sizeof(double);
+}
+
 extern "C" size_t mxm_workspace_bytes(int64_t R, int32_t H, int32_t B) {
-    (void)R;
-    (void)B;                      // restart tiles are processed one after another over the same scratch
-    return (size_t)MXM_MAX_WG * MXM_MAX_BT * (size_t)part_ld(H) * sizeof(double);
+    // restart tiles are processed one after another over the same scratch: one partial row per workgroup and tile member
+    const size_t tiles = (size_t)MXM_MAX_WG * MXM_MAX_BT * (size_t)part_ld(H) * sizeof(double);
+    // the one-launch loops' blocks (the transposed form's z partials are R-sized, not H-sized, and
+    // outgrow the tile scratch of a narrow matrix -- H = 66, R = 1500: 3.2 MB against 2.2 MB)
+    size_t fused = fused_rows_bytes(H, MXM_MAX_WG);
+    if (R > 0 && R <= (int64_t)FCOLS_MAX_RPT * FCOLS_THREADS) fused = std::max(fused, fused_cols_bytes(R, MXM_MAX_WG));
+    fused += fused_sync_bytes() + fused_snapshot_bytes(H, B > 0 ? B : 1) + 512;
+    return std::max(tiles, fused);
 }
 
 extern "C" int64_t mxm_encode_signatures(const char *text, const int64_t *off, int64_t R,
@@ -284,7 +307,8 @@ extern "C" int mxm_build_em_matrix_sparse(const uint8_t *maj, const double *lhit
 
 extern "C" size_t mxm_record_bytes(int64_t R, int32_t H) {
     if (R < 0 || H <= 0) return 0;
-    return (size_t)(R > 0 ? R : 1) * ((size_t)coded_ld(H) + 16 * ENC_MAX_CODES);
+    // the larger of a full byte-coded record and a full wide one
+    return (size_t)(R > 0 ? R : 1) * (2 * (size_t)coded_ld(H) + 16 * ENC_MAX_WIDE);
 }
 
 extern "C" int mxm_build_em_records(const uint8_t *maj, const double *lhit, const double *lmiss,
@@ -731,8 +755,11 @@ extern "C" int mxm_encode_rows(const double *M, int64_t ldm, int64_t R, int32_t 
     const int ldc = coded_ld(H);
     const int nch = (ldc / 4 + ENC_THREADS - 1) / ENC_THREADS;
     const int grid = clamp_grid(R, num_cu() * 4);
+    // first pass: every row, byte codes; second pass: the rows it left without a record, 16-bit codes
+    const int grid_w = clamp_grid((R + ENC_THREADS - 1) / ENC_THREADS, num_cu() * 3);
     switch (nch) {
-#define ENC_CASE(n) case n: hipLaunchKernelGGL((encode_rows_kernel<n>), dim3(grid), dim3(ENC_THREADS), 0, s, M, ldm, R, (int)H, ldc, rec, (int64_t)rec_bytes, rec_off, ndist, rowmax, reinterpret_cast<unsigned long long *>(stats)); break;
+#define ENC_CASE(n) case n: hipLaunchKernelGGL((encode_rows_kernel<n>), dim3(grid), dim3(ENC_THREADS), 0, s, M, ldm, R, (int)H, ldc, rec, (int64_t)rec_bytes, rec_off, ndist, rowmax, reinterpret_cast<unsigned long long *>(stats)); \
+                    hipLaunchKernelGGL((encode_wide_rows_kernel<n>), dim3(grid_w), dim3(ENC_THREADS), 0, s, M, ldm, R, (int)H, ldc, rec, (int64_t)rec_bytes, rec_off, ndist, rowmax, reinterpret_cast<unsigned long long *>(stats)); break;
         ENC_CASE(1) ENC_CASE(2) ENC_CASE(3) ENC_CASE(4) ENC_CASE(5) ENC_CASE(6) ENC_CASE(7) ENC_CASE(8)
 #undef ENC_CASE
         default: return fail(-1, "mxm_encode_rows: H=%s%lld outside the kernel's range", "", H);
@@ -748,6 +775,7 @@ static int coded_check(const mxm_coded *c, int32_t H, const char *who) {
     if (c->R_rest < 0 || (c->R_rest > 0 && (c->P_rest == nullptr || c->ldp_rest < H || (c->ldp_rest & 1) ||
                                             (reinterpret_cast<uintptr_t>(c->P_rest) & 15))))
         return fail(-1, "%s: the dense rest needs 16-byte aligned rows with an even ld >= H", who);
+    if (c->n_wide < 0 || (c->n_wide > 0 && c->wide_rows == nullptr)) return fail(-1, "%s: n_wide > 0 needs wide_rows", who);
     return 0;
 }
 
@@ -776,12 +804,13 @@ extern "C" int mxm_row_argmax_votes_coded(const mxm_coded *c, int32_t H, int32_t
     if (votes != nullptr && (ws == nullptr || ws_bytes < mxm_workspace_bytes(c->R, H, 1)))
         return fail(-1, "mxm_row_argmax_votes_coded: workspace too small%s", "");
     hipStream_t s = (hipStream_t)stream;
-    hipLaunchKernelGGL(posterior_argmax_kernel<true>, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(256), 0, s, c->rec, c->rec_off,
+    const size_t lse_lds = (size_t)n_runs * sizeof(double);
+    hipLaunchKernelGGL(posterior_argmax_kernel<true>, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(256), lse_lds, s, c->rec, c->rec_off,
                        c->ndist, coded_ld(H), (const double *)nullptr, (int64_t)0, (const int64_t *)nullptr, c->R, (int)H,
                        (int)n_runs, ln_props, props, rowmax, best);
     HIP_TRY(hipGetLastError());
     if (n_rest > 0) {
-        hipLaunchKernelGGL(posterior_argmax_kernel<false>, dim3(clamp_grid(n_rest, num_cu() * 8)), dim3(256), 0, s,
+        hipLaunchKernelGGL(posterior_argmax_kernel<false>, dim3(clamp_grid(n_rest, num_cu() * 8)), dim3(256), lse_lds, s,
                            (const uint8_t *)nullptr, (const int64_t *)nullptr, (const int32_t *)nullptr, 0, M_rest, ldm_rest,
                            rest_rows, n_rest, (int)H, (int)n_runs, ln_props, props, rowmax, best);
         HIP_TRY(hipGetLastError());
@@ -858,7 +887,7 @@ template <int THREADS, int NBUF, int MINWG>
 static int launch_coded(int nch, int nwg, hipStream_t stream, const mxm_coded *c, int ldc, const double *w, const double *props,
                         int H, double *partial, int64_t ldpart, const mxm_em_state *state, int run) {
     switch (nch) {
-#define COD_CASE(n) case n: if constexpr (n * THREADS <= 2048) { hipLaunchKernelGGL((em_iter_coded_kernel<THREADS, n, NBUF, MINWG>), dim3(nwg), dim3(THREADS), 0, stream, c->rec, c->rec_off, c->ndist, ldc, w, props, c->R, H, partial, ldpart, state, run); return 0; } break;
+#define COD_CASE(n) case n: if constexpr (n * THREADS <= 2048) { hipLaunchKernelGGL((em_iter_coded_kernel<THREADS, n, NBUF, MINWG>), dim3(nwg), dim3(THREADS), 0, stream, c->rec, c->rec_off, c->ndist, ldc, w, c->wide_rows, c->n_wide, props, c->R, H, partial, ldpart, state, run); return 0; } break;
         COD_CASE(1) COD_CASE(2) COD_CASE(3) COD_CASE(4) COD_CASE(5) COD_CASE(6) COD_CASE(7) COD_CASE(8)
 #undef COD_CASE
         default: break;
@@ -954,13 +983,6 @@ extern "C" int mxm_set_loop_fused(int32_t mode, int32_t chunk) {
     });
 }
 
-static size_t fused_sync_bytes() { return (sizeof(fused_sync) + 255) & ~(size_t)255; }
-// The loop vectors of the restarts in flight are saved at the TAIL of the workspace before every launch of a
-// one-launch loop (3 x [B][H] doubles + B states), so that a launch that gives up (status -3) can be undone.
-static size_t fused_snapshot_bytes(int H, int B) {
-    return ((size_t)3 * B * H * sizeof(double) + (size_t)B * sizeof(mxm_em_state) + 255) & ~(size_t)255;
-}
-
 // The transposed one-launch loop (fused_cols_kernels.hpp): up to 1536 rows, a 256-CU grid.
 static bool fused_cols_eligible(int64_t R, int H, int nwg) {
     if (!T.fused_cols || nwg != 256) return false;          // the Z reduce is laid out for 256 partials per row
@@ -970,6 +992,11 @@ static bool fused_cols_eligible(int64_t R, int H, int nwg) {
     // 24 columns x 3 rows per thread do not fit the register file without scratch (22 x 3 -- Build 17's width
     // on 256 CUs -- do): the widest matrices up to 1024 rows
     return cp <= 22 || R <= 2 * (int64_t)FCOLS_THREADS;
+}
+// ... and its exchange buffers must fit between the sync block and the snapshot (a caller may hand in less than
+// mxm_workspace_bytes asks for today: the rows-split form or the per-iteration kernels then run instead)
+static bool fused_cols_fits(int64_t R, int H, int B, int nwg, size_t ws_bytes) {
+    return ws_bytes >= fused_sync_bytes() + fused_cols_bytes(R, nwg) + fused_snapshot_bytes(H, B) + 256;
 }
 
 // `running`: restarts that still have iterations to do.  Automatic mode takes the one-launch loop for ONE
@@ -984,12 +1011,29 @@ static bool fused_eligible(const double *P, int64_t ldp, int64_t R, int H, int B
     if ((ncol2 + nwg - 1) / nwg > 16 * FUSED_MAX_M) return false;           // slice wider than the column reduce covers
     if ((ncol2 + FUSED_THREADS - 1) / FUSED_THREADS > FUSED_MAX_NCH) return false;   // spill-free instances only
     if ((int64_t)nwg * part_ld(H) * 8 >= ((int64_t)1 << 31)) return false;  // one buffer descriptor over the partials
-    if (ws_bytes < fused_sync_bytes() + (size_t)(nwg + 2) * part_ld(H) * sizeof(double) + fused_snapshot_bytes(H, B) + 256) return false;
+    if (ws_bytes < fused_sync_bytes() + fused_rows_bytes(H, nwg) + fused_snapshot_bytes(H, B) + 256) return false;
     if (T.loop_fused == 1) return true;
     // the transposed form runs a restart-iteration in 12 us at 600 rows whatever the number of restarts; the
     // batched kernels need 18 / 13 / 11 us with 2 / 3 / 4 restarts per pass: up to three restarts stay here
-    if (running <= 3 && fused_cols_eligible(R, H, nwg)) return true;
+    if (running <= 3 && fused_cols_eligible(R, H, nwg) && fused_cols_fits(R, H, B, nwg, ws_bytes)) return true;
     return running <= 1 && (double)R * (double)H <= T.fused_cells;
+}
+
+// The one-launch loop over records (fused_coded_kernels.hpp): any number of rows, restarts one after another (the
+// per-iteration coded kernels take one restart per pass too, so nothing is lost), no dense leftover rows.
+static int fused_coded_grid(int64_t R) {
+    int nwg = num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG;         // two workgroups of 256 per CU
+    if ((int64_t)nwg > R) nwg = (int)R;
+    return nwg < 1 ? 1 : nwg;
+}
+static bool fused_coded_eligible(const mxm_coded *c, int H, int B, size_t ws_bytes) {
+    if (T.loop_fused == 0 || c == nullptr || c->R_rest > 0 || !mxm_linear_supported(H) || (H & 1)) return false;
+    const int nwg = fused_coded_grid(c->R);
+    const int ncol2 = H / 2;
+    if ((ncol2 + nwg - 1) / nwg > 16 * FCODED_MAX_M) return false;           // slice wider than the column reduce covers
+    if ((coded_ld(H) / 4 + FCODED_THREADS - 1) / FCODED_THREADS > 8) return false;
+    if ((int64_t)nwg * part_ld(H) * 8 >= ((int64_t)1 << 31)) return false;   // one buffer descriptor over the partials
+    return ws_bytes >= fused_sync_bytes() + fused_rows_bytes(H, nwg) + fused_snapshot_bytes(H, B) + 256;
 }
 
 // Diagnostic (-DFUSED_STAMPS builds): the per-phase clock sums of the last one-launch loop, from the
@@ -1034,6 +1078,29 @@ static bool launch_fused(int nwg, hipStream_t s, const double *P, int64_t ldp, c
     return true;
 }
 
+template <int NCH>
+static bool launch_fused_coded(int nwg, bool resident, hipStream_t s, const mxm_coded *c, int ldc, const double *w, int H, int B,
+                               double *ln_cur, double *ln_new, double *props_cur, mxm_em_state *state, double tol,
+                               int max_iter, int chunk, double *partial, int64_t ldpart, double *tbuf, fused_sync *sync) {
+    if constexpr (NCH * FCODED_THREADS > 2048) {
+        return false;
+    } else {
+        fcoded_args a;
+        a.partial = partial; a.tbuf = tbuf; a.ln_cur = ln_cur; a.ln_new = ln_new; a.props_cur = props_cur;
+        a.state = state; a.sync = sync; a.ldpart = ldpart; a.tol = tol; a.max_iter = max_iter; a.H = H;
+        if (resident) {
+            if (!grid_fits(em_fused_coded_kernel<NCH, 4, true>, FCODED_THREADS, nwg)) return false;
+            hipLaunchKernelGGL((em_fused_coded_kernel<NCH, 4, true>), dim3(nwg), dim3(FCODED_THREADS), 0, s, c->rec, c->rec_off,
+                               c->ndist, ldc, w, c->wide_rows, c->n_wide, c->R, B, chunk, a);
+        } else {
+            if (!grid_fits(em_fused_coded_kernel<NCH, 4, false>, FCODED_THREADS, nwg)) return false;
+            hipLaunchKernelGGL((em_fused_coded_kernel<NCH, 4, false>), dim3(nwg), dim3(FCODED_THREADS), 0, s, c->rec, c->rec_off,
+                               c->ndist, ldc, w, c->wide_rows, c->n_wide, c->R, B, chunk, a);
+        }
+        return true;
+    }
+}
+
 // The loop of every restart in [0, B) that is not done yet, in launches of at most `chunk` iterations
 // per restart (one launch unless the caller wants to look at the state in between).
 // Returns 0 when every restart has stopped; MXM_FUSED_GAVE_UP when a launch could not run to its end -- the grid does
@@ -1044,14 +1111,14 @@ static bool launch_fused(int nwg, hipStream_t s, const double *P, int64_t ldp, c
 static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t R, int32_t H, int32_t B,
                          double *props_cur, double *ln_cur, double *ln_new, mxm_em_state *state, double tol,
                          int32_t max_iter, int32_t chunk, void *ws, size_t ws_bytes, hipStream_t s,
-                         mxm_em_state *state_host) {
+                         mxm_em_state *state_host, const mxm_coded *coded = nullptr) {
     // The persistent grid needs every workgroup resident, one per CU.  Two such grids in flight on one
     // device (two host threads, two streams) can each hold a part of the CUs and wait for the rest for
     // ever -- the bounded spins would end both after seconds.  Inside one process the launches are
     // therefore serialised here; across processes sharing a GPU nothing can (see the header).
     static std::mutex one_loop_at_a_time;
     std::lock_guard<std::mutex> guard(one_loop_at_a_time);
-    const int nwg = num_cu() < MXM_MAX_WG ? num_cu() : MXM_MAX_WG;
+    const int nwg = coded != nullptr ? fused_coded_grid(coded->R) : (num_cu() < MXM_MAX_WG ? num_cu() : MXM_MAX_WG);
     const int64_t ldpart = part_ld(H);
     char *base = static_cast<char *>(ws);
     fused_sync *sync = reinterpret_cast<fused_sync *>(base);
@@ -1096,9 +1163,21 @@ static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t 
         if (T.fused_force_abort)                                       // test hook: as if a workgroup had given up
             HIP_TRY(hipMemsetAsync(&sync->abort_[0], 1, sizeof(unsigned), s));
         bool fits = true;
-        if (fused_cols_eligible(R, (int)H, nwg)) {
+        if (coded != nullptr) {
+            // records: [sync][T (1 row)][partial rows]; the metadata of a workgroup's rows stays in LDS for the whole
+            // launch when they fit its blocks (256 rows and 256 wide rows per workgroup)
+            const int ldc = coded_ld(H);
+            const int cnch = (ldc / 4 + FCODED_THREADS - 1) / FCODED_THREADS;
+            const bool resident = (coded->R + nwg - 1) / nwg <= FCODED_THREADS && (coded->n_wide + nwg - 1) / nwg <= FCODED_THREADS;
+            switch (cnch) {
+#define FC_CASE(n) case n: fits = launch_fused_coded<n>(nwg, resident, s, coded, ldc, w, (int)H, (int)B, ln_cur, ln_new, props_cur, state, tol, (int)max_iter, (int)chunk, partial, ldpart, tbuf, sync); break;
+                FC_CASE(1) FC_CASE(2) FC_CASE(3) FC_CASE(4) FC_CASE(5) FC_CASE(6) FC_CASE(7) FC_CASE(8)
+#undef FC_CASE
+                default: return fail(-1, "mxm_em_loop_coded: H=%s%lld outside the one-launch loop's range", "", H);
+            }
+        } else if (fused_cols_eligible(R, (int)H, nwg) && fused_cols_fits(R, (int)H, (int)B, nwg, ws_bytes)) {
             // smallest matrices: columns split over the workgroups, the matrix in registers (workspace:
-            // [sync][z partials nwg x ldz][c ldz][l1 partials 2 x nwg], far inside what mxm_workspace_bytes reserves)
+            // [sync][z partials nwg x ldz][c ldz][l1 partials 2 x nwg]; checked against ws_bytes above)
             const int64_t ldz = (R + 1) & ~(int64_t)1;
             double *zpart = reinterpret_cast<double *>(base + fused_sync_bytes());
             double *cbuf = zpart + (int64_t)nwg * ldz;
@@ -1188,7 +1267,19 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     HIP_TRY(hipStreamSynchronize(caller));
     int running = 0;
     for (int b = 0; b < B; ++b) running += (state_host[b].done == 0) ? 1 : 0;
-    if (fused_eligible(P, ldp, R, (int)H, (int)B, ws_bytes, p_is_f32, running)) {
+    if (coded != nullptr && running > 0 && max_iter > 0 && fused_coded_eligible(coded, (int)H, (int)B, ws_bytes)) {
+        // records: the whole loop in persistent launches on the caller's stream, restarts one after another.  A launch
+        // is kept to about half a second (a 10^7-row matrix takes 15 ms per iteration): `chunk` iterations each.
+        int chunk = T.fused_chunk > 0 ? T.fused_chunk : max_iter;
+        if (T.progress != nullptr && chunk > T.progress_every) chunk = T.progress_every;
+        const double est_us = (double)R * ((double)coded_ld(H) + 400.0) / 4.0e6 + 20.0;
+        const int cap = (int)std::max(8.0, 5.0e5 / est_us);
+        if (chunk > cap) chunk = cap;
+        const int frc = em_loop_fused(nullptr, 0, w, R, H, B, props_cur, ln_cur, ln_new, state, tol, max_iter, chunk, ws, ws_bytes,
+                                      caller, state_host, coded);
+        if (frc != MXM_FUSED_GAVE_UP) return frc;
+        if (T.loop_fused == 1) return -3;
+    } else if (fused_eligible(P, ldp, R, (int)H, (int)B, ws_bytes, p_is_f32, running)) {
         // cache-resident matrix: the whole loop in one persistent launch on the caller's stream
         // (the host only waits for it; nothing is decided between iterations)
         int chunk = T.fused_chunk > 0 ? T.fused_chunk : max_iter;

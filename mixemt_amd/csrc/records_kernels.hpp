@@ -15,7 +15,7 @@
 // CODED = false: R_rest dense rows M_rest[i][:] whose row index is rest_rows[i] (the rows without a record).
 // One workgroup of 256 per row; numpy.argmax semantics (first maximum; a NaN wins, the first one).
 // ------------------------------------------------------------------------------------------
-#define RECK_MAX_RUNS 64              // runs folded per launch (their lse sit in LDS)
+#define RECK_MAX_RUNS 4096            // runs folded per launch (their lse sit in dynamic LDS: 8 bytes per run)
 
 template <bool CODED>
 __global__ __launch_bounds__(256) void posterior_argmax_kernel(
@@ -23,8 +23,9 @@ __global__ __launch_bounds__(256) void posterior_argmax_kernel(
     const double *__restrict__ M_rest, int64_t ldm_rest, const int64_t *__restrict__ rest_rows, int64_t R, int H,
     int n_runs, const double *__restrict__ ln_props, const double *__restrict__ props, const double *__restrict__ rowmax,
     int32_t *__restrict__ best) {
-    __shared__ double s_p[CODED ? ENC_MAX_CODES : 1], s_m[CODED ? ENC_MAX_CODES : 1];
-    __shared__ double s_red[4], s_lse[RECK_MAX_RUNS];
+    __shared__ double s_p[CODED ? ENC_MAX_WIDE : 1], s_m[CODED ? ENC_MAX_WIDE : 1];
+    __shared__ double s_red[4];
+    extern __shared__ double s_lse[];                        // [n_runs] (dynamic: any number of runs)
     __shared__ double s_val[4];
     __shared__ int s_idx[4], s_nan[4];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -32,14 +33,19 @@ __global__ __launch_bounds__(256) void posterior_argmax_kernel(
         int64_t r = i;
         const uint8_t *codes = nullptr;
         const double *row = nullptr;
+        bool wide = false;
         if constexpr (CODED) {
             const int nd = ndist[r];
-            if (nd <= 0) continue;                           // uniform
+            if (nd <= 0) {                                   // uniform: no record -- the dense pass fills it in,
+                if (t == 0) best[r] = -1;                    // and a row the caller did not hand over stays "no vote"
+                continue;
+            }
+            wide = nd > ENC_MAX_CODES;
             codes = rec + rec_off[r];
-            const double *ptab = reinterpret_cast<const double *>(codes + ldc);
-            if (t < nd) {
-                s_p[t] = ptab[t];
-                s_m[t] = ptab[nd + t];
+            const double *ptab = reinterpret_cast<const double *>(codes + rec_code_bytes(nd, ldc));
+            for (int j = t; j < nd; j += 256) {
+                s_p[j] = ptab[j];
+                s_m[j] = ptab[nd + j];
             }
             __syncthreads();
         } else {
@@ -47,7 +53,7 @@ __global__ __launch_bounds__(256) void posterior_argmax_kernel(
             row = M_rest + i * ldm_rest;
         }
         auto logv = [&](int h) -> double {
-            if constexpr (CODED) return s_m[codes[h]];
+            if constexpr (CODED) return s_m[rec_code_at(codes, h, wide)];
             else return row[h];
         };
         if (n_runs > 1) {
@@ -55,7 +61,7 @@ __global__ __launch_bounds__(256) void posterior_argmax_kernel(
                 const double *lnp = ln_props + (int64_t)k * H;
                 double lse;
                 if constexpr (CODED) {
-                    lse = coded_row_lse(codes, s_p, s_m, props + (int64_t)k * H, lnp, rowmax[r], H, s_red);
+                    lse = coded_row_lse(codes, wide, s_p, s_m, props + (int64_t)k * H, lnp, rowmax[r], H, s_red);
                 } else {
                     double m = -INFINITY;
                     for (int h = t; h < H; h += 256) m = fmax(m, lnp[h] + row[h]);
@@ -123,7 +129,9 @@ __global__ __launch_bounds__(256) void votes_from_best_kernel(const int32_t *__r
     const int64_t per = (R + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < R) ? lo + per : R;
     for (int64_t r = lo; r < hi; ++r) {
-        volatile double *slot = mine + best[r];              // the same thread wrote the zero / the last sum
+        const int b = best[r];
+        if ((unsigned)b >= (unsigned)H) continue;            // -1: a row without a record that nobody supplied densely
+        volatile double *slot = mine + b;                    // the same thread wrote the zero / the last sum
         *slot = *slot + (w != nullptr ? w[r] : 1.0);
     }
 }

@@ -29,6 +29,7 @@ Two modes:
 """
 
 import math
+import warnings
 
 import numpy
 
@@ -168,17 +169,26 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
                      and (not exchange or dist.get_backend(group) == "nccl"))
         if use_graph and (captured is None or captured[0] != lead):
             # (re)capture: the burst's launches are recorded, not run; a failure leaves the loop eager for good
+            #  only what a refused CAPTURE raises is taken as "not capturable here" -- torch reports those as
+            # RuntimeError (hipErrorStreamCapture*), RCCL as DistBackendError (a RuntimeError); argument / library errors
+            # of the plan (ValueError from _lib.check) are real and propagate.  The fallback is logged once.
             try:
                 torch.cuda.synchronize()
                 cg = torch.cuda.CUDAGraph()
                 with torch.cuda.graph(cg, capture_error_mode="thread_local"):
                     burst()
-                captured = (lead, cg)
-            except Exception:                         # noqa: BLE001 -- any refusal means "not capturable here"
+                captured = (lead, cg, _burst_ptrs(vectors, plan))
+            except RuntimeError as exc:
                 captured = False
                 torch.cuda.synchronize()
+                warnings.warn("sharded EM loop: hipGraph capture of a burst was refused (%s); staying eager" % (exc,),
+                              RuntimeWarning, stacklevel=2)
         first = False
         if use_graph and captured:
+            # a captured burst replays raw pointers: the loop vectors and the plan's buffers must still be the ones
+            # it recorded (they are never reallocated inside this loop; this makes the convention a check)
+            if captured[2] != _burst_ptrs(vectors, plan):
+                raise RuntimeError("sharded EM loop: a buffer of the captured burst was reallocated between bursts")
             captured[1].replay()
             graph_bursts += 1
         else:
@@ -199,6 +209,16 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
 
 
 sharded_em_loop.last_graph_bursts = 0        # bursts the last call replayed from a captured graph (diagnostic)
+
+
+def _burst_ptrs(vectors, plan):
+    """Addresses a captured burst bakes in: the loop vectors and the plan's scratch / matrix buffers."""
+    ptrs = [v.data_ptr() for v in vectors]
+    for name in ("ws", "lin", "mat", "wts"):
+        buf = getattr(plan, name, None)
+        if buf is not None and hasattr(buf, "data_ptr"):
+            ptrs.append(buf.data_ptr())
+    return tuple(ptrs)
 
 
 def _assert_ranks_agree(states, device, group):

@@ -223,31 +223,48 @@ class EmPlan(object):
         self.coded_bytes = self.coded_record_bytes + n_rest * self.n_haps * 8
         self.coded_rest = n_rest
         self.coded_ndist = cm.ndist
-        self._coded_keep = (cm.rec, cm.rec_off, cm.ndist, p_rest, w_rest, cm)
+        wide = cm.wide_rows()
+        self.coded_wide = int(wide.numel())
+        self._coded_keep = (cm.rec, cm.rec_off, cm.ndist, p_rest, w_rest, cm, wide)
         self.records = cm
         self.coded = _lib.Coded(cm.rec.data_ptr(), cm.rec_off.data_ptr(), cm.ndist.data_ptr(), self.n_rows,
                                 p_rest.data_ptr() if n_rest else None, p_rest.stride(0) if n_rest else 0,
-                                w_rest.data_ptr() if n_rest else None, n_rest)
+                                w_rest.data_ptr() if n_rest else None, n_rest,
+                                wide.data_ptr() if self.coded_wide else None, self.coded_wide)
 
     def encode(self):
         """Row-dictionary form of this plan's matrix (mxm_encode_rows) + the dense rest."""
         lib, dev, n_rows, n_haps = self.lib, self.dev, self.n_rows, self.n_haps
-        cap = lib.mxm_coded_bytes(n_rows, n_haps)
+        # the record buffer: room for 64 table entries per row (mean on build_em_matrix rows: 27) instead of the worst
+        # case (mxm_coded_bytes: 27 KB per row); the encoder counts what it would have needed, and an overflow
+        # repeats the pass once with exactly that much
+        ldc = (n_haps + 7) // 8 * 8
+        one = 2 * ldc + 16 * 1024
         if self.coded is not None:                    # encoding again (bench.py times the second run): same buffers
             rec, rec_off, ndist = self._coded_keep[:3]
+            cap = rec.numel()
         else:
+            cap = max(one, min(lib.mxm_coded_bytes(n_rows, n_haps), n_rows * (ldc + 16 * 64) + (1 << 20)))
             rec = device_empty((cap,), torch.uint8, dev, "the coded matrix")
             rec_off = torch.empty(n_rows, dtype=torch.int64, device=dev)
             ndist = torch.empty(n_rows, dtype=torch.int32, device=dev)
             self.rowmax = torch.empty(n_rows, dtype=torch.float64, device=dev)
         stats = torch.zeros(2, dtype=torch.int64, device=dev)
-        _lib.check(lib.mxm_encode_rows(self.mat.data_ptr(), self.mat.stride(0), n_rows, n_haps, rec.data_ptr(), cap,
-                                       rec_off.data_ptr(), ndist.data_ptr(), self.rowmax.data_ptr(), stats.data_ptr(),
-                                       current_stream()), "mxm_encode_rows")
-        used, n_rest = (int(v) for v in stats.cpu())
+        for attempt in (0, 1):
+            _lib.check(lib.mxm_encode_rows(self.mat.data_ptr(), self.mat.stride(0), n_rows, n_haps, rec.data_ptr(), cap,
+                                           rec_off.data_ptr(), ndist.data_ptr(), self.rowmax.data_ptr(), stats.data_ptr(),
+                                           current_stream()), "mxm_encode_rows")
+            used, n_rest = (int(v) for v in stats.cpu())
+            if used <= cap:
+                break
+            if attempt == 1:
+                raise ValueError("mxm_encode_rows: record buffer of %d bytes overflowed (%d needed)" % (cap, used))
+            del rec
+            cap = max(one, used)
+            rec = device_empty((cap,), torch.uint8, dev, "the coded matrix")
         p_rest = w_rest = None
         if n_rest:
-            # rows with more than 256 distinct values: dense, in row order (fixed -> same sums on every run)
+            # rows with more than 1024 distinct values: dense, in row order (fixed -> same sums on every run)
             idx = torch.nonzero(ndist == 0).flatten()
             m_rest = self.mat.index_select(0, idx)
             ldp = (n_haps + 1) // 2 * 2
@@ -260,11 +277,15 @@ class EmPlan(object):
         self.coded_record_bytes = used - 8 * int(ndist.sum().item())
         self.coded_bytes = self.coded_record_bytes + (n_rest * n_haps * 8)
         self.coded_rest = n_rest
-        self._coded_keep = (rec, rec_off, ndist, p_rest, w_rest)      # the tensors self.coded points into
+        # rows with 16-bit codes (257..1024 values), in row order: the EM kernel takes them in a loop of their own
+        wide = torch.nonzero(ndist > 256).flatten()
+        self.coded_wide = int(wide.numel())
+        self._coded_keep = (rec, rec_off, ndist, p_rest, w_rest, wide)      # the tensors self.coded points into
         self.coded_ndist = ndist                      # [R] int32: table entries per row, 0 = the row stays dense
         self.coded = _lib.Coded(rec.data_ptr(), rec_off.data_ptr(), ndist.data_ptr(), n_rows,
                                 p_rest.data_ptr() if n_rest else None, p_rest.stride(0) if n_rest else 0,
-                                w_rest.data_ptr() if n_rest else None, n_rest)
+                                w_rest.data_ptr() if n_rest else None, n_rest,
+                                wide.data_ptr() if self.coded_wide else None, self.coded_wide)
 
     # pointers for the C ABI ------------------------------------------------
     def mat_args(self):
@@ -505,31 +526,43 @@ def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, stora
                              for _ in range(n_multi)])
     inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
     verbose = getattr(args, "verbose", False)
-    live = verbose and n_multi == 1
-    if live:
-        # the reference's own progress text, while the loop runs (em.py:119-135): a dot per 10 iterations
-        sys.stderr.write("Starting EM run 1...\n")
-        shown = [0]
-
-        def on_state(state_host, n_runs, _user):
-            dots = state_host[0].iters // 10 - shown[0]
-            if dots > 0:
-                sys.stderr.write("." * dots)
-                sys.stderr.flush()
-                shown[0] += dots
-        hook = _lib.PROGRESS_FN(on_state)
-        plan.lib.mxm_set_progress_callback(ctypes.cast(hook, ctypes.c_void_p), None, 10)
     t_loop = time.perf_counter()
-    try:
-        ln_cur, ln_new, states = em_loop(plan, inits, args.tolerance, args.max_iter)
-    finally:
-        t_loop = time.perf_counter() - t_loop
-        if live:
+    if verbose:
+        # the reference's own progress text WHILE the loop runs (em.py:119-135): "Starting EM run i...", a dot per 10
+        # iterations, "Converged! (n)".  With several restarts that text is sequential by nature, so -v runs them one
+        # after another (each restart's result does not depend on when it is scheduled: it counts its own iterations);
+        # without -v they advance together and share the passes over the matrix.
+        parts = []
+        try:
+            for run in range(n_multi):
+                sys.stderr.write("Starting EM run %d...\n" % (run + 1))
+                shown = [0]
+
+                def on_state(state_host, n_runs, _user, shown=shown):
+                    dots = state_host[0].iters // 10 - shown[0]
+                    if dots > 0:
+                        sys.stderr.write("." * dots)
+                        sys.stderr.flush()
+                        shown[0] += dots
+                hook = _lib.PROGRESS_FN(on_state)
+                plan.lib.mxm_set_progress_callback(ctypes.cast(hook, ctypes.c_void_p), None, 10)
+                lc, ln, st = em_loop(plan, inits[run:run + 1], args.tolerance, args.max_iter)
+                plan.lib.mxm_set_progress_callback(None, None, 10)
+                missing = st[0][1] // 10 - shown[0]          # (a loop that ended between two read-backs)
+                if missing > 0:
+                    sys.stderr.write("." * missing)
+                if st[0][0] == 1:
+                    sys.stderr.write("\nConverged! (%d)\n" % st[0][1])
+                parts.append((lc, ln, st[0]))
+        finally:
             plan.lib.mxm_set_progress_callback(None, None, 10)
-    if live and states[0][0] == 1:
-        sys.stderr.write("\nConverged! (%d)\n" % states[0][1])
-    res = collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix,
-                         verbose and not live, reuse_linear=True)
+        ln_cur = torch.cat([part[0] for part in parts], dim=0)
+        ln_new = torch.cat([part[1] for part in parts], dim=0)
+        states = [part[2] for part in parts]
+    else:
+        ln_cur, ln_new, states = em_loop(plan, inits, args.tolerance, args.max_iter)
+    t_loop = time.perf_counter() - t_loop
+    res = collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix, False, reuse_linear=True)
     # where the call's time went: plan (allocations -- a 43 GB hipMalloc alone varies between 0.3 and 3 s
     # from process to process -- plus linearise / encode) and the loop itself (blocking, so wall time = device time)
     res["plan_s"], res["loop_s"], res["storage"] = t_plan, t_loop, plan.storage

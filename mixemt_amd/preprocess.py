@@ -439,10 +439,17 @@ class CodedMatrix(object):
         self.rec, self.rec_off, self.ndist, self.rowmax = rec, rec_off, ndist, rowmax
         self.used, self.rest_rows, self.m_rest = used, rest_rows, m_rest
 
+    def wide_rows(self):
+        """Rows whose record has 16-bit codes (257..1024 distinct values), in row order (device int64)."""
+        if getattr(self, "_wide", None) is None:
+            self._wide = torch.nonzero(self.ndist > 256).flatten()
+        return self._wide
+
     def struct(self):
         """mxm_coded view of the records alone (the consumers that take it handle coded rows only)."""
+        wide = self.wide_rows()
         return _lib.Coded(self.rec.data_ptr(), self.rec_off.data_ptr(), self.ndist.data_ptr(), self.n_rows,
-                          None, 0, None, 0)
+                          None, 0, None, 0, wide.data_ptr() if wide.numel() else None, int(wide.numel()))
 
 
 def _gather_csr(row_ptr_d, site_d, obs_d, rows):
@@ -456,15 +463,22 @@ def _gather_csr(row_ptr_d, site_d, obs_d, rows):
     return new_ptr, site_d.index_select(0, src), obs_d.index_select(0, src)
 
 
-def build_em_records_device(tables, row_ptr, site, obs, dense=False):
+RECORD_BYTES_GUESS = 16 * 64          # table bytes per row the first record buffer allows for (mean on synth-v1: 16 x 27)
+
+
+def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None):
     """
     CSR observations -> CodedMatrix: the marker kernel writes each row as a row-dictionary record
     (one byte per haplogroup + the row's distinct values) -- what em.EmPlan(storage="coded") otherwise
     makes from the dense matrix with a pass of its own.  dense=False: NO dense matrix is written (5.5 GB
     instead of 43 GB at 10^6 x 5408; 10^7 rows fit one GPU); rows the marker kernel cannot take (more than
     64 observations, more than 256 distinct values: ~3.5 %) are built densely by the lookup-table kernel and
-    coded from there where they hold at most 256 values; what remains (~2 %) stays dense in `m_rest`.
+    coded from there (mxm_encode_rows: byte codes up to 256 values, 16-bit codes up to 1024); what remains
+    (more than 1024 values: none on build_em_matrix's rows) stays dense in `m_rest`.
     dense=True: returns (CodedMatrix, M) with the full dense matrix as well.
+    cap: bytes of the record buffer.  Default: room for RECORD_BYTES_GUESS table bytes per row instead of the
+    worst case mxm_record_bytes (27 KB per row: a 27 GB hipMalloc at 10^6 rows for 6 GB of records); the kernels
+    count what they would have needed, and an overflow repeats the build once with exactly that much.
     """
     lib = _lib.load()
     dev = require_gpu()
@@ -478,25 +492,19 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False):
     n_rows, n_haps, n_sites = row_ptr_d.numel() - 1, tables.n_haps, len(tables.sites)
     if n_rows <= 0:
         raise ValueError("no rows")
+    ldc = (n_haps + 7) // 8 * 8
+    worst = lib.mxm_record_bytes(n_rows, n_haps)
+    one = 2 * ldc + 16 * 1024                       # a full wide record: the smallest buffer the library accepts
+    if cap is None:
+        cap = min(worst, max(one, n_rows * (ldc + RECORD_BYTES_GUESS) + (1 << 20)))
+    cap = max(int(cap), one)
     mat = device_empty((n_rows, n_haps), torch.float64, dev, "the EM input matrix") if dense else None
-    cap = lib.mxm_record_bytes(n_rows, n_haps)
-    rec = device_empty((cap,), torch.uint8, dev, "the coded matrix")
     rec_off = torch.empty(n_rows, dtype=torch.int64, device=dev)
     ndist = torch.empty(n_rows, dtype=torch.int32, device=dev)
     rowmax = torch.empty(n_rows, dtype=torch.float64, device=dev)
     stats = torch.zeros(2, dtype=torch.int64, device=dev)
     fallback = torch.empty(n_rows, dtype=torch.int64, device=dev)
     n_fallback = torch.zeros(1, dtype=torch.int64, device=dev)
-    _lib.check(lib.mxm_build_em_records(
-        enc["maj"].data_ptr(), enc["lhit"].data_ptr(), enc["lmiss"].data_ptr(), enc["mk_ptr"].data_ptr(),
-        enc["mk_hap"].data_ptr(), enc["mk_base"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(),
-        0, n_rows, n_haps, n_sites, mat.data_ptr() if dense else 0, mat.stride(0) if dense else 0,
-        rec.data_ptr(), cap, rec_off.data_ptr(), ndist.data_ptr(), rowmax.data_ptr(), stats.data_ptr(),
-        fallback.data_ptr(), n_fallback.data_ptr(), current_stream()), "mxm_build_em_records")
-    used, n_rest = (int(v) for v in stats.cpu())
-    left = int(n_fallback.item())
-    rest_rows = torch.nonzero(ndist == 0).flatten()
-    assert rest_rows.numel() == n_rest
 
     def lut_rows(rp, si, ob, order, count, out):
         _lib.check(lib.mxm_build_em_matrix_lut(
@@ -504,41 +512,68 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False):
             lut["obsmap"].data_ptr(), rp.data_ptr(), si.data_ptr(), ob.data_ptr(), order, count, n_haps, n_sites,
             out.data_ptr(), out.stride(0), current_stream()), "mxm_build_em_matrix_lut")
 
-    m_rest = None
-    if dense:
-        if left:
-            rows = fallback[:left].sort().values
-            lut_rows(row_ptr_d, site_d, obs_d, rows.data_ptr(), left, mat)
-        if n_rest:
-            m_rest = mat.index_select(0, rest_rows)
-    elif n_rest:
-        assert left == n_rest                     # without a dense matrix every row without a record is on the list
-        sub_ptr, sub_site, sub_obs = _gather_csr(row_ptr_d, site_d, obs_d, rest_rows)
-        m_rest = torch.empty((n_rest, n_haps), dtype=torch.float64, device=dev)
-        lut_rows(sub_ptr, sub_site, sub_obs, 0, n_rest, m_rest)
-    if m_rest is not None:
-        # the dense rows of long reads mostly hold few distinct values too: code them from their dense form
-        # (mxm_encode_rows) into the tail of the same record buffer; what stays dense has more than 256 values
-        base = (used + 15) // 16 * 16
-        sub_off = torch.empty(n_rest, dtype=torch.int64, device=dev)
-        sub_nd = torch.empty(n_rest, dtype=torch.int32, device=dev)
-        sub_rm = torch.empty(n_rest, dtype=torch.float64, device=dev)
-        sub_stats = torch.zeros(2, dtype=torch.int64, device=dev)
-        _lib.check(lib.mxm_encode_rows(m_rest.data_ptr(), m_rest.stride(0), n_rest, n_haps, rec.data_ptr() + base,
-                                       cap - base, sub_off.data_ptr(), sub_nd.data_ptr(), sub_rm.data_ptr(),
-                                       sub_stats.data_ptr(), current_stream()), "mxm_encode_rows")
-        got = sub_nd > 0
-        rows_c = rest_rows[got]
-        rec_off[rows_c] = sub_off[got] + base
-        ndist[rows_c] = sub_nd[got]
-        rowmax[rows_c] = sub_rm[got]
-        used = base + int(sub_stats[0].item())
-        rest_rows = rest_rows[~got]
-        m_rest = m_rest[~got].contiguous()
-        n_rest = int(rest_rows.numel())
+    for attempt in (0, 1):
+        rec = device_empty((cap,), torch.uint8, dev, "the coded matrix")
+        _lib.check(lib.mxm_build_em_records(
+            enc["maj"].data_ptr(), enc["lhit"].data_ptr(), enc["lmiss"].data_ptr(), enc["mk_ptr"].data_ptr(),
+            enc["mk_hap"].data_ptr(), enc["mk_base"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(),
+            0, n_rows, n_haps, n_sites, mat.data_ptr() if dense else 0, mat.stride(0) if dense else 0,
+            rec.data_ptr(), cap, rec_off.data_ptr(), ndist.data_ptr(), rowmax.data_ptr(), stats.data_ptr(),
+            fallback.data_ptr(), n_fallback.data_ptr(), current_stream()), "mxm_build_em_records")
+        used, n_rest = (int(v) for v in stats.cpu())
+        left = int(n_fallback.item())
+        need = used
+        if used <= cap:
+            rest_rows = torch.nonzero(ndist == 0).flatten()
+            assert rest_rows.numel() == n_rest
+            m_rest = None
+            if dense:
+                if left:
+                    rows = fallback[:left].sort().values
+                    lut_rows(row_ptr_d, site_d, obs_d, rows.data_ptr(), left, mat)
+                if n_rest:
+                    m_rest = mat.index_select(0, rest_rows)
+            elif n_rest:
+                assert left == n_rest             # without a dense matrix every row without a record is on the list
+                sub_ptr, sub_site, sub_obs = _gather_csr(row_ptr_d, site_d, obs_d, rest_rows)
+                m_rest = torch.empty((n_rest, n_haps), dtype=torch.float64, device=dev)
+                lut_rows(sub_ptr, sub_site, sub_obs, 0, n_rest, m_rest)
+            if m_rest is not None:
+                # the dense rows of long reads mostly hold few distinct values too: code them from their dense form
+                # (mxm_encode_rows: bytes, then 16-bit codes) into the tail of the same record buffer
+                base = (used + 15) // 16 * 16
+                sub_off = torch.empty(n_rest, dtype=torch.int64, device=dev)
+                sub_nd = torch.empty(n_rest, dtype=torch.int32, device=dev)
+                sub_rm = torch.empty(n_rest, dtype=torch.float64, device=dev)
+                sub_stats = torch.zeros(2, dtype=torch.int64, device=dev)
+                if cap - base >= one:
+                    _lib.check(lib.mxm_encode_rows(m_rest.data_ptr(), m_rest.stride(0), n_rest, n_haps, rec.data_ptr() + base,
+                                                   cap - base, sub_off.data_ptr(), sub_nd.data_ptr(), sub_rm.data_ptr(),
+                                                   sub_stats.data_ptr(), current_stream()), "mxm_encode_rows")
+                    sub_used = int(sub_stats[0].item())
+                else:
+                    sub_used = n_rest * one               # no room left at all: ask for the worst case of these rows
+                need = base + sub_used
+                if need <= cap:
+                    got = sub_nd > 0
+                    rows_c = rest_rows[got]
+                    rec_off[rows_c] = sub_off[got] + base
+                    ndist[rows_c] = sub_nd[got]
+                    rowmax[rows_c] = sub_rm[got]
+                    used = need
+                    rest_rows = rest_rows[~got]
+                    m_rest = m_rest[~got].contiguous()
+                    n_rest = int(rest_rows.numel())
+        if need <= cap:
+            break
+        if attempt == 1:
+            raise ValueError("build_em_records_device: record buffer of %d bytes overflowed twice (%d needed)" % (cap, need))
+        del rec
+        cap = min(worst, need + (n_rest + 1) * one)       # exact for the marker kernel's records, generous for the rest
     build_em_matrix_device.last_fallback = left
     cm = CodedMatrix(n_rows, n_haps, rec, rec_off, ndist, rowmax, used,
                      rest_rows, m_rest if m_rest is not None else torch.empty((0, n_haps), dtype=torch.float64, device=dev))
+    cm.capacity = cap
     return (cm, mat) if dense else cm
 
 

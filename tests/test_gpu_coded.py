@@ -48,13 +48,13 @@ def test_encoded_rows_decode_to_the_linearised_matrix_bit_for_bit(b17, name):
     coded = em.EmPlan(mat, g["wts"], storage="coded")
     assert coded.coded is not None and coded.lin is None
     nd = _ndist(coded)
-    assert (nd > 0).sum() + coded.coded_rest == len(nd) and (nd <= 256).all()
+    assert (nd > 0).sum() + coded.coded_rest == len(nd) and (nd <= 1024).all()
     assert (nd > 0).mean() > 0.9                      # build_em_matrix rows hold few distinct sums
-    # the dictionary of a row has exactly as many entries as the row has distinct values
-    for r in numpy.flatnonzero(nd > 0)[:50]:
+    assert coded.coded_rest == 0                      # ... and never more than 1024: no row stays dense (round 4)
+    assert coded.coded_wide == (nd > 256).sum()
+    # the dictionary of a row has exactly as many entries as the row has distinct values -- byte-coded or wide
+    for r in list(numpy.flatnonzero(nd > 0)[:50]) + list(numpy.flatnonzero(nd > 256)):
         assert nd[r] == len(numpy.unique(mat[r]))
-    for r in numpy.flatnonzero(nd == 0):
-        assert len(numpy.unique(mat[r])) > 256
     dec = _decode(coded)
     rows = torch.from_numpy(nd > 0).to(dec.device)
     assert torch.equal(dec[rows].view(torch.int64), dense.lin[rows][:, :len(haps)].view(torch.int64))
@@ -111,7 +111,7 @@ def test_rows_that_do_not_code_stay_dense_and_count():
     dense path's; a mixed matrix (half dictionary rows) sums both parts."""
     from mixemt_amd import em
     rng = numpy.random.default_rng(5)
-    n_rows, n_haps = 300, 1000
+    n_rows, n_haps = 300, 1500                                       # 1500 distinct values per random row: beyond wide records
     mat = rng.normal(-25.0, 8.0, size=(n_rows, n_haps))
     few = rng.normal(-25.0, 8.0, size=(n_rows, 7))
     pick = rng.integers(0, 7, size=(n_rows, n_haps))
@@ -156,6 +156,65 @@ def test_shapes_and_ragged_ends(n_rows, n_haps):
     for _ in range(4):
         buf, theta = em_oracle.em_step(mat, wts, theta, buf)
     assert numpy.abs(res["props"] - numpy.exp(theta)).max() < 1e-12
+
+
+@pytest.mark.parametrize("n_rows,n_haps,seed", [(700, 2000, 1), (37, 5408, 2), (3, 1100, 3), (1300, 1026, 4)])
+def test_wide_records_sixteen_bit_codes(n_rows, n_haps, seed):
+    """
+    Rows of 257..1024 distinct values get records with 16-bit codes (round 4: they used to stay dense and cost a kernel
+    launch of their own per iteration): decode == mxm_linearize bit for bit, the table has one entry per distinct
+    value, the EM iteration over a mix of byte-coded, wide and dense rows equals the oracle, and so do the record
+    consumers (posterior, column gather, argmax votes).
+    """
+    import torch
+    from mixemt_amd import assign, em, preprocess
+    rng = numpy.random.default_rng(seed)
+    kinds = rng.integers(0, 4, size=n_rows)                        # 0: few values, 1: ~300, 2: exactly up to 1024, 3: too many
+    kinds[:4] = [0, 1, 2, 3][: min(4, n_rows)]
+    want_d = numpy.where(kinds == 0, 9, numpy.where(kinds == 1, 300, numpy.where(kinds == 2, min(1024, n_haps), n_haps)))
+    mat = numpy.empty((n_rows, n_haps))
+    for r in range(n_rows):
+        vals = rng.normal(-20.0, 6.0, size=want_d[r])
+        idx = rng.integers(0, want_d[r], size=n_haps)
+        idx[rng.permutation(n_haps)[: want_d[r]]] = numpy.arange(want_d[r])     # every value occurs
+        mat[r] = vals[idx]
+    if n_rows > 10:
+        mat[9, : n_haps // 3] = -numpy.inf                          # -inf is a value like any other
+    wts = rng.integers(1, 4, size=n_rows).astype(numpy.float64)
+    plan = em.EmPlan(mat, wts, storage="coded")
+    nd = _ndist(plan)
+    uniq = numpy.array([len(numpy.unique(row)) for row in mat])
+    assert numpy.array_equal(nd, numpy.where(uniq <= 1024, uniq, 0))
+    assert plan.coded_wide == ((uniq > 256) & (uniq <= 1024)).sum() and plan.coded_rest == (uniq > 1024).sum()
+    dense = em.EmPlan(mat, wts, storage="f64")
+    dec = _decode(plan)
+    rows = torch.from_numpy(nd > 0).to(dec.device)
+    assert torch.equal(dec[rows].view(torch.int64), dense.lin[rows][:, :n_haps].view(torch.int64))
+    init = rng.dirichlet([1.0] * n_haps)
+    res = em.run_em_ex(mat, wts, em_args(max_iter=5, tolerance=0.0), inits=init[None, :], storage="coded")
+    theta = numpy.log(init)
+    buf = numpy.empty_like(mat)
+    with numpy.errstate(invalid="ignore"):
+        for _ in range(5):
+            last = theta
+            buf, theta = em_oracle.em_step(mat, wts, theta, buf)
+    assert res["iters"] == [5] and numpy.abs(res["props"] - numpy.exp(theta)).max() < 1e-12
+    # consumers of the records' log tables: posterior under theta_k, column gather, argmax + votes
+    cm = preprocess.CodedMatrix(n_rows, n_haps, *plan._coded_keep[:3], plan.rowmax, 0,
+                                torch.nonzero(plan.coded_ndist == 0).flatten(),
+                                dense.mat[torch.nonzero(plan.coded_ndist == 0).flatten()].contiguous())
+    rec_plan = em.EmPlan(None, wts, records=cm)
+    post = em.posterior(rec_plan, last).cpu().numpy()
+    finite = numpy.isfinite(buf)
+    assert numpy.array_equal(numpy.isfinite(post), finite) and numpy.abs(post[finite] - buf[finite]).max() < 1e-10
+    cols = sorted(rng.choice(n_haps, size=5, replace=False).tolist())
+    haps = ["h%d" % i for i in range(n_haps)]
+    sub, _ = preprocess.reduce_em_records(cm, haps, [["x", haps[c], 0.0] for c in cols])
+    assert numpy.array_equal(sub.cpu().numpy(), mat[:, cols])
+    best, votes = assign.row_argmax_votes_records(cm, last, wts)
+    want_best = (last[None, :] + mat).argmax(axis=1)
+    assert numpy.array_equal(best, want_best)
+    assert numpy.array_equal(votes, numpy.bincount(want_best, weights=wts, minlength=n_haps))
 
 
 def test_unsupported_shapes_iterate_as_fp64():
@@ -238,7 +297,7 @@ def _decode_cm(cm):
     from mixemt_amd._dev import current_stream
     lib = _lib.load()
     out = torch.full((cm.n_rows, cm.n_haps), float("nan"), dtype=torch.float64, device=cm.rec.device)
-    coded = _lib.Coded(cm.rec.data_ptr(), cm.rec_off.data_ptr(), cm.ndist.data_ptr(), cm.n_rows, None, 0, None, 0)
+    coded = _lib.Coded(cm.rec.data_ptr(), cm.rec_off.data_ptr(), cm.ndist.data_ptr(), cm.n_rows, None, 0, None, 0, None, 0)
     _lib.check(lib.mxm_decode_rows(ctypes.byref(coded), cm.n_haps, out.data_ptr(), out.stride(0), current_stream()),
                "mxm_decode_rows")
     return out
@@ -262,10 +321,12 @@ def test_records_straight_from_the_build(b17, name, read_len):
     dense = em.EmPlan(mat, numpy.ones(len(want)))
     nd = cm.ndist.cpu().numpy()
     rest = cm.rest_rows.cpu().numpy()
-    assert numpy.array_equal(rest, numpy.flatnonzero(nd == 0)) and (nd <= 256).all()
+    assert numpy.array_equal(rest, numpy.flatnonzero(nd == 0)) and (nd <= 1024).all()
     long_rows = numpy.flatnonzero(numpy.diff(row_ptr) > 64)                   # beyond the marker kernel's mask: built
     for r in rest:                                                             # densely, then coded from there
-        assert len(numpy.unique(want[r])) > 256                                # only rows with too many values stay dense
+        assert len(numpy.unique(want[r])) > 1024                               # only rows with too many values stay dense
+    for r in numpy.flatnonzero(nd > 256):                                      # wide records: one entry per distinct value
+        assert nd[r] == len(numpy.unique(want[r]))
     if read_len == 260:
         assert len(long_rows) > 100 and (nd[long_rows] > 0).sum() > 50         # long rows with records of their own
     for r in numpy.flatnonzero(nd > 0)[:40]:
@@ -375,11 +436,11 @@ def test_votes_from_records_of_a_multi_run_follow_the_fold(b17):
     v2 = assign.row_argmax_votes_records(cm, res["ln_theta_k"], frac)[1]
     assert numpy.array_equal(v1, v2) and abs(v1.sum() - frac.sum()) < 1e-9
     # every row dense-leftover (the marker kernel hands every row to the fallback list, whose rows are coded from
-    # their dense form only up to 256 values): long reads give rows that stay dense
+    # their dense form only up to 1024 values): very long reads give rows that stay dense
     from mixemt_amd import synth
-    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 300, seed=77, read_len=2500)
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 300, seed=77, read_len=6000)
     cm3, mat3 = preprocess.build_em_records_device(tables, row_ptr, site, obs, dense=True)
-    assert int(cm3.rest_rows.numel()) > 100
+    assert int(cm3.rest_rows.numel()) > 100 or int(cm3.wide_rows().numel()) > 100
     wts3 = numpy.ones(300)
     numpy.random.seed(3)
     r3 = em.run_em_ex(mat3, wts3, em_args(n_multi=2, max_iter=60))
@@ -407,3 +468,100 @@ def test_records_posterior_stays_finite_where_the_dense_pass_does(b17):
     fold_a = em.posterior(rec_plan, lnp + 1.0, out=torch.from_numpy(a.copy()).cuda(), fold=True).cpu().numpy()
     fold_b = em.posterior(dense_plan, lnp + 1.0, out=torch.from_numpy(b.copy()).cuda(), fold=True).cpu().numpy()
     assert numpy.abs(fold_a - fold_b).max() < 1e-9
+
+
+@pytest.fixture()
+def lib():
+    from mixemt_amd import _lib
+    handle = _lib.load()
+    yield handle
+    handle.mxm_set_loop_fused(-1, 0)
+    handle.mxm_diag_fused_force_abort(0)
+
+
+@pytest.mark.parametrize("name,seed,n_multi", [("g4_run_em", 7, 1), ("g9_run_em_2400", 17, 1), ("g5_run_em_multi", 11, 3)])
+def test_one_launch_loop_over_records_reproduces_the_reference_runs(b17, lib, name, seed, n_multi):
+    """
+    em_fused_coded_kernel (round 4): the whole loop over records in one persistent launch -- the reference's stopping
+    iterations, proportions and calls (g4, g9 with 1209 iterations, g5 with three restarts), identical results when the
+    launch is cut into chunks of 7 iterations, rounding-level agreement with the per-iteration kernels, and a launch that
+    gives up is undone and finished by them.
+    """
+    from mixemt_amd import em
+    refseq, phy, haps, tables = b17
+    g = golden(name)
+    mat = _b17_matrix(tables, g, len(haps))
+    runs = {}
+    for label, mode, chunk in (("one launch", 1, 0), ("chunks", 1, 7), ("kernels", 0, 0)):
+        lib.mxm_set_loop_fused(mode, chunk)
+        numpy.random.seed(seed)
+        res = em.run_em_ex(mat, g["wts"], em_args(n_multi=n_multi), storage="coded")
+        assert res["storage"] == "coded" and numpy.array_equal(res["inits"], g["inits"])
+        assert res["iters"] == list(g["iters"]), label
+        assert res["done"] == [1] * n_multi
+        assert numpy.abs(res["props"] - g["props"]).max() < PROPS_ATOL
+        mix = res["read_mix"].cpu().numpy()
+        assert numpy.array_equal(mix.argmax(axis=1), g["mix_argmax"])
+        runs[label] = res
+    assert numpy.array_equal(runs["one launch"]["run_props"], runs["chunks"]["run_props"])   # a resumed launch continues bit for bit
+    assert runs["one launch"]["l1"] == runs["chunks"]["l1"]
+    assert numpy.abs(runs["one launch"]["run_props"] - runs["kernels"]["run_props"]).max() < 1e-12
+    # starved grid: undone from the snapshot, the same call finishes through the per-iteration kernels
+    lib.mxm_set_loop_fused(-1, 0)
+    lib.mxm_diag_fused_force_abort(1)
+    numpy.random.seed(seed)
+    got = em.run_em_ex(mat, g["wts"], em_args(n_multi=n_multi), storage="coded", want_read_mix=False)
+    assert got["iters"] == list(g["iters"]) and numpy.array_equal(got["run_props"], runs["kernels"]["run_props"])
+    lib.mxm_set_loop_fused(1, 0)
+    plan = em.EmPlan(mat, g["wts"], storage="coded")
+    with pytest.raises(ValueError, match="one-launch loop"):
+        em.em_loop(plan, g["inits"], 1e-4, 10000)
+    lib.mxm_diag_fused_force_abort(0)
+    ln_cur, ln_new, states = em.em_loop(plan, g["inits"], 1e-4, 10000)
+    assert [st[1] for st in states] == list(g["iters"])
+
+
+@pytest.mark.parametrize("n_rows,n_haps,seed", [(1, 66, 1), (3, 5408, 2), (700, 130, 3), (513, 8192, 4), (1400, 2050, 5),
+                                                (300, 4096, 6), (40, 1026, 7)])
+def test_one_launch_loop_over_records_vs_oracle_on_random_shapes(lib, n_rows, n_haps, seed):
+    """Fewer rows than workgroups, every chunk count of the kernel, slices of 1 to 8 column pairs, byte-coded and wide
+    rows mixed, zero weights, -inf cells, max_iter exhaustion: the oracle's run_em."""
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(seed)
+    nval = numpy.where(rng.random(n_rows) < 0.8, 30, 400)
+    mat = numpy.empty((n_rows, n_haps))
+    for r in range(n_rows):
+        vals = rng.normal(-12.0, 4.0, size=nval[r])
+        mat[r] = vals[rng.integers(0, nval[r], size=n_haps)]
+    hot = rng.integers(0, 5, size=n_rows)
+    mat[numpy.arange(n_rows), hot] = -1.0                          # a few haplogroups explain most rows
+    if n_rows > 8:
+        mat[7, : n_haps // 2] = -numpy.inf
+    wts = rng.integers(0, 4, size=n_rows).astype(numpy.float64)
+    wts[0] = 2.0
+    for max_iter in (300, 6):
+        args = em_args(max_iter=max_iter)
+        trace = []
+        numpy.random.seed(seed)
+        props, mix = em_oracle.run_em(mat, wts, args, trace=trace)
+        for mode, chunk in ((1, 0), (1, 4)):
+            lib.mxm_set_loop_fused(mode, chunk)
+            numpy.random.seed(seed)
+            res = em.run_em_ex(mat, wts, args, storage="coded")
+            assert res["storage"] == "coded" and res["iters"] == [trace[0]["iters"]], (mode, chunk)
+            assert numpy.abs(res["props"] - props).max() < PROPS_ATOL
+            got = res["read_mix"].cpu().numpy()
+            assert numpy.array_equal(numpy.isfinite(got), numpy.isfinite(mix))
+            assert numpy.abs(numpy.exp(got) - numpy.exp(mix)).max() < 1e-9
+
+
+def test_one_launch_loop_over_records_poisons_like_the_reference(lib):
+    """A row that is -inf everywhere: NaN proportions and max_iter, as the dense path and the reference (em.py:81-83)."""
+    from mixemt_amd import em
+    rng = numpy.random.default_rng(3)
+    few = rng.normal(-15.0, 4.0, size=(64, 9))
+    mat = numpy.take_along_axis(few, rng.integers(0, 9, size=(64, 256)), axis=1)
+    mat[5, :] = -numpy.inf
+    lib.mxm_set_loop_fused(1, 0)
+    res = em.run_em_ex(mat, numpy.ones(64), em_args(max_iter=9), storage="coded", want_read_mix=False)
+    assert res["iters"] == [9] and res["done"] == [2] and numpy.isnan(res["props"]).all()

@@ -182,3 +182,39 @@ def test_a_one_launch_loop_that_gives_up_is_undone_and_finished_by_the_kernels(b
     lib.mxm_diag_fused_force_abort(0)
     ln_cur, ln_new, states = em.em_loop(plan, g["inits"], 1e-4, 10000)
     assert [s[1] for s in states] == list(g["iters"])
+
+
+@pytest.mark.parametrize("n_rows,n_haps", [(1500, 66), (1536, 96), (1100, 80)])
+def test_transposed_loop_on_a_narrow_matrix_stays_inside_its_workspace(lib, n_rows, n_haps):
+    """
+    ADVICE r3 (medium): the transposed one-launch loop's z partials are [workgroups][R] doubles -- 3.2 MB at 1500 rows
+    on 256 CUs -- while the workspace used to be sized by H alone (2.2 MB at H = 66), so they ran past its end and
+    over the give-up snapshot.  The workspace query now covers that layout; the run must match the oracle, and a
+    launch that gives up must be undone from an intact snapshot (same bits as the per-iteration kernels).
+    """
+    from mixemt_amd import _lib, em
+    rng = numpy.random.default_rng(n_rows + n_haps)
+    mat = rng.normal(size=(n_rows, n_haps)) * 3.0 - 8.0
+    mat[numpy.arange(n_rows), rng.integers(0, 5, size=n_rows)] += 10.0
+    wts = rng.integers(1, 4, size=n_rows).astype(numpy.float64)
+    args = em_args(max_iter=400)
+    trace = []
+    numpy.random.seed(3)
+    props, _ = em_oracle.run_em(mat, wts, args, trace=trace)
+    # the query covers sync block + z partials + c + L1 partials + snapshot for a 1024-workgroup grid
+    need = 1025 * ((n_rows + 1) // 2 * 2) * 8
+    assert _lib.load().mxm_workspace_bytes(n_rows, n_haps, 1) > need
+    lib.mxm_set_loop_fused(1, 0)
+    numpy.random.seed(3)
+    res = em.run_em_ex(mat, wts, args, want_read_mix=False)
+    assert res["iters"] == [trace[0]["iters"]]
+    assert numpy.abs(res["props"] - props).max() < PROPS_ATOL
+    lib.mxm_set_loop_fused(0, 0)
+    numpy.random.seed(3)
+    want = em.run_em_ex(mat, wts, args, want_read_mix=False)
+    lib.mxm_set_loop_fused(-1, 0)
+    lib.mxm_diag_fused_force_abort(1)
+    numpy.random.seed(3)
+    got = em.run_em_ex(mat, wts, args, want_read_mix=False)
+    lib.mxm_diag_fused_force_abort(0)
+    assert got["iters"] == want["iters"] and numpy.array_equal(got["run_props"], want["run_props"])

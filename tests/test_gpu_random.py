@@ -124,9 +124,10 @@ def test_random_consumers_vs_numpy(seed):
         assert r in table[name], (r, vals, name)
 
 
-@pytest.mark.parametrize("n_rows,n_haps", [(1, 2), (1, 70), (2, 64), (3, 65), (1, 5408), (7, 8191)])
+@pytest.mark.parametrize("n_rows,n_haps", [(1, 1), (600, 1), (5, 1), (1, 2), (1, 70), (2, 64), (3, 65), (1, 5408), (7, 8191)])
 def test_degenerate_shapes(n_rows, n_haps):
-    """Single rows, two columns, the switch-over width between the two loop kernels."""
+    """Single rows, ONE column (the refinement EM of an unmixed sample, bin/mixemt:311-320), two columns, the switch-over
+    width between the two loop kernels."""
     from mixemt_amd import em
     rng = numpy.random.default_rng(n_rows * 10007 + n_haps)
     mat = rng.normal(-20.0, 5.0, size=(n_rows, n_haps))

@@ -30,6 +30,8 @@ Fixtures (SURVEY.md section 8 c):
         indels, soft clips, lower-case bases)
     g13 consumers of a MULTI-RUN result: the reference's _find_contribs_from_reads / get_contributors / assign_read_indexes
         (assemble.py:103-123, :284-334) on its own n_multi = 3 run of the g5 matrix (the logaddexp fold of three posteriors)
+    g14 the unmixed sample: reduce_em_matrix to ONE contributor column -> run_em on 600 x 1 (n_multi 1 and 3) ->
+        update_contribs -> assign_read_indexes with a single contributor (bin/mixemt:311-320)
     g12 on-disk formats: the bytes the reference's own dump_all writes (bin/mixemt:214-245) for a small run and what its
         load_prev (bin/mixemt:168-211) reads back from them
 """
@@ -418,6 +420,34 @@ def main():
              refined_props=numpy.array([c[2] for c in refined]), refined_iters=riters,
              refined_inits=rinits, refined_assigned=rassigned,
              props=props, iters=iters)
+
+    if want("g14"):
+        # the commonest real input: an UNMIXED sample.  One contributor -> reduce_em_matrix keeps one column
+        # (preprocess.py:247-251) and bin/mixemt:311-320 calls run_em on R x 1, then update_contribs and
+        # assign_read_indexes with a single contributor (assemble.py:211-230, :284-334).
+        for name in ("pysam", "Bio", "Bio.Seq", "Bio.SeqRecord", "Bio.SeqIO"):
+            sys.modules.setdefault(name, types.ModuleType(name))
+        sys.modules["Bio"].SeqIO = sys.modules["Bio.SeqIO"]
+        sys.modules["Bio.Seq"].Seq = object
+        sys.modules["Bio.SeqRecord"].SeqRecord = object
+        import mixemt.assemble
+        row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), 600, seed=4)
+        sigs = synth.signatures(tables, row_ptr, site, obs)
+        m600 = ref.preprocess.build_em_matrix(refseq, phy, sigs, haps, quiet)
+        w600 = numpy.random.default_rng(44).integers(1, 4, size=600).astype(numpy.int64)
+        one = [["hap1", haps[10], 1.0]]
+        sub, sub_names = ref.preprocess.reduce_em_matrix(m600, haps, one)
+        assert sub.shape == (600, 1)
+        props1, mix1, iters1, inits1 = ref_run_em(ref, sub, w600, 13)
+        refined = ref.assemble.update_contribs([list(c) for c in one], (props1, mix1), sub_names)
+        table = ref.assemble.assign_read_indexes(refined, (props1, mix1), sub_names, [[str(i)] for i in range(600)], 2.0)
+        assert list(table) == ["hap1"] and len(table["hap1"]) == 600
+        # and three restarts of the same (the geometric mean of three [1.0] vectors)
+        props3, mix3, iters3, inits3 = ref_run_em(ref, sub, w600, 13, n_multi=3)
+        save("g14_single_contributor", row_ptr=row_ptr, site=site, obs=obs, wts=w600, col=numpy.array([10], dtype=numpy.int32),
+             sub=sub, props=props1, mix=mix1, iters=iters1, inits=inits1, refined_props=numpy.array([c[2] for c in refined]),
+             assigned=numpy.array(sorted(table["hap1"]), dtype=numpy.int32),
+             props3=props3, mix3=mix3, iters3=iters3, inits3=inits3)
 
     if want("g9"):
         # 4x the g4 size, weights as reduce_reads leaves them (preprocess.py:218-220: fragments per

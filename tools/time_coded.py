@@ -67,9 +67,11 @@ assert torch.equal(rowmax, plan.rowmax), "rowmax differs from mxm_linearize"
 rest_idx = torch.nonzero(ndist == 0).flatten()
 p_rest = plan.lin.index_select(0, rest_idx).contiguous() if rest_idx.numel() else None
 w_rest = wts.index_select(0, rest_idx).contiguous() if rest_idx.numel() else None
+wide_idx = torch.nonzero(ndist > 256).flatten()
 coded = _lib.Coded(rec.data_ptr(), rec_off.data_ptr(), ndist.data_ptr(), rows,
                    p_rest.data_ptr() if p_rest is not None else None, p_rest.stride(0) if p_rest is not None else 0,
-                   w_rest.data_ptr() if w_rest is not None else None, int(rest_idx.numel()))
+                   w_rest.data_ptr() if w_rest is not None else None, int(rest_idx.numel()),
+                   wide_idx.data_ptr() if wide_idx.numel() else None, int(wide_idx.numel()))
 
 # decode == linearize, bit for bit (coded rows)
 dec = torch.full_like(plan.lin, -1.0)

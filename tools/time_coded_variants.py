@@ -44,7 +44,11 @@ print("one MI355X; %d synth-v1 reads x %d haplogroups as records (%d coded rows,
 def small_reference():
     """column sums of the first 4096 rows from decoded rows, fp64 torch"""
     n = min(rows, 4096)
-    sub = _lib.Coded(cm.rec.data_ptr(), cm.rec_off.data_ptr(), cm.ndist.data_ptr(), n, None, 0, None, 0)
+    wide_n = cm.wide_rows()
+    wide_n = wide_n[wide_n < n].contiguous()
+    small_reference.keep = wide_n
+    sub = _lib.Coded(cm.rec.data_ptr(), cm.rec_off.data_ptr(), cm.ndist.data_ptr(), n, None, 0, None, 0,
+                     wide_n.data_ptr() if wide_n.numel() else None, int(wide_n.numel()))
     P = torch.zeros((n, H), dtype=torch.float64, device=dev)
     _lib.check(lib0.mxm_decode_rows(ctypes.byref(sub), H, P.data_ptr(), P.stride(0), stream), "decode")
     live = (cm.ndist[:n] > 0).to(torch.float64)

@@ -63,9 +63,11 @@ for n_rows in [int(x) for x in opts.rows.split(",")]:
               % (n_rows, n_rows * len(haps) * 8 / 1e6, label, n_it, dt * 1e3, dt * 1e6 / n_it))
     lib.mxm_set_loop_fused(-1, 0)
     cplan = em.EmPlan(mat, wts, n_runs=opts.restarts, storage="coded")
-    for graph, label in ((0, "row dictionaries"), (1, "row dictionaries+graph"), (0, "row dictionaries")):
+    for fused, graph, label in ((-1, 0, "records, one launch"), (0, 0, "records, kernels"), (0, 1, "records, kernels+graph"),
+                                (-1, 0, "records, one launch"), (0, 0, "records, kernels")):
         if cplan.coded is None:
             break
+        lib.mxm_set_loop_fused(fused, 0)
         lib.mxm_set_loop_graph(graph)
         torch.cuda.synchronize(); t0 = time.perf_counter()
         ln_cur, ln_new, states = em.em_loop(cplan, init, 0.0, opts.max_iter)
@@ -73,6 +75,15 @@ for n_rows in [int(x) for x in opts.rows.split(",")]:
         n_it = sum(st[1] for st in states)
         print("%7d rows (%6.1f MB)  %-23s %4d restart-iterations  %8.2f ms  %7.1f us per restart-iteration"
               % (n_rows, cplan.coded_bytes / 1e6, label, n_it, dt * 1e3, dt * 1e6 / n_it))
+        if opts.stamps and fused:
+            import ctypes
+            st = (ctypes.c_ulonglong * 8)()
+            _lib.check(lib.mxm_diag_fused_stamps(cplan.ws.data_ptr(), st), "mxm_diag_fused_stamps")
+            if st[5]:
+                names = ("row pass", "barrier 1", "slice reduce", "barrier 2", "normalise+test")
+                print("        workgroup 0, us per iteration (stamped build): "
+                      + ", ".join("%s %.2f" % (n, st[i] * 0.01 / st[5]) for i, n in enumerate(names))
+                      + "  (sum %.2f)" % (sum(st[:5]) * 0.01 / st[5]))
     print("        max |delta ln p| one launch vs kernels over finite entries: %.2e"
           % float(numpy.nanmax(numpy.abs(numpy.where(numpy.isfinite(out["kernels"]), out["one launch"] - out["kernels"], 0.0)))))
 lib.mxm_set_loop_fused(-1, 0)
