@@ -42,14 +42,17 @@ extern "C" {
  * P / ldp / rowmax outputs, mxm_row_argmax_votes_coded replaces mxm_row_argmax_coded,
  * mxm_em_step_coded / mxm_gather_columns_coded cover the rows without a record;
  * 400 round 4: mxm_coded gained wide_rows / n_wide (records with 16-bit codes for rows of 257..1024 distinct values),
- * mxm_record_bytes / mxm_coded_bytes grew with them, mxm_workspace_bytes covers the one-launch loops' layouts. */
+ * mxm_record_bytes / mxm_coded_bytes grew with them, mxm_workspace_bytes covers the one-launch loops' layouts,
+ * mxm_em_state gained `ticket` (24 bytes: mxm_m_finalize runs on several workgroups, the last arriver finishes). */
 #define MXM_VERSION 400
 
-/* per-restart loop state, written by mxm_m_finalize (16 bytes) */
+/* per-restart loop state, written by mxm_m_finalize (24 bytes); allocate it ZEROED */
 typedef struct mxm_em_state {
     int32_t done;                /* 0 running, 1 converged, 2 max_iter reached */
     int32_t iters;               /* EM steps executed so far ("Converged! (n)", em.py:135) */
     double  l1;                  /* last sum_h |p_new - p_cur|  (em.py:53-54) */
+    uint32_t ticket;             /* scratch of mxm_m_finalize (arrival count of its workgroups): 0 between calls */
+    uint32_t reserved_;
 } mxm_em_state;
 
 int         mxm_version(void);

@@ -80,6 +80,13 @@ int mxm_set_loop_graph(int32_t mode);
 int mxm_set_loop_fused(int32_t mode, int32_t chunk);
 
 /*
+ * Workgroups of the one-launch loop over records (em_fused_coded_kernel; at most two per CU): 0 = chosen by size.
+ * Fewer workgroups make the per-iteration exchange (one partial row of H doubles per workgroup) cheaper and the row
+ * pass longer.  Results differ by the rounding of another summation order only.
+ */
+int mxm_set_fused_coded_grid(int32_t nwg);
+
+/*
  * Test hook: the next one-launch loops start with their abort flag already raised, i.e. behave as if a workgroup had
  * waited in vain at the first grid barrier (the situation a second process holding CUs creates).  mxm_em_loop must then
  * undo the launch and finish through the per-iteration kernels (mode -1), or return -3 (mode 1).

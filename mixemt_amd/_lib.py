@@ -18,7 +18,7 @@ c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
 
 class EmState(ctypes.Structure):
     """mxm_em_state (include/mixemt_hip.h)."""
-    _fields_ = [("done", c_i32), ("iters", c_i32), ("l1", c_f64)]
+    _fields_ = [("done", c_i32), ("iters", c_i32), ("l1", c_f64), ("ticket", ctypes.c_uint32), ("reserved_", ctypes.c_uint32)]
 
 
 class Coded(ctypes.Structure):
@@ -82,6 +82,7 @@ SIGNATURES = {
     "mxm_assign_reads": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_f64, c_ptr, c_ptr]),
     "mxm_diag_stream_read": (ctypes.c_int, [c_ptr, c_size, c_i32, c_i32, c_ptr, c_ptr]),
     "mxm_diag_fused_force_abort": (ctypes.c_int, [c_i32]),
+    "mxm_set_fused_coded_grid": (ctypes.c_int, [c_i32]),
     "mxm_diag_fused_stamps": (ctypes.c_int, [c_ptr, ctypes.POINTER(ctypes.c_ulonglong)]),
     "mxm_set_timing_events": (ctypes.c_int, [c_ptr, c_ptr]),
     "mxm_set_batch_tile": (ctypes.c_int, [c_i32]),

@@ -238,19 +238,20 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_wide_rows_kernel(
     const double *__restrict__ M, int64_t ldm, int64_t R, int H, int ldc, uint8_t *__restrict__ rec, int64_t rec_cap,
     int64_t *__restrict__ rec_off, int32_t *__restrict__ ndist, double *__restrict__ rowmax,
     unsigned long long *__restrict__ stats) {
-    __shared__ int s_list[ENC_THREADS];
+    constexpr int CH = 32;                               // rows per chunk (2 % of them are candidates: ~0.6 per chunk)
+    __shared__ int s_list[CH];
     __shared__ int s_nlist;
     const int t = threadIdx.x;
-    const int64_t nchunk = (R + ENC_THREADS - 1) / ENC_THREADS;
+    const int64_t nchunk = (R + CH - 1) / CH;
     for (int64_t c = blockIdx.x; c < nchunk; c += gridDim.x) {
         if (t == 0) s_nlist = 0;
         __syncthreads();
-        const int64_t r = c * ENC_THREADS + t;
-        if (r < R && ndist[r] == 0) s_list[atomicAdd(&s_nlist, 1)] = t;
+        const int64_t r = c * CH + t;
+        if (t < CH && r < R && ndist[r] == 0) s_list[atomicAdd(&s_nlist, 1)] = t;
         __syncthreads();
         const int n = s_nlist;                           // uniform
         for (int i = 0; i < n; ++i)
-            encode_one_row<NCH, true>(c * ENC_THREADS + s_list[i], M, ldm, H, ldc, rec, rec_cap, rec_off, ndist, rowmax, stats);
+            encode_one_row<NCH, true>(c * CH + s_list[i], M, ldm, H, ldc, rec, rec_cap, rec_off, ndist, rowmax, stats);
         __syncthreads();
     }
 }
@@ -306,7 +307,7 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_wide_rows_kernel(
 // chunk, the table (<= 8 KB) through LDS, one row in flight ahead of the one being reduced.  They are 2 % of the rows
 // of a build_em_matrix matrix; as dense rows they cost a kernel launch of their own per iteration (0.147 ms at 10^6
 // rows, 9 % of the step).
-template <int THREADS, int NCH, int NBUF, bool NT, bool RESIDENT>
+template <int THREADS, int NCH, int NBUF, bool NT, bool RESIDENT, bool WIDE_PREFETCH>
 __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off,
                                                const int32_t *__restrict__ ndist, int ldc, const double *__restrict__ w,
                                                const int64_t *__restrict__ wide_rows, int64_t n_wide, int64_t R,
@@ -456,6 +457,19 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
         }
     };
 
+    // The wide rows' metadata (second loop below) is asked for HERE, ahead of the main loop, and parked in registers:
+    // two dependent gathers (list -> record offset) that cost ~3 us when they were issued after the main loop --
+    // 27 us of a 238 us pass at 125 000 rows, more than the dense launch they replace.
+    const int64_t nq_w = (n_wide > (int64_t)blockIdx.x) ? (n_wide - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    // (WIDE_PREFETCH: the per-iteration kernel only -- the one-launch loop has no five registers to spare across its
+    // row loop, and its metadata is mostly resident anyway)
+    const bool wide_fetch = WIDE_PREFETCH && nq_w > 0 && (!RESIDENT || !meta_ready);
+    int64_t w_row = -1;
+    if (wide_fetch && t < nq_w) w_row = wide_rows[(int64_t)blockIdx.x + (int64_t)t * (int64_t)gridDim.x];
+    long long w_off = 0;
+    int w_nd = 0;
+    double w_wr = 0.0;
+
     if (deal.nq > 0) {                                   // (a one-launch grid may be larger than a tiny matrix)
         if (!RESIDENT || !meta_ready) {
             __syncthreads();                             // the blocks may still be read by a slower wave of the pass before
@@ -472,6 +486,11 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
         __syncthreads();
         read_meta(NBUF - 1, 0);
         lookup_row(reinterpret_cast<const char *>(&s_tbl[0][0]), cw[0]);
+        if (w_row >= 0) {                                // second level of the wide rows' metadata: in flight under the main loop
+            w_off = rec_off[w_row];
+            w_nd = ndist[w_row];
+            w_wr = (w != nullptr) ? w[w_row] : 1.0;
+        }
         for (int64_t q = 0; q < deal.nq; q += NBUF) {
             step(std::integral_constant<int, 0>{}, q);
             step(std::integral_constant<int, 1>{}, q + 1);
@@ -483,8 +502,13 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
         }
     }
 
+    else if (w_row >= 0) {                               // (no byte-coded row here at all)
+        w_off = rec_off[w_row];
+        w_nd = ndist[w_row];
+        w_wr = (w != nullptr) ? w[w_row] : 1.0;
+    }
+
     // ---- the wide rows of this workgroup: wide_rows[blockIdx.x + i * grid] ----------------------------------------
-    const int64_t nq_w = (n_wide > (int64_t)blockIdx.x) ? (n_wide - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
     if (nq_w > 0) {                                      // workgroup uniform
         __shared__ double s_wide[ENC_MAX_WIDE];
         __shared__ long long s_woff[THREADS];
@@ -494,7 +518,12 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
         const int voff8 = t * 8;
         const int voff8_last = last_w * 8;
         for (int64_t q0 = 0; q0 < nq_w; q0 += THREADS) {
-            if (!RESIDENT || !meta_ready || nq_w > THREADS) {
+            if (q0 == 0 && wide_fetch) {
+                __syncthreads();
+                s_woff[t] = w_off;                       // asked for before the main loop
+                s_wnd[t] = w_nd;
+                s_wwr[t] = w_wr;
+            } else if (q0 > 0 || !RESIDENT || !meta_ready || nq_w > THREADS) {
                 __syncthreads();                         // the previous batch's entries have been read
                 const int64_t q = q0 + t;
                 if (q < nq_w) {
@@ -584,7 +613,7 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
         }
     }
     bool meta_ready = false;
-    coded_row_pass<THREADS, NCH, NBUF, true, false>(rec, rec_off, ndist, ldc, w, wide_rows, n_wide, R, p, acc, meta_ready);
+    coded_row_pass<THREADS, NCH, NBUF, true, false, true>(rec, rec_off, ndist, ldc, w, wide_rows, n_wide, R, p, acc, meta_ready);
 
     double *dst = partial + (int64_t)blockIdx.x * ldpart;
 #pragma unroll

@@ -430,9 +430,165 @@ __global__ __launch_bounds__(COLRED_THREADS) void colreduce_kernel(const double 
 }
 
 // ------------------------------------------------------------------------------------------
-// K5  finalize: em.py:89 (normalise), :39-54 (L1 test), :133-143 (loop state). One WG per restart.
+// K5  finalize: em.py:89 (normalise), :39-54 (L1 test), :133-143 (loop state).
+//
+// The state of the loop is the LOG proportions, as in the reference (em.py:123-124, :140):
+//   colsum_h = T_h = sum_r (w_r / Z_r) P_rh      (no p_h factor: representable however small p_h is)
+//   ln p'_h  = ln p_h + ln T_h - ln sum_h p_h T_h        == em.py:87-89
+//   l1       = sum_h |exp(ln p'_h) - exp(ln p_h)|        == em.py:53-54
+// so a proportion that underflows in linear space keeps a finite log, exactly like the reference's;
+// props_cur = exp(ln_cur) is what the streaming kernel multiplies with.
+//
+// Round 4: rounds 1-3 ran this as ONE workgroup per restart -- 5408 software fp64 logarithms and as many
+// exponentials on one CU, 12 us of an iteration whose streaming kernel takes 14 us at 10^4 rows.  Now
+//   * every workgroup of the grid does the part that needs nothing from the others: u_h = ln p_h + ln T_h for its own
+//     columns (the logarithms, spread over the chip), published through ln_new (write-through);
+//   * the workgroup that ARRIVES LAST (agent-scope ticket in the restart's state: nobody spins, nothing can deadlock)
+//     does what needs all columns: tot = sum p T, the exponentials, the L1 test, the decision and the writes that
+//     depend on it.
+// Every sum has ONE fixed order whatever the grid: 64-column blocks, xor butterfly inside a block, the blocks' sums
+// added in block order -- so the stand-alone kernel (behind a multi-GPU all-reduce) and the form fused behind the column
+// reduce give the same bits.
 // ------------------------------------------------------------------------------------------
-#define FIN_THREADS 1024
+#define FIN_THREADS 1024              // the stand-alone kernel: one thread per column in phase 1, 16 waves in the tail
+#define FIN_MAX_BLOCKS 160            // 64-column blocks a restart may have (H <= 10240; the log-space kernel's LDS stops at 9600)
+#define FIN_KEEP 6                    // blocks per wave whose new values stay in registers (H <= 6144 with 16 waves)
+
+typedef unsigned int fin_u2 __attribute__((ext_vector_type(2)));
+__device__ __forceinline__ double fin_load_sc1(const double *p) {
+    const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(p), 0, 8, 0x00020000);
+    const fin_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, 0, 0, 16 /* sc1 */);
+    return __hiloint2double((int)v.y, (int)v.x);
+}
+
+// Fixed-order sum of n <= FIN_MAX_BLOCKS block sums held in LDS, by wave 0 (result broadcast through s_out): lane l adds
+// v[l] + v[l + 64] + v[l + 128] in that order, then the DPP ladder of wave_sum_lane63.  Contains barriers; uniform.
+__device__ __forceinline__ double fin_sum_blocks(const double *s_v, int n, double *s_out) {
+    static_assert(FIN_MAX_BLOCKS <= 192, "three values per lane");
+    __syncthreads();                                        // the block sums are in place
+    if (threadIdx.x < 64) {
+        const int l = threadIdx.x;
+        double v = (l < n) ? s_v[l] : 0.0;
+        if (l + 64 < n) v += s_v[l + 64];
+        if (l + 128 < n) v += s_v[l + 128];
+        v = wave_sum_lane63(v);
+        if (l == 63) *s_out = v;
+    }
+    __syncthreads();
+    return *s_out;
+}
+
+// The last arriver's part.  THREADS / 64 waves; wave w takes the blocks w, w + NW, ...  `u` = ln_new holds u_h.
+// cs / u were written by other workgroups of this launch (write-through, drained before their ticket): sc1 loads.
+// All of a wave's loads are issued up front (a first version loaded block by block inside the reduction loop and paid
+// the fabric's latency six times over: 19 us for the fused kernel), the block sums are DPP ladders (no LDS permutes).
+template <int THREADS>
+__device__ __forceinline__ void finalize_tail(const double *__restrict__ cs, double *__restrict__ lc, double *__restrict__ ln,
+                                              double *__restrict__ pc, int H, double tol, int max_iter,
+                                              mxm_em_state *__restrict__ st) {
+    constexpr int NW = THREADS / 64;
+    __shared__ double s_blk[FIN_MAX_BLOCKS], s_blk2[FIN_MAX_BLOCKS];
+    __shared__ double s_bc[2];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nblk = (H + 63) >> 6;
+    const auto cs_rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<double *>(cs), 0, H * 8, 0x00020000);
+    const auto u_rs = __builtin_amdgcn_make_buffer_rsrc(ln, 0, H * 8, 0x00020000);
+    const auto pc_rs = __builtin_amdgcn_make_buffer_rsrc(pc, 0, H * 8, 0x00020000);
+    auto ld = [&](decltype(cs_rs) rs, int h, auto AUX) -> double {           // past the vector: 0
+        const fin_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rs, h * 8, 0, decltype(AUX)::value);
+        return __hiloint2double((int)v.y, (int)v.x);
+    };
+    using SC1 = std::integral_constant<int, 16>;                             // bypasses L1 (other workgroups' stores)
+    using PLAIN = std::integral_constant<int, 0>;
+    // ---- this wave's first FIN_KEEP blocks: every load in flight at once -------------------------
+    double cv[FIN_KEEP], uv[FIN_KEEP], pv[FIN_KEEP];
+#pragma unroll
+    for (int q = 0; q < FIN_KEEP; ++q) {
+        const int h = (wv + q * NW) * 64 + lane;            // (blocks past the vector read zeros)
+        cv[q] = ld(cs_rs, h, SC1{});
+        uv[q] = ld(u_rs, h, SC1{});
+        pv[q] = ld(pc_rs, h, PLAIN{});
+    }
+    // ---- tot = sum_h p_h T_h --------------------------------------------------------------------
+#pragma unroll
+    for (int q = 0; q < FIN_KEEP; ++q) {
+        const int blk = wv + q * NW;
+        const double sum = wave_sum_lane63(pv[q] * cv[q]);
+        if (blk < nblk && lane == 63) s_blk[blk] = sum;
+    }
+    for (int blk = wv + FIN_KEEP * NW; blk < nblk; blk += NW) {               // wider than the register window
+        const int h = blk * 64 + lane;
+        const double sum = wave_sum_lane63(ld(pc_rs, h, PLAIN{}) * ld(cs_rs, h, SC1{}));
+        if (lane == 63) s_blk[blk] = sum;
+    }
+    const double ltot = log(fin_sum_blocks(s_blk, nblk, &s_bc[0]));
+    // ---- ln p' = u - ln tot; the exponential of it is the L1 test's term AND the next pass's proportion ----
+    double ek[FIN_KEEP];
+#pragma unroll
+    for (int q = 0; q < FIN_KEEP; ++q) {
+        const int blk = wv + q * NW;
+        const int h = blk * 64 + lane;
+        uv[q] = uv[q] - ltot;
+        ek[q] = exp(uv[q]);
+        const double sum = wave_sum_lane63((h < H) ? fabs(ek[q] - pv[q]) : 0.0);
+        if (blk < nblk && lane == 63) s_blk2[blk] = sum;
+    }
+    for (int blk = wv + FIN_KEEP * NW; blk < nblk; blk += NW) {
+        const int h = blk * 64 + lane;
+        const double e = exp(ld(u_rs, h, SC1{}) - ltot);
+        const double sum = wave_sum_lane63((h < H) ? fabs(e - ld(pc_rs, h, PLAIN{})) : 0.0);
+        if (lane == 63) s_blk2[blk] = sum;
+    }
+    const double l1 = fin_sum_blocks(s_blk2, nblk, &s_bc[1]);
+    const int iters = st->iters + 1;
+    const bool conv = l1 < tol;
+    const bool stop = conv || iters >= max_iter;
+#pragma unroll
+    for (int q = 0; q < FIN_KEEP; ++q) {
+        const int h = (wv + q * NW) * 64 + lane;
+        if (h < H) {
+            ln[h] = uv[q];
+            if (!stop) {
+                lc[h] = uv[q];
+                pc[h] = ek[q];
+            }
+        }
+    }
+    for (int blk = wv + FIN_KEEP * NW; blk < nblk; blk += NW) {               // formed again, same bits
+        const int h = blk * 64 + lane;
+        if (h < H) {
+            const double v = ld(u_rs, h, SC1{}) - ltot;
+            ln[h] = v;
+            if (!stop) {
+                lc[h] = v;
+                pc[h] = exp(v);
+            }
+        }
+    }
+    __syncthreads();                                        // (the re-formed values above read ln before anyone wrote it? no:
+                                                            // each thread rewrites only the columns it read itself)
+    if (t == 0) {
+        st->iters = iters;
+        st->l1 = l1;
+        st->done = conv ? 1 : (stop ? 2 : 0);
+        __hip_atomic_store(&st->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);     // ready for the next call
+    }
+}
+
+// Phase 1 of a restart's finalize for the columns [h0, h0 + n): u_h = ln p_h + ln T_h -> ln_new (write-through), then the
+// ticket.  Returns true in the workgroup whose ticket came last (uniform).  T_h is passed in by the caller's lanes.
+template <int THREADS>
+__device__ __forceinline__ bool finalize_arrive(mxm_em_state *__restrict__ st, int nwg_expected) {
+    __shared__ int s_last;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");       // this wave's write-through stores have left
+    __syncthreads();                                        // ... and every other wave's of the workgroup
+    if (threadIdx.x == 0) {
+        const unsigned old = __hip_atomic_fetch_add(&st->ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (old + 1u == (unsigned)nwg_expected) ? 1 : 0;
+    }
+    __syncthreads();
+    return s_last != 0;
+}
 
 __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(const double *__restrict__ colsum,
                                                                double *__restrict__ ln_cur,
@@ -441,70 +597,72 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(const double *__r
                                                                double tol, int max_iter,
                                                                mxm_em_state *__restrict__ state, int base,
                                                                int use_slots, mxm_slots slots) {
-    // The state of the loop is the LOG proportions, as in the reference (em.py:123-124, :140):
-    //   colsum_h = T_h = sum_r (w_r / Z_r) P_rh      (no p_h factor: representable however small p_h is)
-    //   ln p'_h  = ln p_h + ln T_h - ln sum_h p_h T_h        == em.py:87-89
-    //   l1       = sum_h |exp(ln p'_h) - exp(ln p_h)|        == em.py:53-54
-    // so a proportion that underflows in linear space keeps a finite log, exactly like the
-    // reference's; props_cur = exp(ln_cur) is what the streaming kernel multiplies with.
-    __shared__ double scratch[FIN_THREADS / 64];
-    const int b = use_slots ? slots.s[blockIdx.x] : base + (int)blockIdx.x;       // which restart
+    // grid = (ceil(H / FIN_THREADS), restarts)
+    const int b = use_slots ? slots.s[blockIdx.y] : base + (int)blockIdx.y;       // which restart
     mxm_em_state *st = state + b;
     if (st->done != 0) return;
     const double *cs = colsum + (int64_t)b * H;
     double *lc = ln_cur + (int64_t)b * H;
     double *ln = ln_new + (int64_t)b * H;
     double *pc = props_cur + (int64_t)b * H;
-    const int t = threadIdx.x;
-    double s = 0.0;
-    for (int h = t; h < H; h += FIN_THREADS) s += pc[h] * cs[h];
-    const double ltot = log(block_reduce<FIN_THREADS, false>(s, scratch));
-    double l1 = 0.0;
-    constexpr int FIN_KEEP = 8;                     // columns per thread whose new value stays in registers (8192 columns)
-    double vk[FIN_KEEP], ek[FIN_KEEP];
-#pragma unroll
-    for (int q = 0; q < FIN_KEEP; ++q) {
-        const int h = t + q * FIN_THREADS;
-        vk[q] = 0.0;
-        ek[q] = 0.0;
-        if (h < H) {
-            vk[q] = lc[h] + log(cs[h]) - ltot;
-            ek[q] = exp(vk[q]);
-            ln[h] = vk[q];
-            l1 += fabs(ek[q] - pc[h]);
-        }
+    const int h = (int)blockIdx.x * FIN_THREADS + (int)threadIdx.x;
+    if (h < H) {
+        const double u = lc[h] + log(cs[h]);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(ln, 0, H * 8, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fin_u2, u), rs, h * 8, 0, 16 /* sc1 */);
     }
-    for (int h = t + FIN_KEEP * FIN_THREADS; h < H; h += FIN_THREADS) {       // wider than 8192 (log-space paths only)
-        const double v = lc[h] + log(cs[h]) - ltot;
-        ln[h] = v;
-        l1 += fabs(exp(v) - pc[h]);
-    }
-    l1 = block_reduce<FIN_THREADS, false>(l1, scratch);
-    const int iters = st->iters + 1;
-    const bool conv = l1 < tol;
-    const bool stop = conv || iters >= max_iter;
-    if (!stop) {
-        // the exponential computed for the L1 test IS the next pass's proportion: same bits, one exp less
-#pragma unroll
-        for (int q = 0; q < FIN_KEEP; ++q) {
-            const int h = t + q * FIN_THREADS;
-            if (h < H) {
-                lc[h] = vk[q];
-                pc[h] = ek[q];
-            }
+    if (!finalize_arrive<FIN_THREADS>(st, (int)gridDim.x)) return;
+    finalize_tail<FIN_THREADS>(cs, lc, ln, pc, H, tol, max_iter, st);
+}
+
+// ------------------------------------------------------------------------------------------
+// K4+K5  column reduce with the finalize behind it in ONE launch (the single-GPU per-iteration path, where no
+// collective sits between the two): colreduce_kernel's sums, bit for bit, then phase 1 of the finalize for the block's
+// 64 columns by the wave that holds them, ticket, and the last workgroup's tail.  grid = (ceil(H/64), nb).
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(COLRED_THREADS) void colreduce_finalize_kernel(
+    const double *__restrict__ partial, int64_t ldpart, int nwg, int nb, int H, double *__restrict__ colsum,
+    double *__restrict__ ln_cur, double *__restrict__ ln_new, double *__restrict__ props_cur, double tol, int max_iter,
+    mxm_em_state *__restrict__ state, mxm_slots slots) {
+    constexpr int NW = COLRED_THREADS / 64;
+    __shared__ double part[NW][64];
+    const int b = blockIdx.y;
+    const int run = slots.s[b];
+    mxm_em_state *st = state + run;
+    if (st->done != 0) return;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int h = blockIdx.x * 64 + lane;
+    double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
+    if (h < H) {
+        const double *src = partial + (int64_t)b * ldpart + h;
+        const int64_t step = (int64_t)nb * ldpart;
+        int g = wv;
+        for (; g + 3 * NW < nwg; g += 4 * NW) {
+            s0 += src[(int64_t)g * step];
+            s1 += src[(int64_t)(g + NW) * step];
+            s2 += src[(int64_t)(g + 2 * NW) * step];
+            s3 += src[(int64_t)(g + 3 * NW) * step];
         }
-        for (int h = t + FIN_KEEP * FIN_THREADS; h < H; h += FIN_THREADS) {
-            const double v = ln[h];
-            lc[h] = v;
-            pc[h] = exp(v);
-        }
+        for (; g < nwg; g += NW) s0 += src[(int64_t)g * step];
     }
+    part[wv][lane] = (s0 + s1) + (s2 + s3);
     __syncthreads();
-    if (t == 0) {
-        st->iters = iters;
-        st->l1 = l1;
-        st->done = conv ? 1 : (stop ? 2 : 0);
+    double *cs = colsum + (int64_t)run * H;
+    double *lc = ln_cur + (int64_t)run * H;
+    double *ln = ln_new + (int64_t)run * H;
+    double *pc = props_cur + (int64_t)run * H;
+    if (wv == 0 && h < H) {
+        double tot = part[0][lane];
+#pragma unroll
+        for (int q = 1; q < NW; ++q) tot += part[q][lane];
+        const auto cs_rs = __builtin_amdgcn_make_buffer_rsrc(cs, 0, H * 8, 0x00020000);
+        const auto ln_rs = __builtin_amdgcn_make_buffer_rsrc(ln, 0, H * 8, 0x00020000);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fin_u2, tot), cs_rs, h * 8, 0, 16 /* sc1 */);
+        const double u = lc[h] + log(tot);
+        __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fin_u2, u), ln_rs, h * 8, 0, 16 /* sc1 */);
     }
+    if (!finalize_arrive<COLRED_THREADS>(st, (int)gridDim.x)) return;
+    finalize_tail<COLRED_THREADS>(cs, lc, ln, pc, H, tol, max_iter, st);
 }
 
 #endif  // MIXEMT_EM_KERNELS_HPP

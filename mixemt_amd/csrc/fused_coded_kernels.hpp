@@ -105,7 +105,7 @@ __global__ __launch_bounds__(FCODED_THREADS, 2) void em_fused_coded_kernel(
             for (int k = 0; k < NCH; ++k)
 #pragma unroll
                 for (int e = 0; e < 4; ++e) acc[k][e] = 0.0;
-            coded_row_pass<THREADS, NCH, NBUF, !RESIDENT, RESIDENT>(rec, rec_off, ndist, ldc, w, wide_rows, n_wide, R, p,
+            coded_row_pass<THREADS, NCH, NBUF, !RESIDENT, RESIDENT, false>(rec, rec_off, ndist, ldc, w, wide_rows, n_wide, R, p,
                                                                     acc, meta_ready);
             __syncthreads();                               // (LDS reads below must not move above the row pass)
             // slice geometry and hand-off descriptors, from LDS (see "register budget" above)

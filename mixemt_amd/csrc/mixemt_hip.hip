@@ -74,6 +74,7 @@ struct mxm_tuning {
     int loop_fused = -1;            // -1 auto (by size), 0 never, 1 whenever the shape allows
     int fused_chunk = 0;            // iterations per launch of the one-launch loop (0 = run to the end)
     int fused_cols = 1;             // matrices of up to 1536 rows take the transposed form (columns split)
+    int fused_coded_wg = 0;         // workgroups of the one-launch loop over records (0 = by size)
     int fused_force_abort = 0;      // test hook: the one-launch loop starts with its abort flag raised (as if starved)
     double fused_cells = 1.0e8;     // ~18 000 rows at H = 5408: measured break-even is ~30 000 rows (profiles/r02/small_runs.txt)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;     // timing hook around the dominant kernel
@@ -391,6 +392,10 @@ extern "C" int mxm_set_batch_tile(int32_t bt) {
     return tune_set([bt](mxm_tuning &t) { t.max_bt = bt; });
 }
 
+extern "C" int mxm_set_fused_coded_grid(int32_t nwg) {
+    return tune_set([nwg](mxm_tuning &t) { t.fused_coded_wg = nwg > 0 ? nwg : 0; });
+}
+
 extern "C" int mxm_diag_fused_force_abort(int32_t on) {
     return tune_set([on](mxm_tuning &t) { t.fused_force_abort = on ? 1 : 0; });
 }
@@ -562,16 +567,35 @@ extern "C" int mxm_describe_stream_kernel(int32_t H, int32_t nb, char *buf, size
     return 0;
 }
 
+// What the loop driver hands down when the finalize may ride on the column reduce's launch (no collective in between).
+struct fin_args {
+    double *ln_cur, *ln_new, *props_cur;
+    mxm_em_state *state;
+    double tol;
+    int max_iter;
+};
+
+// column reduce of a tile's partial rows [0, nwg); with `fin` the finalize follows in the same launch
+static int reduce_tile(const double *partial, int nwg, int nb, int H, double *colsum, const mxm_em_state *state,
+                       const mxm_slots &slots, const fin_args *fin, hipStream_t stream) {
+    if (fin != nullptr && H <= 64 * FIN_MAX_BLOCKS)
+        hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((H + 63) / 64, nb), dim3(COLRED_THREADS), 0, stream, partial,
+                           part_ld(H), nwg, nb, H, colsum, fin->ln_cur, fin->ln_new, fin->props_cur, fin->tol, fin->max_iter,
+                           fin->state, slots);
+    else
+        hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, nb), dim3(COLRED_THREADS), 0, stream, partial, part_ld(H), nwg,
+                           nb, H, (const double *)nullptr, colsum, state, slots);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 static int em_iter_linear_tile(const double *P, int64_t ldp, const double *w, const double *props, int64_t R,
                                int H, int nb, mxm_slots slots, const mxm_em_state *state, double *colsum,
-                               double *partial, hipStream_t stream, bool timed) {
+                               double *partial, hipStream_t stream, bool timed, const fin_args *fin = nullptr) {
     int nwg = 0;
     const int rc = stream_linear_tile(P, ldp, w, props, R, H, nb, slots, state, partial, stream, timed, &nwg);
     if (rc != 0) return rc;
-    hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, nb), dim3(COLRED_THREADS), 0, stream, partial, part_ld(H), nwg, nb,
-                       H, (const double *)nullptr, colsum, state, slots);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return reduce_tile(partial, nwg, nb, H, colsum, state, slots, fin, stream);
 }
 
 #ifndef MXM_F32_THREADS
@@ -756,7 +780,7 @@ extern "C" int mxm_encode_rows(const double *M, int64_t ldm, int64_t R, int32_t 
     const int nch = (ldc / 4 + ENC_THREADS - 1) / ENC_THREADS;
     const int grid = clamp_grid(R, num_cu() * 4);
     // first pass: every row, byte codes; second pass: the rows it left without a record, 16-bit codes
-    const int grid_w = clamp_grid((R + ENC_THREADS - 1) / ENC_THREADS, num_cu() * 3);
+    const int grid_w = clamp_grid((R + 31) / 32, num_cu() * 3);
     switch (nch) {
 #define ENC_CASE(n) case n: hipLaunchKernelGGL((encode_rows_kernel<n>), dim3(grid), dim3(ENC_THREADS), 0, s, M, ldm, R, (int)H, ldc, rec, (int64_t)rec_bytes, rec_off, ndist, rowmax, reinterpret_cast<unsigned long long *>(stats)); \
                     hipLaunchKernelGGL((encode_wide_rows_kernel<n>), dim3(grid_w), dim3(ENC_THREADS), 0, s, M, ldm, R, (int)H, ldc, rec, (int64_t)rec_bytes, rec_off, ndist, rowmax, reinterpret_cast<unsigned long long *>(stats)); break;
@@ -898,7 +922,8 @@ static int launch_coded(int nch, int nwg, hipStream_t stream, const mxm_coded *c
 // One restart's pass over a coded matrix: dictionary rows through em_iter_coded_kernel, the dense rest
 // through em_iter_wide_kernel into the partial rows behind, one column reduce over both.
 static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *props, int H, int run,
-                             const mxm_em_state *state, double *colsum, double *partial, hipStream_t stream, bool timed) {
+                             const mxm_em_state *state, double *colsum, double *partial, hipStream_t stream, bool timed,
+                             const fin_args *fin = nullptr) {
     const int64_t ldpart = part_ld(H);
     const int ldc = coded_ld(H);
     const coded_shape sh = g_coded_shapes[g_coded_shape];
@@ -923,10 +948,7 @@ static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *
                                                name of their own in a trace, apart from the dense matrix's passes */);
         if (rc != 0) return rc;
     }
-    hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart,
-                       nwg + nwg_rest, 1, H, (const double *)nullptr, colsum, state, sl);
-    HIP_TRY(hipGetLastError());
-    return 0;
+    return reduce_tile(partial, nwg + nwg_rest, 1, H, colsum, state, sl, fin, stream);
 }
 
 extern "C" int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, int32_t H, int32_t B,
@@ -954,8 +976,9 @@ extern "C" int mxm_restart_tile(int32_t H) {
 extern "C" int mxm_m_finalize(const double *colsum, double *ln_cur, double *ln_new, double *props_cur, int32_t H,
                               int32_t B, double tol, int32_t max_iter, mxm_em_state *state, void *stream) {
     if (H <= 0 || B <= 0 || state == nullptr) return fail(-1, "mxm_m_finalize: bad arguments%s", "");
-    hipLaunchKernelGGL(finalize_kernel, dim3(B), dim3(FIN_THREADS), 0, (hipStream_t)stream, colsum, ln_cur, ln_new,
-                       props_cur, (int)H, tol, (int)max_iter, state, 0, 0, slots_from(0));
+    if (H > 64 * FIN_MAX_BLOCKS) return fail(-1, "mxm_m_finalize: H=%s%lld beyond the kernel's range", "", H);
+    hipLaunchKernelGGL(finalize_kernel, dim3((H + FIN_THREADS - 1) / FIN_THREADS, B), dim3(FIN_THREADS), 0, (hipStream_t)stream,
+                       colsum, ln_cur, ln_new, props_cur, (int)H, tol, (int)max_iter, state, 0, 0, slots_from(0));
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1023,6 +1046,16 @@ static bool fused_eligible(const double *P, int64_t ldp, int64_t R, int H, int B
 // per-iteration coded kernels take one restart per pass too, so nothing is lost), no dense leftover rows.
 static int fused_coded_grid(int64_t R) {
     int nwg = num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG;         // two workgroups of 256 per CU
+    if (T.fused_coded_wg > 0) {
+        if (T.fused_coded_wg < nwg) nwg = T.fused_coded_wg;
+    } else {
+        // an iteration costs ~0.7 us per row of a workgroup plus ~0.026 us per workgroup (barriers, one partial row
+        // each way through the fabric): the minimum of 0.7 R / n + 0.026 n is at n = 5.2 sqrt(R) (measured sweep:
+        // profiles/r04/small_runs_coded_grids.txt -- 600 rows: 128 workgroups 18.8 us, 512 30.1; 10^4 rows: level
+        // from 384 up), in whole eights (the XCDs)
+        const int best = ((int)(5.2 * sqrt((double)R)) + 7) & ~7;
+        if (best < nwg) nwg = best;
+    }
     if ((int64_t)nwg > R) nwg = (int)R;
     return nwg < 1 ? 1 : nwg;
 }
@@ -1227,14 +1260,16 @@ static int enqueue_tile_iteration(const double *M, int64_t ldm, const double *P,
                                   int32_t max_iter, void *ws, size_t ws_bytes, hipStream_t s, bool p_is_f32,
                                   bool timed, const mxm_coded *coded) {
     const bool linear = !p_is_f32 && P != nullptr && mxm_linear_supported(H);
+    // records and the linear fp64 matrix: the finalize rides on the column reduce's launch (one ticket per restart)
+    fin_args fin = {ln_cur, ln_new, props_cur, state, tol, (int)max_iter};
     if (coded != nullptr) {
         for (int i = 0; i < nb; ++i) {
-            const int rc = em_iter_coded_one(coded, w, props_cur, (int)H, tile.s[i], state, colsum, (double *)ws, s, timed && i == 0);
+            const int rc = em_iter_coded_one(coded, w, props_cur, (int)H, tile.s[i], state, colsum, (double *)ws, s, timed && i == 0, &fin);
             if (rc != 0) return rc;
         }
+        return 0;
     } else if (linear) {
-        const int rc = em_iter_linear_tile(P, ldp, w, props_cur, R, (int)H, nb, tile, state, colsum, (double *)ws, s, timed);
-        if (rc != 0) return rc;
+        return em_iter_linear_tile(P, ldp, w, props_cur, R, (int)H, nb, tile, state, colsum, (double *)ws, s, timed, &fin);
     } else {
         for (int i = 0; i < nb; ++i) {
             const int64_t off = (int64_t)tile.s[i] * H;
@@ -1245,8 +1280,9 @@ static int enqueue_tile_iteration(const double *M, int64_t ldm, const double *P,
             if (rc != 0) return rc;
         }
     }
-    hipLaunchKernelGGL(finalize_kernel, dim3(nb), dim3(FIN_THREADS), 0, s, colsum, ln_cur, ln_new, props_cur, (int)H, tol,
-                       (int)max_iter, state, 0, 1, tile);
+    if (H > 64 * FIN_MAX_BLOCKS) return fail(-1, "mxm_em_loop: H=%s%lld beyond the finalize kernel's range", "", H);
+    hipLaunchKernelGGL(finalize_kernel, dim3((H + FIN_THREADS - 1) / FIN_THREADS, nb), dim3(FIN_THREADS), 0, s, colsum, ln_cur,
+                       ln_new, props_cur, (int)H, tol, (int)max_iter, state, 0, 1, tile);
     HIP_TRY(hipGetLastError());
     return 0;
 }

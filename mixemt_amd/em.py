@@ -363,8 +363,8 @@ class EmPlan(object):
 
 
 def new_state(n_runs, dev):
-    """Device array of mxm_em_state (16 bytes each), zeroed."""
-    return torch.zeros(n_runs * 2, dtype=torch.int64, device=dev)
+    """Device array of mxm_em_state (24 bytes each), zeroed."""
+    return torch.zeros(n_runs * (ctypes.sizeof(_lib.EmState) // 8), dtype=torch.int64, device=dev)
 
 
 def read_state(state):

@@ -53,7 +53,7 @@ def test_binding_table_matches_header(lib_path):
     header = open(os.path.join(ROOT, "include", "mixemt_hip.h")).read()
     declared = int(re.search(r"#define\s+MXM_VERSION\s+(\d+)", header).group(1))
     assert lib.mxm_version() == declared == _lib.ABI_VERSION          # header, library and binding agree
-    assert ctypes.sizeof(_lib.EmState) == 16
+    assert ctypes.sizeof(_lib.EmState) == 24
     assert lib.mxm_linear_supported(5408) == 1 and lib.mxm_linear_supported(3) == 0
     assert lib.mxm_linear_supported(8192) == 1 and lib.mxm_linear_supported(8193) == 0
     assert lib.mxm_workspace_bytes(1000000, 5408, 1) >= 1024 * 5408 * 8

@@ -23,6 +23,8 @@ ap.add_argument("--rows", default="600,2400,4600,10000,30000,100000")
 ap.add_argument("--max-iter", type=int, default=200)
 ap.add_argument("--restarts", type=int, default=1, help="restarts per run (the one-launch loop takes them one after "
                 "another, the per-iteration kernels four per pass)")
+ap.add_argument("--coded-grids", default="", help="also time the one-launch loop over records with these many workgroups")
+ap.add_argument("--coded-only", action="store_true", help="skip the dense matrix's loops")
 ap.add_argument("--stamps", action="store_true",
                 help="with a -DFUSED_STAMPS build of the library (MXM_LIB=...): per-phase time shares of the one-launch loop")
 opts = ap.parse_args()
@@ -40,9 +42,10 @@ for n_rows in [int(x) for x in opts.rows.split(",")]:
     numpy.random.seed(7)
     init = numpy.stack([em.init_props(len(haps), 1.0) for _ in range(opts.restarts)])
     out = {}
-    for label, fused, graph in (("one launch", 1, 0), ("one launch, rows split", 2, 0), ("kernels", 0, 0),
-                                ("kernels+graph", 0, 1), ("one launch", 1, 0), ("one launch, rows split", 2, 0),
-                                ("kernels", 0, 0)):
+    for label, fused, graph in (() if opts.coded_only else
+                                (("one launch", 1, 0), ("one launch, rows split", 2, 0), ("kernels", 0, 0),
+                                 ("kernels+graph", 0, 1), ("one launch", 1, 0), ("one launch, rows split", 2, 0),
+                                 ("kernels", 0, 0))):
         lib.mxm_set_loop_fused(fused, 0)
         lib.mxm_set_loop_graph(graph)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -63,10 +66,13 @@ for n_rows in [int(x) for x in opts.rows.split(",")]:
               % (n_rows, n_rows * len(haps) * 8 / 1e6, label, n_it, dt * 1e3, dt * 1e6 / n_it))
     lib.mxm_set_loop_fused(-1, 0)
     cplan = em.EmPlan(mat, wts, n_runs=opts.restarts, storage="coded")
-    for fused, graph, label in ((-1, 0, "records, one launch"), (0, 0, "records, kernels"), (0, 1, "records, kernels+graph"),
-                                (-1, 0, "records, one launch"), (0, 0, "records, kernels")):
+    variants = [(-1, 0, "records, one launch", 0), (0, 0, "records, kernels", 0), (0, 1, "records, kernels+graph", 0),
+                (-1, 0, "records, one launch", 0), (0, 0, "records, kernels", 0)]
+    variants += [(-1, 0, "records, one launch/%d" % int(g), int(g)) for g in opts.coded_grids.split(",") if g]
+    for fused, graph, label, grid in variants:
         if cplan.coded is None:
             break
+        lib.mxm_set_fused_coded_grid(grid)
         lib.mxm_set_loop_fused(fused, 0)
         lib.mxm_set_loop_graph(graph)
         torch.cuda.synchronize(); t0 = time.perf_counter()
@@ -84,7 +90,9 @@ for n_rows in [int(x) for x in opts.rows.split(",")]:
                 print("        workgroup 0, us per iteration (stamped build): "
                       + ", ".join("%s %.2f" % (n, st[i] * 0.01 / st[5]) for i, n in enumerate(names))
                       + "  (sum %.2f)" % (sum(st[:5]) * 0.01 / st[5]))
-    print("        max |delta ln p| one launch vs kernels over finite entries: %.2e"
+    lib.mxm_set_fused_coded_grid(0)
+    if not opts.coded_only:
+      print("        max |delta ln p| one launch vs kernels over finite entries: %.2e"
           % float(numpy.nanmax(numpy.abs(numpy.where(numpy.isfinite(out["kernels"]), out["one launch"] - out["kernels"], 0.0)))))
 lib.mxm_set_loop_fused(-1, 0)
 lib.mxm_set_loop_graph(-1)
