@@ -198,6 +198,23 @@ def parity_in_run(em, torch, slab, cpu, n_iters, tol=1e-4, storage="f64"):
                        "matrix, same Dirichlet init" % (cpu["iters"], n_rows)}
 
 
+def loop_ms_per_iteration(em, torch, plan, props_row, n_iter):
+    """
+    Wall time per iteration of the product's own loop driver (em.em_loop -> mxm_em_loop / mxm_em_loop_coded: for records
+    the whole loop in one persistent launch, em_fused_coded_kernel) over `n_iter` iterations with the tolerance at 0 --
+    launch, final state read-back and host synchronisation included.  The second of two runs is reported.
+    """
+    init = props_row.detach().cpu().numpy().reshape(1, -1)
+    best = None
+    for _ in range(2):
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        _, _, states = em.em_loop(plan, init, 0.0, n_iter)
+        torch.cuda.synchronize()
+        best = (time.perf_counter() - t0) * 1e3 / max(states[0][1], 1)
+    return best
+
+
 def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
     """
     The EM iteration of the default line over the SAME matrix in row-dictionary storage
@@ -244,7 +261,13 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
     torch.cuda.synchronize()
     ms = beg.elapsed_time(end) / steps
     kernel_ms = kev[0].elapsed_time(kev[1])
+    loop_ms = loop_ms_per_iteration(em, torch, cplan, props[0], max(steps, 50))
     return {"ms_per_step": ms, "value": float(n_rows) * n_haps / (ms * 1e-3), "unit": "cells/s",
+            "one_launch_loop_ms_per_iteration": loop_ms,
+            "one_launch_loop_note": "what run_em itself iterates over records: mxm_em_loop_coded, the whole loop in one "
+                                    "persistent launch (em_fused_coded_kernel), wall time incl. launch and state read-back; "
+                                    "ms_per_step is the per-iteration path (kernel + column reduce + finalize launches)",
+            "rows_with_16bit_codes": int(cplan.coded_wide),
             "kernel": "em_iter_coded_kernel", "kernel_ms": kernel_ms,
             "bytes_per_iteration": float(cplan.coded_bytes),
             "kernel_bytes": float(cplan.coded_record_bytes),

@@ -343,6 +343,14 @@ int mxm_row_argmax_votes(const double *X, int64_t ldx, const double *w,
                          void *ws, size_t ws_bytes, void *stream);
 
 /*
+ * Insertion order of the reference's vote table -- assemble.py:116-119 fills a dict row by row, and the contributors
+ * come out in the order their haplogroup FIRST won a row:
+ *   first[h] = the smallest r with best[r] == h, R if no row voted for h   (device int64[H])
+ * so that only H values, not best[R], have to reach the host.  Entries of best outside [0, H) are ignored.
+ */
+int mxm_first_seen(const int32_t *best, int64_t R, int32_t H, int64_t *first, void *stream);
+
+/*
  * Read -> contributor assignment -- assemble.py:284-334 (_find_best_n_for_read :267-281 inlined):
  *   v_c = X[r][c] - log_props[c] for the nC contributor columns cols[];
  *   assigned[r] = ordinal (0..nC-1) of the largest v_c if it beats the runner-up by at least

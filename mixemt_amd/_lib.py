@@ -98,6 +98,7 @@ SIGNATURES = {
     "mxm_set_sparse_max_distinct": (ctypes.c_int, [c_i32]),
     "mxm_row_argmax_votes": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_i64, c_i32, c_ptr, c_ptr,
                                             c_ptr, c_size, c_ptr]),
+    "mxm_first_seen": (ctypes.c_int, [c_ptr, c_i64, c_i32, c_ptr, c_ptr]),
     "mxm_gather_columns": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_i32, c_ptr, c_i64, c_ptr]),
     "mxm_fold_logaddexp": (ctypes.c_int, [c_ptr, c_i64, ctypes.POINTER(c_ptr), ctypes.POINTER(c_i64), c_i32,
                                           c_i64, c_i32, c_f64, c_ptr]),

@@ -23,12 +23,23 @@ from . import _lib
 from ._dev import as_device, current_stream, ptr, require_gpu, torch
 
 
-def row_argmax_votes(read_hap_mat, wts=None):
+def _contributors_on_device(best_d, votes_d, n_haps, min_reads):
     """
-    best[r] = first index of the row maximum (numpy.argmax semantics) and
-    votes[h] = sum of wts over the rows that picked h (mxm_row_argmax_votes).
-    Returns (best int32[R], votes float64[H]) as numpy arrays.
+    Columns with at least min_reads votes in the order their haplogroup first won a row (assemble.py:115-123): the
+    first-seen row of every haplogroup is formed on the device (mxm_first_seen), so 2 x H values come back instead of
+    best[R] (4 MB and a numpy.unique over R at 10^6 rows: 23 ms for a 1.5 ms pass).
     """
+    lib = _lib.load()
+    n_rows = best_d.numel()
+    first = torch.empty(n_haps, dtype=torch.int64, device=best_d.device)
+    _lib.check(lib.mxm_first_seen(best_d.data_ptr(), n_rows, n_haps, first.data_ptr(), current_stream()), "mxm_first_seen")
+    first_h, votes_h = first.cpu().numpy(), votes_d.cpu().numpy()
+    seen = numpy.flatnonzero(first_h < n_rows)
+    order = seen[numpy.argsort(first_h[seen], kind="stable")]
+    return [int(h) for h in order if votes_h[h] >= min_reads], order, votes_h
+
+
+def _row_argmax_votes_device(read_hap_mat, wts):
     lib = _lib.load()
     dev = require_gpu()
     mat = as_device(read_hap_mat, torch.float64, dev)
@@ -42,6 +53,16 @@ def row_argmax_votes(read_hap_mat, wts=None):
         _lib.check(lib.mxm_row_argmax_votes(mat.data_ptr(), mat.stride(0), ptr(w_d), n_rows, n_haps,
                                             best.data_ptr(), votes.data_ptr(), ws.data_ptr(), nbytes,
                                             current_stream()), "mxm_row_argmax_votes")
+    return best, votes
+
+
+def row_argmax_votes(read_hap_mat, wts=None):
+    """
+    best[r] = first index of the row maximum (numpy.argmax semantics) and
+    votes[h] = sum of wts over the rows that picked h (mxm_row_argmax_votes).
+    Returns (best int32[R], votes float64[H]) as numpy arrays.
+    """
+    best, votes = _row_argmax_votes_device(read_hap_mat, wts)
     return best.cpu().numpy(), votes.cpu().numpy()
 
 
@@ -56,6 +77,11 @@ def row_argmax_votes_records(cm, ln_theta_k, wts=None):
     dense copies by the same entry point; votes are summed without float atomics.
     Returns (best int32[R], votes float64[H]) as numpy arrays.
     """
+    best, votes = _row_argmax_votes_records_device(cm, ln_theta_k, wts)
+    return best.cpu().numpy(), votes.cpu().numpy()
+
+
+def _row_argmax_votes_records_device(cm, ln_theta_k, wts=None):
     import ctypes
     lib = _lib.load()
     dev = cm.rec.device
@@ -78,14 +104,22 @@ def row_argmax_votes_records(cm, ln_theta_k, wts=None):
         cm.m_rest.data_ptr() if n_rest else 0, cm.m_rest.stride(0) if n_rest else 0,
         cm.rest_rows.data_ptr() if n_rest else 0, n_rest, ptr(w_d), best.data_ptr(), votes.data_ptr(),
         ws.data_ptr(), nbytes, current_stream()), "mxm_row_argmax_votes_coded")
-    return best.cpu().numpy(), votes.cpu().numpy()
+    return best, votes
 
 
 def find_contribs_from_records(cm, ln_theta_k, wts, args):
     """find_contribs_from_reads (assemble.py:103-123) from records and the EM's log theta_k ([H], or [n_multi][H]
     for a multi-run: see row_argmax_votes_records)."""
-    best, votes = row_argmax_votes_records(cm, ln_theta_k, wts)
-    return [int(h) for h in _first_seen_order(best) if votes[h] >= args.min_reads]
+    best, votes = _row_argmax_votes_records_device(cm, ln_theta_k, wts)
+    return _contributors_on_device(best, votes, cm.n_haps, args.min_reads)[0]
+
+
+def vote_table_from_records(cm, ln_theta_k, wts=None):
+    """(columns in first-seen order, votes[H]) of the records' vote (stats.py:34-45 / assemble.py:115-123); H-sized
+    arrays only leave the device."""
+    best, votes = _row_argmax_votes_records_device(cm, ln_theta_k, wts)
+    _, order, votes_h = _contributors_on_device(best, votes, cm.n_haps, 0)
+    return order, votes_h
 
 
 def _first_seen_order(best):
@@ -101,17 +135,18 @@ def find_contribs_from_reads(read_hap_mat, wts, args):
     args.min_reads fragments (assemble.py:103-123), in the reference's order
     (first appearance among the rows).
     """
-    best, votes = row_argmax_votes(read_hap_mat, wts)
-    return [int(h) for h in _first_seen_order(best) if votes[h] >= args.min_reads]
+    best, votes = _row_argmax_votes_device(read_hap_mat, wts)
+    return _contributors_on_device(best, votes, votes.numel(), args.min_reads)[0]
 
 
 def read_votes(read_hap_mat):
     """Counter {column: number of rows voting for it}, unweighted (stats.py:39-40),
     with the reference's insertion order so that most_common() breaks ties alike."""
-    best, votes = row_argmax_votes(read_hap_mat, None)
+    best, votes = _row_argmax_votes_device(read_hap_mat, None)
+    _, order, votes_h = _contributors_on_device(best, votes, votes.numel(), 0)
     counter = collections.Counter()
-    for h in _first_seen_order(best):
-        counter[int(h)] = int(votes[h])
+    for h in order:
+        counter[int(h)] = int(votes_h[h])
     return counter
 
 

@@ -37,9 +37,10 @@ __global__ __launch_bounds__(256) void add_scalar_kernel(double *__restrict__ x,
 // + weighted votes (assemble.py:115-123).  Candidate order: NaN before numbers, then larger
 // value, then smaller index.
 __device__ __forceinline__ bool cand_better(int an, double av, int ai, int bn, double bv, int bi) {
-    if (an != bn) return an > bn;
-    if (an == 0 && av != bv) return av > bv;
-    return ai < bi;
+    // branch-free (bitwise on purpose): as early returns this compiled to five exec-masked branches per comparison
+    const bool nan_wins = an > bn, same_kind = an == bn;
+    const bool by_value = (an == 0) & (av != bv);
+    return nan_wins | (same_kind & (by_value ? (av > bv) : (ai < bi)));
 }
 
 __global__ __launch_bounds__(ROW_THREADS) void row_argmax_votes_kernel(

@@ -535,9 +535,11 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
             }
             __syncthreads();
             const int n_here = (int)((nq_w - q0) < THREADS ? (nq_w - q0) : THREADS);
-            u2v cwn[NCH];                                // the row in flight: codes (four 16-bit codes per chunk) ...
-            double tn[TPT];                              // ... and this thread's entries of its table
-            auto fetch_wide = [&](int i) {
+            // THREE rows in flight (codes: four 16-bit codes per chunk; this thread's entries of the table): with one,
+            // a row took the memory latency -- 2.4 us against 0.7 us for a byte-coded row (tools/time_coded_parts.py)
+            u2v cwa[NCH], cwb[NCH], cwc[NCH];
+            double tna[TPT], tnb[TPT], tnc[TPT];
+            auto fetch_wide = [&](int i, u2v(&cwn)[NCH], double(&tn)[TPT]) {
                 const long long off = s_woff[i];
                 const int nd = __builtin_amdgcn_readfirstlane(s_wnd[i]);
                 const uint8_t *base = rec + (((long long)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
@@ -553,24 +555,19 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
                     tn[j] = __hiloint2double((int)x.y, (int)x.x);
                 }
             };
-            fetch_wide(0);
-            for (int i = 0; i < n_here; ++i) {
+            auto process_wide = [&](int i, const u2v(&cwn)[NCH], const double(&tn)[TPT]) {
                 const double wr = s_wwr[i];
-                u2v cwc[NCH];
-#pragma unroll
-                for (int k = 0; k < NCH; ++k) cwc[k] = cwn[k];
 #pragma unroll
                 for (int j = 0; j < TPT; ++j) s_wide[t + j * THREADS] = tn[j];
-                if (i + 1 < n_here) fetch_wide(i + 1);   // in flight under this row's reduction
                 __syncthreads();                         // the table is in LDS (and red[0] of the row before is read)
                 const char *tb = reinterpret_cast<const char *>(&s_wide[0]);
                 double s4[4] = {0.0, 0.0, 0.0, 0.0};
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
-                    v[k][0] = *reinterpret_cast<const double *>(tb + ((cwc[k].x & 0xffffu) << 3));
-                    v[k][1] = *reinterpret_cast<const double *>(tb + ((cwc[k].x >> 16) << 3));
-                    v[k][2] = *reinterpret_cast<const double *>(tb + ((cwc[k].y & 0xffffu) << 3));
-                    v[k][3] = *reinterpret_cast<const double *>(tb + ((cwc[k].y >> 16) << 3));
+                    v[k][0] = *reinterpret_cast<const double *>(tb + ((cwn[k].x & 0xffffu) << 3));
+                    v[k][1] = *reinterpret_cast<const double *>(tb + ((cwn[k].x >> 16) << 3));
+                    v[k][2] = *reinterpret_cast<const double *>(tb + ((cwn[k].y & 0xffffu) << 3));
+                    v[k][3] = *reinterpret_cast<const double *>(tb + ((cwn[k].y >> 16) << 3));
                 }
 #pragma unroll
                 for (int k = 0; k < NCH; ++k)
@@ -586,6 +583,18 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
                 for (int k = 0; k < NCH; ++k)
 #pragma unroll
                     for (int e = 0; e < 4; ++e) acc[k][e] = fma(cf, v[k][e], acc[k][e]);
+            };
+            fetch_wide(0, cwa, tna);
+            if (n_here > 1) fetch_wide(1, cwb, tnb);
+            for (int i = 0; i < n_here; i += 3) {        // every branch below is workgroup uniform
+                if (i + 2 < n_here) fetch_wide(i + 2, cwc, tnc);
+                process_wide(i, cwa, tna);
+                if (i + 1 >= n_here) break;
+                if (i + 3 < n_here) fetch_wide(i + 3, cwa, tna);
+                process_wide(i + 1, cwb, tnb);
+                if (i + 2 >= n_here) break;
+                if (i + 4 < n_here) fetch_wide(i + 4, cwb, tnb);
+                process_wide(i + 2, cwc, tnc);
             }
         }
     }

@@ -128,6 +128,16 @@ __device__ __forceinline__ double wave_max_lane63(double v) {
     return v;
 }
 
+__device__ __forceinline__ int wave_min_lane63_i32(int v) {       // the minimum lands in lane 63 (same ladder as above)
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0xB1, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x4E, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x141, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_mov_dpp(v, 0x140, 0xf, 0xf, true));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x142, 0xA, 0xf, false));
+    v = min(v, __builtin_amdgcn_update_dpp(v, v, 0x143, 0xC, 0xf, false));
+    return v;
+}
+
 // Inclusive prefix sum over the wave's 64 lanes by DPP only (row_shr 1 / 2 / 4 / 8 inside the rows of 16, row_bcast
 // 15 / 31 across them): six VALU steps instead of six ds_bpermute round trips on the LDS pipe.
 __device__ __forceinline__ int wave_inclusive_scan_i32(int v) {

@@ -829,9 +829,25 @@ extern "C" int mxm_row_argmax_votes_coded(const mxm_coded *c, int32_t H, int32_t
         return fail(-1, "mxm_row_argmax_votes_coded: workspace too small%s", "");
     hipStream_t s = (hipStream_t)stream;
     const size_t lse_lds = (size_t)n_runs * sizeof(double);
-    hipLaunchKernelGGL(posterior_argmax_kernel<true>, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(256), lse_lds, s, c->rec, c->rec_off,
-                       c->ndist, coded_ld(H), (const double *)nullptr, (int64_t)0, (const int64_t *)nullptr, c->R, (int)H,
-                       (int)n_runs, ln_props, props, rowmax, best);
+    const int ldc_a = coded_ld(H);
+    const int nch_a = (ldc_a / 4 + 255) / 256;
+    bool fast = n_runs == 1 && nch_a <= 8;
+    if (fast) {
+        // one run: the normaliser drops out -- the register-resident form (records_argmax_kernel)
+        switch (nch_a) {
+            // one wave of workgroups: as many as are resident at once (a second, partial wave of equally long workgroups
+            // would double the kernel's time)
+#define RA_CASE(n) case n: { int per_cu = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, records_argmax_kernel<n>, 256, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; } \
+                hipLaunchKernelGGL((records_argmax_kernel<n>), dim3(clamp_grid(c->R, num_cu() * per_cu)), dim3(256), 0, s, c->rec, c->rec_off, c->ndist, ldc_a, c->R, (int)H, ln_props, best); } break;
+            RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) RA_CASE(7) RA_CASE(8)
+#undef RA_CASE
+            default: fast = false;
+        }
+    }
+    if (!fast)
+        hipLaunchKernelGGL(posterior_argmax_kernel<true>, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(256), lse_lds, s, c->rec, c->rec_off,
+                           c->ndist, coded_ld(H), (const double *)nullptr, (int64_t)0, (const int64_t *)nullptr, c->R, (int)H,
+                           (int)n_runs, ln_props, props, rowmax, best);
     HIP_TRY(hipGetLastError());
     if (n_rest > 0) {
         hipLaunchKernelGGL(posterior_argmax_kernel<false>, dim3(clamp_grid(n_rest, num_cu() * 8)), dim3(256), lse_lds, s,
@@ -1635,6 +1651,23 @@ extern "C" int mxm_row_argmax_votes(const double *X, int64_t ldx, const double *
                            (const mxm_em_state *)nullptr, slots_from(0));
         HIP_TRY(hipGetLastError());
     }
+    return 0;
+}
+
+extern "C" int mxm_first_seen(const int32_t *best, int64_t R, int32_t H, int64_t *first, void *stream) {
+    if (best == nullptr || first == nullptr || R < 0 || H <= 0) return fail(-1, "mxm_first_seen: bad arguments%s", "");
+    hipStream_t s = (hipStream_t)stream;
+    hipLaunchKernelGGL(fill_u64_kernel, dim3(clamp_grid((H + 255) / 256, 64)), dim3(256), 0, s,
+                       reinterpret_cast<unsigned long long *>(first), (int64_t)H, (unsigned long long)R);
+    if (H > FSEEN_MAX_H) return fail(-1, "mxm_first_seen: more than %s%lld haplogroups", "", (long long)FSEEN_MAX_H);
+    if (R > 0) {
+        // ranges of at least 1024 rows and below 2^32 (32-bit offsets in LDS)
+        int grid = clamp_grid((R + 1023) / 1024, num_cu() * 4);
+        while ((R + grid - 1) / grid >= ((int64_t)1 << 32)) grid *= 2;
+        hipLaunchKernelGGL(first_seen_kernel, dim3(grid), dim3(256), 0, s, best, R, (int)H,
+                           reinterpret_cast<unsigned long long *>(first));
+    }
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 

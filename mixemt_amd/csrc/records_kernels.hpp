@@ -114,6 +114,155 @@ __global__ __launch_bounds__(256) void posterior_argmax_kernel(
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// The single-run case of the above, laid out like the EM iteration (round 4): best[r] = first index of
+// max_h (ln_props[h] + M[r][h]).  Thread t owns the columns 4 (t + 256 k) + e for ALL rows and keeps their log
+// proportions in registers; a row arrives as 4 code bytes (8 for a wide record) per thread and chunk plus its log table
+// through LDS; the next row's loads are in flight while this one is reduced.  The one-workgroup-per-row kernel above
+// read single code bytes and every ln_props[h] from memory per row: 14.4 ms at 10^6 rows (profiles/r04), this one 2.
+// Rows without a record get best[r] = -1 (the dense pass fills them in).
+// ------------------------------------------------------------------------------------------
+template <int NCH>
+__global__ __launch_bounds__(256) void records_argmax_kernel(const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off,
+                                                             const int32_t *__restrict__ ndist, int ldc, int64_t R, int H,
+                                                             const double *__restrict__ ln_props, int32_t *__restrict__ best) {
+    constexpr int THREADS = 256, TPT = ENC_MAX_WIDE / THREADS;
+    __shared__ double s_m[2][ENC_MAX_WIDE];
+    __shared__ double s_val[2][4];
+    __shared__ int s_idx[2][4], s_nan[2][4];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    double lp[NCH][4];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (t + k * THREADS) + e;
+            lp[k][e] = (c < H) ? ln_props[c] : -INFINITY;     // columns past the row can never win (log values are < +inf)
+        }
+    const int nword = ldc >> 2;
+    u2v cw[NCH];
+    double tn[TPT];
+    // record offsets and table sizes of 256 of this workgroup's rows at a time, gathered by one thread per row (as
+    // scalar loads inside the row loop they were two dependent memory round trips per row: 14 us a row)
+    __shared__ long long s_off[THREADS];
+    __shared__ int s_nd[THREADS];
+    const int64_t grid = gridDim.x;
+    const int64_t nq = (R > (int64_t)blockIdx.x) ? (R - blockIdx.x + grid - 1) / grid : 0;
+    auto fetch = [&](int i) {                                // codes and this thread's entries of the LOG table of step i
+        const int nd = __builtin_amdgcn_readfirstlane(s_nd[i]);
+        if (nd <= 0) return;                                 // uniform
+        const long long off = s_off[i];
+        const uint8_t *base = rec + (((long long)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+                                     (unsigned int)__builtin_amdgcn_readfirstlane((int)off));
+        const bool wide = nd > ENC_MAX_CODES;
+        const int cbytes = wide ? 2 * ldc : ldc;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, cbytes, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            int wd = t + k * THREADS;
+            if (wd > nword - 1) wd = nword - 1;              // words past the row: clamped (their columns are masked below)
+            if (wide) {
+                cw[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, wd * 8, 0, 0);
+            } else {
+                cw[k].x = __builtin_amdgcn_raw_buffer_load_b32(rs, wd * 4, 0, 0);
+                cw[k].y = 0;
+            }
+        }
+        const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base + cbytes + 8 * (int64_t)nd), 0, nd * 8, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < TPT; ++j) {
+            const u2v x = __builtin_amdgcn_raw_buffer_load_b64(rt, (t + j * THREADS) * 8, 0, 0);
+            tn[j] = __hiloint2double((int)x.y, (int)x.x);
+        }
+    };
+    int buf = 0;
+    for (int64_t q0 = 0; q0 < nq; q0 += THREADS) {
+        __syncthreads();                                     // the block before has been read
+        {
+            const int64_t r = (int64_t)blockIdx.x + (q0 + t) * grid;
+            s_nd[t] = (q0 + t < nq) ? ndist[r] : 0;
+            s_off[t] = (q0 + t < nq) ? rec_off[r] : 0;
+        }
+        __syncthreads();
+        const int n_here = (int)((nq - q0) < THREADS ? (nq - q0) : THREADS);
+        fetch(0);
+        for (int i = 0; i < n_here; ++i, buf ^= 1) {
+            const int64_t r = (int64_t)blockIdx.x + (q0 + i) * grid;
+            const int nd = __builtin_amdgcn_readfirstlane(s_nd[i]);
+            if (nd <= 0) {                                   // uniform
+                if (t == 0) best[r] = -1;
+                if (i + 1 < n_here) fetch(i + 1);
+                continue;
+            }
+            const bool wide = nd > ENC_MAX_CODES;
+            u2v cc[NCH];
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) cc[k] = cw[k];
+#pragma unroll
+            for (int j = 0; j < TPT; ++j) s_m[buf][t + j * THREADS] = tn[j];
+            if (i + 1 < n_here) fetch(i + 1);                // in flight under this row's reduction
+            __syncthreads();                                 // the table is in LDS (double buffered: the row before is done with the other)
+            int cn = 0, ci = 0x7fffffff;
+            double cv = -INFINITY;
+            auto cell = [&](int k, int e, int code) {
+                const int c = 4 * (t + k * THREADS) + e;     // increasing per thread: the first maximum is kept
+                const double v = lp[k][e] + s_m[buf][code];
+                // a later column only replaces a strictly smaller non-NaN maximum (a NaN wins, the first one)
+                const bool take = (cn == 0) & !(v <= cv);
+                cn = take ? ((v != v) ? 1 : 0) : cn;
+                cv = take ? v : cv;
+                ci = take ? c : ci;
+            };
+            if (wide) {                                      // uniform
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    cell(k, 0, (int)(cc[k].x & 0xffffu));
+                    cell(k, 1, (int)(cc[k].x >> 16));
+                    cell(k, 2, (int)(cc[k].y & 0xffffu));
+                    cell(k, 3, (int)(cc[k].y >> 16));
+                }
+            } else {
+#pragma unroll
+                for (int k = 0; k < NCH; ++k) {
+                    cell(k, 0, (int)(cc[k].x & 0xffu));
+                    cell(k, 1, (int)((cc[k].x >> 8) & 0xffu));
+                    cell(k, 2, (int)((cc[k].x >> 16) & 0xffu));
+                    cell(k, 3, (int)(cc[k].x >> 24));
+                }
+            }
+            // the wave's candidate by DPP ladders (no LDS permutes): a NaN wins, else the maximum; among equals the
+            // smallest column.  No NaN lane -> every cv is a number and the max ladder is exact.
+            {
+                const bool any_nan = __builtin_amdgcn_ballot_w64(cn != 0) != 0ull;          // uniform
+                double m = 0.0;
+                bool cand;
+                if (any_nan) {
+                    cand = cn != 0;
+                } else {
+                    m = readlane_f64(wave_max_lane63(cv), 63);
+                    cand = cv == m;
+                }
+                const int wi = __builtin_amdgcn_readlane(wave_min_lane63_i32(cand ? ci : 0x7fffffff), 63);
+                if (lane == 0) {
+                    s_val[buf][wv] = any_nan ? __builtin_nan("") : m;
+                    s_idx[buf][wv] = wi;
+                    s_nan[buf][wv] = any_nan ? 1 : 0;
+                }
+                cn = any_nan ? 1 : 0;                        // thread 0 continues from its wave's candidate
+                cv = any_nan ? __builtin_nan("") : m;
+                ci = wi;
+            }
+            __syncthreads();
+            if (t == 0) {
+                for (int q = 1; q < 4; ++q)
+                    if (cand_better(s_nan[buf][q], s_val[buf][q], s_idx[buf][q], cn, cv, ci)) { cn = s_nan[buf][q]; cv = s_val[buf][q]; ci = s_idx[buf][q]; }
+                best[r] = (ci >= H) ? 0 : ci;
+            }
+        }
+    }
+}
+
 // votes[h] = sum of w[r] over the rows with best[r] == h (assemble.py:116-119) without float atomics: workgroup g takes
 // the contiguous rows [g * per, (g + 1) * per), ONE thread adds them in row order into the workgroup's row of
 // `vote_part` (zeroed here first); colreduce_kernel then sums the workgroups in fixed order -- fractional weights
@@ -134,6 +283,35 @@ __global__ __launch_bounds__(256) void votes_from_best_kernel(const int32_t *__r
         volatile double *slot = mine + b;                    // the same thread wrote the zero / the last sum
         *slot = *slot + (w != nullptr ? w[r] : 1.0);
     }
+}
+
+// first[h] = the smallest row index r with best[r] == h (R where nobody voted for h): the insertion order of the
+// reference's vote table (assemble.py:116-119, a dict filled row by row) without bringing best[] to the host.
+// An integer minimum is order independent, so atomics are exact here.  A workgroup takes a contiguous range of rows,
+// keeps the minima of ITS range in LDS (offsets into the range: 32 bits) and sends one global atomic per haplogroup
+// it saw -- a handful; a first version with one global atomic per row took 3.6 ms at 10^6 rows (three hot addresses).
+#define FSEEN_MAX_H 8192
+__global__ __launch_bounds__(256) void first_seen_kernel(const int32_t *__restrict__ best, int64_t R, int H,
+                                                         unsigned long long *__restrict__ first) {
+    __shared__ unsigned int s_first[FSEEN_MAX_H];
+    const int64_t per = (R + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < R) ? lo + per : R;
+    if (lo >= hi) return;
+    for (int h = threadIdx.x; h < H; h += 256) s_first[h] = 0xFFFFFFFFu;
+    __syncthreads();
+    for (int64_t r = lo + threadIdx.x; r < hi; r += 256) {
+        const int b = best[r];
+        if ((unsigned)b < (unsigned)H) atomicMin(&s_first[b], (unsigned int)(r - lo));
+    }
+    __syncthreads();
+    for (int h = threadIdx.x; h < H; h += 256) {
+        const unsigned int v = s_first[h];
+        if (v != 0xFFFFFFFFu) atomicMin(&first[h], (unsigned long long)(lo + v));
+    }
+}
+
+__global__ __launch_bounds__(256) void fill_u64_kernel(unsigned long long *__restrict__ x, int64_t n, unsigned long long v) {
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) x[i] = v;
 }
 
 #endif  // MIXEMT_RECORDS_KERNELS_HPP

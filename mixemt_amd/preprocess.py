@@ -31,6 +31,28 @@ MUT_WT = 0.01       # preprocess.py:39 defaults; not CLI flags (build_em_matrix 
 MUT_MAX = 0.5
 
 
+class _LazyLut(object):
+    """lut() of HapVarTables: obsmap at once, the 22 MB `ecode` table only if someone asks for it on the host (the
+    device path gathers it on the device)."""
+
+    def __init__(self, expected, n_haps, code_of, obsmap):
+        self._expected, self._n_haps, self.code_of = expected, n_haps, code_of
+        self._items = {"obsmap": obsmap}
+
+    def __getitem__(self, key):
+        if key == "ecode" and "ecode" not in self._items:
+            ecode = self.code_of[self._expected]            # pad byte 0 -> 0: never equals an observation code
+            ecode[:, self._n_haps:] = 0
+            self._items["ecode"] = numpy.ascontiguousarray(ecode)
+        return self._items[key]
+
+    def __contains__(self, key):
+        return key in ("ecode", "obsmap")
+
+    def keys(self):
+        return ["ecode", "obsmap"]
+
+
 class HapVarTables(object):
     """
     Flat form of HapVarBaseMatrix for a fixed haplogroup (column) order.
@@ -58,6 +80,8 @@ class HapVarTables(object):
         for k, p in enumerate(sites):
             if int(p) >= 0:
                 self.site_of_pos[int(p)] = k
+        self._marker_flat = None
+        self._ref_codes = None
         self._dev = None
         self._lut = None
         self._lut_dev = None
@@ -75,22 +99,40 @@ class HapVarTables(object):
         expected = numpy.zeros((n_sites, lde), dtype=numpy.uint8)
         ref_codes = numpy.array([ord(refseq[int(p)]) for p in sites], dtype=numpy.uint8)
         expected[:, :n_haps] = ref_codes[:, None]
+        # markers: (site index, haplogroup index, derived base) in the reference's iteration order.  A tree has a few
+        # thousand DISTINCT variant strings for 280 000 (haplogroup, variant) pairs: each string is parsed once.
+        parsed = {}
+        flat, der_codes = [], []
         for j, hap in enumerate(haplogroups):
             for var in phylo.hap_var[hap]:
-                pos = phylotree.pos_from_var(var)
-                der = phylotree.der_allele(var)
-                k = where.get(pos)
-                if k is not None and der != refseq[pos]:
-                    # a derived allele equal to the reference base leaves no
-                    # marker (:63-66): the expected base stays whatever it was
-                    expected[k, j] = ord(der)
+                ent = parsed.get(var)
+                if ent is None:
+                    pos = phylotree.pos_from_var(var)
+                    der = phylotree.der_allele(var)
+                    k = where.get(pos)
+                    # a derived allele equal to the reference base leaves no marker (:63-66): the expected base stays
+                    # whatever it was
+                    ent = (k * lde, ord(der)) if (k is not None and der != refseq[pos]) else False
+                    parsed[var] = ent
+                if ent:
+                    flat.append(ent[0] + j)
+                    der_codes.append(ent[1])
+        flat = numpy.asarray(flat, dtype=numpy.int64)
+        if flat.size:
+            # repeated (site, haplogroup) pairs: the last assignment stands, as in the reference's dict (:60-66)
+            expected.reshape(-1)[flat] = numpy.asarray(der_codes, dtype=numpy.uint8)
         lhit = numpy.empty(n_sites)
         lmiss = numpy.empty(n_sites)
         for k, pos in enumerate(sites):
             mu = min(mut_max, mut_wt * sum(phylo.variants[int(pos)].values()))
             lhit[k] = math.log(1.0 - mu)
             lmiss[k] = math.log(mu / 3.0)
-        return cls(sites, expected, lhit, lmiss, list(haplogroups), n_haps)
+        tables = cls(sites, expected, lhit, lmiss, list(haplogroups), n_haps)
+        # where the table differs from the reference base, as flat indexes (sorted: site-major, haplogroup ascending):
+        # sparse() and lut() work from these 264 000 cells instead of sweeping all 22 million
+        tables._marker_flat = numpy.unique(flat)
+        tables._ref_codes = ref_codes
+        return tables
 
     def lut(self):
         """
@@ -103,7 +145,10 @@ class HapVarTables(object):
         if self._lut is not None:
             return self._lut or None
         n_sites, n_haps = len(self.sites), self.n_haps
-        alphabet = numpy.unique(self.expected[:, :n_haps])
+        if self._marker_flat is not None:                   # build(): reference bases + marker bases are all there is
+            alphabet = numpy.unique(numpy.concatenate([self._ref_codes, self.expected.reshape(-1)[self._marker_flat]]))
+        else:
+            alphabet = numpy.flatnonzero(numpy.bincount(self.expected[:, :n_haps].reshape(-1), minlength=256)).astype(numpy.uint8)
         alphabet = alphabet[alphabet != 0]
         if (len(alphabet) > 14 or n_sites == 0 or n_haps > 8192
                 or n_sites * self.expected.shape[1] >= (1 << 31)):
@@ -113,9 +158,7 @@ class HapVarTables(object):
         code_of[alphabet] = numpy.arange(1, len(alphabet) + 1, dtype=numpy.uint8) << 3
         obsmap = numpy.full(256, 15 << 3, dtype=numpy.uint8)
         obsmap[alphabet] = code_of[alphabet]
-        ecode = code_of[self.expected]                      # pad byte 0 -> 0: never equals an observation code
-        ecode[:, n_haps:] = 0
-        self._lut = {"ecode": numpy.ascontiguousarray(ecode), "obsmap": obsmap}
+        self._lut = _LazyLut(self.expected, n_haps, code_of, obsmap)
         return self._lut
 
     def sparse(self):
@@ -128,10 +171,31 @@ class HapVarTables(object):
         if self._sparse is None:
             exp = self.expected[:, :self.n_haps]
             n_sites = exp.shape[0]
-            maj = numpy.zeros(n_sites, dtype=numpy.uint8)
-            for s in range(n_sites):
-                maj[s] = numpy.bincount(exp[s], minlength=256).argmax()
-            site_i, hap_i = numpy.nonzero(exp != maj[:, None])           # row-major: sorted by site
+            if self._marker_flat is not None and n_sites:
+                # from the marker cells alone (build()): per site a histogram of the marker bases, the reference base
+                # holding every other haplogroup; the most frequent byte wins, ties to the smallest (as
+                # bincount().argmax() over the row gives)
+                lde = self.expected.shape[1]
+                k_u, j_u = self._marker_flat // lde, self._marker_flat % lde
+                v_u = self.expected.reshape(-1)[self._marker_flat]
+                cnt = numpy.bincount(k_u * 256 + v_u, minlength=n_sites * 256).reshape(n_sites, 256)
+                cnt[numpy.arange(n_sites), self._ref_codes] += self.n_haps - numpy.bincount(k_u, minlength=n_sites)
+                maj = cnt.argmax(axis=1).astype(numpy.uint8)
+                keep = v_u != maj[k_u]
+                site_i, hap_i = k_u[keep], j_u[keep]
+                special = numpy.flatnonzero(maj != self._ref_codes)  # sites where most haplogroups carry a marker
+                if special.size:
+                    drop = numpy.isin(site_i, special)
+                    xs, xh = numpy.nonzero(exp[special] != maj[special, None])
+                    site_i = numpy.concatenate([site_i[~drop], special[xs]])
+                    hap_i = numpy.concatenate([hap_i[~drop], xh])
+                    order = numpy.lexsort((hap_i, site_i))
+                    site_i, hap_i = site_i[order], hap_i[order]
+            else:
+                maj = numpy.zeros(n_sites, dtype=numpy.uint8)
+                for s in range(n_sites):
+                    maj[s] = numpy.bincount(exp[s], minlength=256).argmax()
+                site_i, hap_i = numpy.nonzero(exp != maj[:, None])       # row-major: sorted by site
             mk_ptr = numpy.zeros(n_sites + 1, dtype=numpy.int32)
             numpy.cumsum(numpy.bincount(site_i, minlength=n_sites), out=mk_ptr[1:])
             self._sparse = {"maj": maj, "mk_ptr": mk_ptr, "mk_hap": hap_i.astype(numpy.uint16),
@@ -158,9 +222,12 @@ class HapVarTables(object):
             return None
         if self._lut_dev is None:
             dev = require_gpu()
-            _, lhit_d, lmiss_d = self.device()
-            self._lut_dev = {"ecode": torch.from_numpy(enc["ecode"]).to(dev),
-                             "obsmap": torch.from_numpy(enc["obsmap"]).to(dev),
+            exp_d, lhit_d, lmiss_d = self.device()
+            # the code table from the expected-base table on the device: a 22 MB gather there instead of on the host
+            code_d = torch.from_numpy(enc.code_of).to(dev)
+            ecode_d = code_d[exp_d.reshape(-1).to(torch.int64)].reshape(exp_d.shape).contiguous()
+            ecode_d[:, self.n_haps:] = 0
+            self._lut_dev = {"ecode": ecode_d, "obsmap": torch.from_numpy(enc["obsmap"]).to(dev),
                              "lhit": lhit_d, "lmiss": lmiss_d}
         return self._lut_dev
 

@@ -92,9 +92,8 @@ def main():
     t0 = time.perf_counter()
     if opts.records:
         # votes and contributors from the records' log tables under theta_k (no posterior matrix exists)
-        best, votes = assign.row_argmax_votes_records(cm, res["ln_theta_k"], None)     # every run of a --multi N
+        seen, votes = assign.vote_table_from_records(cm, res["ln_theta_k"], None)     # every run of a --multi N
         sys.stderr.write("\nTop 10 haplogroups by read probabilities...\n")
-        seen = assign._first_seen_order(best)
         for hap_i in sorted(seen, key=lambda h: -votes[h])[:10]:
             sys.stderr.write("%s\t%d\n" % (haps[hap_i], int(votes[hap_i])))
         sys.stderr.write("\n")
