@@ -307,9 +307,11 @@ def pmc_traffic(n_rows, n_haps, storage="f64", kernel=None, algo_bytes=None, roo
         if have != storage:
             continue
         for name, rec in data.items():
-            if name.startswith("_") or (kernel is not None and name != kernel):
+            if name.startswith("_") or (kernel is not None and not kernel.endswith("*") and name != kernel):
                 continue
             if kernel is None and not name.startswith("em_iter_wide_kernel"):
+                continue
+            if kernel is not None and kernel.endswith("*") and not name.startswith(kernel[:-1]):
                 continue
             val = float(rec["hbm_bytes_per_launch"])
             if algo_bytes and not (0.9 * algo_bytes <= val <= 1.5 * algo_bytes):
@@ -674,6 +676,10 @@ def bench_rows(opts, env):
             kernel_name = name_buf.value.decode()
         if n_runs == 1:
             traffic = pmc_traffic(n_rows, n_haps, "f64", kernel_name, algo_bytes)
+    elif plan.storage == "coded" and n_runs == 1:
+        # the records' kernel: counter bytes calibrated against a bare reader of exactly the same records in the same
+        # counter pass (tools/pmc_calibrate_coded.py -> tools/pmc_summary.py); same [0.9, 1.5] x rule as the dense line
+        traffic = pmc_traffic(n_rows, n_haps, "coded", "em_iter_coded_kernel*", algo_bytes)
     return {
         "metric": "read x hap cells/sec through the EM iteration (EM iters/sec reported beside it as "
                   "em_iters_per_s), %d reads x %d haps in total, whole job" % (total_rows, n_haps),
@@ -721,11 +727,25 @@ def bench_rows(opts, env):
         "step_remainder_us": (None if batched else
                               (elapsed / opts.steps * 1e3 - max(kernel_ms_per_rank)) * 1e3
                               - (max(all_reduce_us_per_rank) if all_reduce_us_per_rank else 0.0)),
+        # What this run's own numbers allow at best: with the exchange free, a step costs the slowest rank's kernel plus
+        # the fixed remainder, and one GPU holding all N shards would need N kernels plus the same remainder
+        # (the streaming kernel's time is linear in the rows).  ceiling = (N k + rem) / (k + rem); the measured
+        # speed-up can only be lower (the all-reduce, waiting for the slowest rank).
+        "projected_scaling_ceiling": (None if batched else _scaling_ceiling(world, max(kernel_ms_per_rank),
+                                                                            elapsed / opts.steps * 1e3, all_reduce_us_per_rank)),
         "matrix_build_cells_per_s": float(n_rows) * n_haps / build_s,
         "linearize_ms": linearize_s * 1e3,
         "posterior_pass_ms": posterior_ms,
         "sanity_ok": bool(sane),
     }
+
+
+def _scaling_ceiling(world, kernel_ms, step_ms, all_reduce_us_per_rank):
+    exchange_ms = (max(all_reduce_us_per_rank) if all_reduce_us_per_rank else 0.0) * 1e-3
+    rem_ms = max(step_ms - kernel_ms - exchange_ms, 0.0)
+    return {"speedup_at_most": (world * kernel_ms + rem_ms) / (kernel_ms + rem_ms), "n_gpus": world,
+            "kernel_ms": kernel_ms, "remainder_ms": rem_ms, "exchange_ms": exchange_ms,
+            "formula": "(N * kernel + remainder) / (kernel + remainder): the exchange taken as free"}
 
 
 def bench_restarts(opts, env):

@@ -43,11 +43,22 @@ int mxm_describe_stream_kernel(int32_t H, int32_t nb, char *buf, size_t len);
  * (16 B per lane, 8 loads in flight per lane, `wg_per_cu` workgroups of 256 per CU; blocked = 0:
  * grid-stride plain loads, 1: one contiguous block per workgroup, non-temporal loads, 2: the
  * streaming EM kernel's own pattern without its arithmetic -- 43 264-byte rows dealt over
- * workgroups of 512, per-row buffer descriptors, non-temporal loads, a ring of 3 rows) to measure
+ * workgroups of 512, per-row buffer descriptors, non-temporal loads, a ring of 3 rows; 3: em_iter_coded_kernel's
+ * pattern -- records of 5408 code bytes read 4 B per lane + a 27-entry table read 8 B per lane, workgroups of 256:
+ * the counter calibration for that access width, tools/pmc_summary.py) to measure
  * the practical HBM read ceiling on the device at hand (tools/stream_ceiling.py).
  */
 int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_per_cu, int32_t blocked,
                          void *sink, void *stream);
+
+/*
+ * Diagnostic: exactly the loads em_iter_coded_kernel issues over the records of `c` (code words, P tables, the wide
+ * rows' 16-bit codes and tables; H in (5120, 6144]) and nothing else -- the bare-read time of a record buffer, and the
+ * counter calibration for that kernel: FETCH_SIZE of this launch is what the counter makes of the bytes the EM
+ * iteration has to read (tools/pmc_calibrate_coded.py, tools/pmc_summary.py).
+ */
+struct mxm_coded;
+int mxm_diag_stream_coded(const struct mxm_coded *c, int32_t H, int32_t wg_per_cu, void *sink, void *stream);
 
 /*
  * Progress hook for mxm_em_loop (the reference prints a dot every 10 iterations while it runs,

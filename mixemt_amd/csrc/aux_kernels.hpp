@@ -375,4 +375,99 @@ __global__ __launch_bounds__(512, 2) void diag_stream_dealt_kernel(const double 
     if (acc == 0x9e3779b9u) sink[0] = acc;
 }
 
+// Diagnostic only: em_iter_coded_kernel's access pattern with the arithmetic taken out -- 256 threads, records of
+// `rec_bytes` bytes (code words as 4 B per lane, NCH of them per thread, then a table of `tbl` doubles read as 8 B per
+// lane by the first `tbl` threads) dealt over the workgroups, non-temporal, three records in flight.  Used to calibrate
+// the FETCH_SIZE counter for this access width (tools/pmc_summary.py) and as the bare-read ceiling of that pattern.
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void diag_stream_records_kernel(const uint8_t *__restrict__ src, int64_t R, int rec_bytes,
+                                                                     int code_bytes, int tbl, unsigned int *__restrict__ sink) {
+    constexpr int THREADS = 256, NBUF = 3;
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    const int t = threadIdx.x;
+    const row_deal deal(R);
+    const int nword = code_bytes >> 2;
+    int last = t + (NCH - 1) * THREADS;
+    if (last > nword - 1) last = nword - 1;
+    unsigned int x[NBUF][NCH];
+    u2v y[NBUF];
+    unsigned int acc = 0;
+    auto load_rec = [&](unsigned int(&xr)[NCH], u2v &yr, int64_t q) {
+        const uint8_t *base = src + deal.row(q) * (int64_t)rec_bytes;
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, code_bytes, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NCH - 1; ++k) xr[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, t * 4, k * THREADS * 4, 2);
+        xr[NCH - 1] = __builtin_amdgcn_raw_buffer_load_b32(rs, last * 4, 0, 2);
+        const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base + code_bytes), 0, tbl * 8, 0x00020000);
+        yr = __builtin_amdgcn_raw_buffer_load_b64(rt, t * 8, 0, 2);
+    };
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j) load_rec(x[j], y[j], j);
+    for (int64_t q = 0; q < deal.nq; q += NBUF) {
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) {
+            load_rec(x[(j + NBUF - 1) % NBUF], y[(j + NBUF - 1) % NBUF], q + j + NBUF - 1);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) acc ^= x[j][k];
+            acc ^= y[j].x ^ y[j].y;
+        }
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;
+}
+
+// Diagnostic only: em_iter_coded_kernel's OWN loads over a real record buffer -- every byte-coded row's code words
+// (4 B per lane) and P table (8 B per lane), the wide rows' 16-bit codes and tables, through the same per-row
+// descriptors, non-temporal, three rows in flight -- and nothing else.  What FETCH_SIZE shows for this kernel is what
+// the counter makes of exactly the bytes the EM kernel has to read; the EM kernel's own reading divided by it is its
+// traffic ratio, whatever the counter's factor for these access widths is (tools/pmc_calibrate_coded.py).
+template <int NCH>
+__global__ __launch_bounds__(256, 2) void diag_stream_coded_kernel(const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off,
+                                                                   const int32_t *__restrict__ ndist, int ldc, int64_t R,
+                                                                   unsigned int *__restrict__ sink) {
+    constexpr int THREADS = 256, NBUF = 3;
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    const int t = threadIdx.x;
+    const row_deal deal(R);
+    const int nword = ldc >> 2;
+    int last = t + (NCH - 1) * THREADS;
+    if (last > nword - 1) last = nword - 1;
+    u2v x[NBUF][NCH];
+    u2v y[NBUF][4];
+    unsigned int acc = 0;
+    auto load_rec = [&](u2v(&xr)[NCH], u2v(&yr)[4], int64_t q) {
+        const int64_t r = deal.row(q);
+        const int nd = ndist[r];
+        const uint8_t *base = rec + rec_off[r];
+        const bool wide = nd > 256;
+        const int cbytes = nd > 0 ? (wide ? 2 * ldc : ldc) : 0;      // a row without a record: nothing is read
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, cbytes, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int wd = (k < NCH - 1) ? t + k * THREADS : last;
+            if (wide) {
+                xr[k] = __builtin_amdgcn_raw_buffer_load_b64(rs, wd * 8, 0, 2);
+            } else {
+                xr[k].x = __builtin_amdgcn_raw_buffer_load_b32(rs, wd * 4, 0, 2);
+                xr[k].y = 0;
+            }
+        }
+        const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base + cbytes), 0, (nd > 0 ? nd : 0) * 8, 0x00020000);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) yr[j] = __builtin_amdgcn_raw_buffer_load_b64(rt, (t + j * THREADS) * 8, 0, 2);
+    };
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j) load_rec(x[j], y[j], j);
+    for (int64_t q = 0; q < deal.nq; q += NBUF) {
+#pragma unroll
+        for (int j = 0; j < NBUF; ++j) {
+            load_rec(x[(j + NBUF - 1) % NBUF], y[(j + NBUF - 1) % NBUF], q + j + NBUF - 1);
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) acc ^= x[j][k].x ^ x[j][k].y;
+#pragma unroll
+            for (int k = 0; k < 4; ++k) acc ^= y[j][k].x ^ y[j][k].y;
+        }
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;
+}
+
 #endif  // MIXEMT_AUX_KERNELS_HPP

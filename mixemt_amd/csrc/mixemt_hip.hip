@@ -1593,6 +1593,16 @@ extern "C" int mxm_assign_reads(const double *X, int64_t ldx, const double *log_
 extern "C" int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_per_cu, int32_t blocked, void *sink,
                                     void *stream) {
     if (src == nullptr || sink == nullptr || bytes < 16 || wg_per_cu < 1) return fail(-1, "mxm_diag_stream_read: bad arguments%s", "");
+    if (blocked == 3) {
+        // em_iter_coded_kernel's pattern: records of 5408 code bytes + 27 doubles (5624 bytes), two workgroups per CU
+        const int code_bytes = 5408, tbl = 27, rec_bytes = code_bytes + tbl * 8;
+        const int64_t recs = (int64_t)bytes / rec_bytes;
+        if (recs < 1) return fail(-1, "mxm_diag_stream_read: buffer smaller than one record%s", "");
+        hipLaunchKernelGGL(diag_stream_records_kernel<6>, dim3(clamp_grid(recs, num_cu() * wg_per_cu)), dim3(256), 0,
+                           (hipStream_t)stream, (const uint8_t *)src, recs, rec_bytes, code_bytes, tbl, (unsigned int *)sink);
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     if (blocked == 2) {
         // the EM kernel's pattern: rows of 5408 doubles (2704 x 16 B) dealt over one workgroup per CU
         const int row16 = 2704;
@@ -1606,6 +1616,18 @@ extern "C" int mxm_diag_stream_read(const void *src, size_t bytes, int32_t wg_pe
     else
         hipLaunchKernelGGL(diag_stream_read_kernel<false>, dim3(num_cu() * wg_per_cu), dim3(256), 0, (hipStream_t)stream,
                            (const uint4 *)src, (int64_t)(bytes / 16), (unsigned int *)sink);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_diag_stream_coded(const mxm_coded *c, int32_t H, int32_t wg_per_cu, void *sink, void *stream) {
+    const int rc = coded_check(c, H, "mxm_diag_stream_coded");
+    if (rc != 0) return rc;
+    if (sink == nullptr || wg_per_cu < 1) return fail(-1, "mxm_diag_stream_coded: bad arguments%s", "");
+    const int ldc = coded_ld(H);
+    if ((ldc / 4 + 255) / 256 != 6) return fail(-1, "mxm_diag_stream_coded: built for H in (5120, 6144]%s", "");
+    hipLaunchKernelGGL(diag_stream_coded_kernel<6>, dim3(clamp_grid(c->R, num_cu() * wg_per_cu)), dim3(256), 0, (hipStream_t)stream,
+                       c->rec, c->rec_off, c->ndist, ldc, c->R, (unsigned int *)sink);
     HIP_TRY(hipGetLastError());
     return 0;
 }

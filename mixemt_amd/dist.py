@@ -29,6 +29,7 @@ Two modes:
 """
 
 import math
+import time
 import warnings
 
 import numpy
@@ -80,8 +81,12 @@ def broadcast_inits(n_runs, n_haps, alpha, device, group=None, src=0):
     return buf.cpu().numpy()
 
 
+GRAPH_AUTO_ISSUE_SHARE = 0.5       # graph="auto": replay bursts from a hipGraph once the host needs more than this share
+                                   # of a burst's wall time just to ENQUEUE it (the device would otherwise wait for Python)
+
+
 def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8, compact=True,
-                    window=None, verify=True, graph=False):
+                    window=None, verify=True, graph="auto"):
     """
     The EM loop over a row-sharded matrix.  `plan` is the rank-local EmPlan (or
     any object with its em_iter / finalize / alloc / read_state surface -- the
@@ -101,13 +106,16 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     verify: at every state check the ranks compare (done, iters) of all restarts
     (two tiny all-reduces, MIN and MAX) and fail loudly if they ever disagree --
     the loop's correctness rests on bit-identical all-reduce results on all ranks.
-    graph (opt-in): replay each burst of `check_every` iterations -- streaming kernel, column reduce, all-reduce,
+    graph: replay each burst of `check_every` iterations -- streaming kernel, column reduce, all-reduce,
     finalize -- from ONE captured hipGraph instead of enqueueing 4 x check_every operations from Python, for shards so
-    small that the host would otherwise be what a step waits for (bench.py reports host_issue_us_per_step: ~60 us
-    against 0.85 ms at 125 000 rows per GPU, so the default path does not need it).  The first burst always runs
-    eagerly; a burst whose set of iterating restarts changed is re-captured; whenever capture is not possible (gloo,
-    CPU tensors, a backend that refuses collectives under capture) the loop silently stays eager.  Results are
-    bit-identical either way (same kernels, same order).
+    small that the host would otherwise be what a step waits for.  "auto" (default) decides by a rule the loop applies
+    itself: the first burst always runs eagerly and is timed -- how long the host took to ENQUEUE it against how long
+    it took until its state came back; above GRAPH_AUTO_ISSUE_SHARE (bench.py: ~40 us of issue per step against
+    0.83 ms at 125 000 dense rows per GPU -> eager; against 0.27 ms of a records shard it is close) the next bursts are
+    captured.  Every rank must take the same decision (a captured collective and an eager one do not pair up), so the
+    shares are max-reduced over the ranks first.  True / False force it.  A burst whose set of iterating restarts
+    changed is re-captured; whenever capture is not possible (gloo, CPU tensors, a backend that refuses collectives
+    under capture) the loop logs once and stays eager.  Results are bit-identical either way (same kernels, same order).
     """
     exchange = _collective(group)
     ln0, p0 = _em.log_inits(inits)
@@ -165,7 +173,7 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
                 plan.finalize(colsum[:lead], ln_cur[:lead], ln_new[:lead], props_cur[:lead], state[:lead],
                               tolerance, max_iter)
 
-        use_graph = (graph and not first and captured is not False and props_cur.is_cuda
+        use_graph = (graph is True and not first and captured is not False and props_cur.is_cuda
                      and (not exchange or dist.get_backend(group) == "nccl"))
         if use_graph and (captured is None or captured[0] != lead):
             # (re)capture: the burst's launches are recorded, not run; a failure leaves the loop eager for good
@@ -183,7 +191,7 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
                 torch.cuda.synchronize()
                 warnings.warn("sharded EM loop: hipGraph capture of a burst was refused (%s); staying eager" % (exc,),
                               RuntimeWarning, stacklevel=2)
-        first = False
+        was_first, first = first, False
         if use_graph and captured:
             # a captured burst replays raw pointers: the loop vectors and the plan's buffers must still be the ones
             # it recorded (they are never reallocated inside this loop; this makes the convention a check)
@@ -191,9 +199,22 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
                 raise RuntimeError("sharded EM loop: a buffer of the captured burst was reallocated between bursts")
             captured[1].replay()
             graph_bursts += 1
+            states = plan.read_state(state)
         else:
+            t_burst = time.perf_counter()
             burst()
-        states = plan.read_state(state)
+            t_issue = time.perf_counter() - t_burst
+            states = plan.read_state(state)                  # (synchronises: the burst's state is back)
+            t_wall = time.perf_counter() - t_burst
+            if was_first and graph == "auto":
+                share = t_issue / max(t_wall, 1e-9)
+                if exchange:                                 # one decision for all ranks
+                    agreed = torch.tensor([share], dtype=torch.float64, device=props_cur.device)
+                    dist.all_reduce(agreed, op=dist.ReduceOp.MAX, group=group)
+                    share = float(agreed.item())
+                graph = bool(share > GRAPH_AUTO_ISSUE_SHARE and props_cur.is_cuda
+                             and (not exchange or dist.get_backend(group) == "nccl"))
+                sharded_em_loop.last_issue_share = share
         if exchange and verify:
             _assert_ranks_agree(states, props_cur.device, group)
     if slot_run != list(range(n_runs)):                        # back to the caller's run order
@@ -209,6 +230,7 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
 
 
 sharded_em_loop.last_graph_bursts = 0        # bursts the last call replayed from a captured graph (diagnostic)
+sharded_em_loop.last_issue_share = None      # graph="auto": host enqueue time / wall time of the first burst (max over ranks)
 
 
 def _burst_ptrs(vectors, plan):

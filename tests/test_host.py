@@ -285,6 +285,26 @@ def test_bench_quotes_counter_traffic_of_the_kernel_it_ran(tmp_path):
     assert val == 1.02 * algo and path == os.path.join("profiles", "r07", "pmc_traffic_a.json")
 
 
+def test_bench_quotes_calibrated_counter_traffic_for_the_records_kernel():
+    """`bench.py --storage coded` quotes roofline.traffic for em_iter_coded_kernel from a counter file whose
+    factor was CALIBRATED (a bare reader of exactly the same records in the same FETCH_SIZE pass), under the dense line's
+    [0.9, 1.5] x rule: within 10 % of the 5.8 GB of codes + P tables the kernel has to read at 10^6 x 5408."""
+    import json
+    import sys
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import bench
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cal = json.load(open(os.path.join(root, "profiles", "r04", "pmc_calibration_coded.json")))
+    algo = float(cal["record_bytes_read_per_pass"])
+    got = bench.pmc_traffic(10 ** 6, 5408, "coded", "em_iter_coded_kernel*", algo)
+    assert got is not None and abs(got[0] - algo) < 0.10 * algo, got
+    data = json.load(open(os.path.join(root, got[1])))
+    rec = next(v for k, v in data.items() if k.startswith("em_iter_coded_kernel"))
+    assert "diag_stream_coded_kernel" in rec["fetch_correction_source"] and 1.0 < rec["fetch_correction"] <= 2.0
+    # the dense matrix's figure is never taken for it, nor the other way round
+    assert bench.pmc_traffic(10 ** 6, 5408, "f64", "em_iter_coded_kernel*", algo) is None
+
+
 def test_committed_profiles_name_the_kernel_instances_this_source_builds():
     """profile files must come from the binary that ships.  The latest round's rocprofv3 kernel statistics
     and counter summary name exactly the template instances this source tree launches for the benchmark's workload
@@ -309,7 +329,7 @@ def test_committed_profiles_name_the_kernel_instances_this_source_builds():
     lut = open(os.path.join(root, "mixemt_amd", "csrc", "build_lut_kernels.hpp")).read()
     cpl = int(re.search(r"#define LUT_CPL (\d+)", lut).group(1))
     expected = [stream_kernel, "build_sparse_kernel<11, %d, false>" % passes, "build_lut_kernel<6, %d>" % cpl,
-                "em_iter_coded_kernel<256, 6, 4, 2>", "em_iter_wide_kernel<256, 11, 1, 2, 1>"]
+                "em_iter_coded_kernel<256, 6, 4, 2>", "em_fused_coded_kernel<6, 4, false>", "encode_wide_rows_kernel<6>"]
     for name in expected:
         assert name in stats, "%s: not in %s/bench_1m_kernel_stats.csv -- regenerate the profiles from this binary" % (name, latest)
     assert stream_kernel in traffic and traffic["_workload"]["storage"] == "f64"

@@ -14,12 +14,16 @@ from mixemt_amd import _lib
 from mixemt_amd._dev import current_stream
 
 lib = _lib.load()
-nbytes = int(float(sys.argv[1])) if len(sys.argv) > 1 else 43264000000
+nbytes = int(float(sys.argv[1])) if len(sys.argv) > 1 and sys.argv[1][0] != "-" else 43264000000
 buf = torch.empty(nbytes // 8, dtype=torch.float64, device="cuda").uniform_()
 sink = torch.zeros(4, dtype=torch.int32, device="cuda")
-NAMES = {0: "grid-stride", 1: "blocked, nt", 2: "dealt 43 KB rows, nt, ring 3, 512 thr"}
-for blocked in (0, 1, 2):
-    for wg in ((1, 2) if blocked == 2 else (1, 2, 4, 8, 16)):
+NAMES = {0: "grid-stride", 1: "blocked, nt", 2: "dealt 43 KB rows, nt, ring 3, 512 thr",
+         3: "records: 5408 code bytes at 4 B/lane + 27-entry table at 8 B/lane, nt, 256 thr"}
+patterns = (3,) if "--records" in sys.argv else (0, 1, 2, 3)
+for blocked in patterns:
+    if blocked == 3:
+        nbytes = nbytes // 5624 * 5624
+    for wg in ((1, 2) if blocked == 2 else ((2, 3, 4) if blocked == 3 else (1, 2, 4, 8, 16))):
         times = []
         for rep in range(6):
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
