@@ -138,7 +138,10 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? SPB_WAVES_EMIT : SPB_WAVES)) v
         }
         __syncthreads();
         const int total = s_cum[n];
-        int slot[NCH][2];
+        // table slot of the thread's two haplogroups per chunk, PACKED (low / high 16 bits; 0xffff = the majority value):
+        // eleven registers instead of twenty-two at H = 5408 -- the kernel is compiled for 80 VGPRs (six rows per CU)
+        // and used to spill 34 of them
+        unsigned int slot2[NCH];
         // ---- 2a. the row's first SPB_GATHER * 256 marker entries are looked up ONCE (site by a search in the prefix
         // sums, haplogroup and base from the global lists, flip against the majority term) and kept packed in
         // registers {haplogroup: 13 bits, observation index: 6 bits}, ~0 = no flip; every column range then only
@@ -187,7 +190,7 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? SPB_WAVES_EMIT : SPB_WAVES)) v
             const int h_lo = pass * SPAN;
             if (h_lo >= H) {
 #pragma unroll
-                for (int k = pass * KPP; k < NCH && k < (pass + 1) * KPP; ++k) slot[k][0] = slot[k][1] = -1;
+                for (int k = pass * KPP; k < NCH && k < (pass + 1) * KPP; ++k) slot2[k] = 0xffffffffu;
                 continue;
             }
             // ---- 2. OR the flips into the masks of this pass's haplogroups: the kept entries first, then what a long
@@ -241,6 +244,7 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? SPB_WAVES_EMIT : SPB_WAVES)) v
                     if (h0 + 1 >= H) both.y = 0ull;
                     if ((both.x | both.y) != 0ull) *reinterpret_cast<ull2 *>(&s_dev[h0 - h_lo]) = ull2{0ull, 0ull};
                 }
+                int sl_pair[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
                     const int h = 2 * (t + k * SPB_THREADS) + e;
@@ -248,7 +252,7 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? SPB_WAVES_EMIT : SPB_WAVES)) v
                     if (h < H) {
                         const unsigned long long mask = e == 0 ? both.x : both.y;
                         if (e == 1 && mask != 0ull && mask == both.x) {
-                            sl = slot[k][0];
+                            sl = sl_pair[0];
                         } else if (mask != 0ull) {
                             unsigned int hs = (unsigned int)((mask ^ (mask >> 29)) * 0x9E3779B97F4A7C15ull >> 40) & (SPB_SLOTS - 1);
                             for (int probes = 0;; ++probes) {
@@ -263,8 +267,9 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? SPB_WAVES_EMIT : SPB_WAVES)) v
                             sl = (int)hs;
                         }
                     }
-                    slot[k][e] = sl;
+                    sl_pair[e] = sl;
                 }
+                slot2[k] = ((unsigned int)sl_pair[0] & 0xffffu) | ((unsigned int)sl_pair[1] << 16);
             }
             __syncthreads();                                 // masks read and zeroed: the next pass may scatter
         }
@@ -381,8 +386,9 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? SPB_WAVES_EMIT : SPB_WAVES)) v
                 for (int k = 0; k < NCH; ++k) {
                     const int h = 2 * (t + k * SPB_THREADS);
                     if (h < out.ldc) {
-                        const unsigned int c0 = (h < H && slot[k][0] >= 0) ? s_code[slot[k][0]] : 0u;
-                        const unsigned int c1 = (h + 1 < H && slot[k][1] >= 0) ? s_code[slot[k][1]] : 0u;
+                        const unsigned int sa = slot2[k] & 0xffffu, sb = slot2[k] >> 16;
+                        const unsigned int c0 = (h < H && sa != 0xffffu) ? s_code[sa] : 0u;
+                        const unsigned int c1 = (h + 1 < H && sb != 0xffffu) ? s_code[sb] : 0u;
                         cw[t + k * SPB_THREADS] = (unsigned short)(c0 | (c1 << 8));
                     }
                 }
@@ -395,18 +401,23 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? SPB_WAVES_EMIT : SPB_WAVES)) v
                 no_record(r);                               // more than 256 values: the dense row below is its form
             }
         }
-        double *dst = M + r * ldm;
+        // the row goes out through ONE descriptor over it (scalar registers) with the thread's offset t * 16 and the
+        // chunk as an immediate: as eleven 64-bit addresses per thread the compiler hoisted them out of the row loop and
+        // spilled them (22 of the kernel's 80 VGPRs; ScratchSize 100 -> 0).  A store past the row's H doubles is dropped.
+        if (M != nullptr) {                                  // uniform
+            typedef unsigned int su4 __attribute__((ext_vector_type(4)));
+            typedef unsigned int su2 __attribute__((ext_vector_type(2)));
+            const auto mrs = __builtin_amdgcn_make_buffer_rsrc(M + r * ldm, 0, H * 8, 0x00020000);
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            const int h = 2 * (t + k * SPB_THREADS);
-            if (M != nullptr && h < H) {
-                const double v0 = slot[k][0] < 0 ? sum0 : __longlong_as_double((long long)s_key[slot[k][0]]);
-                const double v1 = slot[k][1] < 0 ? sum0 : __longlong_as_double((long long)s_key[slot[k][1]]);
-                if (vec_ok && h + 1 < H) {
-                    __builtin_nontemporal_store(d2{v0, v1}, reinterpret_cast<d2 *>(dst + h));
+            for (int k = 0; k < NCH; ++k) {
+                const unsigned int sa = slot2[k] & 0xffffu, sb = slot2[k] >> 16;
+                const double v0 = sa == 0xffffu ? sum0 : __longlong_as_double((long long)s_key[sa]);
+                const double v1 = sb == 0xffffu ? sum0 : __longlong_as_double((long long)s_key[sb]);
+                if (vec_ok && ((H & 1) == 0)) {
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(su4, d2{v0, v1}), mrs, t * 16, k * SPB_THREADS * 16, 2 /* nt */);
                 } else {
-                    dst[h] = v0;
-                    if (h + 1 < H) dst[h + 1] = v1;
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(su2, v0), mrs, t * 16, k * SPB_THREADS * 16, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(su2, v1), mrs, t * 16, k * SPB_THREADS * 16 + 8, 0);
                 }
             }
         }
