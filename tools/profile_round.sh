@@ -1,11 +1,11 @@
 #!/bin/bash
 # Re-create the judged profile files of a round on the GPU box (run through gpurun from the
-# repo root):  bash tools/profile_round.sh r03 [a|b|all]   (a gpurun call is capped at 20 minutes: two calls, a then b)
+# repo root):  bash tools/profile_round.sh r04 [a|b|all]   (a gpurun call is capped at 20 minutes: two calls, a then b)
 # Writes under gpurun_out/<round>/; copy what should be kept into profiles/<round>/.
 # rocprofv3 gets the program itself after `--` (python3 <script>), never a shell or env hop, and
 # counter passes (--pmc) are separate runs with --kernel-trace only.
 set -u
-round=${1:-r03}
+round=${1:-r04}
 part=${2:-all}        # a: headline + counters + row dictionaries; b: pipelines, other configurations, small runs, build; all: both
 repo=$PWD
 out=$repo/gpurun_out/$round
@@ -35,17 +35,20 @@ python3 $repo/bench.py --storage coded > $out/bench_1m_coded.json 2> $out/bench_
 echo "[profile_round] step 8 done"
 rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt_coded -o kt -- python3 $repo/bench.py --storage coded --no-cpu-baseline > $out/bench_1m_coded_under_rocprof.json 2> $out/kt_coded.log
 echo "[profile_round] step 9 done"
-rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch_coded -o f -- python3 $repo/bench.py --storage coded --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_fetch_coded.log
+# counter traffic of the records kernel, CALIBRATED: a bare reader of exactly the same records runs in the same FETCH_SIZE pass
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch_coded -o f -- python3 $repo/tools/pmc_calibrate_coded.py > $out/pmc_calibration_coded.json 2> $out/pmc_fetch_coded.log
 echo "[profile_round] step 10 done"
-rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write_coded -o w -- python3 $repo/bench.py --storage coded --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_write_coded.log
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write_coded -o w -- python3 $repo/tools/pmc_calibrate_coded.py > /dev/null 2> $out/pmc_write_coded.log
 echo "[profile_round] step 11 done"
-python3 $repo/tools/pmc_summary.py $out/pmc_fetch_coded/f_counter_collection.csv $out/pmc_write_coded/w_counter_collection.csv 1000000 5408 coded > $out/pmc_traffic_coded_1m.json
+python3 $repo/tools/pmc_summary.py $out/pmc_fetch_coded/f_counter_collection.csv $out/pmc_write_coded/w_counter_collection.csv 1000000 5408 coded $out/pmc_calibration_coded.json > $out/pmc_traffic_coded_1m.json
 echo "[profile_round] step 12 done"
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $out/pmc_sq_coded -o sq -- python3 $repo/bench.py --storage coded --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_sq_coded.log
 echo "[profile_round] step 13 done"
 python3 $repo/tools/sq_summary.py $out/pmc_sq_coded/sq_counter_collection.csv > $out/coded_pmc_sq_summary.txt 2>&1
 echo "[profile_round] step 14 done"
 python3 $repo/tools/time_coded.py > $out/coded_storage_1m.txt 2>&1
+python3 $repo/tools/time_coded_parts.py 10000 125000 1000000 > $out/coded_parts.txt 2>&1
+python3 $repo/tools/stream_ceiling.py 5624000000 --records > $out/records_read_ceiling.txt 2>&1
 echo "[profile_round] step 15 done"
 python3 $repo/bench.py --storage coded --restarts 10 --no-cpu-baseline > $out/bench_1m_coded_10restarts.json 2> /dev/null
 echo "[profile_round] step 16 done"
