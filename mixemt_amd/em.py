@@ -105,9 +105,10 @@ def em_step(read_hap_mat, weights, ln_props, read_mix_mat):
     return out, ln_new
 
 
-AUTO_CODED_MIN_CELLS = 5.0e7        # storage="auto": measured break-even against the one-launch loops over the dense
-                                    # matrix (profiles/r02/small_runs_coded.txt: 67 vs 80 us per iteration at 10 000 x 5408,
-                                    # 60 vs 39 at 4 600)
+AUTO_CODED_MIN_CELLS = 1.5e7        # storage="auto": measured break-even of the one-launch loop over records against the
+                                    # one-launch loops over the dense matrix (profiles/r04/small_runs_breakeven.txt: 26 vs 26 us
+                                    # per iteration at 2400 x 5408, 31 vs 41 at 4600, 36 vs 58 at 7000; round 3, with the
+                                    # records' iteration still four launches: 5e7)
 AUTO_CODED_MAX_REST = 0.25          # ... and at most this share of the rows may stay dense
 
 
@@ -129,7 +130,7 @@ class EmPlan(object):
         (mxm_encode_rows; rows with more than 256 of them stay dense): the matrix
         build's rows hold a few dozen distinct sums, so the loop reads ~8x fewer
         bytes.  Matrices it does not apply to (odd / narrow H, unaligned rows)
-        iterate as "f64".  "auto" = "coded" where it pays: more than 5 * 10^7 cells
+        iterate as "f64".  "auto" = "coded" where it pays: more than 1.5 * 10^7 cells
         (below that the one-launch loops over the dense matrix are faster) and at
         most a quarter of the rows left dense by the encoder; otherwise "f64".
         `plan.storage` says what the plan iterates.
@@ -513,8 +514,8 @@ def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, stora
     """
     n_multi = int(args.n_multi)
     # "auto" (default since round 3, once golden g10 pinned that branch to a reference run): the dense fp64 matrix up to
-    # 5e7 cells -- there the one-launch loops are the fastest form -- and lossless row dictionaries above, where an
-    # iteration reads 8x fewer bytes (3.4x faster at 10^6 x 5408); same stopping iterations, proportions within 1e-9
+    # 1.5e7 cells -- there the dense one-launch loops are the fastest form -- and lossless row dictionaries above, where an
+    # iteration reads 8x fewer bytes (4.2x faster at 10^6 x 5408); same stopping iterations, proportions within 1e-9
     storage = storage or getattr(args, "storage", "auto")
     t_plan = time.perf_counter()
     plan = EmPlan(read_hap_mat, weights, n_runs=n_multi, storage=storage, records=records)

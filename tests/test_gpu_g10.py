@@ -83,7 +83,7 @@ def test_storage_auto_takes_the_row_dictionaries_and_reproduces_it(g10):
     g = g10["g"]
     numpy.random.seed(23)
     res = em.run_em_ex(g10["mat"], g10["wts"], em_args())            # the default
-    assert res["storage"] == "coded"                                 # 1.08e8 cells > 5e7: the coded branch
+    assert res["storage"] == "coded"                                 # 1.08e8 cells > 1.5e7: the coded branch
     _check(res, g, mix=res["read_mix"])
 
 

@@ -35,7 +35,7 @@ def main():
     ap.add_argument("--records", action="store_true", help="(the default since round 3; kept for old command lines)")
     ap.add_argument("--storage", default="auto", choices=["f64", "f32", "coded", "auto"],
                     help="with --dense: form of the matrix the EM loop streams (EmPlan): coded = lossless row dictionaries, "
-                         "auto = coded from 5e7 cells on")
+                         "auto = coded from 1.5e7 cells on")
     opts = ap.parse_args()
     opts.records = not opts.dense
     args = argparse.Namespace(init_alpha=1.0, tolerance=1e-4, max_iter=10000, n_multi=opts.multi,
