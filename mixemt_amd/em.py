@@ -245,7 +245,7 @@ class EmPlan(object):
             rec, rec_off, ndist = self._coded_keep[:3]
             cap = rec.numel()
         else:
-            cap = max(one, min(lib.mxm_coded_bytes(n_rows, n_haps), n_rows * (ldc + 16 * 64) + (1 << 20)))
+            cap = max(one, min(lib.mxm_coded_bytes(n_rows, n_haps), n_rows * (ldc + 16 * 96) + (1 << 20)))
             rec = device_empty((cap,), torch.uint8, dev, "the coded matrix")
             rec_off = torch.empty(n_rows, dtype=torch.int64, device=dev)
             ndist = torch.empty(n_rows, dtype=torch.int32, device=dev)

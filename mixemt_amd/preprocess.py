@@ -530,7 +530,8 @@ def _gather_csr(row_ptr_d, site_d, obs_d, rows):
     return new_ptr, site_d.index_select(0, src), obs_d.index_select(0, src)
 
 
-RECORD_BYTES_GUESS = 16 * 64          # table bytes per row the first record buffer allows for (mean on synth-v1: 16 x 27)
+RECORD_BYTES_GUESS = 16 * 96          # table bytes per row the first record buffer allows for (synth-v1 needs 16 x 61 on average,
+                                      # wide records included: 6.39 KB per row at H = 5408)
 
 
 def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None):
