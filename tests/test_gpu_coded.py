@@ -477,6 +477,7 @@ def lib():
     yield handle
     handle.mxm_set_loop_fused(-1, 0)
     handle.mxm_diag_fused_force_abort(0)
+    handle.mxm_set_fused_coded_grid(0)
 
 
 @pytest.mark.parametrize("name,seed,n_multi", [("g4_run_em", 7, 1), ("g9_run_em_2400", 17, 1), ("g5_run_em_multi", 11, 3)])
@@ -565,3 +566,44 @@ def test_one_launch_loop_over_records_poisons_like_the_reference(lib):
     lib.mxm_set_loop_fused(1, 0)
     res = em.run_em_ex(mat, numpy.ones(64), em_args(max_iter=9), storage="coded", want_read_mix=False)
     assert res["iters"] == [9] and res["done"] == [2] and numpy.isnan(res["props"]).all()
+
+
+@pytest.mark.parametrize("grid", [8, 40])
+def test_one_launch_loop_over_records_with_many_rows_per_workgroup(b17, lib, grid):
+    """
+    The paths a 10^6-row matrix takes, at test size: with the grid held to a few workgroups (mxm_set_fused_coded_grid) a
+    workgroup has more than 256 rows -- the metadata blocks are refetched inside the pass (the non-resident instance) --
+    and more than 256 WIDE rows (several batches of the second loop).  g9's rows (2400, repeat weights) tiled four times
+    with every fifth row replaced by a wide one: same stopping iteration and proportions as the per-iteration kernels and
+    as the oracle's run on the same matrix.
+    """
+    from mixemt_amd import em
+    refseq, phy, haps, tables = b17
+    g = golden("g9_run_em_2400")
+    base = _b17_matrix(tables, g, len(haps))
+    rng = numpy.random.default_rng(grid)
+    mat = numpy.tile(base, (4, 1))
+    wts = numpy.tile(g["wts"], 4).astype(numpy.float64)
+    wide = numpy.arange(0, len(mat), 5)
+    vals = rng.normal(-20.0, 5.0, size=(len(wide), 700))
+    pick = rng.integers(0, 700, size=(len(wide), len(haps)))
+    mat[wide] = numpy.take_along_axis(vals, pick, axis=1) + base[wide % len(base)].max(axis=1, keepdims=True) - 40.0
+    plan = em.EmPlan(mat, wts, storage="coded")
+    assert plan.coded_wide >= len(wide) and plan.coded_rest == 0
+    args = em_args(max_iter=12)                                      # (the oracle's step takes a second at this size)
+    numpy.random.seed(5)
+    init = em.init_props(len(haps), 1.0)[None, :]
+    lib.mxm_set_loop_fused(0, 0)
+    want = em.run_em_ex(mat, wts, args, inits=init, storage="coded", want_read_mix=False)
+    lib.mxm_set_fused_coded_grid(grid)
+    for chunk in (0, 9):
+        lib.mxm_set_loop_fused(1, chunk)
+        got = em.run_em_ex(mat, wts, args, inits=init, storage="coded", want_read_mix=False)
+        assert got["iters"] == want["iters"] and got["done"] == want["done"]
+        assert numpy.abs(got["run_props"] - want["run_props"]).max() < 1e-12
+    lib.mxm_set_fused_coded_grid(0)
+    theta = numpy.log(init[0])
+    buf = numpy.empty_like(mat)
+    for _ in range(want["iters"][0]):
+        buf, theta = em_oracle.em_step(mat, wts, theta, buf)
+    assert numpy.abs(want["run_props"][0] - numpy.exp(theta)).max() < 1e-11
