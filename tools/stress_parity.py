@@ -36,7 +36,8 @@ def ns(**kw):
     return a
 
 
-widths = [65, 66, 67, 127, 128, 129, 255, 256, 511, 512, 513, 1000, 1023, 1024, 1025, 2047, 2048, 2049,
+widths = [1, 1, 2, 3, 4, 5, 8, 9, 16, 17, 31, 32, 33, 63, 64,        # the narrow (log-space) kernels: the refinement EM's shapes
+          65, 66, 67, 127, 128, 129, 255, 256, 511, 512, 513, 1000, 1023, 1024, 1025, 2047, 2048, 2049,
           3000, 4095, 4096, 4097, 5407, 5408, 5409, 6143, 6144, 6145, 7000, 8191, 8192]
 for case in range(opts.cases):
     if time.time() - t_start > opts.budget:
@@ -90,6 +91,26 @@ for case in range(opts.cases):
             fails += 1
             line += "  %s MISMATCH (iters %s, dprops %.2e)" % (label, res["iters"],
                                                               float(numpy.nanmax(numpy.abs(res["props"] - want_props))))
+    # the same run over row-dictionary records where the shape allows them (even H in 66..8192): a random row holds H
+    # distinct values -- byte codes up to 256 columns, 16-bit codes up to 1024, dense beyond -- through the one-launch
+    # loop over records and through the per-iteration kernels
+    if n_haps % 2 == 0 and 66 <= n_haps <= 8192:
+        for label, mode, chunk in (("records-one-launch", 1, 0), ("records-chunks", 1, int(rng.integers(1, 9))),
+                                   ("records-kernels", 0, 0)):
+            lib.mxm_set_loop_fused(mode, chunk)
+            numpy.random.seed(seed)
+            res = em.run_em_ex(mat, wts, args, storage="coded")
+            got_mix = res["read_mix"].cpu().numpy()
+            ok = res["iters"] == want_iters and res["storage"] == "coded"
+            ok = ok and float(numpy.nanmax(numpy.abs(res["props"] - want_props))) < 1e-9
+            ok = ok and numpy.array_equal(numpy.isfinite(got_mix), numpy.isfinite(want_mix))
+            with numpy.errstate(all="ignore"):
+                ok = ok and float(numpy.nanmax(numpy.abs(numpy.exp(got_mix) - numpy.exp(want_mix)))) < 1e-9
+            if not ok:
+                fails += 1
+                line += "  %s MISMATCH (iters %s, dprops %.2e)" % (label, res["iters"],
+                                                                  float(numpy.nanmax(numpy.abs(res["props"] - want_props))))
+        line += "  [+ records x3]"
     print(line + ("" if "MISMATCH" in line else "  ok"))
     sys.stdout.flush()
 lib.mxm_set_loop_fused(-1, 0)
