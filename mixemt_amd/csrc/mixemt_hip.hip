@@ -837,8 +837,9 @@ extern "C" int mxm_row_argmax_votes_coded(const mxm_coded *c, int32_t H, int32_t
         switch (nch_a) {
             // one wave of workgroups: as many as are resident at once (a second, partial wave of equally long workgroups
             // would double the kernel's time)
-#define RA_CASE(n) case n: { int per_cu = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, records_argmax_kernel<n>, 256, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; } \
-                hipLaunchKernelGGL((records_argmax_kernel<n>), dim3(clamp_grid(c->R, num_cu() * per_cu)), dim3(256), 0, s, c->rec, c->rec_off, c->ndist, ldc_a, c->R, (int)H, ln_props, best); } break;
+#define RA_CASE(n) case n: { int per_cu = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, records_argmax_narrow_kernel<n>, 256, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; } \
+                hipLaunchKernelGGL((records_argmax_narrow_kernel<n>), dim3(clamp_grid(c->R, num_cu() * per_cu)), dim3(256), 0, s, c->rec, c->rec_off, c->ndist, ldc_a, c->R, (int)H, ln_props, best); \
+                if (c->n_wide > 0) hipLaunchKernelGGL((records_argmax_kernel<n>), dim3(clamp_grid(c->n_wide, num_cu() * 2)), dim3(256), 0, s, c->rec, c->rec_off, c->ndist, ldc_a, c->n_wide, (int)H, ln_props, best, c->wide_rows); } break;
             RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) RA_CASE(7) RA_CASE(8)
 #undef RA_CASE
             default: fast = false;
@@ -858,7 +859,11 @@ extern "C" int mxm_row_argmax_votes_coded(const mxm_coded *c, int32_t H, int32_t
     if (votes != nullptr) {
         const int64_t ldpart = part_ld(H);
         const int nwg = clamp_grid((c->R + 255) / 256, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
-        hipLaunchKernelGGL(votes_from_best_kernel, dim3(nwg), dim3(256), 0, s, best, w, c->R, (int)H, (double *)ws, ldpart);
+        const size_t vlds = (size_t)H * sizeof(double);
+        if (vlds > 150 * 1024) return fail(-1, "mxm_row_argmax_votes_coded: H=%s%lld too wide for the vote kernel", "", H);
+        if (vlds > 60 * 1024 && raise_dynamic_lds(reinterpret_cast<const void *>(&votes_from_best_kernel), vlds, "votes_from_best_kernel") != hipSuccess)
+            return -2;
+        hipLaunchKernelGGL(votes_from_best_kernel, dim3(nwg), dim3(256), vlds, s, best, w, c->R, (int)H, (double *)ws, ldpart);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, s, (const double *)ws, ldpart, nwg,
                            1, (int)H, (const double *)nullptr, votes, (const mxm_em_state *)nullptr, slots_from(0));

@@ -122,10 +122,13 @@ __global__ __launch_bounds__(256) void posterior_argmax_kernel(
 // read single code bytes and every ln_props[h] from memory per row: 14.4 ms at 10^6 rows (profiles/r04), this one 2.
 // Rows without a record get best[r] = -1 (the dense pass fills them in).
 // ------------------------------------------------------------------------------------------
+// `rows` (nullable): the kernel then takes the rows rows[0 .. R) instead of 0 .. R-1 -- the wide rows' list, behind
+// records_argmax_narrow_kernel, which leaves those to it.
 template <int NCH>
 __global__ __launch_bounds__(256) void records_argmax_kernel(const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off,
                                                              const int32_t *__restrict__ ndist, int ldc, int64_t R, int H,
-                                                             const double *__restrict__ ln_props, int32_t *__restrict__ best) {
+                                                             const double *__restrict__ ln_props, int32_t *__restrict__ best,
+                                                             const int64_t *__restrict__ rows) {
     constexpr int THREADS = 256, TPT = ENC_MAX_WIDE / THREADS;
     __shared__ double s_m[2][ENC_MAX_WIDE];
     __shared__ double s_val[2][4];
@@ -146,6 +149,7 @@ __global__ __launch_bounds__(256) void records_argmax_kernel(const uint8_t *__re
     // record offsets and table sizes of 256 of this workgroup's rows at a time, gathered by one thread per row (as
     // scalar loads inside the row loop they were two dependent memory round trips per row: 14 us a row)
     __shared__ long long s_off[THREADS];
+    __shared__ long long s_row[THREADS];
     __shared__ int s_nd[THREADS];
     const int64_t grid = gridDim.x;
     const int64_t nq = (R > (int64_t)blockIdx.x) ? (R - blockIdx.x + grid - 1) / grid : 0;
@@ -180,15 +184,17 @@ __global__ __launch_bounds__(256) void records_argmax_kernel(const uint8_t *__re
     for (int64_t q0 = 0; q0 < nq; q0 += THREADS) {
         __syncthreads();                                     // the block before has been read
         {
-            const int64_t r = (int64_t)blockIdx.x + (q0 + t) * grid;
+            int64_t r = (int64_t)blockIdx.x + (q0 + t) * grid;
+            if (rows != nullptr && q0 + t < nq) r = rows[r];
             s_nd[t] = (q0 + t < nq) ? ndist[r] : 0;
             s_off[t] = (q0 + t < nq) ? rec_off[r] : 0;
+            s_row[t] = r;
         }
         __syncthreads();
         const int n_here = (int)((nq - q0) < THREADS ? (nq - q0) : THREADS);
         fetch(0);
         for (int i = 0; i < n_here; ++i, buf ^= 1) {
-            const int64_t r = (int64_t)blockIdx.x + (q0 + i) * grid;
+            const int64_t r = s_row[i];
             const int nd = __builtin_amdgcn_readfirstlane(s_nd[i]);
             if (nd <= 0) {                                   // uniform
                 if (t == 0) best[r] = -1;
@@ -263,6 +269,128 @@ __global__ __launch_bounds__(256) void records_argmax_kernel(const uint8_t *__re
     }
 }
 
+// The byte-coded rows alone (97.9 % of a build_em_matrix matrix), THREE rows in flight: a row is 4 code bytes per thread
+// and chunk plus ONE table entry per thread, so three of them cost 24 registers and the kernel fits four workgroups per
+// CU.  records_argmax_kernel, with room for a wide record per row in flight, ran one row ahead at 154 VGPRs and was
+// bound by the memory latency per row (4.7 us per row and workgroup: 6.1 ms at 10^6 rows).  Wide rows are left to that
+// kernel (launched over their list); rows without a record get best[r] = -1.
+template <int NCH>
+__global__ __launch_bounds__(256, 4) void records_argmax_narrow_kernel(const uint8_t *__restrict__ rec,
+                                                                       const int64_t *__restrict__ rec_off,
+                                                                       const int32_t *__restrict__ ndist, int ldc, int64_t R, int H,
+                                                                       const double *__restrict__ ln_props,
+                                                                       int32_t *__restrict__ best) {
+    constexpr int THREADS = 256;
+    __shared__ double s_m[2][ENC_MAX_CODES];
+    __shared__ double s_val[2][4];
+    __shared__ int s_idx[2][4], s_nan[2][4];
+    __shared__ long long s_off[THREADS];
+    __shared__ int s_nd[THREADS];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    double lp[NCH][4];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (t + k * THREADS) + e;
+            lp[k][e] = (c < H) ? ln_props[c] : -INFINITY;     // columns past the row can never win
+        }
+    const int nword = ldc >> 2;
+    int last = t + (NCH - 1) * THREADS;
+    if (last > nword - 1) last = nword - 1;
+    const int64_t grid = gridDim.x;
+    const int64_t nq = (R > (int64_t)blockIdx.x) ? (R - blockIdx.x + grid - 1) / grid : 0;
+    unsigned int cwa[NCH], cwb[NCH], cwc[NCH];
+    double tna = 0.0, tnb = 0.0, tnc = 0.0;
+    auto fetch = [&](int i, unsigned int(&cw)[NCH], double &tn) {
+        int nd = __builtin_amdgcn_readfirstlane(s_nd[i]);
+        if (nd > ENC_MAX_CODES) nd = 0;                      // a wide row: not ours (nothing is read)
+        const long long off = s_off[i];
+        const uint8_t *base = rec + (((long long)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+                                     (unsigned int)__builtin_amdgcn_readfirstlane((int)off));
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, nd > 0 ? ldc : 0, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NCH - 1; ++k) cw[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, t * 4, k * THREADS * 4, 0);
+        cw[NCH - 1] = __builtin_amdgcn_raw_buffer_load_b32(rs, last * 4, 0, 0);
+        const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base + ldc + 8 * (int64_t)(nd > 0 ? nd : 0)), 0,
+                                                          (nd > 0 ? nd : 0) * 8, 0x00020000);
+        const u2v x = __builtin_amdgcn_raw_buffer_load_b64(rt, t * 8, 0, 0);
+        tn = __hiloint2double((int)x.y, (int)x.x);
+    };
+    int buf = 0;
+    auto process = [&](int64_t r, int nd, const unsigned int(&cw)[NCH], double tn) {
+        if (nd <= 0 || nd > ENC_MAX_CODES) {                 // uniform
+            if (nd <= 0 && t == 0) best[r] = -1;
+            return;
+        }
+        s_m[buf][t] = tn;
+        __syncthreads();                                     // the table is in LDS (double buffered)
+        int cn = 0, ci = 0x7fffffff;
+        double cv = -INFINITY;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * (t + k * THREADS) + e;     // increasing per thread: the first maximum is kept
+                const double v = lp[k][e] + s_m[buf][(cw[k] >> (8 * e)) & 0xffu];
+                const bool take = (cn == 0) & !(v <= cv);    // a NaN wins, the first one; else a strictly larger value
+                cn = take ? ((v != v) ? 1 : 0) : cn;
+                cv = take ? v : cv;
+                ci = take ? c : ci;
+            }
+        }
+        const bool any_nan = __builtin_amdgcn_ballot_w64(cn != 0) != 0ull;      // uniform
+        double m = 0.0;
+        bool cand;
+        if (any_nan) {
+            cand = cn != 0;
+        } else {
+            m = readlane_f64(wave_max_lane63(cv), 63);
+            cand = cv == m;
+        }
+        const int wi = __builtin_amdgcn_readlane(wave_min_lane63_i32(cand ? ci : 0x7fffffff), 63);
+        if (lane == 0) {
+            s_val[buf][wv] = any_nan ? __builtin_nan("") : m;
+            s_idx[buf][wv] = wi;
+            s_nan[buf][wv] = any_nan ? 1 : 0;
+        }
+        __syncthreads();
+        if (t == 0) {
+            int bn = s_nan[buf][0], bi = s_idx[buf][0];
+            double bv = s_val[buf][0];
+            for (int q = 1; q < 4; ++q)
+                if (cand_better(s_nan[buf][q], s_val[buf][q], s_idx[buf][q], bn, bv, bi)) { bn = s_nan[buf][q]; bv = s_val[buf][q]; bi = s_idx[buf][q]; }
+            best[r] = (bi >= H) ? 0 : bi;
+        }
+        buf ^= 1;
+    };
+    for (int64_t q0 = 0; q0 < nq; q0 += THREADS) {
+        __syncthreads();                                     // the block before has been read
+        {
+            const int64_t r = (int64_t)blockIdx.x + (q0 + t) * grid;
+            s_nd[t] = (q0 + t < nq) ? ndist[r] : 0;
+            s_off[t] = (q0 + t < nq) ? rec_off[r] : 0;
+        }
+        __syncthreads();
+        const int n_here = (int)((nq - q0) < THREADS ? (nq - q0) : THREADS);
+        auto row_of = [&](int i) { return (int64_t)blockIdx.x + (q0 + i) * grid; };
+        auto nd_of = [&](int i) { return __builtin_amdgcn_readfirstlane(s_nd[i]); };
+        fetch(0, cwa, tna);
+        if (n_here > 1) fetch(1, cwb, tnb);
+        for (int i = 0; i < n_here; i += 3) {                // every branch below is workgroup uniform
+            if (i + 2 < n_here) fetch(i + 2, cwc, tnc);
+            process(row_of(i), nd_of(i), cwa, tna);
+            if (i + 1 >= n_here) break;
+            if (i + 3 < n_here) fetch(i + 3, cwa, tna);
+            process(row_of(i + 1), nd_of(i + 1), cwb, tnb);
+            if (i + 2 >= n_here) break;
+            if (i + 4 < n_here) fetch(i + 4, cwb, tnb);
+            process(row_of(i + 2), nd_of(i + 2), cwc, tnc);
+        }
+    }
+}
+
 // votes[h] = sum of w[r] over the rows with best[r] == h (assemble.py:116-119) without float atomics: workgroup g takes
 // the contiguous rows [g * per, (g + 1) * per), ONE thread adds them in row order into the workgroup's row of
 // `vote_part` (zeroed here first); colreduce_kernel then sums the workgroups in fixed order -- fractional weights
@@ -270,19 +398,24 @@ __global__ __launch_bounds__(256) void records_argmax_kernel(const uint8_t *__re
 __global__ __launch_bounds__(256) void votes_from_best_kernel(const int32_t *__restrict__ best, const double *__restrict__ w,
                                                               int64_t R, int H, double *__restrict__ vote_part,
                                                               int64_t ldpart) {
-    double *mine = vote_part + (int64_t)blockIdx.x * ldpart;
-    for (int h = threadIdx.x; h < H; h += 256) mine[h] = 0.0;
-    __threadfence_block();
+    // round 4: the one thread that adds in row order adds into LDS (a 30 ns round trip; the workgroup's row of
+    // `vote_part` in global memory cost ~0.7 us per row: 1.4 ms at 10^6 rows, 14 ms at 10^7), then all threads write
+    // the row out.  Same order, same bits.
+    extern __shared__ double s_votes[];
+    for (int h = threadIdx.x; h < H; h += 256) s_votes[h] = 0.0;
     __syncthreads();
-    if (threadIdx.x != 0) return;
-    const int64_t per = (R + gridDim.x - 1) / gridDim.x;
-    const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < R) ? lo + per : R;
-    for (int64_t r = lo; r < hi; ++r) {
-        const int b = best[r];
-        if ((unsigned)b >= (unsigned)H) continue;            // -1: a row without a record that nobody supplied densely
-        volatile double *slot = mine + b;                    // the same thread wrote the zero / the last sum
-        *slot = *slot + (w != nullptr ? w[r] : 1.0);
+    if (threadIdx.x == 0) {
+        const int64_t per = (R + gridDim.x - 1) / gridDim.x;
+        const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < R) ? lo + per : R;
+        for (int64_t r = lo; r < hi; ++r) {
+            const int b = best[r];
+            if ((unsigned)b >= (unsigned)H) continue;        // -1: a row without a record that nobody supplied densely
+            s_votes[b] += (w != nullptr ? w[r] : 1.0);
+        }
     }
+    __syncthreads();
+    double *mine = vote_part + (int64_t)blockIdx.x * ldpart;
+    for (int h = threadIdx.x; h < H; h += 256) mine[h] = s_votes[h];
 }
 
 // first[h] = the smallest row index r with best[r] == h (R where nobody voted for h): the insertion order of the
