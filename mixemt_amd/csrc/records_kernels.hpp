@@ -326,18 +326,40 @@ __global__ __launch_bounds__(256, 4) void records_argmax_narrow_kernel(const uin
         }
         s_m[buf][t] = tn;
         __syncthreads();                                     // the table is in LDS (double buffered)
+        // the thread's first maximum, NaN-free form: five instructions per cell (code byte, add, compare, index, max); the
+        // column index is kept WITHOUT the thread's 4 t, so that every candidate is a literal.  A NaN (none in a matrix
+        // of log-likelihood sums; numpy.argmax lets the first one win) sends the wave through the general form below.
         int cn = 0, ci = 0x7fffffff;
         double cv = -INFINITY;
+        bool seen_nan = false;
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const int c = 4 * (t + k * THREADS) + e;     // increasing per thread: the first maximum is kept
                 const double v = lp[k][e] + s_m[buf][(cw[k] >> (8 * e)) & 0xffu];
-                const bool take = (cn == 0) & !(v <= cv);    // a NaN wins, the first one; else a strictly larger value
-                cn = take ? ((v != v) ? 1 : 0) : cn;
-                cv = take ? v : cv;
-                ci = take ? c : ci;
+                seen_nan |= (v != v);
+                ci = (v > cv) ? 4 * k * THREADS + e : ci;    // increasing per thread: the first maximum is kept
+                cv = (v > cv) ? v : cv;
+            }
+        }
+        ci = (ci == 0x7fffffff) ? ci : ci + 4 * t;
+        if (__builtin_amdgcn_ballot_w64(seen_nan) != 0ull) {  // wave uniform
+            cn = 0;
+            ci = 0x7fffffff;
+            cv = -INFINITY;
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                unsigned int cx = cw[k];
+                asm volatile("" : "+v"(cx));                 // looked up again: the values of the loop above are not kept for this
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int c = 4 * (t + k * THREADS) + e;
+                    const double v = lp[k][e] + s_m[buf][(cx >> (8 * e)) & 0xffu];
+                    const bool take = (cn == 0) & !(v <= cv);    // a NaN wins, the first one; else a strictly larger value
+                    cn = take ? ((v != v) ? 1 : 0) : cn;
+                    cv = take ? v : cv;
+                    ci = take ? c : ci;
+                }
             }
         }
         const bool any_nan = __builtin_amdgcn_ballot_w64(cn != 0) != 0ull;      // uniform
