@@ -195,6 +195,19 @@ __device__ __forceinline__ double logaddexp_f64(double a, double b) {
 // (scalar work), so no workgroup ever needs a descriptor range beyond one row.
 // Requires gridDim.x <= R.
 // ------------------------------------------------------------------------------------------
+// byte E of a code word, times 8 (the byte offset of a table entry): one SDWA shift -- the compiler takes a bit-field
+// extract and a shift for it
+template <int E>
+__device__ __forceinline__ unsigned int code_byte_x8(unsigned int word) {
+    const unsigned int three = 3;
+    unsigned int r;
+    if constexpr (E == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(three), "v"(word));
+    else if constexpr (E == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(three), "v"(word));
+    else if constexpr (E == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(three), "v"(word));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(three), "v"(word));
+    return r;
+}
+
 struct row_deal {
     int64_t nq;                                     // steps (rows) of this workgroup
     __device__ explicit row_deal(int64_t R) : nq((R - blockIdx.x + gridDim.x - 1) / gridDim.x) {}

@@ -281,9 +281,9 @@ __global__ __launch_bounds__(256, 4) void records_argmax_narrow_kernel(const uin
                                                                        const double *__restrict__ ln_props,
                                                                        int32_t *__restrict__ best) {
     constexpr int THREADS = 256;
-    __shared__ double s_m[2][ENC_MAX_CODES];
-    __shared__ double s_val[2][4];
-    __shared__ int s_idx[2][4], s_nan[2][4];
+    __shared__ double s_m[3][ENC_MAX_CODES];             // one table per row in flight (slot)
+    __shared__ double s_val[3][4];
+    __shared__ int s_idx[3][4], s_nan[3][4];
     __shared__ long long s_off[THREADS];
     __shared__ int s_nd[THREADS];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
@@ -318,29 +318,47 @@ __global__ __launch_bounds__(256, 4) void records_argmax_narrow_kernel(const uin
         const u2v x = __builtin_amdgcn_raw_buffer_load_b64(rt, t * 8, 0, 0);
         tn = __hiloint2double((int)x.y, (int)x.x);
     };
-    int buf = 0;
-    auto process = [&](int64_t r, int nd, const unsigned int(&cw)[NCH], double tn) {
+    // A row: its table into the slot's LDS buffer (the slot is a compile-time constant: the buffer's base is the
+    // lookups' immediate offset), then the thread's first maximum over its 24 cells.  The lookups of chunk k + 1 are
+    // issued before chunk k is compared (the scheduling barriers keep them there): issued where they are used, every
+    // one of them waited for its own LDS round trip -- 24 of them in a row, 3.2 ms at 10^6 rows.
+    // NaN-free form first: code byte, add, compare, index, maximum; the column index is kept WITHOUT the thread's 4 t,
+    // so that every candidate is a literal.  A NaN (none in a matrix of log-likelihood sums; numpy.argmax lets the
+    // first one win) sends the wave through the general form.
+    auto process = [&](auto SLOT, int64_t r, int nd, const unsigned int(&cw)[NCH], double tn) {
+        constexpr int slot = decltype(SLOT)::value;
         if (nd <= 0 || nd > ENC_MAX_CODES) {                 // uniform
             if (nd <= 0 && t == 0) best[r] = -1;
             return;
         }
-        s_m[buf][t] = tn;
-        __syncthreads();                                     // the table is in LDS (double buffered)
-        // the thread's first maximum, NaN-free form: five instructions per cell (code byte, add, compare, index, max); the
-        // column index is kept WITHOUT the thread's 4 t, so that every candidate is a literal.  A NaN (none in a matrix
-        // of log-likelihood sums; numpy.argmax lets the first one win) sends the wave through the general form below.
+        s_m[slot][t] = tn;
+        __syncthreads();                                     // the table is in LDS
+        const char *tb = reinterpret_cast<const char *>(&s_m[slot][0]);
+        auto lookup4 = [&](unsigned int word, double(&out)[4]) {
+            out[0] = *reinterpret_cast<const double *>(tb + code_byte_x8<0>(word));
+            out[1] = *reinterpret_cast<const double *>(tb + code_byte_x8<1>(word));
+            out[2] = *reinterpret_cast<const double *>(tb + code_byte_x8<2>(word));
+            out[3] = *reinterpret_cast<const double *>(tb + code_byte_x8<3>(word));
+        };
         int cn = 0, ci = 0x7fffffff;
         double cv = -INFINITY;
         bool seen_nan = false;
+        double cur[4], nxt[4];
+        lookup4(cw[0], cur);
 #pragma unroll
         for (int k = 0; k < NCH; ++k) {
+            if (k + 1 < NCH) lookup4(cw[k + 1], nxt);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
-                const double v = lp[k][e] + s_m[buf][(cw[k] >> (8 * e)) & 0xffu];
+                const double v = lp[k][e] + cur[e];
                 seen_nan |= (v != v);
                 ci = (v > cv) ? 4 * k * THREADS + e : ci;    // increasing per thread: the first maximum is kept
                 cv = (v > cv) ? v : cv;
             }
+            __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
         }
         ci = (ci == 0x7fffffff) ? ci : ci + 4 * t;
         if (__builtin_amdgcn_ballot_w64(seen_nan) != 0ull) {  // wave uniform
@@ -354,7 +372,7 @@ __global__ __launch_bounds__(256, 4) void records_argmax_narrow_kernel(const uin
 #pragma unroll
                 for (int e = 0; e < 4; ++e) {
                     const int c = 4 * (t + k * THREADS) + e;
-                    const double v = lp[k][e] + s_m[buf][(cx >> (8 * e)) & 0xffu];
+                    const double v = lp[k][e] + s_m[slot][(cx >> (8 * e)) & 0xffu];
                     const bool take = (cn == 0) & !(v <= cv);    // a NaN wins, the first one; else a strictly larger value
                     cn = take ? ((v != v) ? 1 : 0) : cn;
                     cv = take ? v : cv;
@@ -373,20 +391,22 @@ __global__ __launch_bounds__(256, 4) void records_argmax_narrow_kernel(const uin
         }
         const int wi = __builtin_amdgcn_readlane(wave_min_lane63_i32(cand ? ci : 0x7fffffff), 63);
         if (lane == 0) {
-            s_val[buf][wv] = any_nan ? __builtin_nan("") : m;
-            s_idx[buf][wv] = wi;
-            s_nan[buf][wv] = any_nan ? 1 : 0;
+            s_val[slot][wv] = any_nan ? __builtin_nan("") : m;
+            s_idx[slot][wv] = wi;
+            s_nan[slot][wv] = any_nan ? 1 : 0;
         }
         __syncthreads();
         if (t == 0) {
-            int bn = s_nan[buf][0], bi = s_idx[buf][0];
-            double bv = s_val[buf][0];
+            int bn = s_nan[slot][0], bi = s_idx[slot][0];
+            double bv = s_val[slot][0];
             for (int q = 1; q < 4; ++q)
-                if (cand_better(s_nan[buf][q], s_val[buf][q], s_idx[buf][q], bn, bv, bi)) { bn = s_nan[buf][q]; bv = s_val[buf][q]; bi = s_idx[buf][q]; }
+                if (cand_better(s_nan[slot][q], s_val[slot][q], s_idx[slot][q], bn, bv, bi)) { bn = s_nan[slot][q]; bv = s_val[slot][q]; bi = s_idx[slot][q]; }
             best[r] = (bi >= H) ? 0 : bi;
         }
-        buf ^= 1;
     };
+    using S0 = std::integral_constant<int, 0>;
+    using S1 = std::integral_constant<int, 1>;
+    using S2 = std::integral_constant<int, 2>;
     for (int64_t q0 = 0; q0 < nq; q0 += THREADS) {
         __syncthreads();                                     // the block before has been read
         {
@@ -402,13 +422,13 @@ __global__ __launch_bounds__(256, 4) void records_argmax_narrow_kernel(const uin
         if (n_here > 1) fetch(1, cwb, tnb);
         for (int i = 0; i < n_here; i += 3) {                // every branch below is workgroup uniform
             if (i + 2 < n_here) fetch(i + 2, cwc, tnc);
-            process(row_of(i), nd_of(i), cwa, tna);
+            process(S0{}, row_of(i), nd_of(i), cwa, tna);
             if (i + 1 >= n_here) break;
             if (i + 3 < n_here) fetch(i + 3, cwa, tna);
-            process(row_of(i + 1), nd_of(i + 1), cwb, tnb);
+            process(S1{}, row_of(i + 1), nd_of(i + 1), cwb, tnb);
             if (i + 2 >= n_here) break;
             if (i + 4 < n_here) fetch(i + 4, cwb, tnb);
-            process(row_of(i + 2), nd_of(i + 2), cwc, tnc);
+            process(S2{}, row_of(i + 2), nd_of(i + 2), cwc, tnc);
         }
     }
 }

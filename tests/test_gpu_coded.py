@@ -215,6 +215,18 @@ def test_wide_records_sixteen_bit_codes(n_rows, n_haps, seed):
     want_best = (last[None, :] + mat).argmax(axis=1)
     assert numpy.array_equal(best, want_best)
     assert numpy.array_equal(votes, numpy.bincount(want_best, weights=wts, minlength=n_haps))
+    # a NaN counts as the maximum, the first one (numpy.argmax): the kernels' general form, byte-coded and wide rows
+    poisoned = last.copy()
+    poisoned[[n_haps // 2, n_haps - 3]] = numpy.nan
+    poisoned[: n_haps // 4] = -numpy.inf
+    best_n, _ = assign.row_argmax_votes_records(cm, poisoned, wts)
+    with numpy.errstate(invalid="ignore"):
+        want_n = (poisoned[None, :] + mat).argmax(axis=1)
+    assert numpy.array_equal(best_n, want_n) and (want_n == n_haps // 2).all()
+    poisoned[[n_haps // 2, n_haps - 3]] = -numpy.inf           # ... and without it: -inf columns never win
+    best_i, _ = assign.row_argmax_votes_records(cm, poisoned, wts)
+    with numpy.errstate(invalid="ignore"):
+        assert numpy.array_equal(best_i, (poisoned[None, :] + mat).argmax(axis=1))
 
 
 def test_unsupported_shapes_iterate_as_fp64():
