@@ -1686,13 +1686,13 @@ extern "C" int mxm_first_seen(const int32_t *best, int64_t R, int32_t H, int64_t
     hipStream_t s = (hipStream_t)stream;
     hipLaunchKernelGGL(fill_u64_kernel, dim3(clamp_grid((H + 255) / 256, 64)), dim3(256), 0, s,
                        reinterpret_cast<unsigned long long *>(first), (int64_t)H, (unsigned long long)R);
-    if (H > FSEEN_MAX_H) return fail(-1, "mxm_first_seen: more than %s%lld haplogroups", "", (long long)FSEEN_MAX_H);
     if (R > 0) {
         // ranges of at least 1024 rows and below 2^32 (32-bit offsets in LDS)
         int grid = clamp_grid((R + 1023) / 1024, num_cu() * 4);
         while ((R + grid - 1) / grid >= ((int64_t)1 << 32)) grid *= 2;
-        hipLaunchKernelGGL(first_seen_kernel, dim3(grid), dim3(256), 0, s, best, R, (int)H,
-                           reinterpret_cast<unsigned long long *>(first));
+        for (int h0 = 0; h0 < H; h0 += FSEEN_MAX_H)          // (one launch up to 8192 haplogroups)
+            hipLaunchKernelGGL(first_seen_kernel, dim3(grid), dim3(256), 0, s, best, R, h0,
+                               (int)(H - h0 < FSEEN_MAX_H ? H - h0 : FSEEN_MAX_H), reinterpret_cast<unsigned long long *>(first));
     }
     HIP_TRY(hipGetLastError());
     return 0;

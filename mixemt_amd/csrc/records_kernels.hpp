@@ -466,22 +466,23 @@ __global__ __launch_bounds__(256) void votes_from_best_kernel(const int32_t *__r
 // keeps the minima of ITS range in LDS (offsets into the range: 32 bits) and sends one global atomic per haplogroup
 // it saw -- a handful; a first version with one global atomic per row took 3.6 ms at 10^6 rows (three hot addresses).
 #define FSEEN_MAX_H 8192
-__global__ __launch_bounds__(256) void first_seen_kernel(const int32_t *__restrict__ best, int64_t R, int H,
+// One launch covers the haplogroups [h0, h0 + span), span <= FSEEN_MAX_H (wider matrices: one launch per block).
+__global__ __launch_bounds__(256) void first_seen_kernel(const int32_t *__restrict__ best, int64_t R, int h0, int span,
                                                          unsigned long long *__restrict__ first) {
     __shared__ unsigned int s_first[FSEEN_MAX_H];
     const int64_t per = (R + gridDim.x - 1) / gridDim.x;
     const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < R) ? lo + per : R;
     if (lo >= hi) return;
-    for (int h = threadIdx.x; h < H; h += 256) s_first[h] = 0xFFFFFFFFu;
+    for (int h = threadIdx.x; h < span; h += 256) s_first[h] = 0xFFFFFFFFu;
     __syncthreads();
     for (int64_t r = lo + threadIdx.x; r < hi; r += 256) {
-        const int b = best[r];
-        if ((unsigned)b < (unsigned)H) atomicMin(&s_first[b], (unsigned int)(r - lo));
+        const int b = best[r] - h0;
+        if ((unsigned)b < (unsigned)span) atomicMin(&s_first[b], (unsigned int)(r - lo));
     }
     __syncthreads();
-    for (int h = threadIdx.x; h < H; h += 256) {
+    for (int h = threadIdx.x; h < span; h += 256) {
         const unsigned int v = s_first[h];
-        if (v != 0xFFFFFFFFu) atomicMin(&first[h], (unsigned long long)(lo + v));
+        if (v != 0xFFFFFFFFu) atomicMin(&first[h0 + h], (unsigned long long)(lo + v));
     }
 }
 

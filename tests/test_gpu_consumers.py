@@ -43,6 +43,26 @@ def test_contributors_from_read_votes(run600):
     assert got_np == got
 
 
+@pytest.mark.parametrize("n_haps", [1, 66, 8192, 8193, 20001])
+def test_contributors_first_seen_order_at_any_width(n_haps):
+    """assemble.py:103-123 restated with a dict filled row by row (its insertion order IS the result's order): the
+    device forms the first-seen row of every haplogroup (mxm_first_seen) in blocks of 8192 haplogroups."""
+    import torch
+    from mixemt_amd import assign
+    rng = numpy.random.default_rng(n_haps)
+    n_rows = 3000
+    mat = rng.normal(-30.0, 1.0, size=(n_rows, n_haps))
+    winners = rng.choice(n_haps, size=min(n_haps, 40), replace=False)
+    mat[numpy.arange(n_rows), winners[rng.integers(0, len(winners), size=n_rows) ** 2 % len(winners)]] = 0.0
+    wts = rng.integers(1, 4, size=n_rows).astype(numpy.float64)
+    votes = {}
+    for r, h in enumerate(mat.argmax(axis=1)):
+        votes[int(h)] = votes.get(int(h), 0.0) + wts[r]
+    want = [h for h in votes if votes[h] >= 25]
+    got = assign.find_contribs_from_reads(torch.from_numpy(mat).cuda(), wts, argparse.Namespace(min_reads=25))
+    assert got == want and (n_haps == 1 or 1 < len(want) < len(votes) or len(votes) == len(want))
+
+
 def test_report_read_votes_text(run600):
     """stats.py:34-45: identical stderr text (counts, order, tie order)."""
     from mixemt_amd import assign
