@@ -327,9 +327,9 @@ __global__ __launch_bounds__(256, 4) void records_argmax_narrow_kernel(const uin
     // first one win) sends the wave through the general form.
     auto process = [&](auto SLOT, int64_t r, int nd, const unsigned int(&cw)[NCH], double tn) {
         constexpr int slot = decltype(SLOT)::value;
-        if (nd <= 0 || nd > ENC_MAX_CODES) {                 // uniform
-            if (nd <= 0 && t == 0) best[r] = -1;
-            return;
+        if (nd <= 0 || nd > ENC_MAX_CODES) {                 // uniform: no record, or a wide one -- the launch over the
+            if (t == 0) best[r] = -1;                        // wide rows' list, behind this one on the stream, fills those in
+            return;                                          // (a descriptor without the list leaves them at -1: no vote)
         }
         s_m[slot][t] = tn;
         __syncthreads();                                     // the table is in LDS
