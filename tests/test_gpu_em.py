@@ -147,6 +147,30 @@ def test_run_em_b17_golden(b17):
     assert numpy.allclose(mix.max(axis=1), g["mix_rowmax"], rtol=0, atol=1e-8)
 
 
+@pytest.mark.parametrize("storage", ["f64", "coded"])
+@pytest.mark.parametrize("fused", [-1, 0])
+def test_run_em_b17_stopped_by_max_iter_golden(b17, storage, fused):
+    """
+    g15: the reference's loop stopped by max_iter after 5 and 25 iterations (em.py:140-142) -- a mid-run pin: exactly
+    k iterations, state "max_iter reached", the LAST step's proportions and posterior; dense and records, one launch and
+    per-iteration kernels.
+    """
+    from mixemt_amd import _lib, em
+    refseq, phy, haps, tables = b17
+    g = golden("g15_run_em_max_iter")
+    mat = _b17_matrix(tables, g, len(haps))
+    _lib.load().mxm_set_loop_fused(fused, 0)                # (conftest resets every knob after the test)
+    for k in (5, 25):
+        numpy.random.seed(7)
+        res = em.run_em_ex(mat, g["wts"], em_args(max_iter=k), storage=storage)
+        assert res["iters"] == [k] and res["done"] == [2] and res["storage"] == storage
+        assert numpy.abs(res["props"] - g["props_%d" % k]).max() < PROPS_ATOL
+        mix = res["read_mix"].cpu().numpy()
+        assert numpy.array_equal(mix.argmax(axis=1), g["mix_argmax_%d" % k])
+        assert numpy.allclose(mix[:4], g["mix_rows_%d" % k], rtol=0, atol=1e-8)
+        assert numpy.allclose(mix.max(axis=1), g["mix_rowmax_%d" % k], rtol=0, atol=1e-8)
+
+
 def test_run_em_b17_golden_2400_rows_with_repeat_weights(b17):
     """
     g9: the reference's run_em on 2400 x 5408 with the weights reduce_reads leaves

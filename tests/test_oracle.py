@@ -179,6 +179,27 @@ def test_run_em_refinement_shape_bitwise(b17):
     assert numpy.array_equal(props, g["props"]) and numpy.array_equal(mix, g["mix"])
 
 
+def test_run_em_b17_stopped_by_max_iter_bitwise(b17):
+    """
+    g15: the reference's run_em on the g4 inputs (600 x 5408) stopped by max_iter = 5 and 25 -- its loop's "never
+    converged" exit (em.py:140-142).  The oracle's loop reproduces proportions and posterior bit for bit: a Build-17-size
+    pin of the LOOP in the default suite (the runs to convergence, g4 / g5 / g9, are `-m slow`).
+    """
+    refseq, phy, haps, tables = b17
+    g = golden("g15_run_em_max_iter")
+    flat = build_oracle.flat_tables(refseq, phy, haps)
+    mat = c_oracle.build_em_matrix(flat[1], flat[2], flat[3], g["row_ptr"], g["site"], g["obs"], len(haps))
+    for k in (5, 25):
+        trace = []
+        numpy.random.seed(7)
+        props, mix = em_oracle.run_em(mat, g["wts"], em_args(max_iter=k), trace=trace)
+        assert [t["iters"] for t in trace] == [k]
+        assert numpy.array_equal(props, g["props_%d" % k])
+        assert numpy.array_equal(mix[:4], g["mix_rows_%d" % k])
+        assert numpy.array_equal(mix.max(axis=1), g["mix_rowmax_%d" % k])
+        assert numpy.array_equal(mix.argmax(axis=1), g["mix_argmax_%d" % k])
+
+
 @pytest.mark.slow
 @pytest.mark.parametrize("name,seed,n_multi", [("g4_run_em", 7, 1), ("g5_run_em_multi", 11, 3)])
 def test_run_em_b17_bitwise_slow(b17, name, seed, n_multi):

@@ -19,6 +19,7 @@ Fixtures (SURVEY.md section 8 c):
     g6  refinement shape: 600 x 5 contributor columns
     g7  config 1: 1000 x 100
     g8  consumers of the result on the g4 run: contributor votes, read assignment, refinement
+    g15 run_em on the g4 inputs stopped by max_iter = 5 and 25 (the loop's "never converged" exit, em.py:140-142)
     g9  run_em on 2400 x 5408 with de-duplication-style weights (repeats up to 400), n_multi = 1
     g10 build_em_matrix + run_em on 20 000 x 5408 (Zipf weights): the size at which the product
         leaves the one-launch loops / takes the row-dictionary branch of storage="auto".
@@ -332,7 +333,7 @@ def main():
 
     mat600 = None
     wts600 = None
-    if want("g4") or want("g5") or want("g6"):
+    if want("g4") or want("g5") or want("g6") or want("g15"):
         row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), 600, seed=4)
         sigs = synth.signatures(tables, row_ptr, site, obs)
         t0 = time.time()
@@ -356,6 +357,20 @@ def main():
         save("g4_run_em", props=props, iters=iters, inits=inits, mix_rows=mix[:4].copy(),
              mix_argmax=best, votes=votes, mix_rowmax=mix.max(axis=1),
              contributors=numpy.flatnonzero(votes >= 10).astype(numpy.int32), **common)
+
+    if want("g15"):
+        # the reference's own loop stopped by max_iter (em.py:140-142, "never converged": the vectors are flipped back
+        # and the last step's results returned) after 5 and after 25 iterations of the g4 run: cheap enough for the
+        # default CPU suite to pin the oracle's loop on a Build-17 matrix bit for bit, and a mid-run pin for the GPU loop
+        out = {}
+        for k in (5, 25):
+            numpy.random.seed(7)
+            props, mix = ref.em.run_em(mat600, wts600, ns(max_iter=k))
+            out["props_%d" % k] = props
+            out["mix_rows_%d" % k] = mix[:4].copy()
+            out["mix_rowmax_%d" % k] = mix.max(axis=1)
+            out["mix_argmax_%d" % k] = mix.argmax(axis=1).astype(numpy.int32)
+        save("g15_run_em_max_iter", **out, **common)
 
     if want("g5"):
         t0 = time.time()
