@@ -9,7 +9,8 @@ can resume the other's run:
     PREFIX.mat.npy    posterior matrix      float64 [R][H]
     PREFIX.prop.npy   proportions           float64 [H]
 
-Matrices may live on the GPU: they are streamed to the .npy files in row slabs
+Matrices may live on the GPU -- as tensors or as row-dictionary records (preprocess.CodedMatrix): they are streamed
+to the .npy files in row slabs
 through a memory-mapped array, so a 43 GB matrix never needs a host copy.
 """
 
@@ -27,13 +28,18 @@ SLAB_BYTES = 256 << 20
 
 def save_matrix(path, mat):
     """numpy.save-compatible write of a numpy array or (device) tensor."""
-    if torch is None or not isinstance(mat, torch.Tensor):
+    records = hasattr(mat, "dense") and hasattr(mat, "rec")       # preprocess.CodedMatrix: decoded slab by slab
+    if not records and (torch is None or not isinstance(mat, torch.Tensor)):
         numpy.save(path, mat)
         return
     if not path.endswith(".npy"):
         path += ".npy"                      # numpy.save appends it too
     out = numpy.lib.format.open_memmap(path, mode="w+", dtype=numpy.float64, shape=tuple(mat.shape))
-    if mat.dim() == 1:
+    if records:
+        step = max(1, SLAB_BYTES // max(1, mat.shape[1] * 8))
+        for lo in range(0, mat.shape[0], step):
+            out[lo:lo + step] = mat.dense(lo, lo + step).cpu().numpy()
+    elif mat.dim() == 1:
         out[:] = mat.cpu().numpy()
     else:
         step = max(1, SLAB_BYTES // max(1, mat.shape[1] * 8))

@@ -512,6 +512,43 @@ class CodedMatrix(object):
             self._wide = torch.nonzero(self.ndist > 256).flatten()
         return self._wide
 
+    def rows(self, lo, hi):
+        """The rows [lo, hi) as a CodedMatrix of their own (views: nothing is copied but the re-based list of its
+        dense rows)."""
+        lo, hi = max(0, int(lo)), min(self.n_rows, int(hi))
+        if self.rest_rows.numel():
+            bounds = torch.searchsorted(self.rest_rows, torch.tensor([lo, hi], dtype=torch.int64, device=self.rest_rows.device))
+            a, b = int(bounds[0]), int(bounds[1])
+        else:
+            a = b = 0
+        return CodedMatrix(hi - lo, self.n_haps, self.rec, self.rec_off[lo:hi], self.ndist[lo:hi], self.rowmax[lo:hi],
+                           self.used, self.rest_rows[a:b] - lo, self.m_rest[a:b])
+
+    def dense(self, lo=0, hi=None):
+        """
+        The log matrix rows [lo, hi) as a dense [hi - lo][H] float64 device tensor -- build_em_matrix's own bits (a
+        record's log table holds the row's distinct sums; mxm_gather_columns_coded with every column).  For
+        io.save_matrix (`-s`) and for tests; the EM and its consumers never need it.
+        """
+        import ctypes
+        part = self.rows(lo, self.n_rows if hi is None else hi)
+        dev = self.rec.device
+        out = device_empty((part.n_rows, self.n_haps), torch.float64, dev, "rows of the EM matrix decoded from records")
+        if part.n_rows:
+            cols_d = torch.arange(self.n_haps, dtype=torch.int32, device=dev)
+            coded = part.struct()
+            n_rest = int(part.rest_rows.numel())
+            _lib.check(_lib.load().mxm_gather_columns_coded(
+                ctypes.byref(coded), self.n_haps, cols_d.data_ptr(), self.n_haps,
+                part.m_rest.data_ptr() if n_rest else 0, part.m_rest.stride(0) if n_rest else 0,
+                part.rest_rows.data_ptr() if n_rest else 0, n_rest, out.data_ptr(), out.stride(0), current_stream()),
+                "mxm_gather_columns_coded")
+        return out
+
+    @property
+    def shape(self):
+        return (self.n_rows, self.n_haps)
+
     def struct(self):
         """mxm_coded view of the records alone (the consumers that take it handle coded rows only)."""
         wide = self.wide_rows()

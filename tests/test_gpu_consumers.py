@@ -207,6 +207,27 @@ def test_save_files_stream_from_device(tmp_path, run600):
     assert numpy.array_equal(props, run600["props"])
 
 
+def test_save_files_stream_from_records(tmp_path, b17, monkeypatch):
+    """`-s` on the records route: the .em.npy written from a CodedMatrix (decoded slab by slab from the records' log
+    tables, rows without a record from their dense copies) holds build_em_matrix's own bits -- byte-coded, 16-bit-coded
+    and dense rows, slabs that cut through all three."""
+    from mixemt_amd import io as mio, preprocess, synth
+    refseq, phy, haps, tables = b17
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), 900, seed=21, read_len=260)   # long reads: wide and dense rows
+    cm = preprocess.build_em_records_device(tables, row_ptr, site, obs)
+    want = preprocess.build_em_matrix_device(tables, row_ptr, site, obs).cpu().numpy()
+    nd = cm.ndist.cpu().numpy()
+    assert (nd > 256).any() and ((nd > 0) & (nd <= 256)).any()
+    assert numpy.array_equal(cm.dense().cpu().numpy(), want)
+    assert numpy.array_equal(cm.dense(101, 347).cpu().numpy(), want[101:347])
+    monkeypatch.setattr(mio, "SLAB_BYTES", 97 * len(haps) * 8)          # ten slabs
+    prefix = str(tmp_path / "rec")
+    props = numpy.full(len(haps), 1.0 / len(haps))
+    mio.dump_all(prefix, haps, [["id%d" % i] for i in range(900)], cm, (props, want))
+    loaded = mio.load_prev(prefix)
+    assert numpy.array_equal(loaded[3], want)
+
+
 @pytest.mark.parametrize("n_rows,n_haps,seed", [(1, 64, 1), (300, 66, 2), (257, 1024, 3), (130, 5408, 4), (65, 8192, 5),
                                                 (90, 4098, 6), (40, 1001, 7)])
 def test_row_argmax_votes_shapes_ties_and_nans(n_rows, n_haps, seed):
