@@ -458,6 +458,37 @@ def posterior(plan, ln_theta, out=None, fold=False):
     return out
 
 
+class RecordsPosterior(object):
+    """
+    run_em's returned posterior (em.py:145-165: the E-step under every run's theta_k, folded with logaddexp, minus
+    log n_multi) for a matrix that exists only as records, formed on demand for a range of rows -- what
+    run_em_ex(..., records=cm, want_read_mix=False) did not materialise.  ln_theta_k: its "ln_theta_k" ([n_multi][H]).
+    io.save_matrix / dump_all write it slab by slab (`-s` on the records route).
+    """
+
+    def __init__(self, cm, ln_theta_k):
+        self.cm, self.rec = cm, cm.rec
+        self.ln_theta_k = numpy.atleast_2d(numpy.asarray(ln_theta_k, dtype=numpy.float64))
+        self.shape = (cm.n_rows, cm.n_haps)
+
+    def dense(self, lo=0, hi=None):
+        import types
+        part = self.cm.rows(lo, self.cm.n_rows if hi is None else hi)
+        lib = _lib.load()
+        shim = types.SimpleNamespace(dev=self.rec.device, n_rows=part.n_rows, n_haps=self.cm.n_haps, mat=None,
+                                     records=part, lib=lib)
+        out = device_empty((part.n_rows, self.cm.n_haps), torch.float64, self.rec.device, "rows of the posterior matrix")
+        if part.n_rows == 0:
+            return out
+        n_multi = self.ln_theta_k.shape[0]
+        for run in range(n_multi):
+            posterior(shim, self.ln_theta_k[run], out=out, fold=(run > 0))
+        if n_multi > 1:
+            _lib.check(lib.mxm_add_scalar(out.data_ptr(), out.stride(0), part.n_rows, self.cm.n_haps,
+                                          -math.log(n_multi), current_stream()), "mxm_add_scalar")
+        return out
+
+
 def collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix=True, verbose=False,
                    reuse_linear=False):
     """

@@ -226,6 +226,19 @@ def test_save_files_stream_from_records(tmp_path, b17, monkeypatch):
     mio.dump_all(prefix, haps, [["id%d" % i] for i in range(900)], cm, (props, want))
     loaded = mio.load_prev(prefix)
     assert numpy.array_equal(loaded[3], want)
+    # ... and the posterior run_em returns (three runs folded), never materialised on the records route
+    from mixemt_amd import em
+    wts = numpy.ones(900)
+    numpy.random.seed(3)
+    res = em.run_em_ex(None, wts, em_args(n_multi=3, max_iter=30), records=cm, want_read_mix=False)
+    numpy.random.seed(3)
+    ref = em.run_em_ex(want, wts, em_args(n_multi=3, max_iter=30), storage="f64")
+    assert res["read_mix"] is None and res["iters"] == ref["iters"]
+    mio.dump_all(prefix, haps, [["id%d" % i] for i in range(900)], cm, (res["props"], em.RecordsPosterior(cm, res["ln_theta_k"])))
+    mix = mio.load_prev(prefix)[4][1]
+    want_mix = ref["read_mix"].cpu().numpy()
+    finite = numpy.isfinite(want_mix)
+    assert numpy.array_equal(numpy.isfinite(mix), finite) and numpy.abs(mix[finite] - want_mix[finite]).max() < 1e-8
 
 
 @pytest.mark.parametrize("n_rows,n_haps,seed", [(1, 64, 1), (300, 66, 2), (257, 1024, 3), (130, 5408, 4), (65, 8192, 5),
