@@ -130,7 +130,6 @@ def test_build_em_input_equals_the_reference_run(b17, as_records, capsys):
     import hashlib
     import json
     import torch
-    from mixemt_amd import _lib
     refseq, phy, haps, tables = b17
     g, alns = _g11()
     assert str(g["ref_died_with"]).startswith("ValueError")

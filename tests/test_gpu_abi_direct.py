@@ -4,8 +4,6 @@ NULL weights, sub-streams, and the error contract (negative status + message,
 no exception, no crash) -- what a non-Python binder of include/mixemt_hip.h
 relies on.
 """
-import ctypes
-
 import numpy
 import pytest
 

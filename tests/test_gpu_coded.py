@@ -394,7 +394,6 @@ def test_run_em_from_build_records_reproduces_the_reference(b17):
 def test_consumers_from_records_match_the_dense_pipeline(b17):
     """Contributors from read votes, the vote table, the reduced matrix and the refinement EM from records
     alone == the same steps over the dense matrix and posterior (g9: 2400 rows, repeat weights)."""
-    import argparse
     from mixemt_amd import assign, em, preprocess
     refseq, phy, haps, tables = b17
     g = golden("g9_run_em_2400")

@@ -12,7 +12,7 @@ import numpy
 import pytest
 
 from conftest import em_args, golden
-from oracle import build_oracle, c_oracle
+from oracle import build_oracle
 
 pytestmark = pytest.mark.gpu
 

@@ -1,4 +1,4 @@
-import torch, time
+import torch
 x = torch.empty((1000000, 5408), dtype=torch.float64, device="cuda")
 for name, fn in (("zero_", lambda: x.zero_()), ("fill_(1.5)", lambda: x.fill_(1.5))):
     fn(); torch.cuda.synchronize()
