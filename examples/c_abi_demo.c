@@ -5,6 +5,8 @@
  *   build_em_matrix  (preprocess.py:177-198)  ->  mxm_build_em_matrix
  *   run_em loop      (em.py:126-143)          ->  mxm_linearize + mxm_em_loop
  *   posterior        (em.py:80-83)            ->  mxm_em_step
+ * With a third argument "records" the loop and the posterior run over row-dictionary records instead of the dense
+ * matrix:  mxm_encode_rows -> mxm_em_loop_coded -> mxm_em_step_coded.
  *
  * Reads a problem file (flat tables + CSR observations + initial proportions, written by
  * tests/test_gpu_c_demo.py), runs the path on GPU 0 and writes proportions, iteration count and
@@ -12,7 +14,7 @@
  *
  *   gcc -std=c99 -D__HIP_PLATFORM_AMD__ -I/opt/rocm/include -Iinclude examples/c_abi_demo.c \
  *       -Lmixemt_amd/lib -lmixemt_hip -L/opt/rocm/lib -lamdhip64 -lm -o c_abi_demo
- *   LD_LIBRARY_PATH=mixemt_amd/lib:/opt/rocm/lib ./c_abi_demo problem.bin result.bin
+ *   LD_LIBRARY_PATH=mixemt_amd/lib:/opt/rocm/lib ./c_abi_demo problem.bin result.bin [records]
  *
  * problem.bin: int64 header {R, H, S, nnz, lde, max_iter} ; double tol ;
  *              uint8 E[S*lde] ; double lhit[S] ; double lmiss[S] ; int64 row_ptr[R+1] ;
@@ -44,7 +46,8 @@ static void *to_device(const void *host, size_t bytes) {
 }
 
 int main(int argc, char **argv) {
-    if (argc != 3) { fprintf(stderr, "usage: %s problem.bin result.bin\n", argv[0]); return 1; }
+    if (argc != 3 && argc != 4) { fprintf(stderr, "usage: %s problem.bin result.bin [records]\n", argv[0]); return 1; }
+    const int records = (argc == 4);
     FILE *in = fopen(argv[1], "rb");
     if (in == NULL) { perror(argv[1]); return 1; }
     int64_t hdr[6];
@@ -95,12 +98,44 @@ int main(int argc, char **argv) {
     HIP_OK(hipMemcpy(dlnnew, ln0, (size_t)H * 8, hipMemcpyHostToDevice));
     HIP_OK(hipMemcpy(dprops, p0, (size_t)H * 8, hipMemcpyHostToDevice));
     const int linear = mxm_linear_supported((int32_t)H);
-    if (linear) MXM_OK(mxm_linearize(dM, H, R, (int32_t)H, dP, ldp, drowmax, NULL));
-    MXM_OK(mxm_em_loop(dM, H, linear ? dP : NULL, linear ? ldp : 0, (const double *)dw, R, (int32_t)H, 1,
-                       dprops, dlncur, dlnnew, dcolsum, dstate, tol, (int32_t)max_iter, 16, ws, ws_bytes,
-                       NULL, &hstate));
-    /* the reference returns the E-step under theta_k with theta_{k+1} (em.py:130-143) */
-    MXM_OK(mxm_em_step(dM, H, NULL, dlncur, R, (int32_t)H, dmix, H, 0, NULL, NULL, 0, NULL));
+    if (!records) {
+        if (linear) MXM_OK(mxm_linearize(dM, H, R, (int32_t)H, dP, ldp, drowmax, NULL));
+        MXM_OK(mxm_em_loop(dM, H, linear ? dP : NULL, linear ? ldp : 0, (const double *)dw, R, (int32_t)H, 1,
+                           dprops, dlncur, dlnnew, dcolsum, dstate, tol, (int32_t)max_iter, 16, ws, ws_bytes,
+                           NULL, &hstate));
+        /* the reference returns the E-step under theta_k with theta_{k+1} (em.py:130-143) */
+        MXM_OK(mxm_em_step(dM, H, NULL, dlncur, R, (int32_t)H, dmix, H, 0, NULL, NULL, 0, NULL));
+    } else {
+        /* the same loop over row-dictionary records: one code per cell + the row's distinct values (lossless) */
+        if (!linear || (H & 1)) { fprintf(stderr, "records need an even H in [66, 8192]\n"); return 6; }
+        const size_t rec_bytes = mxm_coded_bytes(R, (int32_t)H);
+        uint8_t *drec;
+        int64_t *drec_off, *dstats, stats[2];
+        int32_t *dndist, *ndist = (int32_t *)malloc((size_t)R * 4);
+        HIP_OK(hipMalloc((void **)&drec, rec_bytes));
+        HIP_OK(hipMalloc((void **)&drec_off, (size_t)R * 8));
+        HIP_OK(hipMalloc((void **)&dndist, (size_t)R * 4));
+        HIP_OK(hipMalloc((void **)&dstats, 16));
+        MXM_OK(mxm_encode_rows(dM, H, R, (int32_t)H, drec, rec_bytes, drec_off, dndist, drowmax, dstats, NULL));
+        HIP_OK(hipMemcpy(stats, dstats, 16, hipMemcpyDeviceToHost));
+        HIP_OK(hipMemcpy(ndist, dndist, (size_t)R * 4, hipMemcpyDeviceToHost));
+        if (stats[1] != 0) { fprintf(stderr, "%lld rows with more than 1024 distinct values: keep them dense (mxm_coded.P_rest)\n", (long long)stats[1]); return 6; }
+        /* the rows with 16-bit codes, in row order, are part of the descriptor */
+        int64_t *wide = (int64_t *)malloc((size_t)R * 8), n_wide = 0;
+        for (int64_t r = 0; r < R; ++r) if (ndist[r] > 256) wide[n_wide++] = r;
+        void *dwide = n_wide ? to_device(wide, (size_t)n_wide * 8) : NULL;
+        mxm_coded c = {drec, drec_off, dndist, R, NULL, 0, NULL, 0, (const int64_t *)dwide, n_wide};
+        printf("records: %.1f KB for a %.1f KB matrix, %lld rows with 16-bit codes\n", stats[0] / 1024.0,
+               (double)(R * H) * 8 / 1024.0, (long long)n_wide);
+        MXM_OK(mxm_em_loop_coded(&c, (const double *)dw, (int32_t)H, 1, dprops, dlncur, dlnnew, dcolsum, dstate, tol,
+                                 (int32_t)max_iter, 16, ws, ws_bytes, NULL, &hstate));
+        /* posterior under theta_k from the records' log tables; it wants exp(ln theta_k) beside the logs */
+        double *lnk = (double *)malloc((size_t)H * 8);
+        HIP_OK(hipMemcpy(lnk, dlncur, (size_t)H * 8, hipMemcpyDeviceToHost));
+        for (int64_t h = 0; h < H; ++h) lnk[h] = exp(lnk[h]);
+        void *dpk = to_device(lnk, (size_t)H * 8);
+        MXM_OK(mxm_em_step_coded(&c, (int32_t)H, dlncur, (const double *)dpk, drowmax, NULL, 0, NULL, 0, dmix, H, 0, NULL));
+    }
     HIP_OK(hipDeviceSynchronize());
 
     double *lnnew = (double *)malloc((size_t)H * 8);

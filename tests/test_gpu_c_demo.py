@@ -30,7 +30,7 @@ def demo(tmp_path_factory):
     return exe
 
 
-def _run(exe, tmp_path, tables, row_ptr, site, obs, wts, init, tol, max_iter):
+def _run(exe, tmp_path, tables, row_ptr, site, obs, wts, init, tol, max_iter, records=False):
     n_rows, n_haps, n_sites = len(row_ptr) - 1, tables.n_haps, len(tables.sites)
     prob, res = str(tmp_path / "problem.bin"), str(tmp_path / "result.bin")
     with open(prob, "wb") as f:
@@ -40,7 +40,8 @@ def _run(exe, tmp_path, tables, row_ptr, site, obs, wts, init, tol, max_iter):
                         (row_ptr, numpy.int64), (site, numpy.uint16), (obs, numpy.uint8),
                         (wts, numpy.float64), (init, numpy.float64)):
             f.write(numpy.ascontiguousarray(arr, dtype=dt).tobytes())
-    proc = subprocess.run([exe, prob, res], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+    proc = subprocess.run([exe, prob, res] + (["records"] if records else []), stdout=subprocess.PIPE,
+                          stderr=subprocess.STDOUT, text=True)
     assert proc.returncode == 0, proc.stdout
     raw = open(res, "rb").read()
     iters, done = struct.unpack_from("<2q", raw, 0)
@@ -80,3 +81,19 @@ def test_config1_from_c(demo, tmp_path, b17):
     assert (iters, done) == (int(g["iters"][0]), 1)
     assert numpy.abs(props - g["props"]).max() < 1e-9
     assert numpy.array_equal(mix.argmax(axis=1), g["mix"].argmax(axis=1))
+
+
+def test_config1_from_c_over_records(demo, tmp_path, b17):
+    """The same problem with the loop and the posterior over row-dictionary records (mxm_encode_rows ->
+    mxm_em_loop_coded -> mxm_em_step_coded), descriptor filled in by hand from C."""
+    from mixemt_amd import preprocess
+    refseq, phy, haps, tables = b17
+    g = golden("g7_config1")
+    sub = preprocess.HapVarTables.build(refseq, phy, [haps[c] for c in g["cols"]])
+    iters, done, props, mat, mix = _run(demo, tmp_path, sub, g["row_ptr"], g["site"], g["obs"],
+                                        numpy.ones(1000), g["inits"][0], 1e-4, 10000, records=True)
+    assert numpy.array_equal(mat, g["mat"])
+    assert (iters, done) == (int(g["iters"][0]), 1)
+    assert numpy.abs(props - g["props"]).max() < 1e-9
+    assert numpy.array_equal(mix.argmax(axis=1), g["mix"].argmax(axis=1))
+    assert numpy.allclose(numpy.exp(mix), numpy.exp(g["mix"]), rtol=0, atol=1e-9)
