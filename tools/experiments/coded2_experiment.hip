@@ -16,7 +16,9 @@
 
 #define C2_MAX_CODES 256
 
-template <int THREADS, int NCH, int NRUN, int NBUF, int WG_PER_CU>
+// KEEPV = false: the row's values are not kept between the dot product and the accumulation (48 registers) but looked
+// up a second time -- the shape that fits three workgroups per CU.
+template <int THREADS, int NCH, int NRUN, int NBUF, int WG_PER_CU, bool KEEPV = true>
 __global__ __launch_bounds__(THREADS, WG_PER_CU *THREADS / 256) void coded2_kernel(
     const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off, const int32_t *__restrict__ ndist, int ldc,
     const double *__restrict__ w, const double *__restrict__ props, int64_t R, int H, double *__restrict__ partial,
@@ -94,6 +96,12 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU *THREADS / 256) void coded2_kern
             v[k][3] = *reinterpret_cast<const double *>(tb + code_byte_x8<3>(cws[k]));
         }
     };
+    auto look4 = [&](const char *tb, unsigned int word, double(&out)[4]) {
+        out[0] = *reinterpret_cast<const double *>(tb + code_byte_x8<0>(word));
+        out[1] = *reinterpret_cast<const double *>(tb + code_byte_x8<1>(word));
+        out[2] = *reinterpret_cast<const double *>(tb + code_byte_x8<2>(word));
+        out[3] = *reinterpret_cast<const double *>(tb + code_byte_x8<3>(word));
+    };
     auto step = [&](auto J, int64_t q) {
         constexpr int j = decltype(J)::value;
         constexpr int jn = (j + 1) % NBUF, jl = (j + NBUF - 1) % NBUF;
@@ -101,14 +109,35 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU *THREADS / 256) void coded2_kern
         load_row(cw[jl], tring[jl]);
         const double wr = pre_wr;
         double s[NRUN];
-#pragma unroll
-        for (int b = 0; b < NRUN; ++b) {
+        const char *tbc = reinterpret_cast<const char *>(&s_tbl[j][0]);       // this row's table (published a step ago)
+        if constexpr (!KEEPV) {
+            static_assert(NRUN == 1 || KEEPV, "one restart in this form");
+            // one chunk (4 cells) of lookups in flight ahead of the chunk being multiplied; scheduling barriers keep the
+            // compiler from hoisting all 24 (and the next unrolled step's) into registers of their own
             double s4[4] = {0.0, 0.0, 0.0, 0.0};
+            double cur[4], nxt[4];
+            look4(tbc, cw[j][0], cur);
 #pragma unroll
-            for (int k = 0; k < NCH; ++k)
+            for (int k = 0; k < NCH; ++k) {
+                if (k + 1 < NCH) look4(tbc, cw[j][k + 1], nxt);
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                for (int e = 0; e < 4; ++e) s4[e] = fma(v[k][e], p[b][k][e], s4[e]);
-            s[b] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+                for (int e = 0; e < 4; ++e) s4[e] = fma(cur[e], p[0][k][e], s4[e]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
+            }
+            s[0] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        } else {
+#pragma unroll
+            for (int b = 0; b < NRUN; ++b) {
+                double s4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+                for (int k = 0; k < NCH; ++k)
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) s4[e] = fma(v[k][e], p[b][k][e], s4[e]);
+                s[b] = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+            }
         }
         __builtin_amdgcn_s_setprio(1);
 #pragma unroll
@@ -136,19 +165,41 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU *THREADS / 256) void coded2_kern
         const char *tbn = reinterpret_cast<const char *>(&s_tbl[jn][0]);
         auto upd = [&](int k, auto E) {
             constexpr int e = decltype(E)::value;
+            if constexpr (!KEEPV) {
+                acc[0][k][e] = fma(cf[0], *reinterpret_cast<const double *>(tbc + code_byte_x8<e>(cw[j][k])), acc[0][k][e]);
+            } else {
 #pragma unroll
-            for (int b = 0; b < NRUN; ++b) {
-                acc[b][k][e] = fma(cf[b], v[k][e], acc[b][k][e]);
-                asm volatile("" : "+v"(acc[b][k][e]));
+                for (int b = 0; b < NRUN; ++b) {
+                    acc[b][k][e] = fma(cf[b], v[k][e], acc[b][k][e]);
+                    asm volatile("" : "+v"(acc[b][k][e]));
+                }
+                v[k][e] = *reinterpret_cast<const double *>(tbn + code_byte_x8<e>(cw[jn][k]));
             }
-            v[k][e] = *reinterpret_cast<const double *>(tbn + code_byte_x8<e>(cw[jn][k]));
         };
+        if constexpr (!KEEPV) {
+            double cur[4], nxt[4];
+            look4(tbc, cw[j][0], cur);
 #pragma unroll
-        for (int k = 0; k < NCH; ++k) {
-            upd(k, std::integral_constant<int, 0>{});
-            upd(k, std::integral_constant<int, 1>{});
-            upd(k, std::integral_constant<int, 2>{});
-            upd(k, std::integral_constant<int, 3>{});
+            for (int k = 0; k < NCH; ++k) {
+                if (k + 1 < NCH) look4(tbc, cw[j][k + 1], nxt);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[0][k][e] = fma(cf[0], cur[e], acc[0][k][e]);
+                    asm volatile("" : "+v"(acc[0][k][e]));
+                }
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cur[e] = nxt[e];
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < NCH; ++k) {
+                upd(k, std::integral_constant<int, 0>{});
+                upd(k, std::integral_constant<int, 1>{});
+                upd(k, std::integral_constant<int, 2>{});
+                upd(k, std::integral_constant<int, 3>{});
+            }
         }
     };
     if (deal.nq > 0) {
@@ -162,7 +213,7 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU *THREADS / 256) void coded2_kern
         if (tbl_thread) s_tbl[0][tslot] = tring[0];
         __syncthreads();
         read_meta(NBUF - 1, 0);
-        lookup_row(reinterpret_cast<const char *>(&s_tbl[0][0]), cw[0]);
+        if constexpr (KEEPV) lookup_row(reinterpret_cast<const char *>(&s_tbl[0][0]), cw[0]);
         for (int64_t q = 0; q < deal.nq; q += NBUF) {
             step(std::integral_constant<int, 0>{}, q);
             step(std::integral_constant<int, 1>{}, q + 1);
@@ -187,6 +238,8 @@ __global__ __launch_bounds__(THREADS, WG_PER_CU *THREADS / 256) void coded2_kern
 // variant 1: 512 threads x 12 cells, two restarts, one workgroup per CU  (VERDICT r3 #3's shape)
 // variant 2: 256 threads x 24 cells, two restarts, one workgroup per CU (one wave per SIMD, up to 512 registers)
 // variant 3: 512 threads x 12 cells, one restart, two workgroups per CU
+// variant 4: 256 threads x 24 cells, one restart, THREE workgroups per CU, the row's values looked up twice
+// variant 5: the same at two workgroups per CU;  variant 6: variant 4 with three rows in flight instead of four
 // partial: [grid][NRUN][ldpart]; returns the average kernel time of `reps` launches in ms (negative: error)
 extern "C" float coded2_time(int variant, const uint8_t *rec, const int64_t *rec_off, const int32_t *ndist, int ldc,
                              const double *w, const double *props, int64_t R, int H, double *partial, int64_t ldpart,
@@ -204,10 +257,16 @@ extern "C" float coded2_time(int variant, const uint8_t *rec, const int64_t *rec
                 hipLaunchKernelGGL((coded2_kernel<256, 6, 2, 4, 1>), dim3(grid), dim3(256), 0, 0, rec, rec_off, ndist, ldc, w, props, R, H, partial, ldpart); break;
             case 3: grid = n_cu * 2; nrun = 1;
                 hipLaunchKernelGGL((coded2_kernel<512, 3, 1, 4, 2>), dim3(grid), dim3(512), 0, 0, rec, rec_off, ndist, ldc, w, props, R, H, partial, ldpart); break;
+            case 4: grid = n_cu * 3; nrun = 1;
+                hipLaunchKernelGGL((coded2_kernel<256, 6, 1, 4, 3, false>), dim3(grid), dim3(256), 0, 0, rec, rec_off, ndist, ldc, w, props, R, H, partial, ldpart); break;
+            case 5: grid = n_cu * 2; nrun = 1;
+                hipLaunchKernelGGL((coded2_kernel<256, 6, 1, 4, 2, false>), dim3(grid), dim3(256), 0, 0, rec, rec_off, ndist, ldc, w, props, R, H, partial, ldpart); break;
+            case 6: grid = n_cu * 3; nrun = 1;
+                hipLaunchKernelGGL((coded2_kernel<256, 6, 1, 3, 3, false>), dim3(grid), dim3(256), 0, 0, rec, rec_off, ndist, ldc, w, props, R, H, partial, ldpart); break;
             default: break;
         }
     };
-    if (variant < 0 || variant > 3 || ldc / 4 > 1536) return -2.0f;
+    if (variant < 0 || variant > 6 || ldc / 4 > 1536) return -2.0f;
     launch();
     if (hipDeviceSynchronize() != hipSuccess) return -3.0f;
     hipEventRecord(a, 0);

@@ -44,15 +44,18 @@ want = colsum.cpu().numpy()
 n_cu = torch.cuda.get_device_properties(0).multi_processor_count
 ldc = (H + 7) & ~7
 ldpart = (H + 7) & ~7
-partial = torch.zeros((2 * n_cu * 2, ldpart), dtype=torch.float64, device=dev)
+partial = torch.zeros((3 * n_cu * 2, ldpart), dtype=torch.float64, device=dev)
 names = {0: "256 threads x 24 cells, 1 restart, 2 workgroups per CU (the product kernel's shape)",
          1: "512 threads x 12 cells, 2 restarts, 1 workgroup per CU",
          2: "256 threads x 24 cells, 2 restarts, 1 workgroup per CU (1 wave per SIMD, 256 VGPRs + 77 AGPRs)",
-         3: "512 threads x 12 cells, 1 restart, 2 workgroups per CU"}
+         3: "512 threads x 12 cells, 1 restart, 2 workgroups per CU",
+         4: "256 threads x 24 cells, 1 restart, 3 workgroups per CU, values looked up twice",
+         5: "256 threads x 24 cells, 1 restart, 2 workgroups per CU, values looked up twice",
+         6: "as 4 with three rows in flight (NBUF 3)"}
 print("one MI355X; %d rows x %d haplogroups as records (%.2f GB), %d of them byte-coded; average of 20 launches"
       % (rows, H, cm.used / 1e9, int(wts.sum().item())))
 for rep in range(2):
-    for variant in (0, 1, 2, 3):
+    for variant in (0, 1, 2, 3, 4, 5, 6):
         g, n = ctypes.c_int(0), ctypes.c_int(0)
         partial.zero_()
         torch.cuda.synchronize()
