@@ -385,7 +385,8 @@ def exchange_fold_blocks(fold, has_fold, n_rows, n_haps, delta, dev, group=None,
     return mine
 
 
-def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_read_mix=True, timing=None):
+def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_read_mix=True, timing=None,
+                            records=None):
     """
     Config 5: the matrix is replicated, the n_multi restarts are dealt
     round-robin over the ranks (run i -> rank i % world) and run with no
@@ -402,13 +403,21 @@ def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_rea
     `rows` = shard_bounds(R, rank, world) of read_mix, like run_em_sharded does.
     A rank without restarts (world > n_multi) builds no plan at all.
     `timing` (dict) receives loop_s / fold_s / combine_s of this rank.
+    records: the replicated matrix as a preprocess.CodedMatrix (build_em_records_device); `mat` may then be None.
+    Each rank's restarts then run one after another through the records loop (mxm_em_loop_coded), and with
+    want_read_mix the posterior blocks are decoded from the records' log tables (em.posterior); without it the
+    caller forms posterior rows on demand from "ln_theta_k" (em.RecordsPosterior).
     """
     import math
     import time
     rank, world = _world(group)
     n_multi = int(args.n_multi)
-    dev = require_gpu() if not isinstance(mat, torch.Tensor) else mat.device
-    n_rows, n_haps = mat.shape
+    if records is not None:
+        dev = records.rec.device
+        n_rows, n_haps = records.n_rows, records.n_haps
+    else:
+        dev = require_gpu() if not isinstance(mat, torch.Tensor) else mat.device
+        n_rows, n_haps = mat.shape
     if inits is None:
         inits = broadcast_inits(n_multi, n_haps, args.init_alpha, dev, group)
     inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
@@ -429,7 +438,7 @@ def run_em_restart_parallel(mat, weights, args, inits=None, group=None, want_rea
     ln_k = None
     plan = None
     if mine:
-        plan = _em.EmPlan(mat, weights, n_runs=len(mine))
+        plan = _em.EmPlan(mat, weights, n_runs=len(mine), records=records)
         ln_cur, ln_new, states = _em.em_loop(plan, inits[mine], args.tolerance, args.max_iter)
         ln_k = ln_cur.cpu().numpy()
         ln_sum += ln_new.sum(dim=0)
