@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-/* 0.4.0.  Bumped whenever a signature or a documented default of this header changes; mxm_version() returns
+/* 0.5.0.  Bumped whenever a signature or a documented default of this header changes; mxm_version() returns
  * the value the loaded library was built with, and a binding must refuse a library whose value differs from the
  * header it was written against (mixemt_amd/_lib.py does).  History: 100 rounds 1-2 (mxm_row_argmax_votes gained
  * ws / ws_bytes and mxm_set_compact_restarts became 0/1/2 inside that number -- the reason for this rule);
@@ -43,8 +43,9 @@ extern "C" {
  * mxm_em_step_coded / mxm_gather_columns_coded cover the rows without a record;
  * 400 round 4: mxm_coded gained wide_rows / n_wide (records with 16-bit codes for rows of 257..1024 distinct values),
  * mxm_record_bytes / mxm_coded_bytes grew with them, mxm_workspace_bytes covers the one-launch loops' layouts,
- * mxm_em_state gained `ticket` (24 bytes: mxm_m_finalize runs on several workgroups, the last arriver finishes). */
-#define MXM_VERSION 400
+ * mxm_em_state gained `ticket` (24 bytes: mxm_m_finalize runs on several workgroups, the last arriver finishes);
+ * 500 round 5: mxm_aln_* (the batched alignment front end) added. */
+#define MXM_VERSION 500
 
 /* per-restart loop state, written by mxm_m_finalize (24 bytes); allocate it ZEROED */
 typedef struct mxm_em_state {
@@ -397,6 +398,56 @@ int mxm_fold_logaddexp(double *acc, int64_t lda, const double *const *in_host,
 int64_t mxm_encode_signatures(const char *text, const int64_t *off, int64_t R,
                               const int32_t *site_of_pos, int64_t ref_len, int64_t *row_ptr,
                               uint16_t *site, uint8_t *obs, int64_t cap);
+
+/*
+ * HOST functions (no device work): the alignment front end, batched -- what preprocess.process_reads
+ * (preprocess.py:99-139), read_signature (:142-148), reduce_reads (:163-174) and the row order / weights / id lists
+ * of build_em_input (:218-220, :225) produce together, from alignments held as COLUMNS instead of one Python object
+ * per read and one interpreter step per aligned base:
+ *   ref_start[i]   pysam reference_start (0-based);  mapq[i]  mapping_quality;  frag[i] in [0, n_frag): the
+ *                  alignment's fragment (query_name; mates share one)
+ *   cigar[cig_ptr[i] .. cig_ptr[i+1])   BAM encoding, length << 4 | op  (0 M, 1 I, 2 D, 3 N, 4 S, 5 H, 6 P, 7 =, 8 X)
+ *   seq / qual [seq_ptr[i] .. seq_ptr[i+1])   query_sequence (ASCII) and query_qualities (phred, same offsets);
+ *                  qual == NULL: no alignment has qualities; has_qual[i] == 0: this one has none (None in pysam)
+ * An observation is made at every variant site under an M / = / X operation of an alignment with mapq >= min_mq
+ * whose base quality is >= min_bq (or absent); the base is upper-cased; a (fragment, site) seen with two different
+ * bases, or as 'N', is dropped (:126-138).  Fragments with equal observation lists share one row; rows come in
+ * the order of Python's sorted() over the signature strings 'pos:base,pos:base,...' (pos = site_pos[site]).
+ *   site_of_pos[ref_len]  position -> site index or -1;  site_pos[n_sites]  its inverse (ascending)
+ *   n_threads     host threads to use (<= 0: the hardware's, at most 16)
+ * mxm_aln_encode allocates the result (host memory owned by the library); sizes via mxm_aln_sizes_of, copies via
+ * mxm_aln_fetch* (NULL = not wanted), released by mxm_aln_free.  Returns 0, -1 (bad arguments) or -4: an alignment
+ * whose CIGAR runs past its sequence or holds an unknown operation -- the caller then takes the object-by-object
+ * path, which raises what the reference raises.
+ *   rows:       row_ptr[n_rows+1], site[nnz], obs[nnz]  (the CSR mxm_build_em_matrix* take), weights[n_rows]
+ *               (fragments per signature), group_ptr[n_rows+1] / group_frag[n_grouped] (each row's fragments in the
+ *               reference's list order), text / text_off[n_rows+1] (the signatures, '\n' after each)
+ *   dropped[n_dropped]  fragments left with NO site (signature '': the reference dies on it in int(''), :156-160)
+ *   fragments:  process_reads' own result in its dict order: frag_id[n_frag_seen], frag_ptr[n_frag_seen+1], site, obs
+ */
+typedef struct mxm_aln_columns {
+    int64_t         n_aln, n_frag;
+    const int64_t  *ref_start;
+    const int32_t  *mapq;
+    const int64_t  *frag;
+    const int64_t  *cig_ptr;
+    const uint32_t *cigar;
+    const int64_t  *seq_ptr;
+    const uint8_t  *seq;
+    const uint8_t  *qual;
+    const uint8_t  *has_qual;
+} mxm_aln_columns;
+typedef struct mxm_aln_sizes {
+    int64_t n_rows, nnz, n_grouped, n_dropped, text_bytes, n_frag_seen, frag_nnz;
+} mxm_aln_sizes;
+typedef struct mxm_aln_enc mxm_aln_enc;
+int  mxm_aln_encode(const mxm_aln_columns *cols, const int32_t *site_of_pos, int64_t ref_len, const int64_t *site_pos,
+                    int32_t n_sites, int32_t min_mq, int32_t min_bq, int32_t n_threads, mxm_aln_enc **out);
+int  mxm_aln_sizes_of(const mxm_aln_enc *enc, mxm_aln_sizes *sizes);
+int  mxm_aln_fetch(const mxm_aln_enc *enc, int64_t *row_ptr, uint16_t *site, uint8_t *obs, int64_t *weights,
+                   int64_t *group_ptr, int64_t *group_frag, int64_t *dropped, char *text, int64_t *text_off);
+int  mxm_aln_fetch_fragments(const mxm_aln_enc *enc, int64_t *frag_id, int64_t *frag_ptr, uint16_t *site, uint8_t *obs);
+void mxm_aln_free(mxm_aln_enc *enc);
 
 #ifdef __cplusplus
 }

@@ -28,6 +28,19 @@ class Coded(ctypes.Structure):
                 ("wide_rows", c_ptr), ("n_wide", c_i64)]
 
 
+class AlnColumns(ctypes.Structure):
+    """mxm_aln_columns (include/mixemt_hip.h): alignments as columns (host pointers)."""
+    _fields_ = [("n_aln", c_i64), ("n_frag", c_i64), ("ref_start", c_ptr), ("mapq", c_ptr), ("frag", c_ptr),
+                ("cig_ptr", c_ptr), ("cigar", c_ptr), ("seq_ptr", c_ptr), ("seq", c_ptr), ("qual", c_ptr),
+                ("has_qual", c_ptr)]
+
+
+class AlnSizes(ctypes.Structure):
+    """mxm_aln_sizes (include/mixemt_hip.h)."""
+    _fields_ = [("n_rows", c_i64), ("nnz", c_i64), ("n_grouped", c_i64), ("n_dropped", c_i64), ("text_bytes", c_i64),
+                ("n_frag_seen", c_i64), ("frag_nnz", c_i64)]
+
+
 # name -> (restype, argtypes); must list every symbol the two headers declare
 # (include/mixemt_hip.h: the boundary; include/mixemt_hip_tuning.h: measurement / shape knobs)
 SIGNATURES = {
@@ -89,6 +102,12 @@ SIGNATURES = {
     "mxm_set_batch_tile": (ctypes.c_int, [c_i32]),
     "mxm_encode_signatures": (ctypes.c_int64, [ctypes.c_char_p, c_ptr, c_i64, c_ptr, c_i64, c_ptr, c_ptr, c_ptr,
                                                c_i64]),
+    "mxm_aln_encode": (ctypes.c_int, [ctypes.POINTER(AlnColumns), c_ptr, c_i64, c_ptr, c_i32, c_i32, c_i32, c_i32,
+                                      ctypes.POINTER(c_ptr)]),
+    "mxm_aln_sizes_of": (ctypes.c_int, [c_ptr, ctypes.POINTER(AlnSizes)]),
+    "mxm_aln_fetch": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mxm_aln_fetch_fragments": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mxm_aln_free": (None, [c_ptr]),
     "mxm_set_compact_restarts": (ctypes.c_int, [c_i32]),
     "mxm_set_loop_graph": (ctypes.c_int, [c_i32]),
     "mxm_set_loop_fused": (ctypes.c_int, [c_i32, c_i32]),
@@ -106,7 +125,7 @@ SIGNATURES = {
 }
 
 # the MXM_VERSION of include/mixemt_hip.h these signatures were written for; load() refuses any other
-ABI_VERSION = 400
+ABI_VERSION = 500
 
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.POINTER(EmState), c_i32, c_ptr)
 

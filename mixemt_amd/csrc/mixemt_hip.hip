@@ -26,6 +26,7 @@
 //   fused_cols_kernels.hpp  em_fused_cols_kernel (the same for up to 1536 rows, columns split over the workgroups, matrix in registers)
 //   coded_kernels.hpp   encode_rows_kernel, em_iter_coded_kernel (row-dictionary storage: one byte per cell + the row's distinct values)
 //   fused_coded_kernels.hpp  em_fused_coded_kernel (the whole EM loop over records in one persistent launch)
+//   aln_encode.hpp      HOST code: mxm_aln_encode, the batched alignment front end (process_reads + reduce_reads + row order)
 // This file: the host side of the C ABI (shape checks, grid sizing, dispatch, the loop driver).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
@@ -43,6 +44,7 @@
 #include "mixemt_hip_tuning.h"
 
 #include "common.hpp"
+#include "aln_encode.hpp"
 #include "coded_kernels.hpp"
 #include "build_kernels.hpp"
 #include "build_lut_kernels.hpp"

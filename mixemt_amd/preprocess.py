@@ -685,7 +685,15 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None):
 build_em_matrix_device.last_fallback = 0       # rows the marker kernel handed to the lookup-table kernel, last call
 
 
-def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False, as_records=False):
+def _warn_dropped(dropped):
+    # never silent: weights and read ids no longer cover these fragments (the reference would have died on
+    # them), so the accounting must show it whatever the verbosity
+    sys.stderr.write("Warning: skipped %d fragment(s) whose every site was conflicted away "
+                     "(empty signature; the reference stops at int('') there): %s%s\n"
+                     % (len(dropped), ", ".join(str(x) for x in dropped[:5]), ", ..." if len(dropped) > 5 else ""))
+
+
+def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False, as_records=False, frontend="auto"):
     """
     Drop-in for mixemt.preprocess.build_em_input (preprocess.py:201-227):
     (em_matrix, weights, haplogroups, read_ids) with rows = sorted distinct
@@ -694,25 +702,67 @@ def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False, as_reco
     which the reference dies (int('') at :156-160); it is skipped here.
     as_records=True: the first element is a CodedMatrix (build_em_records_device: no dense matrix on the
     device or the host) for em.run_em_ex(None, weights, args, records=...).
+    frontend: "batched" = the alignments are read into columns and encoded by ONE call of the library
+    (alignments.encode_alignments: no interpreter step per aligned base, no signature strings; read_ids is then an
+    alignments.ReadIdGroups -- the reference's list of lists, materialised row by row on demand); "python" = the
+    reference's own object-by-object walk (process_reads / reduce_reads below); "auto" = batched, falling back to
+    python for input the encoder hands back (so that the exception raised is the reference's).
+    `bamfile` may also be an alignments.AlignmentColumns (a columnar reader's output).
     """
+    from . import alignments
+    if frontend not in ("auto", "batched", "python"):
+        raise ValueError("frontend must be 'auto', 'batched' or 'python'")
     var_pos = phylo.get_variant_pos()
-    read_obs = process_reads(bamfile.fetch(), var_pos, args.min_mq, args.min_bq)
+    haplogroups = sorted(phylo.hap_var)
+    verbose = getattr(args, "verbose", False)
+    enc = None
+    columns = bamfile if isinstance(bamfile, alignments.AlignmentColumns) else None
+    if frontend != "python":
+        alns = None
+        try:
+            if columns is None:
+                alns = list(bamfile.fetch())          # (kept: the python path below must see the same alignments)
+                columns = alignments.AlignmentColumns.from_alignments(alns)
+            enc = alignments.encode_alignments(columns, var_pos, len(refseq), args.min_mq, args.min_bq)
+        except alignments.NeedsSlowPath:
+            if frontend == "batched" or alns is None:
+                raise
+            enc = None
+    if enc is not None:
+        dropped = enc.dropped
+        if dropped:
+            _warn_dropped(dropped)
+        build_em_input.last_dropped = list(dropped)
+        if verbose:
+            sys.stderr.write("Using %d aligned fragments (MQ>=%d) (%d distinct sub-haplotypes)\n\n"
+                             % (enc.n_fragments - len(dropped), args.min_mq, enc.n_rows))
+        tables = HapVarTables.build(refseq, phylo, haplogroups)
+        if not numpy.array_equal(tables.sites, numpy.asarray(var_pos, dtype=numpy.int64)):
+            raise ValueError("build_em_input: the tables' sites are not phylo.get_variant_pos()")
+        if verbose:
+            sys.stderr.write("Building EM input matrix...\n")
+        if as_records:
+            em_matrix = build_em_records_device(tables, enc.row_ptr, enc.site, enc.obs)
+        else:
+            em_matrix = build_em_matrix_device(tables, enc.row_ptr, enc.site, enc.obs)
+            if not as_device_tensor:
+                em_matrix = to_host(em_matrix)
+        if verbose:
+            sys.stderr.write("  processed %d fragments...\nDone.\n\n" % enc.n_rows)
+        build_em_input.last_frontend = "batched"
+        return em_matrix, enc.weights, haplogroups, enc.read_ids
+    build_em_input.last_frontend = "python"
+    read_obs = process_reads(alns if frontend != "python" else bamfile.fetch(), var_pos, args.min_mq, args.min_bq)
     read_sigs = reduce_reads(read_obs)
     dropped = read_sigs.pop("", None)
     if dropped:
-        # never silent: weights and read ids below no longer cover these fragments (the reference
-        # would have died on them), so the accounting must show it whatever the verbosity
-        sys.stderr.write("Warning: skipped %d fragment(s) whose every site was conflicted away "
-                         "(empty signature; the reference stops at int('') there): %s%s\n"
-                         % (len(dropped), ", ".join(str(x) for x in dropped[:5]),
-                            ", ..." if len(dropped) > 5 else ""))
+        _warn_dropped(dropped)
         build_em_input.last_dropped = list(dropped)
     else:
         build_em_input.last_dropped = []
-    if getattr(args, "verbose", False):
+    if verbose:
         sys.stderr.write("Using %d aligned fragments (MQ>=%d) (%d distinct sub-haplotypes)\n\n"
                          % (len(read_obs) - len(dropped or ()), args.min_mq, len(read_sigs)))
-    haplogroups = sorted(phylo.hap_var)
     reads = sorted(read_sigs)
     weights = numpy.array([len(read_sigs[r]) for r in reads])
     if as_records:
@@ -724,6 +774,10 @@ def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False, as_reco
                                     as_device_tensor=as_device_tensor)
     read_ids = [read_sigs[r] for r in reads]
     return em_matrix, weights, haplogroups, read_ids
+
+
+build_em_input.last_dropped = []
+build_em_input.last_frontend = None
 
 
 def reduce_em_matrix(em_mat, haplogroups, contrib_props):

@@ -105,3 +105,139 @@ def signatures(tables, row_ptr, site, obs):
         beg, end = int(row_ptr[i]), int(row_ptr[i + 1])
         out.append(",".join("%d:%s" % (pos[site[j]], chr(obs[j])) for j in range(beg, end)))
     return out
+
+
+# --------------------------------------------------------------------------------------------------
+# synth-aln-v1: synthetic ALIGNMENTS as columns (alignments.AlignmentColumns) -- input of the front end
+# (preprocess.process_reads -> reduce_reads, preprocess.py:99-174) at any size, generated without a Python
+# object per read.  The build's own code (the reference's tests build a handful of pysam objects by hand,
+# preprocess_test.py:102-124).  tests/_fake_aln.py turns the columns into pysam-like objects for the
+# object-by-object path, so both front ends can be run on the same input.
+# --------------------------------------------------------------------------------------------------
+def _ragged(lengths):
+    """(owner index, offset within owner) of every element of segments with the given lengths."""
+    lengths = numpy.asarray(lengths, dtype=numpy.int64)
+    ptr = numpy.zeros(len(lengths) + 1, dtype=numpy.int64)
+    numpy.cumsum(lengths, out=ptr[1:])
+    owner = numpy.repeat(numpy.arange(len(lengths), dtype=numpy.int64), lengths)
+    return ptr, owner, numpy.arange(int(ptr[-1]), dtype=numpy.int64) - ptr[owner]
+
+
+def synth_alignments(tables, refseq, n_frag, seed=1, contrib=DEFAULT_CONTRIB, props=DEFAULT_PROPS, mate_share=0.4,
+                     err=0.004, shuffle=True):
+    """
+    -> alignments.AlignmentColumns of n_frag fragments (plus a mate for `mate_share` of them) shed by the three
+    contributors' sequences (the reference sequence carrying the contributor's expected base at every variant site):
+    lengths 80-150; a sixth each with an insertion, a deletion, a soft clip; sequencing errors and a few 'N' bases;
+    a tenth in lower case; mapping qualities from {60 x4, 42, 30, 29, 10, 0}; base qualities 31-40, a fifth of the
+    alignments with a tenth of their bases below 30, a fifth with NO quality array; a third of the fragments at one of
+    five fixed starts with length 120 (equal signatures: weights > 1); mates overlap their fragment's first read by
+    20-60 bases, and half of them get one substituted base inside the overlap (half of those at low quality) -- where
+    that base sits on a variant site the fragment sees two different bases there.  Alignment order is shuffled.
+    """
+    from .alignments import AlignmentColumns
+    rng = numpy.random.default_rng([int(seed), 0xA11])
+    ref_len = len(refseq)
+    sites = numpy.asarray(tables.sites)
+    srcs = []
+    for col in contrib:
+        seq = numpy.frombuffer(refseq.encode("ascii"), dtype=numpy.uint8).copy()
+        seq[sites] = tables.expected[:, col]
+        srcs.append(seq)
+    src = numpy.stack(srcs)                                              # [3][ref_len]
+    who = rng.choice(len(props), size=n_frag, p=numpy.asarray(props, dtype=float))
+    length = rng.integers(80, 151, size=n_frag)
+    start = rng.integers(0, ref_len - 400, size=n_frag)
+    fixed = rng.random(n_frag) < 0.33
+    start[fixed] = rng.choice(numpy.array([310, 2700, 7020, 11710, 16120]), size=int(fixed.sum()))
+    length[fixed] = 120
+    has_mate = rng.random(n_frag) < mate_share
+    m_idx = numpy.flatnonzero(has_mate)
+    overlap = rng.integers(20, 61, size=len(m_idx))
+    # alignment table: fragments' first reads, then the mates
+    a_frag = numpy.concatenate([numpy.arange(n_frag, dtype=numpy.int64), m_idx])
+    a_who = numpy.concatenate([who, who[m_idx]])
+    a_len = numpy.concatenate([length, rng.integers(80, 151, size=len(m_idx))])
+    a_start = numpy.concatenate([start, start[m_idx] + length[m_idx] - overlap])
+    n_aln = len(a_frag)
+    is_mate = numpy.arange(n_aln) >= n_frag
+    kind = rng.choice(6, size=n_aln)                                     # 0-2 plain, 3 ins, 4 del, 5 clip
+    kind[is_mate] = 0
+    at = rng.integers(10, 70, size=n_aln)                                # where the indel sits (all lengths are >= 80)
+    k = numpy.where(kind == 3, rng.integers(1, 4, size=n_aln), numpy.where(kind == 4, rng.integers(1, 6, size=n_aln),
+                                                                            rng.integers(2, 9, size=n_aln)))
+    mapq = rng.choice(numpy.array([60, 60, 60, 60, 42, 30, 29, 10, 0]), size=n_aln).astype(numpy.int32)
+    qkind = rng.choice(5, size=n_aln)                                    # 0-2 ok, 3 low, 4 none
+    lower = rng.random(n_aln) < 0.1
+    # bases: source position of every query offset (-1 = a random base: inserted / clipped)
+    seq_ptr, own, off = _ragged(a_len)
+    kk, aa, kd = k[own], at[own], kind[own]
+    shift = numpy.zeros(len(own), dtype=numpy.int64)
+    rand = numpy.zeros(len(own), dtype=bool)
+    ins = kd == 3
+    rand |= ins & (off >= aa) & (off < aa + kk)
+    shift[ins & (off >= aa + kk)] = -kk[ins & (off >= aa + kk)]
+    dele = kd == 4
+    shift[dele & (off >= aa)] = kk[dele & (off >= aa)]
+    clip = kd == 5
+    rand |= clip & (off < kk)
+    shift[clip & (off >= kk)] = -kk[clip & (off >= kk)]
+    pos = a_start[own] + off + shift
+    seq = src[a_who[own], numpy.clip(pos, 0, ref_len - 1)]
+    seq[rand] = ALPHABET[rng.integers(0, 4, size=int(rand.sum()))]
+    flip = rng.random(len(seq)) < err
+    seq[flip] = ALPHABET[rng.integers(0, 4, size=int(flip.sum()))]
+    seq[rng.random(len(seq)) < 0.0005] = ord("N")
+    qual = rng.integers(31, 41, size=len(seq)).astype(numpy.uint8)
+    low = (qkind[own] == 3) & (rng.random(len(seq)) < 0.1)
+    qual[low] = rng.integers(2, 30, size=int(low.sum())).astype(numpy.uint8)
+    # mates: one substituted base inside the overlap for half of them, half of those at low quality
+    hit = numpy.flatnonzero(is_mate & (rng.random(n_aln) < 0.5))
+    where = seq_ptr[hit] + (rng.random(len(hit)) * overlap[hit - n_frag]).astype(numpy.int64)
+    code = numpy.zeros(len(where), dtype=numpy.int64)
+    for i, base in enumerate(ALPHABET):
+        code[seq[where] == base] = i
+    seq[where] = ALPHABET[(code + rng.integers(1, 4, size=len(where))) % 4]
+    qual[where] = numpy.where(rng.random(len(where)) < 0.5, 5, 38).astype(numpy.uint8)
+    seq[lower[own]] |= 0x20                                               # lower case (letters only: A-Z, N)
+    has_qual = (qkind != 4).astype(numpy.uint8)
+    # CIGARs (BAM encoding: length << 4 | op): plain LM; aM kI (L-a-k)M; aM kD (L-a)M; kS (L-k)M
+    n_ops = numpy.where(kind <= 2, 1, numpy.where(kind == 5, 2, 3))
+    cig_ptr, c_own, c_off = _ragged(n_ops)
+    ck, ca, cl, ckd = k[c_own], at[c_own], a_len[c_own], kind[c_own]
+    op = numpy.zeros(len(c_own), dtype=numpy.int64)
+    ln = cl.copy()
+    sel = (ckd == 3)
+    ln[sel & (c_off == 0)] = ca[sel & (c_off == 0)]
+    op[sel & (c_off == 1)] = 1
+    ln[sel & (c_off == 1)] = ck[sel & (c_off == 1)]
+    ln[sel & (c_off == 2)] = (cl - ca - ck)[sel & (c_off == 2)]
+    sel = (ckd == 4)
+    ln[sel & (c_off == 0)] = ca[sel & (c_off == 0)]
+    op[sel & (c_off == 1)] = 2
+    ln[sel & (c_off == 1)] = ck[sel & (c_off == 1)]
+    ln[sel & (c_off == 2)] = (cl - ca)[sel & (c_off == 2)]
+    sel = (ckd == 5)
+    op[sel & (c_off == 0)] = 4
+    ln[sel & (c_off == 0)] = ck[sel & (c_off == 0)]
+    ln[sel & (c_off == 1)] = (cl - ck)[sel & (c_off == 1)]
+    cigar = ((ln << 4) | op).astype(numpy.uint32)
+    names = ["f%07d" % i for i in range(n_frag)]
+    if shuffle:                                                           # file order is not fragment order
+        perm = rng.permutation(n_aln)
+        new_sptr, s_own, s_off = _ragged(a_len[perm])
+        gather = seq_ptr[perm][s_own] + s_off
+        seq, qual = seq[gather], qual[gather]
+        new_cptr, cc_own, cc_off = _ragged(n_ops[perm])
+        cigar = cigar[cig_ptr[perm][cc_own] + cc_off]
+        seq_ptr, cig_ptr = new_sptr, new_cptr
+        a_start, mapq, a_frag, has_qual = a_start[perm], mapq[perm], a_frag[perm], has_qual[perm]
+        # fragment ids in order of first appearance in the file, as a reader's name table would number them
+        first = numpy.full(n_frag, n_aln, dtype=numpy.int64)
+        numpy.minimum.at(first, a_frag, numpy.arange(n_aln, dtype=numpy.int64))
+        rank = numpy.empty(n_frag, dtype=numpy.int64)
+        rank[numpy.argsort(first, kind="stable")] = numpy.arange(n_frag, dtype=numpy.int64)
+        a_frag = rank[a_frag]
+        inv = numpy.argsort(rank)
+        names = [names[i] for i in inv]
+    return AlignmentColumns(a_start, mapq, a_frag, cig_ptr, cigar, seq_ptr, seq, qual, has_qual, names)

@@ -38,3 +38,19 @@ class FakeBam(object):
 
     def fetch(self):
         return iter(self.alns)
+
+
+def from_columns(cols):
+    """alignments.AlignmentColumns -> list of FakeAln (the same alignments, one object each)."""
+    ops = "MIDNSHP=XB"
+    out = []
+    seq = cols.seq.tobytes().decode("ascii")
+    for i in range(len(cols)):
+        a, b = int(cols.seq_ptr[i]), int(cols.seq_ptr[i + 1])
+        quals = None
+        if cols.qual is not None and (cols.has_qual is None or cols.has_qual[i]):
+            quals = cols.qual[a:b].tolist()
+        cig = "".join("%d%s" % (int(c) >> 4, ops[int(c) & 15])
+                      for c in cols.cigar[int(cols.cig_ptr[i]):int(cols.cig_ptr[i + 1])])
+        out.append(FakeAln(cols.names[int(cols.frag[i])], int(cols.ref_start[i]), int(cols.mapq[i]), seq[a:b], quals, cig))
+    return out

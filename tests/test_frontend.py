@@ -121,8 +121,9 @@ def test_process_and_reduce_reads_equal_the_reference_run(b17):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("frontend", ["batched", "python"])
 @pytest.mark.parametrize("as_records", [False, True])
-def test_build_em_input_equals_the_reference_run(b17, as_records, capsys):
+def test_build_em_input_equals_the_reference_run(b17, as_records, frontend, capsys):
     """preprocess.py:201-227 end to end: rows = sorted distinct signatures, weights, read-id lists, haplogroup order
     and the matrix itself (sha256 of the reference's) -- dense and as row-dictionary records; the fragment the
     reference dies on (recorded in the fixture) is skipped with a warning."""
@@ -134,7 +135,9 @@ def test_build_em_input_equals_the_reference_run(b17, as_records, capsys):
     g, alns = _g11()
     assert str(g["ref_died_with"]).startswith("ValueError")
     args = argparse.Namespace(min_mq=int(g["min_mq"]), min_bq=int(g["min_bq"]), verbose=False)
-    mat, wts, hap_order, read_ids = preprocess.build_em_input(FakeBam(alns), refseq, phy, args, as_records=as_records)
+    mat, wts, hap_order, read_ids = preprocess.build_em_input(FakeBam(alns), refseq, phy, args, as_records=as_records,
+                                                              frontend=frontend)
+    assert preprocess.build_em_input.last_frontend == frontend
     assert preprocess.build_em_input.last_dropped == [str(g["empty_name"])]
     assert "skipped 1 fragment" in capsys.readouterr().err
     assert hashlib.sha256("\n".join(hap_order).encode()).hexdigest() == str(g["hap_sha256"])

@@ -317,7 +317,8 @@ def test_committed_profiles_name_the_kernel_instances_this_source_builds():
     from mixemt_amd import _lib
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     rounds = sorted(glob.glob(os.path.join(root, "profiles", "r[0-9]*")), key=lambda p: int(re.search(r"r(\d+)$", p).group(1)))
-    latest = rounds[-1]
+    # (a round's directory fills up as the round goes; its kernel statistics are regenerated from the final binary)
+    latest = [p for p in rounds if os.path.exists(os.path.join(p, "bench_1m_kernel_stats.csv"))][-1]
     stats = open(os.path.join(latest, "bench_1m_kernel_stats.csv")).read()
     traffic = json.load(open(os.path.join(latest, "pmc_traffic_1m.json")))
     lib = _lib.load()

@@ -6,7 +6,12 @@ synthetic reads, device-resident end to end:
     CSR observations -> build_em_matrix_device -> run_em -> contributors from read votes
     -> refinement EM on the contributor columns -> read assignment -> contributor table
 
-    python tools/run_pipeline.py [--reads N] [--seed S] [--multi M] [--dense [--storage f64|f32|coded|auto]]
+    python tools/run_pipeline.py [--reads N] [--seed S] [--multi M] [--dense [--storage f64|f32|coded|auto]] [--alignments]
+
+--alignments (round 5): start one step earlier, from ALIGNMENTS -- N synthetic fragments (synth-aln-v1: mates, indels,
+clips, low qualities, duplicates) as columns -> the library's batched front end (alignments.encode_alignments =
+process_reads + reduce_reads + the row order of build_em_input, preprocess.py:99-174, :218-225) -> CSR + weights + id
+groups, and the stage is timed beside the others.
 
 Default (round 3): the build leaves the matrix as row-dictionary records -- no dense matrix, no posterior matrix; the
 contributors, the vote table and the reduced matrix for the refinement come from the records.  --dense takes the
@@ -33,6 +38,9 @@ def main():
     ap.add_argument("--dense", action="store_true",
                     help="build the dense matrix and the posterior matrix (the reference's data flow); default: records only")
     ap.add_argument("--records", action="store_true", help="(the default since round 3; kept for old command lines)")
+    ap.add_argument("--alignments", action="store_true",
+                    help="input = synthetic alignments as columns through the batched front end (instead of ready-made rows)")
+    ap.add_argument("--threads", type=int, default=0, help="with --alignments: host threads of the encoder (0 = its default)")
     ap.add_argument("--storage", default="auto", choices=["f64", "f32", "coded", "auto"],
                     help="with --dense: form of the matrix the EM loop streams (EmPlan): coded = lossless row dictionaries, "
                          "auto = coded from 1.5e7 cells on")
@@ -47,10 +55,28 @@ def main():
     phy = phylotree.load_build17(refseq)
     haps = sorted(phy.hap_var)
     tables = preprocess.HapVarTables.build(refseq, phy, haps)
-    row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), opts.reads, seed=1)
-    reads = [[str(i)] for i in range(opts.reads)]     # the read ids behind each row (synthetic input, like the fragments)
-    sys.stderr.write("Using %d variant sites from %d haplogroups; %d synthetic fragments (%.1f s)\n"
-                     % (len(tables.sites), len(haps), opts.reads, time.perf_counter() - t0))
+    weights_host = None
+    if opts.alignments:
+        from mixemt_amd import alignments
+        cols = synth.synth_alignments(tables, refseq, opts.reads, seed=1)
+        sys.stderr.write("%d synthetic alignments of %d fragments as columns (%.1f s of generation, not part of the pipeline)\n"
+                         % (len(cols), cols.n_frag, time.perf_counter() - t0))
+        t0 = time.perf_counter()
+        enc = alignments.encode_alignments(cols, tables.sites, len(refseq), 30, 30, n_threads=opts.threads)
+        t_enc = time.perf_counter() - t0
+        row_ptr, site, obs = enc.row_ptr, enc.site, enc.obs
+        reads = enc.read_ids
+        weights_host = enc.weights
+        sys.stderr.write("front end (alignments -> fragments -> signatures -> de-dup -> sorted rows): %.1f ms for %d alignments "
+                         "(%.2f s per 10^6): %d fragments with a site, %d distinct signatures, %d observations, %d dropped\n"
+                         % (t_enc * 1e3, len(cols), t_enc / max(1, len(cols)) * 1e6, enc.n_fragments, enc.n_rows, len(site),
+                            len(enc.dropped)))
+        opts.reads = enc.n_rows
+    else:
+        row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), opts.reads, seed=1)
+        reads = [[str(i)] for i in range(opts.reads)]     # the read ids behind each row (synthetic input, like the fragments)
+        sys.stderr.write("Using %d variant sites from %d haplogroups; %d synthetic fragments (%.1f s)\n"
+                         % (len(tables.sites), len(haps), opts.reads, time.perf_counter() - t0))
 
     # the process's first HIP calls (context, the library's code object) are the runtime's, not the pipeline's: timed apart
     t0 = time.perf_counter()
@@ -69,7 +95,8 @@ def main():
     sys.stderr.write("haplogroup tables encoded and uploaded: %.1f ms\n" % ((time.perf_counter() - t0) * 1e3))
 
     t0 = time.perf_counter()
-    wts = torch.ones(opts.reads, dtype=torch.float64, device="cuda")
+    wts = (torch.ones(opts.reads, dtype=torch.float64, device="cuda") if weights_host is None
+           else torch.from_numpy(weights_host).to(device="cuda", dtype=torch.float64))
     if opts.records:
         em_mat = None
         cm = preprocess.build_em_records_device(tables, row_ptr, site, obs)
