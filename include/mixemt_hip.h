@@ -44,7 +44,8 @@ extern "C" {
  * 400 round 4: mxm_coded gained wide_rows / n_wide (records with 16-bit codes for rows of 257..1024 distinct values),
  * mxm_record_bytes / mxm_coded_bytes grew with them, mxm_workspace_bytes covers the one-launch loops' layouts,
  * mxm_em_state gained `ticket` (24 bytes: mxm_m_finalize runs on several workgroups, the last arriver finishes);
- * 500 round 5: mxm_aln_* (the batched alignment front end) added. */
+ * 500 round 5: mxm_aln_* (the batched alignment front end) added; mxm_em_state.reserved_ became .error and
+ * mxm_em_iter_coded's state lost its const (the wide-rows list is checked where it is used). */
 #define MXM_VERSION 500
 
 /* per-restart loop state, written by mxm_m_finalize (24 bytes); allocate it ZEROED */
@@ -53,7 +54,9 @@ typedef struct mxm_em_state {
     int32_t iters;               /* EM steps executed so far ("Converged! (n)", em.py:135) */
     double  l1;                  /* last sum_h |p_new - p_cur|  (em.py:53-54) */
     uint32_t ticket;             /* scratch of mxm_m_finalize (arrival count of its workgroups): 0 between calls */
-    uint32_t reserved_;
+    uint32_t error;              /* 0 = fine; 1 = mxm_em_iter_coded found that mxm_coded.wide_rows is not exactly the set of
+                                    rows with more than 256 values (colsum is then NaN throughout); mxm_em_loop_coded
+                                    returns -1 instead of iterating on */
 } mxm_em_state;
 
 int         mxm_version(void);
@@ -243,8 +246,13 @@ typedef struct mxm_coded {
     int64_t        ldp_rest;
     const double  *w_rest;       /* their weights (NULL = 1) */
     int64_t        R_rest;
-    const int64_t *wide_rows;    /* [n_wide] the rows with ndist > 256, in any FIXED order (it is the order their terms
-                                    are added in: sorted = the same sums on every run); only the EM iteration reads it */
+    const int64_t *wide_rows;    /* [n_wide] EXACTLY the rows with ndist > 256, ASCENDING (torch.nonzero(ndist > 256)).  The
+                                    EM iteration skips those rows in its main pass and takes them from this list, so
+                                    its sums depend on it: mxm_em_loop_coded checks the list on entry (-1 if it is
+                                    not that set), mxm_em_iter_coded checks it on the device in every pass (a fault:
+                                    colsum all NaN and state[b].error = 1; faulty entries are never dereferenced).
+                                    Nothing else reads it: the vote, the posterior, the gathers and the decoder find
+                                    the wide rows from ndist themselves. */
     int64_t        n_wide;
 } mxm_coded;
 size_t mxm_coded_bytes(int64_t R, int32_t H);
@@ -279,7 +287,8 @@ int mxm_gather_columns_coded(const mxm_coded *c, int32_t H, const int32_t *cols,
                              const double *M_rest, int64_t ldm_rest, const int64_t *rest_rows, int64_t n_rest,
                              double *out, int64_t ldo, void *stream);
 int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, int32_t H, int32_t B,
-                      const mxm_em_state *state, double *colsum, void *ws, size_t ws_bytes, void *stream);
+                      mxm_em_state *state /* nullable; only .error is ever written */, double *colsum, void *ws,
+                      size_t ws_bytes, void *stream);
 int mxm_em_loop_coded(const mxm_coded *c, const double *w, int32_t H, int32_t B,
                       double *props_cur, double *ln_cur, double *ln_new, double *colsum,
                       mxm_em_state *state, double tol, int32_t max_iter, int32_t check_every,

@@ -18,7 +18,7 @@ c_ptr, c_size = ctypes.c_void_p, ctypes.c_size_t
 
 class EmState(ctypes.Structure):
     """mxm_em_state (include/mixemt_hip.h)."""
-    _fields_ = [("done", c_i32), ("iters", c_i32), ("l1", c_f64), ("ticket", ctypes.c_uint32), ("reserved_", ctypes.c_uint32)]
+    _fields_ = [("done", c_i32), ("iters", c_i32), ("l1", c_f64), ("ticket", ctypes.c_uint32), ("error", ctypes.c_uint32)]
 
 
 class Coded(ctypes.Structure):

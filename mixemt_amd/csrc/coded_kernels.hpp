@@ -307,11 +307,21 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_wide_rows_kernel(
 // chunk, the table (<= 8 KB) through LDS, one row in flight ahead of the one being reduced.  They are 2 % of the rows
 // of a build_em_matrix matrix; as dense rows they cost a kernel launch of their own per iteration (0.147 ms at 10^6
 // rows, 9 % of the step).
-template <int THREADS, int NCH, int NBUF, bool NT, bool RESIDENT, bool WIDE_PREFETCH>
+// CHECK (the per-iteration kernel): the sums are only right if `wide_rows` lists EVERY row with more than 256
+// values -- the main loop skips those.  The pass therefore counts the wide rows its main loop meets (fetch_meta has
+// their ndist in hand: one LDS atomic per wide row, no register across the row loop) and looks at every list entry it
+// takes (in range, ascending, really wide; a faulty entry is neutralised instead of dereferenced) and leaves
+// {wide rows met, list fault} in chk_result[0..1] (uniform; the kernel stores it beside its partial row, at an address
+// formed from values that are live at the end anyway -- a pointer parameter carried across the row loop cost two
+// registers the kernel does not have); the column reduce compares the total with n_wide and poisons
+// the sums (NaN) + raises mxm_em_state.error when the list is not exactly the set of wide rows.  The one-launch loop is
+// instantiated without it (its register budget; mxm_em_loop_coded validates the list once on entry instead).
+template <int THREADS, int NCH, int NBUF, bool NT, bool RESIDENT, bool WIDE_PREFETCH, bool CHECK = false>
 __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off,
                                                const int32_t *__restrict__ ndist, int ldc, const double *__restrict__ w,
                                                const int64_t *__restrict__ wide_rows, int64_t n_wide, int64_t R,
-                                               const double (&p)[NCH][4], double (&acc)[NCH][4], bool &meta_ready) {
+                                               const double (&p)[NCH][4], double (&acc)[NCH][4], bool &meta_ready,
+                                               int *chk_result = nullptr) {
     static_assert(NBUF >= 3, "codes NBUF - 1 rows ahead, tables NBUF - 2");
     constexpr int NW = THREADS / 64;
     constexpr int AUX = NT ? 2 : 0;
@@ -327,6 +337,34 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
     const bool tbl_thread = (THREADS <= ENC_MAX_CODES) || t < ENC_MAX_CODES;
     const int tslot = t & (ENC_MAX_CODES - 1);
     typedef unsigned int u2v __attribute__((ext_vector_type(2)));
+    __shared__ int s_chk[2];                              // CHECK: {wide rows the main loop met, a list entry was faulty}
+    if constexpr (CHECK) {
+        if (t == 0) s_chk[0] = s_chk[1] = 0;
+        __syncthreads();
+    }
+    // entry e of the wide rows' list; CHECK: -1 (and the fault noted) unless it is in range and above its predecessor
+    auto list_row = [&](int64_t e) -> int64_t {
+        int64_t r = wide_rows[e];
+        if constexpr (CHECK) {
+            if (r < 0 || r >= R || (e > 0 && wide_rows[e - 1] >= r)) {
+                s_chk[1] = 1;
+                r = -1;
+            }
+        }
+        return r;
+    };
+    // table entries of a listed row; CHECK: a row that is not wide at all must not be read as 16-bit codes
+    auto list_nd = [&](int64_t r) -> int {
+        if (r < 0) return 0;
+        int nd = ndist[r];
+        if constexpr (CHECK) {
+            if (nd <= ENC_MAX_CODES) {
+                s_chk[1] = 1;
+                nd = 0;
+            }
+        }
+        return nd;
+    };
 
     // Per-step metadata {record offset, table entries, weight} of THREADS steps at a time in LDS (double
     // buffered): fetched by one thread per step, read back at a uniform address.  As scalar loads inside the
@@ -338,7 +376,12 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
         const int64_t q = q0 + t;
         const int64_t r = deal.row(q);
         int nd = ndist[r];
-        if (nd > ENC_MAX_CODES) nd = 0;                  // a wide row: the second loop's (empty table here, weight 0)
+        if (nd > ENC_MAX_CODES) {                        // a wide row: the second loop's (empty table here, weight 0)
+            if constexpr (CHECK) {
+                if (deal.live(q)) atomicAdd(&s_chk[0], 1);
+            }
+            nd = 0;
+        }
         s_off[half][t] = rec_off[r];
         s_nd[half][t] = nd;
         s_wr[half][t] = (deal.live(q) && nd > 0) ? (w != nullptr ? w[r] : 1.0) : 0.0;   // dense rows are not ours
@@ -465,9 +508,9 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
     // row loop, and its metadata is mostly resident anyway)
     const bool wide_fetch = WIDE_PREFETCH && nq_w > 0 && (!RESIDENT || !meta_ready);
     int64_t w_row = -1;
-    if (wide_fetch && t < nq_w) w_row = wide_rows[(int64_t)blockIdx.x + (int64_t)t * (int64_t)gridDim.x];
+    if (wide_fetch && t < nq_w) w_row = list_row((int64_t)blockIdx.x + (int64_t)t * (int64_t)gridDim.x);
     long long w_off = 0;
-    int w_nd = 0;
+    int w_nd = CHECK ? -1 : 0;
     double w_wr = 0.0;
 
     if (deal.nq > 0) {                                   // (a one-launch grid may be larger than a tiny matrix)
@@ -487,8 +530,8 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
         read_meta(NBUF - 1, 0);
         lookup_row(reinterpret_cast<const char *>(&s_tbl[0][0]), cw[0]);
         if (w_row >= 0) {                                // second level of the wide rows' metadata: in flight under the main loop
-            w_off = rec_off[w_row];
-            w_nd = ndist[w_row];
+            w_off = rec_off[w_row];                      // (CHECK looks at w_nd where it is consumed, not here: a use
+            w_nd = ndist[w_row];                         //  would wait for the loads instead of leaving them in flight)
             w_wr = (w != nullptr) ? w[w_row] : 1.0;
         }
         for (int64_t q = 0; q < deal.nq; q += NBUF) {
@@ -520,6 +563,13 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
         for (int64_t q0 = 0; q0 < nq_w; q0 += THREADS) {
             if (q0 == 0 && wide_fetch) {
                 __syncthreads();
+                if constexpr (CHECK) {                   // a listed row that is not wide must not be read as 16-bit codes
+                    if (w_nd >= 0 && w_nd <= ENC_MAX_CODES) s_chk[1] = 1;      // (-1: no entry, or one list_row struck)
+                    if (w_nd <= ENC_MAX_CODES) {
+                        w_nd = 0;
+                        w_wr = 0.0;
+                    }
+                }
                 s_woff[t] = w_off;                       // asked for before the main loop
                 s_wnd[t] = w_nd;
                 s_wwr[t] = w_wr;
@@ -527,10 +577,11 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
                 __syncthreads();                         // the previous batch's entries have been read
                 const int64_t q = q0 + t;
                 if (q < nq_w) {
-                    const int64_t r = wide_rows[(int64_t)blockIdx.x + q * (int64_t)gridDim.x];
-                    s_woff[t] = rec_off[r];
-                    s_wnd[t] = ndist[r];
-                    s_wwr[t] = (w != nullptr) ? w[r] : 1.0;
+                    const int64_t r = list_row((int64_t)blockIdx.x + q * (int64_t)gridDim.x);
+                    const int nd = list_nd(r);
+                    s_woff[t] = (r >= 0) ? rec_off[r] : 0;
+                    s_wnd[t] = nd;
+                    s_wwr[t] = (nd > 0) ? ((w != nullptr) ? w[r] : 1.0) : 0.0;
                 }
             }
             __syncthreads();
@@ -599,6 +650,11 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
         }
     }
     meta_ready = true;
+    if constexpr (CHECK) {
+        __syncthreads();                                 // every fault and every count is in
+        chk_result[0] = s_chk[0];
+        chk_result[1] = s_chk[1];
+    }
 }
 
 template <int THREADS, int NCH, int NBUF, int MINWG>
@@ -622,7 +678,13 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
         }
     }
     bool meta_ready = false;
-    coded_row_pass<THREADS, NCH, NBUF, true, false, true>(rec, rec_off, ndist, ldc, w, wide_rows, n_wide, R, p, acc, meta_ready);
+    int chk[2];
+    coded_row_pass<THREADS, NCH, NBUF, true, false, true, true>(rec, rec_off, ndist, ldc, w, wide_rows, n_wide, R, p, acc, meta_ready, chk);
+    if (t == 0) {                                        // {wide rows met, list fault}: behind the partial rows this path can use
+        int *out = reinterpret_cast<int *>(partial + (int64_t)MXM_MAX_WG * ldpart) + 2 * blockIdx.x;
+        out[0] = chk[0];
+        out[1] = chk[1];
+    }
 
     double *dst = partial + (int64_t)blockIdx.x * ldpart;
 #pragma unroll
@@ -632,6 +694,28 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
         for (int e = 0; e < 4; ++e)
             if (c + e < H) dst[c + e] = acc[k][e];
     }
+}
+
+// The wide rows' list against ndist, for the blocking entry point (mxm_em_loop_coded validates once, on entry):
+// out[0] += rows with more than 256 values, out[1] = 1 if a list entry is out of range, not ascending or not wide.
+__global__ __launch_bounds__(256) void coded_validate_kernel(const int32_t *__restrict__ ndist, int64_t R,
+                                                            const int64_t *__restrict__ wide_rows, int64_t n_wide,
+                                                            unsigned long long *__restrict__ out) {
+    __shared__ unsigned long long s_n;
+    if (threadIdx.x == 0) s_n = 0;
+    __syncthreads();
+    unsigned long long n = 0;
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t r = (int64_t)blockIdx.x * 256 + threadIdx.x; r < R; r += stride) n += (ndist[r] > ENC_MAX_CODES) ? 1 : 0;
+    bool bad = false;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_wide; e += stride) {
+        const int64_t r = wide_rows[e];
+        bad = bad || r < 0 || r >= R || (e > 0 && wide_rows[e - 1] >= r) || ndist[r < 0 || r >= R ? 0 : r] <= ENC_MAX_CODES;
+    }
+    if (n) atomicAdd(&s_n, n);
+    if (bad) out[1] = 1ull;
+    __syncthreads();
+    if (threadIdx.x == 0 && s_n) atomicAdd(&out[0], s_n);
 }
 
 // decode (tests, posterior pass from records): P[r][h] = table[codes[h]] for coded rows; others untouched

@@ -389,12 +389,36 @@ __global__ __launch_bounds__(ROW_THREADS) void linearize_f32_kernel(const double
 // (the loop's finalize works from the unscaled sums, see finalize_kernel).
 // ------------------------------------------------------------------------------------------
 #define COLRED_THREADS 1024
+// What the records' row pass leaves beside its partial rows (coded_kernels.hpp, CHECK): {wide rows met, list fault} per
+// workgroup.  The list of wide rows is exactly the set of rows with more than 256 values iff no fault was seen and the
+// counts add up to n_wide; otherwise rows were skipped or read twice and the sums are NOT the matrix's: poisoned.
+struct wide_check {
+    const int *chk;                   // nullptr: nothing to check (dense matrices, votes)
+    int n_chk;
+    long long n_wide;
+};
+__device__ __forceinline__ bool wide_check_failed(const wide_check &wc) {
+    if (wc.chk == nullptr) return false;                    // uniform
+    __shared__ int s_v[2];
+    if (threadIdx.x == 0) s_v[0] = s_v[1] = 0;
+    __syncthreads();
+    int c = 0, bad = 0;
+    for (int i = threadIdx.x; i < wc.n_chk; i += blockDim.x) {
+        c += wc.chk[2 * i];
+        bad |= wc.chk[2 * i + 1];
+    }
+    if (c) atomicAdd(&s_v[0], c);
+    if (bad) s_v[1] = 1;
+    __syncthreads();
+    return s_v[1] != 0 || (long long)s_v[0] != wc.n_wide;
+}
+
 __global__ __launch_bounds__(COLRED_THREADS) void colreduce_kernel(const double *__restrict__ partial,
                                                                    int64_t ldpart, int nwg, int nb, int H,
                                                                    const double *__restrict__ props,
                                                                    double *__restrict__ colsum,
-                                                                   const mxm_em_state *__restrict__ state,
-                                                                   mxm_slots slots) {
+                                                                   mxm_em_state *__restrict__ state,
+                                                                   mxm_slots slots, wide_check wc) {
     // grid = (ceil(H/64), nb); partial is [nwg][nb][ldpart] (tile-local b); props / colsum / state are
     // the loop vectors' bases, indexed by the restart slots.s[b].
     // 16 waves take interleaved sixteenths of the partial rows, four independent chains each
@@ -404,6 +428,8 @@ __global__ __launch_bounds__(COLRED_THREADS) void colreduce_kernel(const double 
     const int b = blockIdx.y;
     const int run = slots.s[b];
     if (state != nullptr && state[run].done != 0) return;
+    const bool poisoned = wide_check_failed(wc);
+    if (poisoned && state != nullptr && blockIdx.x == 0 && threadIdx.x == 0) state[run].error = 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int h = blockIdx.x * 64 + lane;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -425,6 +451,7 @@ __global__ __launch_bounds__(COLRED_THREADS) void colreduce_kernel(const double 
         double tot = part[0][lane];
 #pragma unroll
         for (int q = 1; q < NW; ++q) tot += part[q][lane];
+        if (poisoned) tot = __builtin_nan("");
         colsum[(int64_t)run * H + h] = (props != nullptr) ? props[(int64_t)run * H + h] * tot : tot;
     }
 }
@@ -565,8 +592,12 @@ __device__ __forceinline__ void finalize_tail(const double *__restrict__ cs, dou
             }
         }
     }
-    __syncthreads();                                        // (the re-formed values above read ln before anyone wrote it? no:
-                                                            // each thread rewrites only the columns it read itself)
+    // The columns beyond the register window are formed twice from u = ln[h] (once for the L1 sum, once here).  That is
+    // race-free without a barrier in between: column h is read AND rewritten by the one thread that owns it (h = blk * 64
+    // + lane, blk = wv + k * NW) -- no other thread of this workgroup touches ln[h], and the other workgroups finished
+    // with ln before their ticket (finalize_arrive), which this workgroup saw as the last arriver.  The barrier below
+    // only orders the state write after every wave's vector writes.
+    __syncthreads();
     if (t == 0) {
         st->iters = iters;
         st->l1 = l1;
@@ -623,13 +654,15 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(const double *__r
 __global__ __launch_bounds__(COLRED_THREADS) void colreduce_finalize_kernel(
     const double *__restrict__ partial, int64_t ldpart, int nwg, int nb, int H, double *__restrict__ colsum,
     double *__restrict__ ln_cur, double *__restrict__ ln_new, double *__restrict__ props_cur, double tol, int max_iter,
-    mxm_em_state *__restrict__ state, mxm_slots slots) {
+    mxm_em_state *__restrict__ state, mxm_slots slots, wide_check wc) {
     constexpr int NW = COLRED_THREADS / 64;
     __shared__ double part[NW][64];
     const int b = blockIdx.y;
     const int run = slots.s[b];
     mxm_em_state *st = state + run;
     if (st->done != 0) return;
+    const bool poisoned = wide_check_failed(wc);
+    if (poisoned && blockIdx.x == 0 && threadIdx.x == 0) st->error = 1;
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int h = blockIdx.x * 64 + lane;
     double s0 = 0.0, s1 = 0.0, s2 = 0.0, s3 = 0.0;
@@ -655,6 +688,7 @@ __global__ __launch_bounds__(COLRED_THREADS) void colreduce_finalize_kernel(
         double tot = part[0][lane];
 #pragma unroll
         for (int q = 1; q < NW; ++q) tot += part[q][lane];
+        if (poisoned) tot = __builtin_nan("");
         const auto cs_rs = __builtin_amdgcn_make_buffer_rsrc(cs, 0, H * 8, 0x00020000);
         const auto ln_rs = __builtin_amdgcn_make_buffer_rsrc(ln, 0, H * 8, 0x00020000);
         __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(fin_u2, tot), cs_rs, h * 8, 0, 16 /* sc1 */);

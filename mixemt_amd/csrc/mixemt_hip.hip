@@ -579,14 +579,15 @@ struct fin_args {
 
 // column reduce of a tile's partial rows [0, nwg); with `fin` the finalize follows in the same launch
 static int reduce_tile(const double *partial, int nwg, int nb, int H, double *colsum, const mxm_em_state *state,
-                       const mxm_slots &slots, const fin_args *fin, hipStream_t stream) {
+                       const mxm_slots &slots, const fin_args *fin, hipStream_t stream,
+                       wide_check wc = wide_check{nullptr, 0, 0}) {
     if (fin != nullptr && H <= 64 * FIN_MAX_BLOCKS)
         hipLaunchKernelGGL(colreduce_finalize_kernel, dim3((H + 63) / 64, nb), dim3(COLRED_THREADS), 0, stream, partial,
                            part_ld(H), nwg, nb, H, colsum, fin->ln_cur, fin->ln_new, fin->props_cur, fin->tol, fin->max_iter,
-                           fin->state, slots);
+                           fin->state, slots, wc);
     else
         hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, nb), dim3(COLRED_THREADS), 0, stream, partial, part_ld(H), nwg,
-                           nb, H, (const double *)nullptr, colsum, state, slots);
+                           nb, H, (const double *)nullptr, colsum, const_cast<mxm_em_state *>(state), slots, wc);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -643,7 +644,7 @@ static int em_iter_f32_one(const float *P, int64_t ldp, const double *w, const d
     HIP_TRY(hipGetLastError());
     if (timed && T.ev_stop != nullptr) HIP_TRY(hipEventRecord(T.ev_stop, stream));
     hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg,
-                       1, H, (const double *)nullptr, colsum, state, slots_from(0));
+                       1, H, (const double *)nullptr, colsum, const_cast<mxm_em_state *>(state), slots_from(0), wide_check{nullptr, 0, 0});
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -691,7 +692,7 @@ static int em_iter_log_one(const double *M, int64_t ldm, const double *w, const 
         HIP_TRY(hipGetLastError());
     }
     hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, stream, partial, ldpart, nwg, 1,
-                       H, (const double *)nullptr, colsum, state, slots_from(0));
+                       H, (const double *)nullptr, colsum, const_cast<mxm_em_state *>(state), slots_from(0), wide_check{nullptr, 0, 0});
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -841,7 +842,8 @@ extern "C" int mxm_row_argmax_votes_coded(const mxm_coded *c, int32_t H, int32_t
             // would double the kernel's time)
 #define RA_CASE(n) case n: { int per_cu = 2; if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, records_argmax_narrow_kernel<n>, 256, 0) != hipSuccess || per_cu < 1) { (void)hipGetLastError(); per_cu = 2; } \
                 hipLaunchKernelGGL((records_argmax_narrow_kernel<n>), dim3(clamp_grid(c->R, num_cu() * per_cu)), dim3(256), 0, s, c->rec, c->rec_off, c->ndist, ldc_a, c->R, (int)H, ln_props, best); \
-                if (c->n_wide > 0) hipLaunchKernelGGL((records_argmax_kernel<n>), dim3(clamp_grid(c->n_wide, num_cu() * 2)), dim3(256), 0, s, c->rec, c->rec_off, c->ndist, ldc_a, c->n_wide, (int)H, ln_props, best, c->wide_rows); } break;
+                /* the wide rows, found from ndist itself (no list: the vote must not depend on one) */ \
+                hipLaunchKernelGGL((records_argmax_kernel<n, true>), dim3(clamp_grid((c->R + 255) / 256, num_cu() * 2)), dim3(256), 0, s, c->rec, c->rec_off, c->ndist, ldc_a, c->R, (int)H, ln_props, best, (const int64_t *)nullptr); } break;
             RA_CASE(1) RA_CASE(2) RA_CASE(3) RA_CASE(4) RA_CASE(5) RA_CASE(6) RA_CASE(7) RA_CASE(8)
 #undef RA_CASE
             default: fast = false;
@@ -868,7 +870,7 @@ extern "C" int mxm_row_argmax_votes_coded(const mxm_coded *c, int32_t H, int32_t
         hipLaunchKernelGGL(votes_from_best_kernel, dim3(nwg), dim3(256), vlds, s, best, w, c->R, (int)H, (double *)ws, ldpart);
         HIP_TRY(hipGetLastError());
         hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, s, (const double *)ws, ldpart, nwg,
-                           1, (int)H, (const double *)nullptr, votes, (const mxm_em_state *)nullptr, slots_from(0));
+                           1, (int)H, (const double *)nullptr, votes, (mxm_em_state *)nullptr, slots_from(0), wide_check{nullptr, 0, 0});
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -956,6 +958,9 @@ static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *
     if (cap < 1) cap = 1;
     const int nwg = clamp_grid((c->R + sh.nbuf - 1) / sh.nbuf, cap);
     if (timed && T.ev_start != nullptr) HIP_TRY(hipEventRecord(T.ev_start, stream));
+    // {wide rows met, list fault} per workgroup: the kernel leaves them behind the partial rows this path can use
+    // (coded_row_pass, CHECK; em_iter_coded_kernel forms the same address)
+    int *chk = reinterpret_cast<int *>(partial + (int64_t)MXM_MAX_WG * ldpart);
     int lrc;
     lrc = launch_coded<256, 4, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run);
     if (lrc != 0) return lrc;
@@ -971,11 +976,11 @@ static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *
                                                name of their own in a trace, apart from the dense matrix's passes */);
         if (rc != 0) return rc;
     }
-    return reduce_tile(partial, nwg + nwg_rest, 1, H, colsum, state, sl, fin, stream);
+    return reduce_tile(partial, nwg + nwg_rest, 1, H, colsum, state, sl, fin, stream, wide_check{chk, nwg, (long long)c->n_wide});
 }
 
 extern "C" int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, int32_t H, int32_t B,
-                                 const mxm_em_state *state, double *colsum, void *ws, size_t ws_bytes, void *stream) {
+                                 mxm_em_state *state, double *colsum, void *ws, size_t ws_bytes, void *stream) {
     MXM_ENTER();
     const int rc = coded_check(c, H, "mxm_em_iter_coded");
     if (rc != 0) return rc;
@@ -1459,6 +1464,11 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
         }
         LOOP_TRY(hipMemcpyAsync(state_host, state, sizeof(mxm_em_state) * B, hipMemcpyDeviceToHost, s));
         LOOP_TRY(hipStreamSynchronize(s));
+        for (int b = 0; b < B; ++b)
+            if (state_host[b].error != 0) {
+                rc = fail(-1, "mxm_em_loop: the records' wide_rows list does not match the rows with more than 256 values%s", "");
+                goto done;
+            }
         if (T.progress != nullptr) T.progress(state_host, B, T.progress_user);
         std::vector<int> still;
         for (int b : order)
@@ -1494,6 +1504,23 @@ extern "C" int mxm_em_loop_coded(const mxm_coded *c, const double *w, int32_t H,
     MXM_ENTER();
     const int rc = coded_check(c, H, "mxm_em_loop_coded");
     if (rc != 0) return rc;
+    if (ws == nullptr || ws_bytes < mxm_workspace_bytes(c->R, H, B)) return fail(-1, "mxm_em_loop_coded: workspace too small%s", "");
+    {
+        // The loop skips the rows with 16-bit codes in its main pass and takes them from `wide_rows`: the list must be
+        // exactly those rows.  This call blocks anyway, so it is checked once, here (the one-launch loop has no room for
+        // the in-kernel check the per-iteration kernel carries).
+        unsigned long long *chk = static_cast<unsigned long long *>(ws), host[2] = {0, 0};
+        hipStream_t s = (hipStream_t)stream;
+        HIP_TRY(hipMemsetAsync(chk, 0, 2 * sizeof(unsigned long long), s));
+        hipLaunchKernelGGL(coded_validate_kernel, dim3(clamp_grid((c->R + 255) / 256, num_cu() * 4)), dim3(256), 0, s, c->ndist, c->R,
+                           c->wide_rows, c->n_wide, chk);
+        HIP_TRY(hipGetLastError());
+        HIP_TRY(hipMemcpyAsync(host, chk, sizeof(host), hipMemcpyDeviceToHost, s));
+        HIP_TRY(hipStreamSynchronize(s));
+        if (host[1] != 0 || (long long)host[0] != (long long)c->n_wide)
+            return fail(-1, "mxm_em_loop_coded: wide_rows must list exactly the rows with more than 256 values, ascending "
+                            "%s(%lld such rows, n_wide = %lld)", "", (long long)host[0], (long long)c->n_wide);
+    }
     return em_loop_impl(nullptr, 0, nullptr, 0, w, c->R, H, B, props_cur, ln_cur, ln_new, colsum, state, tol, max_iter,
                         check_every, ws, ws_bytes, stream, state_host, false, c);
 }
@@ -1560,7 +1587,7 @@ extern "C" int mxm_em_step(const double *M, int64_t ldm, const double *w, const 
     HIP_TRY(hipGetLastError());
     if (colsum != nullptr) {
         hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, s, (const double *)ws, ldpart, nwg,
-                           1, (int)H, (const double *)nullptr, colsum, (const mxm_em_state *)nullptr, slots_from(0));
+                           1, (int)H, (const double *)nullptr, colsum, (mxm_em_state *)nullptr, slots_from(0), wide_check{nullptr, 0, 0});
         HIP_TRY(hipGetLastError());
     }
     return 0;
@@ -1677,7 +1704,7 @@ extern "C" int mxm_row_argmax_votes(const double *X, int64_t ldx, const double *
     if (votes != nullptr) {
         hipLaunchKernelGGL(colreduce_kernel, dim3((H + 63) / 64, 1), dim3(COLRED_THREADS), 0, (hipStream_t)stream,
                            (const double *)part, ldpart, nwg, 1, (int)H, (const double *)nullptr, votes,
-                           (const mxm_em_state *)nullptr, slots_from(0));
+                           (mxm_em_state *)nullptr, slots_from(0), wide_check{nullptr, 0, 0});
         HIP_TRY(hipGetLastError());
     }
     return 0;

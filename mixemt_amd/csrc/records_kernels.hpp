@@ -122,9 +122,12 @@ __global__ __launch_bounds__(256) void posterior_argmax_kernel(
 // read single code bytes and every ln_props[h] from memory per row: 14.4 ms at 10^6 rows (profiles/r04), this one 2.
 // Rows without a record get best[r] = -1 (the dense pass fills them in).
 // ------------------------------------------------------------------------------------------
-// `rows` (nullable): the kernel then takes the rows rows[0 .. R) instead of 0 .. R-1 -- the wide rows' list, behind
-// records_argmax_narrow_kernel, which leaves those to it.
-template <int NCH>
+// `rows` (nullable): the kernel then takes the rows rows[0 .. R) instead of 0 .. R-1.
+// ONLY_WIDE: behind records_argmax_narrow_kernel, which leaves the wide rows (more than 256 values) to this kernel: every
+// block of 256 rows is looked at and only its wide rows are taken (compacted in LDS; in any order -- rows are
+// independent); the others are neither read nor written.  It finds the wide rows from ndist itself: the vote never
+// depends on a caller's list.
+template <int NCH, bool ONLY_WIDE = false>
 __global__ __launch_bounds__(256) void records_argmax_kernel(const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off,
                                                              const int32_t *__restrict__ ndist, int ldc, int64_t R, int H,
                                                              const double *__restrict__ ln_props, int32_t *__restrict__ best,
@@ -181,17 +184,33 @@ __global__ __launch_bounds__(256) void records_argmax_kernel(const uint8_t *__re
         }
     };
     int buf = 0;
+    __shared__ int s_cnt;
     for (int64_t q0 = 0; q0 < nq; q0 += THREADS) {
         __syncthreads();                                     // the block before has been read
+        int n_here = (int)((nq - q0) < THREADS ? (nq - q0) : THREADS);
         {
             int64_t r = (int64_t)blockIdx.x + (q0 + t) * grid;
             if (rows != nullptr && q0 + t < nq) r = rows[r];
-            s_nd[t] = (q0 + t < nq) ? ndist[r] : 0;
-            s_off[t] = (q0 + t < nq) ? rec_off[r] : 0;
-            s_row[t] = r;
+            const int nd = (q0 + t < nq) ? ndist[r] : 0;
+            const long long off = (q0 + t < nq) ? rec_off[r] : 0;
+            if constexpr (ONLY_WIDE) {
+                if (t == 0) s_cnt = 0;
+                __syncthreads();
+                if (nd > ENC_MAX_CODES) {
+                    const int k = atomicAdd(&s_cnt, 1);
+                    s_nd[k] = nd;
+                    s_off[k] = off;
+                    s_row[k] = r;
+                }
+            } else {
+                s_nd[t] = nd;
+                s_off[t] = off;
+                s_row[t] = r;
+            }
         }
         __syncthreads();
-        const int n_here = (int)((nq - q0) < THREADS ? (nq - q0) : THREADS);
+        if constexpr (ONLY_WIDE) n_here = s_cnt;
+        if (n_here == 0) continue;                           // uniform
         fetch(0);
         for (int i = 0; i < n_here; ++i, buf ^= 1) {
             const int64_t r = s_row[i];

@@ -618,3 +618,80 @@ def test_one_launch_loop_over_records_with_many_rows_per_workgroup(b17, lib, gri
     for _ in range(want["iters"][0]):
         buf, theta = em_oracle.em_step(mat, wts, theta, buf)
     assert numpy.abs(want["run_props"][0] - numpy.exp(theta)).max() < 1e-11
+
+
+def test_the_wide_rows_list_is_checked_where_it_is_used(b17):
+    """the EM iteration skips rows with 16-bit codes in its main pass and takes them from mxm_coded.wide_rows,
+    so a descriptor WITHOUT the list (or with an incomplete / unsorted / wrong one) must fail loudly instead of dropping
+    2 % of the rows: mxm_em_iter_coded poisons its sums (NaN) and raises state.error on the device, mxm_em_loop_coded
+    refuses on entry; the vote finds the wide rows from ndist itself and never needs the list."""
+    import torch
+    from mixemt_amd import _lib, assign, em, preprocess, synth
+    from mixemt_amd._dev import current_stream
+    refseq, phy, haps, tables = b17
+    n_rows, n_haps = 3000, len(haps)
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=77)
+    cm = preprocess.build_em_records_device(tables, row_ptr, site, obs)
+    wide = cm.wide_rows()
+    assert wide.numel() >= 10 and cm.rest_rows.numel() == 0
+    wts = torch.ones(n_rows, dtype=torch.float64, device="cuda")
+    plan = em.EmPlan(None, wts, records=cm)
+    lib = _lib.load()
+    props = torch.from_numpy(numpy.random.default_rng(5).dirichlet([1.0] * n_haps)[None, :]).cuda()
+    good = torch.zeros_like(props)
+    plan.em_iter(props, torch.log(props), em.new_state(1, props.device), good)
+    assert torch.isfinite(good).all() and abs(float((props * good).sum()) - n_rows) < 1e-9 * n_rows
+
+    def descriptor(rows):
+        return _lib.Coded(cm.rec.data_ptr(), cm.rec_off.data_ptr(), cm.ndist.data_ptr(), n_rows, None, 0, None, 0,
+                          rows.data_ptr() if rows is not None and rows.numel() else None, 0 if rows is None else int(rows.numel()))
+
+    unsorted = wide.flip(0).contiguous()
+    not_wide = wide.clone()
+    not_wide[3] = int(torch.nonzero(cm.ndist <= 256)[0])                       # a byte-coded row passed off as wide
+    not_wide = not_wide.sort().values
+    out_of_range = wide.clone()
+    out_of_range[-1] = n_rows + 12345
+    for label, rows in (("no list", None), ("one missing", wide[1:].contiguous()), ("unsorted", unsorted),
+                        ("not wide", not_wide), ("out of range", out_of_range)):
+        coded = descriptor(rows)
+        state = em.new_state(1, props.device)
+        colsum = torch.zeros_like(props)
+        _lib.check(lib.mxm_em_iter_coded(ctypes.byref(coded), wts.data_ptr(), props.data_ptr(), n_haps, 1, state.data_ptr(),
+                                         colsum.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, current_stream()), label)
+        torch.cuda.synchronize()
+        assert torch.isnan(colsum).all(), label                                 # never a plausible, wrong sum
+        with pytest.raises(ValueError, match="wide_rows"):
+            em.read_state(state)
+        # without a state the sums are poisoned all the same
+        colsum.zero_()
+        _lib.check(lib.mxm_em_iter_coded(ctypes.byref(coded), wts.data_ptr(), props.data_ptr(), n_haps, 1, None,
+                                         colsum.data_ptr(), plan.ws.data_ptr(), plan.ws_bytes, current_stream()), label)
+        assert torch.isnan(colsum).all(), label
+        # the blocking loop refuses on entry, the loop vectors untouched
+        ln0 = torch.log(props).clone()
+        ln_cur, ln_new, pc = ln0.clone(), ln0.clone(), props.clone()
+        st = em.new_state(1, props.device)
+        host_state = (_lib.EmState * 1)()
+        rc = lib.mxm_em_loop_coded(ctypes.byref(coded), wts.data_ptr(), n_haps, 1, pc.data_ptr(), ln_cur.data_ptr(), ln_new.data_ptr(),
+                                   colsum.data_ptr(), st.data_ptr(), 1e-4, 50, 8, plan.ws.data_ptr(), plan.ws_bytes, current_stream(),
+                                   host_state)
+        assert rc == -1 and b"wide_rows" in lib.mxm_last_error(), label
+        assert torch.equal(ln_cur, ln0) and torch.equal(pc, props)
+    # the right list again: same bits as before (the check itself changes nothing)
+    again = torch.zeros_like(props)
+    coded = descriptor(wide)
+    _lib.check(lib.mxm_em_iter_coded(ctypes.byref(coded), wts.data_ptr(), props.data_ptr(), n_haps, 1, None, again.data_ptr(),
+                                     plan.ws.data_ptr(), plan.ws_bytes, current_stream()), "good list")
+    assert torch.equal(again, good)
+    # the vote does not read the list at all: a descriptor without it gives every row its call
+    ln_theta = torch.log(props)[0]
+    best_ref = assign.row_argmax_votes_records(cm, ln_theta.cpu().numpy(), None)[0]
+    assert (best_ref >= 0).all()
+    best = torch.full((n_rows,), -7, dtype=torch.int32, device="cuda")
+    coded = descriptor(None)
+    _lib.check(lib.mxm_row_argmax_votes_coded(ctypes.byref(coded), n_haps, 1, ln_theta.data_ptr(), None, None, None, 0, None, 0,
+                                              None, best.data_ptr(), None, None, 0, current_stream()), "votes without the list")
+    assert numpy.array_equal(best.cpu().numpy(), best_ref)
+    dense = cm.dense().cpu().numpy() + ln_theta.cpu().numpy()[None, :]
+    assert numpy.array_equal(best_ref, dense.argmax(axis=1))
