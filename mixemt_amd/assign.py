@@ -15,6 +15,7 @@ Matrices may be numpy arrays (uploaded) or ROCm tensors.
 """
 
 import collections
+import collections.abc
 import sys
 
 import numpy
@@ -85,13 +86,19 @@ def _row_argmax_votes_records_device(cm, ln_theta_k, wts=None):
     import ctypes
     lib = _lib.load()
     dev = cm.rec.device
-    lnp = as_device(ln_theta_k, torch.float64, dev)
-    lnp = lnp.reshape(1, -1) if lnp.dim() == 1 else lnp
-    lnp = lnp.contiguous()
+    if isinstance(ln_theta_k, torch.Tensor):
+        lnp = as_device(ln_theta_k, torch.float64, dev)
+        lnp = (lnp.reshape(1, -1) if lnp.dim() == 1 else lnp).contiguous()
+        props = torch.exp(lnp)
+    else:
+        # H values per run: exponentiated on the host (the process's first torch.exp on the device loads torch's
+        # elementwise kernels -- 18 ms that landed in this 3 ms stage)
+        host = numpy.atleast_2d(numpy.ascontiguousarray(ln_theta_k, dtype=numpy.float64))
+        lnp = torch.from_numpy(host).to(dev)
+        props = torch.from_numpy(numpy.exp(host)).to(dev)
     n_runs = lnp.shape[0]
     if lnp.dim() != 2 or lnp.shape[1] != cm.n_haps:
         raise ValueError("ln_theta_k does not match the matrix width")
-    props = torch.exp(lnp)
     best = torch.zeros(cm.n_rows, dtype=torch.int32, device=dev)
     votes = torch.zeros(cm.n_haps, dtype=torch.float64, device=dev)
     w_d = None if wts is None else as_device(wts, torch.float64, dev)
@@ -167,27 +174,86 @@ def update_contribs(contribs, em_results, haps):
     return contribs
 
 
+class AssignedReads(collections.abc.Mapping):
+    """
+    assign_read_indexes' result -- contributor name -> set of row indexes, plus 'unassigned' (assemble.py:284-334) -- held
+    as ONE small integer per row: the sets are only formed when someone looks at them (a 10^6-row table of Python
+    integers costs 40 ms to build and nothing downstream of the EM needs it before a writer asks).  Behaves like the
+    reference's defaultdict(set) for reading: keys are the names that got at least one row (contributors in their
+    order, then 'unassigned'), table[name] is a set (empty for a name without rows), dict(table) the reference's dict.
+        count(name)   rows of `name` without forming the set
+        rows(name)    their indexes as a numpy array (ascending)
+    """
+
+    def __init__(self, assigned, names):
+        self._assigned = numpy.asarray(assigned)             # ordinal of the contributor, -1 = unassigned
+        self._names = list(names)
+        counts = numpy.bincount(self._assigned[self._assigned >= 0], minlength=len(self._names)) if self._assigned.size \
+            else numpy.zeros(len(self._names), dtype=numpy.int64)
+        self._counts = {name: int(counts[i]) for i, name in enumerate(self._names)}
+        n_un = int((self._assigned < 0).sum())
+        self._keys = [name for name in self._names if self._counts[name] > 0]
+        if n_un:
+            self._counts["unassigned"] = n_un
+            self._keys.append("unassigned")
+        self._sets = {}
+
+    def rows(self, name):
+        if name == "unassigned" and "unassigned" not in self._names:
+            return numpy.flatnonzero(self._assigned < 0)
+        if name not in self._names:
+            return numpy.zeros(0, dtype=numpy.int64)
+        return numpy.flatnonzero(self._assigned == self._names.index(name))
+
+    def count(self, name):
+        return self._counts.get(name, 0)
+
+    def __getitem__(self, name):
+        got = self._sets.get(name)
+        if got is None:
+            got = set(self.rows(name).tolist())
+            if name in self._keys:
+                self._sets[name] = got
+        return got
+
+    def __iter__(self):
+        return iter(self._keys)
+
+    def __len__(self):
+        return len(self._keys)
+
+    def __contains__(self, name):
+        return name in self._keys
+
+    def __eq__(self, other):
+        try:
+            return dict(self) == dict(other)
+        except (TypeError, ValueError):
+            return NotImplemented
+
+    def __repr__(self):
+        return "AssignedReads(%s)" % ", ".join("%s: %d" % (k, self._counts[k]) for k in self._keys)
+
+
 def assign_read_indexes(contribs, em_results, haps, reads, min_fold):
     """
     assemble.assign_read_indexes (assemble.py:284-334): contributor name -> set
     of row indexes, plus 'unassigned'; a row goes to its best contributor when,
     after dividing out the mixture proportions, it beats the runner-up by
     min_fold.  One gather kernel (mxm_assign_reads) instead of an argsort of
-    all H columns per row.
+    all H columns per row; the result is an AssignedReads (one integer per row, sets formed on demand).
     """
     props, read_hap_mat = em_results
-    out = collections.defaultdict(set)
     n_rows = len(reads)
+    names = [hap_n for hap_n, _, _ in contribs]
     if len(contribs) <= 1:
-        out[contribs[0][0]].update(range(n_rows))
-        return out
+        return AssignedReads(numpy.zeros(n_rows, dtype=numpy.int32), names[:1])
     lib = _lib.load()
     dev = require_gpu()
     mat = as_device(read_hap_mat, torch.float64, dev)
     with numpy.errstate(divide="ignore"):
         log_props = numpy.log(numpy.asarray(props, dtype=numpy.float64))
     cols = numpy.array([haps.index(group) for _, group, _ in contribs], dtype=numpy.int32)
-    names = [hap_n for hap_n, _, _ in contribs]
     lp_d = torch.from_numpy(log_props).to(dev)
     cols_d = torch.from_numpy(cols).to(dev)
     assigned = torch.empty(n_rows, dtype=torch.int32, device=dev)
@@ -195,12 +261,4 @@ def assign_read_indexes(contribs, em_results, haps, reads, min_fold):
         _lib.check(lib.mxm_assign_reads(mat.data_ptr(), mat.stride(0), lp_d.data_ptr(), cols_d.data_ptr(),
                                         len(cols), n_rows, mat.shape[1], float(numpy.log(min_fold)),
                                         assigned.data_ptr(), current_stream()), "mxm_assign_reads")
-    host = assigned.cpu().numpy()
-    for i, name in enumerate(names):
-        mine = numpy.flatnonzero(host == i)
-        if mine.size:                      # like the reference's defaultdict: no key without reads
-            out[name].update(mine.tolist())
-    rest = numpy.flatnonzero(host < 0)
-    if rest.size:
-        out["unassigned"].update(rest.tolist())
-    return out
+    return AssignedReads(assigned.cpu().numpy(), names)

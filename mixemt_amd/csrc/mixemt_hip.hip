@@ -26,6 +26,7 @@
 //   fused_cols_kernels.hpp  em_fused_cols_kernel (the same for up to 1536 rows, columns split over the workgroups, matrix in registers)
 //   coded_kernels.hpp   encode_rows_kernel, em_iter_coded_kernel (row-dictionary storage: one byte per cell + the row's distinct values)
 //   fused_coded_kernels.hpp  em_fused_coded_kernel (the whole EM loop over records in one persistent launch)
+//   fused_narrow_kernels.hpp  em_fused_narrow_kernel (the same for the refinement EM's few columns: the matrix in registers)
 //   aln_encode.hpp      HOST code: mxm_aln_encode, the batched alignment front end (process_reads + reduce_reads + row order)
 // This file: the host side of the C ABI (shape checks, grid sizing, dispatch, the loop driver).
 #include <hip/hip_runtime.h>
@@ -56,6 +57,7 @@
 #include "fused_kernels.hpp"
 #include "fused_cols_kernels.hpp"
 #include "fused_coded_kernels.hpp"
+#include "fused_narrow_kernels.hpp"
 
 
 // ------------------------------------------------------------------------------------------
@@ -1162,6 +1164,48 @@ static bool launch_fused_coded(int nwg, bool resident, hipStream_t s, const mxm_
     }
 }
 
+// The one-launch loop of a narrow matrix (fused_narrow_kernels.hpp): grid and rows per thread, or 0 if it does not apply
+// (more than 32 columns, more rows than the grid's registers hold).
+static int fused_narrow_grid(int64_t R, int H, int *rpt_out) {
+    if (H < 1 || H > 16 || R < 1) return 0;
+    const int hmax = H <= 4 ? 4 : (H <= 8 ? 8 : 16);
+    int cap = num_cu() < FNARROW_MAX_WG ? num_cu() : FNARROW_MAX_WG;          // one workgroup of 512 per CU
+    const int nwg = clamp_grid((R + FNARROW_THREADS - 1) / FNARROW_THREADS, cap);
+    const int64_t per = (R + (int64_t)nwg * FNARROW_THREADS - 1) / ((int64_t)nwg * FNARROW_THREADS);
+    int rpt = 1;
+    while (rpt < per) rpt *= 2;
+    if (rpt * hmax > FNARROW_MAX_CELLS || (hmax == 16 && rpt > 1)) return 0;      // the instances that compile without scratch
+    *rpt_out = rpt;
+    return nwg;
+}
+static size_t fused_narrow_bytes(int H, int nwg) { return (size_t)2 * H * ((nwg + 7) & ~7) * sizeof(double); }
+
+template <int HMAX, int RPT>
+static bool launch_fused_narrow_one(int nwg, hipStream_t s, const double *M, int64_t ldm, const double *w, int64_t R, int H, int B,
+                                    double *ln_cur, double *ln_new, double *props_cur, mxm_em_state *state, double tol,
+                                    int max_iter, int chunk, double *partial, fused_sync *sync) {
+    if constexpr (HMAX * RPT > FNARROW_MAX_CELLS || (HMAX == 16 && RPT > 1)) {
+        return false;
+    } else {
+        if (!grid_fits(em_fused_narrow_kernel<HMAX, RPT>, FNARROW_THREADS, nwg)) return false;
+        hipLaunchKernelGGL((em_fused_narrow_kernel<HMAX, RPT>), dim3(nwg), dim3(FNARROW_THREADS), 0, s, M, ldm, w, R, H, B, ln_cur,
+                           ln_new, props_cur, state, tol, max_iter, chunk, partial, (nwg + 7) & ~7, sync);
+        return true;
+    }
+}
+static bool launch_fused_narrow(int nwg, int rpt, hipStream_t s, const double *M, int64_t ldm, const double *w, int64_t R, int H,
+                                int B, double *ln_cur, double *ln_new, double *props_cur, mxm_em_state *state, double tol,
+                                int max_iter, int chunk, double *partial, fused_sync *sync) {
+#define FN_ARGS nwg, s, M, ldm, w, R, H, B, ln_cur, ln_new, props_cur, state, tol, max_iter, chunk, partial, sync
+#define FN_RPT(hm) (rpt == 1 ? launch_fused_narrow_one<hm, 1>(FN_ARGS) : rpt == 2 ? launch_fused_narrow_one<hm, 2>(FN_ARGS) \
+                   : rpt == 4 ? launch_fused_narrow_one<hm, 4>(FN_ARGS) : rpt == 8 ? launch_fused_narrow_one<hm, 8>(FN_ARGS) : false)
+    if (H <= 4) return FN_RPT(4);
+    if (H <= 8) return FN_RPT(8);
+    return FN_RPT(16);
+#undef FN_RPT
+#undef FN_ARGS
+}
+
 // The loop of every restart in [0, B) that is not done yet, in launches of at most `chunk` iterations
 // per restart (one launch unless the caller wants to look at the state in between).
 // Returns 0 when every restart has stopped; MXM_FUSED_GAVE_UP when a launch could not run to its end -- the grid does
@@ -1172,14 +1216,18 @@ static bool launch_fused_coded(int nwg, bool resident, hipStream_t s, const mxm_
 static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t R, int32_t H, int32_t B,
                          double *props_cur, double *ln_cur, double *ln_new, mxm_em_state *state, double tol,
                          int32_t max_iter, int32_t chunk, void *ws, size_t ws_bytes, hipStream_t s,
-                         mxm_em_state *state_host, const mxm_coded *coded = nullptr) {
+                         mxm_em_state *state_host, const mxm_coded *coded = nullptr, const double *M_narrow = nullptr,
+                         int64_t ldm_narrow = 0) {
     // The persistent grid needs every workgroup resident, one per CU.  Two such grids in flight on one
     // device (two host threads, two streams) can each hold a part of the CUs and wait for the rest for
     // ever -- the bounded spins would end both after seconds.  Inside one process the launches are
     // therefore serialised here; across processes sharing a GPU nothing can (see the header).
     static std::mutex one_loop_at_a_time;
     std::lock_guard<std::mutex> guard(one_loop_at_a_time);
-    const int nwg = coded != nullptr ? fused_coded_grid(coded->R) : (num_cu() < MXM_MAX_WG ? num_cu() : MXM_MAX_WG);
+    int narrow_rpt = 1;
+    const int nwg = M_narrow != nullptr ? fused_narrow_grid(R, (int)H, &narrow_rpt)
+                    : coded != nullptr  ? fused_coded_grid(coded->R)
+                                        : (num_cu() < MXM_MAX_WG ? num_cu() : MXM_MAX_WG);
     const int64_t ldpart = part_ld(H);
     char *base = static_cast<char *>(ws);
     fused_sync *sync = reinterpret_cast<fused_sync *>(base);
@@ -1224,7 +1272,11 @@ static int em_loop_fused(const double *P, int64_t ldp, const double *w, int64_t 
         if (T.fused_force_abort)                                       // test hook: as if a workgroup had given up
             HIP_TRY(hipMemsetAsync(&sync->abort_[0], 1, sizeof(unsigned), s));
         bool fits = true;
-        if (coded != nullptr) {
+        if (M_narrow != nullptr) {
+            // narrow matrix: [sync][partial sums 2 x H x grid]; the rows live in registers for the whole launch
+            fits = launch_fused_narrow(nwg, narrow_rpt, s, M_narrow, ldm_narrow, w, R, (int)H, (int)B, ln_cur, ln_new, props_cur,
+                                       state, tol, (int)max_iter, (int)chunk, reinterpret_cast<double *>(base + fused_sync_bytes()), sync);
+        } else if (coded != nullptr) {
             // records: [sync][T (1 row)][partial rows]; the metadata of a workgroup's rows stays in LDS for the whole
             // launch when they fit its blocks (256 rows and 256 wide rows per workgroup)
             const int ldc = coded_ld(H);
@@ -1341,6 +1393,17 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
         if (chunk > cap) chunk = cap;
         const int frc = em_loop_fused(nullptr, 0, w, R, H, B, props_cur, ln_cur, ln_new, state, tol, max_iter, chunk, ws, ws_bytes,
                                       caller, state_host, coded);
+        if (frc != MXM_FUSED_GAVE_UP) return frc;
+        if (T.loop_fused == 1) return -3;
+    } else if (int nrpt = 0; !p_is_f32 && coded == nullptr && M != nullptr && T.loop_fused != 0 && running > 0 && max_iter > 0 &&
+                            !(P != nullptr && mxm_linear_supported(H)) && fused_narrow_grid(R, (int)H, &nrpt) > 0 &&
+                            ws_bytes >= fused_sync_bytes() + fused_narrow_bytes((int)H, FNARROW_MAX_WG) + fused_snapshot_bytes(H, B) + 256) {
+        // narrow matrix (the refinement EM on the contributors' columns): the whole loop in one persistent launch,
+        // restarts one after another, the rows in registers
+        int chunk = T.fused_chunk > 0 ? T.fused_chunk : max_iter;
+        if (T.progress != nullptr && chunk > T.progress_every) chunk = T.progress_every;
+        const int frc = em_loop_fused(nullptr, 0, w, R, H, B, props_cur, ln_cur, ln_new, state, tol, max_iter, chunk, ws, ws_bytes,
+                                      caller, state_host, nullptr, M, ldm);
         if (frc != MXM_FUSED_GAVE_UP) return frc;
         if (T.loop_fused == 1) return -3;
     } else if (fused_eligible(P, ldp, R, (int)H, (int)B, ws_bytes, p_is_f32, running)) {

@@ -569,21 +569,73 @@ def _gather_csr(row_ptr_d, site_d, obs_d, rows):
 
 RECORD_BYTES_GUESS = 16 * 96          # table bytes per row the first record buffer allows for (synth-v1 needs 16 x 61 on average,
                                       # wide records included: 6.39 KB per row at H = 5408)
+REST_SLAB_ROWS = 8192                 # rows without a marker-kernel record are built densely and coded this many at a time
 
 
-def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None):
+def record_buffer_bytes(n_rows, n_haps):
+    """Size of the record buffer build_em_records_device asks for first (a guess; an overflow repeats the build once)."""
+    ldc = (n_haps + 7) // 8 * 8
+    one = 2 * ldc + 16 * 1024
+    worst = int(n_rows) * one
+    return max(one, min(worst, int(n_rows) * (ldc + RECORD_BYTES_GUESS) + (1 << 20)))
+
+
+class RecordBufferReservation(object):
+    """
+    The record buffer, allocated on a helper thread while the host does something else (round 5).  A fresh device
+    allocation of this size is not free -- the driver hands out cleared pages: 0.11-0.36 s for the 7 GB of 10^6 rows
+    (profiles/r04/pipeline_1m_records.txt), 6-20 x the 18 ms the build's kernels take -- and nothing it has to wait for
+    exists before the rows are counted.  build_em_input starts it as soon as the front end knows the number of rows, so
+    it runs under HapVarTables.build / the CSR upload; a caller with a row count of its own can start it earlier still:
+        res = preprocess.reserve_record_buffer(n_rows, n_haps)
+        ... host work ...
+        cm = preprocess.build_em_records_device(tables, row_ptr, site, obs, rec=res)
+    """
+
+    def __init__(self, nbytes, dev):
+        import threading
+        self.nbytes, self._dev, self._buf, self._exc = int(nbytes), dev, None, None
+        self._thread = threading.Thread(target=self._run, daemon=True)
+        self._thread.start()
+
+    def _run(self):
+        try:
+            torch.cuda.set_device(self._dev)
+            self._buf = torch.empty((self.nbytes,), dtype=torch.uint8, device=self._dev)
+        except Exception as exc:       # (surfaced by get(): an allocation failure becomes the caller's ValueError)
+            self._exc = exc
+
+    def get(self):
+        self._thread.join()
+        if self._exc is not None:
+            if isinstance(self._exc, torch.cuda.OutOfMemoryError):
+                raise ValueError("not enough device memory for the coded matrix (%.1f GB): %s" % (self.nbytes / 1e9, self._exc))
+            raise self._exc
+        return self._buf
+
+
+def reserve_record_buffer(n_rows, n_haps, nbytes=None):
+    """Start allocating build_em_records_device's record buffer in the background (RecordBufferReservation)."""
+    dev = require_gpu()
+    return RecordBufferReservation(record_buffer_bytes(n_rows, n_haps) if nbytes is None else nbytes, dev)
+
+
+def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, rec=None):
     """
     CSR observations -> CodedMatrix: the marker kernel writes each row as a row-dictionary record
     (one byte per haplogroup + the row's distinct values) -- what em.EmPlan(storage="coded") otherwise
     makes from the dense matrix with a pass of its own.  dense=False: NO dense matrix is written (5.5 GB
     instead of 43 GB at 10^6 x 5408; 10^7 rows fit one GPU); rows the marker kernel cannot take (more than
     64 observations, more than 256 distinct values: ~3.5 %) are built densely by the lookup-table kernel and
-    coded from there (mxm_encode_rows: byte codes up to 256 values, 16-bit codes up to 1024); what remains
-    (more than 1024 values: none on build_em_matrix's rows) stays dense in `m_rest`.
+    coded from there (mxm_encode_rows: byte codes up to 256 values, 16-bit codes up to 1024) REST_SLAB_ROWS at a
+    time, so the detour never holds more than one slab of dense rows (round 4 built all of them at once: 1.4 GB at
+    10^6 rows, 14 GB at 10^7); what remains (more than 1024 values: none on build_em_matrix's rows) stays dense in `m_rest`.
     dense=True: returns (CodedMatrix, M) with the full dense matrix as well.
     cap: bytes of the record buffer.  Default: room for RECORD_BYTES_GUESS table bytes per row instead of the
     worst case mxm_record_bytes (27 KB per row: a 27 GB hipMalloc at 10^6 rows for 6 GB of records); the kernels
     count what they would have needed, and an overflow repeats the build once with exactly that much.
+    rec: a buffer to build into -- a uint8 device tensor or a RecordBufferReservation (reserve_record_buffer: the
+    allocation then ran beside the caller's host work); too small a one is only the first attempt.
     """
     lib = _lib.load()
     dev = require_gpu()
@@ -600,8 +652,14 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None):
     ldc = (n_haps + 7) // 8 * 8
     worst = lib.mxm_record_bytes(n_rows, n_haps)
     one = 2 * ldc + 16 * 1024                       # a full wide record: the smallest buffer the library accepts
-    if cap is None:
-        cap = min(worst, max(one, n_rows * (ldc + RECORD_BYTES_GUESS) + (1 << 20)))
+    if isinstance(rec, RecordBufferReservation):
+        rec = rec.get()
+    if rec is not None and (rec.dtype != torch.uint8 or not rec.is_cuda or rec.numel() < one or rec.data_ptr() % 16):
+        rec = None
+    if rec is not None:
+        cap = rec.numel()
+    elif cap is None:
+        cap = record_buffer_bytes(n_rows, n_haps)
     cap = max(int(cap), one)
     mat = device_empty((n_rows, n_haps), torch.float64, dev, "the EM input matrix") if dense else None
     rec_off = torch.empty(n_rows, dtype=torch.int64, device=dev)
@@ -618,62 +676,74 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None):
             out.data_ptr(), out.stride(0), current_stream()), "mxm_build_em_matrix_lut")
 
     for attempt in (0, 1):
-        rec = device_empty((cap,), torch.uint8, dev, "the coded matrix")
+        if rec is None:
+            rec = device_empty((cap,), torch.uint8, dev, "the coded matrix")
         _lib.check(lib.mxm_build_em_records(
             enc["maj"].data_ptr(), enc["lhit"].data_ptr(), enc["lmiss"].data_ptr(), enc["mk_ptr"].data_ptr(),
             enc["mk_hap"].data_ptr(), enc["mk_base"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(),
             0, n_rows, n_haps, n_sites, mat.data_ptr() if dense else 0, mat.stride(0) if dense else 0,
             rec.data_ptr(), cap, rec_off.data_ptr(), ndist.data_ptr(), rowmax.data_ptr(), stats.data_ptr(),
             fallback.data_ptr(), n_fallback.data_ptr(), current_stream()), "mxm_build_em_records")
-        used, n_rest = (int(v) for v in stats.cpu())
-        left = int(n_fallback.item())
+        counts = torch.cat([stats, n_fallback]).cpu()
+        used, n_rest, left = (int(v) for v in counts)
         need = used
+        m_rest = None
         if used <= cap:
             rest_rows = torch.nonzero(ndist == 0).flatten()
             assert rest_rows.numel() == n_rest
-            m_rest = None
-            if dense:
-                if left:
-                    rows = fallback[:left].sort().values
-                    lut_rows(row_ptr_d, site_d, obs_d, rows.data_ptr(), left, mat)
-                if n_rest:
-                    m_rest = mat.index_select(0, rest_rows)
-            elif n_rest:
+            if dense and left:
+                rows = fallback[:left].sort().values
+                lut_rows(row_ptr_d, site_d, obs_d, rows.data_ptr(), left, mat)
+            if not dense:
                 assert left == n_rest             # without a dense matrix every row without a record is on the list
-                sub_ptr, sub_site, sub_obs = _gather_csr(row_ptr_d, site_d, obs_d, rest_rows)
-                m_rest = torch.empty((n_rest, n_haps), dtype=torch.float64, device=dev)
-                lut_rows(sub_ptr, sub_site, sub_obs, 0, n_rest, m_rest)
-            if m_rest is not None:
-                # the dense rows of long reads mostly hold few distinct values too: code them from their dense form
-                # (mxm_encode_rows: bytes, then 16-bit codes) into the tail of the same record buffer
-                base = (used + 15) // 16 * 16
-                sub_off = torch.empty(n_rest, dtype=torch.int64, device=dev)
-                sub_nd = torch.empty(n_rest, dtype=torch.int32, device=dev)
-                sub_rm = torch.empty(n_rest, dtype=torch.float64, device=dev)
+            if n_rest:
+                # the dense rows of long reads mostly hold few distinct values too: built (or taken from the dense matrix)
+                # a slab at a time and coded from their dense form (mxm_encode_rows: bytes, then 16-bit codes) into the
+                # tail of the same record buffer; what still has no record afterwards is kept, dense
+                slab = min(n_rest, REST_SLAB_ROWS)
+                m_slab = None if dense else torch.empty((slab, n_haps), dtype=torch.float64, device=dev)
+                sub_off = torch.empty(slab, dtype=torch.int64, device=dev)
+                sub_nd = torch.empty(slab, dtype=torch.int32, device=dev)
+                sub_rm = torch.empty(slab, dtype=torch.float64, device=dev)
                 sub_stats = torch.zeros(2, dtype=torch.int64, device=dev)
-                if cap - base >= one:
-                    _lib.check(lib.mxm_encode_rows(m_rest.data_ptr(), m_rest.stride(0), n_rest, n_haps, rec.data_ptr() + base,
-                                                   cap - base, sub_off.data_ptr(), sub_nd.data_ptr(), sub_rm.data_ptr(),
-                                                   sub_stats.data_ptr(), current_stream()), "mxm_encode_rows")
-                    sub_used = int(sub_stats[0].item())
-                else:
-                    sub_used = n_rest * one               # no room left at all: ask for the worst case of these rows
-                need = base + sub_used
+                kept_rows, kept_dense = [], []
+                for lo in range(0, n_rest, slab):
+                    rows_s = rest_rows[lo:lo + slab]
+                    n_s = int(rows_s.numel())
+                    if dense:
+                        m_s = mat.index_select(0, rows_s)
+                    else:
+                        sub_ptr, sub_site, sub_obs = _gather_csr(row_ptr_d, site_d, obs_d, rows_s)
+                        m_s = m_slab[:n_s]
+                        lut_rows(sub_ptr, sub_site, sub_obs, 0, n_s, m_s)
+                    base = (need + 15) // 16 * 16
+                    if cap - base >= one:
+                        _lib.check(lib.mxm_encode_rows(m_s.data_ptr(), m_s.stride(0), n_s, n_haps, rec.data_ptr() + base,
+                                                       cap - base, sub_off.data_ptr(), sub_nd.data_ptr(), sub_rm.data_ptr(),
+                                                       sub_stats.data_ptr(), current_stream()), "mxm_encode_rows")
+                        sub_used = int(sub_stats[0].item())
+                    else:
+                        sub_used = n_s * one              # no room left at all: ask for the worst case of these rows
+                    if base + sub_used <= cap and cap - base >= one:
+                        got = sub_nd[:n_s] > 0
+                        rows_c = rows_s[got]
+                        rec_off[rows_c] = sub_off[:n_s][got] + base
+                        ndist[rows_c] = sub_nd[:n_s][got]
+                        rowmax[rows_c] = sub_rm[:n_s][got]
+                        if not bool(got.all()):
+                            kept_rows.append(rows_s[~got])
+                            kept_dense.append(m_s[~got].clone())
+                    need = base + sub_used
                 if need <= cap:
-                    got = sub_nd > 0
-                    rows_c = rest_rows[got]
-                    rec_off[rows_c] = sub_off[got] + base
-                    ndist[rows_c] = sub_nd[got]
-                    rowmax[rows_c] = sub_rm[got]
                     used = need
-                    rest_rows = rest_rows[~got]
-                    m_rest = m_rest[~got].contiguous()
+                    rest_rows = torch.cat(kept_rows) if kept_rows else rest_rows[:0]
+                    m_rest = torch.cat(kept_dense) if kept_dense else None
                     n_rest = int(rest_rows.numel())
         if need <= cap:
             break
         if attempt == 1:
             raise ValueError("build_em_records_device: record buffer of %d bytes overflowed twice (%d needed)" % (cap, need))
-        del rec
+        rec = None
         cap = min(worst, need + (n_rest + 1) * one)       # exact for the marker kernel's records, generous for the rest
     build_em_matrix_device.last_fallback = left
     cm = CodedMatrix(n_rows, n_haps, rec, rec_off, ndist, rowmax, used,
@@ -736,13 +806,15 @@ def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False, as_reco
         if verbose:
             sys.stderr.write("Using %d aligned fragments (MQ>=%d) (%d distinct sub-haplotypes)\n\n"
                              % (enc.n_fragments - len(dropped), args.min_mq, enc.n_rows))
+        # the record buffer's allocation runs beside the table set-up (RecordBufferReservation)
+        reservation = reserve_record_buffer(enc.n_rows, len(haplogroups)) if (as_records and enc.n_rows > 0) else None
         tables = HapVarTables.build(refseq, phylo, haplogroups)
         if not numpy.array_equal(tables.sites, numpy.asarray(var_pos, dtype=numpy.int64)):
             raise ValueError("build_em_input: the tables' sites are not phylo.get_variant_pos()")
         if verbose:
             sys.stderr.write("Building EM input matrix...\n")
         if as_records:
-            em_matrix = build_em_records_device(tables, enc.row_ptr, enc.site, enc.obs)
+            em_matrix = build_em_records_device(tables, enc.row_ptr, enc.site, enc.obs, rec=reservation)
         else:
             em_matrix = build_em_matrix_device(tables, enc.row_ptr, enc.site, enc.obs)
             if not as_device_tensor:

@@ -271,6 +271,163 @@ __global__ __launch_bounds__(256, WG_PER_CU) void delayed_kernel(const uint8_t *
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Part 3: TWO rows per step -- rows 2s and 2s + 1 of the workgroup share one barrier; their ladders and divisions are
+// independent instruction streams the scheduler can interleave (the product kernel's chain has nothing beside it).
+// Costs a second set of row values (48 registers); proportions stay in registers.  NP pairs in the ring.
+// ------------------------------------------------------------------------------------------------------------------
+template <int NCH, int NP, int WG_PER_CU>
+__global__ __launch_bounds__(256, WG_PER_CU) void pair_kernel(const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off,
+                                                              const int32_t *__restrict__ ndist, int ldc,
+                                                              const double *__restrict__ w, const double *__restrict__ props,
+                                                              int64_t R, int H, double *__restrict__ partial, int64_t ldpart) {
+    constexpr int THREADS = 256, NW = 4;
+    static_assert(NP >= 3, "codes NP - 1 pairs ahead, tables NP - 2");
+    __shared__ double s_tbl[NP][2][C3_MAX_CODES];
+    __shared__ __attribute__((aligned(16))) double red[NP][2][NW];
+    __shared__ long long s_off[2][THREADS];
+    __shared__ double s_wr[2][THREADS];
+    __shared__ int s_nd[2][THREADS];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const int nword = ldc >> 2;
+    const row_deal deal(R);
+    const int voff = t * 4;
+    int last_w = t + (NCH - 1) * THREADS;
+    if (last_w > nword - 1) last_w = nword - 1;
+    const int voff_last = last_w * 4;
+    const int tslot = t & (C3_MAX_CODES - 1);
+    double p[NCH][4], acc[NCH][4];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (t + k * THREADS) + e;
+            p[k][e] = (c < H) ? props[c] : 0.0;
+            acc[k][e] = 0.0;
+        }
+    auto fetch_meta = [&](int half, int64_t q0) {
+        const int64_t q = q0 + t;
+        const int64_t r = deal.row(q);
+        int nd = ndist[r];
+        if (nd > C3_MAX_CODES) nd = 0;
+        s_off[half][t] = rec_off[r];
+        s_nd[half][t] = nd;
+        s_wr[half][t] = (deal.live(q) && nd > 0) ? (w != nullptr ? w[r] : 1.0) : 0.0;
+    };
+    unsigned int cw[NP][2][NCH];
+    double tring[NP][2];
+    auto load_row = [&](int64_t q, unsigned int(&cws)[NCH], double &tbl_entry) {
+        const int half = (int)((q / THREADS) & 1), idx = (int)(q % THREADS);
+        const long long off = s_off[half][idx];
+        const int nd = __builtin_amdgcn_readfirstlane(s_nd[half][idx]);
+        const uint8_t *base = rec + (((long long)__builtin_amdgcn_readfirstlane((int)(off >> 32)) << 32) |
+                                     (unsigned int)__builtin_amdgcn_readfirstlane((int)off));
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, ldc, 0x00020000);
+#pragma unroll
+        for (int k = 0; k < NCH - 1; ++k) cws[k] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff, k * THREADS * 4, 2);
+        cws[NCH - 1] = __builtin_amdgcn_raw_buffer_load_b32(rs, voff_last, 0, 2);
+        const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base + ldc), 0, nd * 8, 0x00020000);
+        const c3_u2 v = __builtin_amdgcn_raw_buffer_load_b64(rt, tslot * 8, 0, 2);
+        tbl_entry = __hiloint2double((int)v.y, (int)v.x);
+    };
+    auto lookup = [&](const char *tb, unsigned int word, auto E) -> double {
+        return *reinterpret_cast<const double *>(tb + code_byte_x8<decltype(E)::value>(word));
+    };
+    using E0 = std::integral_constant<int, 0>;
+    using E1 = std::integral_constant<int, 1>;
+    using E2 = std::integral_constant<int, 2>;
+    using E3 = std::integral_constant<int, 3>;
+    double va[NCH][4], vb[NCH][4];
+    auto step = [&](auto J, int64_t q) {                  // q = first row of the pair
+        constexpr int j = decltype(J)::value;
+        constexpr int jn = (j + 1) % NP, jl = (j + NP - 1) % NP;
+        // metadata blocks: the loads below read steps q + 2 (NP - 1), + 1; a block of 256 steps is fetched when the
+        // pair index crosses into its second half (THREADS is even, so pairs never straddle a block)
+        if ((q % THREADS) == 0) fetch_meta((int)((q / THREADS + 1) & 1), q + THREADS);
+        load_row(q + 2 * (NP - 1), cw[jl][0], tring[jl][0]);
+        load_row(q + 2 * (NP - 1) + 1, cw[jl][1], tring[jl][1]);
+        const double wra = s_wr[(q / THREADS) & 1][q % THREADS], wrb = s_wr[((q + 1) / THREADS) & 1][(q + 1) % THREADS];
+        double sa4[4] = {0.0, 0.0, 0.0, 0.0}, sb4[4] = {0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                sa4[e] = fma(va[k][e], p[k][e], sa4[e]);
+                sb4[e] = fma(vb[k][e], p[k][e], sb4[e]);
+            }
+        double sa = (sa4[0] + sa4[1]) + (sa4[2] + sa4[3]), sb = (sb4[0] + sb4[1]) + (sb4[2] + sb4[3]);
+        __builtin_amdgcn_s_setprio(1);
+        sa = wave_sum_lane63(sa);
+        sb = wave_sum_lane63(sb);
+        if (lane == 63) {
+            red[j][0][wv] = sa;
+            red[j][1][wv] = sb;
+        }
+        s_tbl[jn][0][tslot] = tring[jn][0];
+        s_tbl[jn][1][tslot] = tring[jn][1];
+        __syncthreads();
+        typedef double d2v __attribute__((ext_vector_type(2)));
+        const d2v a0 = *reinterpret_cast<const d2v *>(&red[j][0][0]), a1 = *reinterpret_cast<const d2v *>(&red[j][0][2]);
+        const d2v b0 = *reinterpret_cast<const d2v *>(&red[j][1][0]), b1 = *reinterpret_cast<const d2v *>(&red[j][1][2]);
+        const double cfa = readlane_f64(weight_over_norm(wra, (a0.x + a0.y) + (a1.x + a1.y)), 0);
+        const double cfb = readlane_f64(weight_over_norm(wrb, (b0.x + b0.y) + (b1.x + b1.y)), 0);
+        __builtin_amdgcn_s_setprio(0);
+        const char *tna = reinterpret_cast<const char *>(&s_tbl[jn][0][0]);
+        const char *tnb = reinterpret_cast<const char *>(&s_tbl[jn][1][0]);
+        auto upd = [&](int k, auto E) {
+            constexpr int e = decltype(E)::value;
+            acc[k][e] = fma(cfa, va[k][e], acc[k][e]);
+            acc[k][e] = fma(cfb, vb[k][e], acc[k][e]);
+            asm volatile("" : "+v"(acc[k][e]));
+            va[k][e] = lookup(tna, cw[jn][0][k], E);
+            vb[k][e] = lookup(tnb, cw[jn][1][k], E);
+        };
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            upd(k, E0{});
+            upd(k, E1{});
+            upd(k, E2{});
+            upd(k, E3{});
+        }
+    };
+    if (deal.nq > 0) {
+        fetch_meta(0, 0);
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < NP - 1; ++j) {
+            load_row(2 * j, cw[j][0], tring[j][0]);
+            load_row(2 * j + 1, cw[j][1], tring[j][1]);
+        }
+        s_tbl[0][0][tslot] = tring[0][0];
+        s_tbl[0][1][tslot] = tring[0][1];
+        __syncthreads();
+        const char *ta = reinterpret_cast<const char *>(&s_tbl[0][0][0]), *tb = reinterpret_cast<const char *>(&s_tbl[0][1][0]);
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            va[k][0] = lookup(ta, cw[0][0][k], E0{}); va[k][1] = lookup(ta, cw[0][0][k], E1{});
+            va[k][2] = lookup(ta, cw[0][0][k], E2{}); va[k][3] = lookup(ta, cw[0][0][k], E3{});
+            vb[k][0] = lookup(tb, cw[0][1][k], E0{}); vb[k][1] = lookup(tb, cw[0][1][k], E1{});
+            vb[k][2] = lookup(tb, cw[0][1][k], E2{}); vb[k][3] = lookup(tb, cw[0][1][k], E3{});
+        }
+        const int64_t nsteps = (deal.nq + 2 * NP - 1) / (2 * NP) * (2 * NP);
+        for (int64_t q = 0; q < nsteps; q += 2 * NP) {
+            step(std::integral_constant<int, 0>{}, q);
+            step(std::integral_constant<int, 1>{}, q + 2);
+            step(std::integral_constant<int, 2>{}, q + 4);
+            if constexpr (NP > 3) step(std::integral_constant<int, 3>{}, q + 6);
+        }
+    }
+    double *dst = partial + (int64_t)blockIdx.x * ldpart;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = 4 * (t + k * THREADS);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < H) dst[c + e] = acc[k][e];
+    }
+}
+
 static float time_launches(int reps, const std::function<void()> &launch) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.0f;
@@ -319,6 +476,8 @@ extern "C" float coded3_time(int variant, const uint8_t *rec, const int64_t *rec
         case 1: grid = n_cu * 2; ms = time_launches(reps, DL(6, true, 2)); break;      // ... five rows in flight
         case 2: grid = n_cu * 2; ms = time_launches(reps, DL(4, false, 2)); break;     // p in registers (spills expected)
         case 3: grid = n_cu; ms = time_launches(reps, DL(4, false, 1)); break;         // p in registers, one workgroup per CU
+        case 4: grid = n_cu * 2; ms = time_launches(reps, [&]() { hipLaunchKernelGGL((pair_kernel<6, 3, 2>), dim3(grid), dim3(256), 0, 0, rec, rec_off, ndist, ldc, w, props, R, H, partial, ldpart); }); break;
+        case 5: grid = n_cu * 2; ms = time_launches(reps, [&]() { hipLaunchKernelGGL((pair_kernel<6, 4, 2>), dim3(grid), dim3(256), 0, 0, rec, rec_off, ndist, ldc, w, props, R, H, partial, ldpart); }); break;
         default: return -5.0f;
     }
 #undef DL

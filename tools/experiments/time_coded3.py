@@ -81,7 +81,9 @@ partial = torch.zeros((n_cu * 2, ldpart), dtype=torch.float64, device=dev)
 names = {0: "accumulation one row behind, proportions in LDS, 3 rows in flight, 2 workgroups per CU",
          1: "... 5 rows in flight (48 B scratch)",
          2: "... proportions in registers, 3 rows in flight, 2 workgroups per CU",
-         3: "... proportions in registers, 1 workgroup per CU"}
+         3: "... proportions in registers, 1 workgroup per CU",
+         4: "TWO rows per step (one barrier per pair, two independent chains), 2 pairs in flight, 2 workgroups per CU",
+         5: "... 3 pairs in flight"}
 for rep in range(2):
     for v in sorted(names):
         g = I(0)
