@@ -73,6 +73,17 @@ __device__ __forceinline__ void encode_one_row(int64_t r, const double *__restri
         x[k][2] = b.x;
         x[k][3] = b.y;
     }
+    if (H & 1) {
+        // odd width (round 5): the row's last double is the first half of a 16-byte load whose second half lies past the
+        // descriptor.  Whether such a load keeps its in-range half is not something to depend on: its owner fetches the
+        // column again by itself.
+        const double tail = M[r * ldm + (H - 1)];
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            if (4 * (t + k * ENC_THREADS) == H - 1) x[k][0] = tail;
+            if (4 * (t + k * ENC_THREADS) + 2 == H - 1) x[k][2] = tail;
+        }
+    }
 #pragma unroll
     for (int q = 0; q < SPT; ++q) s_key[t + q * ENC_THREADS] = ENC_EMPTY;
     if (t == 0) {

@@ -646,6 +646,47 @@ __global__ __launch_bounds__(FIN_THREADS) void finalize_kernel(const double *__r
     finalize_tail<FIN_THREADS>(cs, lc, ln, pc, H, tol, max_iter, st);
 }
 
+// K5g  finalize for ANY width (round 5; finalize_kernel's block bookkeeping stops at 64 * FIN_MAX_BLOCKS columns): one
+// workgroup per restart, every thread its own columns t, t + 1024, ..., the two sums through block_reduce -- ONE fixed
+// order whatever the caller, so every rank of a sharded run still takes the same decision.  Same update, same state.
+__global__ __launch_bounds__(FIN_THREADS) void finalize_any_kernel(const double *__restrict__ colsum, double *__restrict__ ln_cur,
+                                                                   double *__restrict__ ln_new, double *__restrict__ props_cur,
+                                                                   int H, double tol, int max_iter, mxm_em_state *__restrict__ state,
+                                                                   int base, int use_slots, mxm_slots slots) {
+    __shared__ double scratch[FIN_THREADS / 64];
+    const int b = use_slots ? slots.s[blockIdx.y] : base + (int)blockIdx.y;
+    mxm_em_state *st = state + b;
+    if (st->done != 0) return;
+    const double *cs = colsum + (int64_t)b * H;
+    double *lc = ln_cur + (int64_t)b * H, *ln = ln_new + (int64_t)b * H, *pc = props_cur + (int64_t)b * H;
+    const int t = threadIdx.x;
+    double s = 0.0;
+    for (int h = t; h < H; h += FIN_THREADS) s = fma(pc[h], cs[h], s);
+    const double ltot = log(block_reduce<FIN_THREADS, false>(s, scratch));
+    double d = 0.0;
+    for (int h = t; h < H; h += FIN_THREADS) {
+        const double v = lc[h] + log(cs[h]) - ltot;       // em.py:87-89
+        ln[h] = v;
+        d += fabs(exp(v) - pc[h]);                         // em.py:53-54
+    }
+    const double l1 = block_reduce<FIN_THREADS, false>(d, scratch);
+    const int iters = st->iters + 1;
+    const bool conv = l1 < tol;
+    const bool stop = conv || iters >= max_iter;
+    if (!stop)
+        for (int h = t; h < H; h += FIN_THREADS) {         // (each thread rewrites the columns it wrote itself)
+            const double v = ln[h];
+            lc[h] = v;
+            pc[h] = exp(v);
+        }
+    __syncthreads();
+    if (t == 0) {
+        st->iters = iters;
+        st->l1 = l1;
+        st->done = conv ? 1 : (stop ? 2 : 0);
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // K4+K5  column reduce with the finalize behind it in ONE launch (the single-GPU per-iteration path, where no
 // collective sits between the two): colreduce_kernel's sums, bit for bit, then phase 1 of the finalize for the block's

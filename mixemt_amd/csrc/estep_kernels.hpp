@@ -74,6 +74,59 @@ __global__ __launch_bounds__(ROW_THREADS) void estep_log_kernel(
 }
 
 // ------------------------------------------------------------------------------------------
+// K6g estep_global: estep_log_kernel for ANY width (round 5: the reference takes whatever Phylotree build and custom
+// haplogroups it is given, phylotree.py:231-250; K6 keeps two vectors of H doubles in LDS and stops at 9600 columns).
+// The log proportions are read from global memory and the column sums live in the workgroup's OWN partial row there
+// (thread t owns the columns t, t + 256, ...: a plain read-modify-write, no atomics, fixed order): everything is
+// L2-resident, nothing depends on H but the loop counts.  The fallback of the fallback: correctness, not speed.
+// ------------------------------------------------------------------------------------------
+template <bool ITER>
+__global__ __launch_bounds__(ROW_THREADS) void estep_global_kernel(
+    const double *__restrict__ M, int64_t ldm, const double *__restrict__ w,
+    const double *__restrict__ ln_props, int64_t R, int H, double *__restrict__ out, int64_t ldo,
+    int mode, double *__restrict__ partial, int64_t ldpart,
+    const mxm_em_state *__restrict__ state, const int64_t *__restrict__ out_rows = nullptr) {
+    __shared__ double scratch[ROW_THREADS / 64];
+    if (state != nullptr && state->done != 0) return;
+    const int t = threadIdx.x;
+    double *acc = partial != nullptr ? partial + (int64_t)blockIdx.x * ldpart : nullptr;
+    if (acc != nullptr)
+        for (int h = t; h < H; h += ROW_THREADS) acc[h] = 0.0;
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const double *src = M + r * ldm;
+        const double wr = (w != nullptr) ? w[r] : 1.0;
+        if constexpr (ITER) {
+            double m = -INFINITY;
+            for (int h = t; h < H; h += ROW_THREADS) m = fmax(m, src[h]);
+            m = block_reduce<ROW_THREADS, true>(m, scratch);
+            const double shift = isfinite(m) ? m : 0.0;
+            double z = 0.0;
+            for (int h = t; h < H; h += ROW_THREADS) z += exp(ln_props[h] + (src[h] - shift));
+            z = block_reduce<ROW_THREADS, false>(z, scratch);
+            const double c = weight_over_norm(wr, z);
+            for (int h = t; h < H; h += ROW_THREADS) acc[h] += c * exp(src[h] - shift);
+        } else {
+            double m = -INFINITY;
+            for (int h = t; h < H; h += ROW_THREADS) m = fmax(m, ln_props[h] + src[h]);
+            m = block_reduce<ROW_THREADS, true>(m, scratch);
+            const double shift = isfinite(m) ? m : 0.0;
+            double s = 0.0;
+            for (int h = t; h < H; h += ROW_THREADS) s += exp((ln_props[h] + src[h]) - shift);
+            s = block_reduce<ROW_THREADS, false>(s, scratch);
+            const double lse = log(s) + m;          // m (not shift): -inf rows give -inf, as scipy does
+            for (int h = t; h < H; h += ROW_THREADS) {
+                const double v = (ln_props[h] + src[h]) - lse;
+                if (out != nullptr) {
+                    double *o = out + (out_rows != nullptr ? out_rows[r] : r) * ldo + h;
+                    *o = (mode == 1) ? logaddexp_f64(*o, v) : v;
+                }
+                if (acc != nullptr && wr != 0.0) acc[h] += wr * exp(v);   // scipy drops zero-weight rows, NaN or not
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // K6n estep_narrow: the same two computations for matrices with a handful of columns -- the
 // refinement EM on the contributors' columns (bin/mixemt:311-320, H = 2..10) and its posterior.
 // One THREAD per row (grid-stride): the row, the proportions and the column sums sit in

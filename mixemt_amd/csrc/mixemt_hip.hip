@@ -323,8 +323,8 @@ extern "C" int mxm_build_em_records(const uint8_t *maj, const double *lhit, cons
                                     uint8_t *rec, size_t rec_bytes, int64_t *rec_off, int32_t *ndist, double *rowmax,
                                     int64_t *stats, int64_t *fallback, int64_t *n_fallback, void *stream) {
     MXM_ENTER();
-    if (!mxm_linear_supported(H) || (H & 1))
-        return fail(-1, "mxm_build_em_records: records need an even H in [66, 8192]%s (H=%lld)", "", H);
+    if (!mxm_linear_supported(H))
+        return fail(-1, "mxm_build_em_records: records need H in [65, 8192]%s (H=%lld)", "", H);
     if (rec == nullptr || (reinterpret_cast<uintptr_t>(rec) & 15) || rec_bytes < (size_t)coded_ld(H) + 16 * ENC_MAX_CODES ||
         rec_off == nullptr || ndist == nullptr || rowmax == nullptr || stats == nullptr)
         return fail(-1, "mxm_build_em_records: record buffer (16-byte aligned, >= one record) and output arrays required%s", "");
@@ -680,15 +680,22 @@ static int em_iter_log_one(const double *M, int64_t ldm, const double *w, const 
     if (M == nullptr) return fail(-1, "mxm_em_iter: M is NULL and the linear path does not apply%s", "");
     if (ln_props == nullptr) return fail(-1, "mxm_em_iter: ln_props is NULL and the log-space path needs it%s", "");
     const size_t lds = 2 * (size_t)H * sizeof(double);
-    if (lds > 150 * 1024) return fail(-1, "mxm_em_iter: H=%s%lld too large for the log-space kernel", "", H);
     const int64_t ldpart = part_ld(H);
     int nwg;
-    if (H <= MXM_NARROW_MAX_H) {
+    if (lds > 150 * 1024) {
+        // wider than the log-space kernel's LDS vectors (9600 columns): the any-width form (vectors in global memory)
+        nwg = clamp_grid(R, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
+        hipLaunchKernelGGL((estep_global_kernel<true>), dim3(nwg), dim3(ROW_THREADS), 0, stream, M, ldm, w, ln_props, R, H,
+                           (double *)nullptr, (int64_t)0, 0, partial, ldpart, state, (const int64_t *)nullptr);
+        HIP_TRY(hipGetLastError());
+    } else if (H <= MXM_NARROW_MAX_H) {
         const int rc = launch_narrow<true>(M, ldm, w, ln_props, R, H, (double *)nullptr, (int64_t)0, 0, partial, ldpart,
                                            state, stream, &nwg);
         if (rc != 0) return rc;
     } else {
         nwg = clamp_grid(R, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
+        if (lds > 60 * 1024 && raise_dynamic_lds(reinterpret_cast<const void *>(&estep_log_kernel<true>), lds, "estep_log_kernel") != hipSuccess)
+            return -2;
         hipLaunchKernelGGL((estep_log_kernel<true>), dim3(nwg), dim3(ROW_THREADS), lds, stream, M, ldm, w, ln_props,
                            R, H, (double *)nullptr, (int64_t)0, 0, partial, ldpart, state);
         HIP_TRY(hipGetLastError());
@@ -773,8 +780,11 @@ extern "C" size_t mxm_coded_bytes(int64_t R, int32_t H) { return mxm_record_byte
 extern "C" int mxm_encode_rows(const double *M, int64_t ldm, int64_t R, int32_t H, uint8_t *rec, size_t rec_bytes,
                                int64_t *rec_off, int32_t *ndist, double *rowmax, int64_t *stats, void *stream) {
     if (R <= 0 || H <= 0 || ldm < H) return fail(-1, "mxm_encode_rows: bad shape R=%s%lld H=%lld", "", R, H);
-    if (!mxm_linear_supported(H) || !wide_rows_ok(M, ldm, H))
-        return fail(-1, "mxm_encode_rows: needs an even H in [66, 8192] and 16-byte aligned rows%s (H=%lld ldm=%lld)", "", H, ldm);
+    // (round 5: any H in the linear kernels' range and any row stride -- a row's loads go through a descriptor of exactly
+    // H doubles and need the doubles' own 8-byte alignment only; an odd H or an odd stride used to send the matrix back to
+    // the 7 x larger dense form)
+    if (!mxm_linear_supported(H) || (reinterpret_cast<uintptr_t>(M) & 7) != 0)
+        return fail(-1, "mxm_encode_rows: needs H in [65, 8192]%s (H=%lld ldm=%lld)", "", H, ldm);
     if (rec == nullptr || (reinterpret_cast<uintptr_t>(rec) & 15) || rec_bytes < (size_t)coded_ld(H) + 16 * ENC_MAX_CODES)
         return fail(-1, "mxm_encode_rows: record buffer missing, unaligned or smaller than one record%s", "");
     if (rec_off == nullptr || ndist == nullptr || rowmax == nullptr || stats == nullptr)
@@ -798,7 +808,7 @@ extern "C" int mxm_encode_rows(const double *M, int64_t ldm, int64_t R, int32_t 
 }
 
 static int coded_check(const mxm_coded *c, int32_t H, const char *who) {
-    if (c == nullptr || c->R <= 0 || H <= 0 || !mxm_linear_supported(H) || (H & 1))
+    if (c == nullptr || c->R <= 0 || H <= 0 || !mxm_linear_supported(H))
         return fail(-1, "%s: bad coded matrix (rows %lld, H %lld)", who, c ? c->R : 0, H);
     if (c->rec == nullptr || c->rec_off == nullptr || c->ndist == nullptr) return fail(-1, "%s: coded matrix arrays missing", who);
     if (c->R_rest < 0 || (c->R_rest > 0 && (c->P_rest == nullptr || c->ldp_rest < H || (c->ldp_rest & 1) ||
@@ -1006,7 +1016,12 @@ extern "C" int mxm_restart_tile(int32_t H) {
 extern "C" int mxm_m_finalize(const double *colsum, double *ln_cur, double *ln_new, double *props_cur, int32_t H,
                               int32_t B, double tol, int32_t max_iter, mxm_em_state *state, void *stream) {
     if (H <= 0 || B <= 0 || state == nullptr) return fail(-1, "mxm_m_finalize: bad arguments%s", "");
-    if (H > 64 * FIN_MAX_BLOCKS) return fail(-1, "mxm_m_finalize: H=%s%lld beyond the kernel's range", "", H);
+    if (H > 64 * FIN_MAX_BLOCKS) {                        // any width: one workgroup per restart
+        hipLaunchKernelGGL(finalize_any_kernel, dim3(1, B), dim3(FIN_THREADS), 0, (hipStream_t)stream, colsum, ln_cur, ln_new,
+                           props_cur, (int)H, tol, (int)max_iter, state, 0, 0, slots_from(0));
+        HIP_TRY(hipGetLastError());
+        return 0;
+    }
     hipLaunchKernelGGL(finalize_kernel, dim3((H + FIN_THREADS - 1) / FIN_THREADS, B), dim3(FIN_THREADS), 0, (hipStream_t)stream,
                        colsum, ln_cur, ln_new, props_cur, (int)H, tol, (int)max_iter, state, 0, 0, slots_from(0));
     HIP_TRY(hipGetLastError());
@@ -1360,9 +1375,12 @@ static int enqueue_tile_iteration(const double *M, int64_t ldm, const double *P,
             if (rc != 0) return rc;
         }
     }
-    if (H > 64 * FIN_MAX_BLOCKS) return fail(-1, "mxm_em_loop: H=%s%lld beyond the finalize kernel's range", "", H);
-    hipLaunchKernelGGL(finalize_kernel, dim3((H + FIN_THREADS - 1) / FIN_THREADS, nb), dim3(FIN_THREADS), 0, s, colsum, ln_cur,
-                       ln_new, props_cur, (int)H, tol, (int)max_iter, state, 0, 1, tile);
+    if (H > 64 * FIN_MAX_BLOCKS)
+        hipLaunchKernelGGL(finalize_any_kernel, dim3(1, nb), dim3(FIN_THREADS), 0, s, colsum, ln_cur, ln_new, props_cur, (int)H, tol,
+                           (int)max_iter, state, 0, 1, tile);
+    else
+        hipLaunchKernelGGL(finalize_kernel, dim3((H + FIN_THREADS - 1) / FIN_THREADS, nb), dim3(FIN_THREADS), 0, s, colsum, ln_cur,
+                           ln_new, props_cur, (int)H, tol, (int)max_iter, state, 0, 1, tile);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -1642,10 +1660,16 @@ extern "C" int mxm_em_step(const double *M, int64_t ldm, const double *w, const 
         if (rc != 0) return rc;
     } else {
         const size_t lds = 2 * (size_t)H * sizeof(double);
-        if (lds > 150 * 1024) return fail(-1, "mxm_em_step: H=%s%lld too large", "", H);
         nwg = clamp_grid(R, num_cu() * 2 < MXM_MAX_WG ? num_cu() * 2 : MXM_MAX_WG);
-        hipLaunchKernelGGL((estep_log_kernel<false>), dim3(nwg), dim3(ROW_THREADS), lds, s, M, ldm, w, ln_props, R,
-                           (int)H, out, ldo, (int)mode, partial, ldpart, (const mxm_em_state *)nullptr, (const int64_t *)nullptr);
+        if (lds > 150 * 1024) {                            // any width: the vectors in global memory
+            hipLaunchKernelGGL((estep_global_kernel<false>), dim3(nwg), dim3(ROW_THREADS), 0, s, M, ldm, w, ln_props, R, (int)H, out,
+                               ldo, (int)mode, partial, ldpart, (const mxm_em_state *)nullptr, (const int64_t *)nullptr);
+        } else {
+            if (lds > 60 * 1024 && raise_dynamic_lds(reinterpret_cast<const void *>(&estep_log_kernel<false>), lds, "estep_log_kernel") != hipSuccess)
+                return -2;
+            hipLaunchKernelGGL((estep_log_kernel<false>), dim3(nwg), dim3(ROW_THREADS), lds, s, M, ldm, w, ln_props, R,
+                               (int)H, out, ldo, (int)mode, partial, ldpart, (const mxm_em_state *)nullptr, (const int64_t *)nullptr);
+        }
     }
     HIP_TRY(hipGetLastError());
     if (colsum != nullptr) {

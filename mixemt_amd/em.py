@@ -127,9 +127,9 @@ class EmPlan(object):
         ~1e-8 of the fp64 path on the goldens, inside the 1e-6 parity bar, but
         NOT what the headline benchmark runs.  "coded" keeps every fp64 bit and
         stores each row as one byte per column plus the row's distinct values
-        (mxm_encode_rows; rows with more than 256 of them stay dense): the matrix
+        (mxm_encode_rows; 16-bit codes up to 1024 values, denser rows stay dense): the matrix
         build's rows hold a few dozen distinct sums, so the loop reads ~8x fewer
-        bytes.  Matrices it does not apply to (odd / narrow H, unaligned rows)
+        bytes.  Matrices it does not apply to (fewer than 65 or more than 8192 columns)
         iterate as "f64".  "auto" = "coded" where it pays: more than 1.5 * 10^7 cells
         (below that the one-launch loops over the dense matrix are faster) and at
         most a quarter of the rows left dense by the encoder; otherwise "f64".
@@ -163,8 +163,9 @@ class EmPlan(object):
             storage = "coded" if (float(self.n_rows) * self.n_haps > AUTO_CODED_MIN_CELLS) else "f64"
             self.storage = storage
         if storage == "coded":
-            if (self.n_rows > 0 and self.lib.mxm_linear_supported(self.n_haps) and self.n_haps % 2 == 0
-                    and self.mat.stride(1) == 1 and self.mat.stride(0) % 2 == 0 and self.mat.data_ptr() % 16 == 0):
+            # (round 5: any width the linear kernels take, odd included, and any row stride -- an odd H, e.g. Build 17 plus
+            # one custom haplogroup, used to fall back to the 7 x larger dense matrix here)
+            if self.n_rows > 0 and self.lib.mxm_linear_supported(self.n_haps) and self.mat.stride(1) == 1:
                 self.encode()
                 if auto and self.coded_rest > AUTO_CODED_MAX_REST * self.n_rows:
                     self.coded = None                 # rows do not compress (not a build_em_matrix matrix): dense

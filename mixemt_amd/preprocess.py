@@ -639,8 +639,8 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
     """
     lib = _lib.load()
     dev = require_gpu()
-    if tables.lut() is None or tables.n_haps > 8192 or tables.n_haps % 2 or not lib.mxm_linear_supported(tables.n_haps):
-        raise ValueError("records need tables that qualify for the lookup-table kernel and an even H in [66, 8192]")
+    if tables.lut() is None or tables.n_haps > 8192 or not lib.mxm_linear_supported(tables.n_haps):
+        raise ValueError("records need tables that qualify for the lookup-table kernel and H in [65, 8192]")
     enc = tables.sparse_device()
     lut = tables.lut_device()
     row_ptr_d = as_device(row_ptr, torch.int64, dev)
