@@ -262,14 +262,18 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
     ms = beg.elapsed_time(end) / steps
     kernel_ms = kev[0].elapsed_time(kev[1])
     loop_ms = loop_ms_per_iteration(em, torch, cplan, props[0], max(steps, 50))
-    return {"ms_per_step": loop_ms, "value": float(n_rows) * n_haps / (loop_ms * 1e-3), "unit": "cells/s",
-            "ms_per_step_is": "what run_em itself iterates over records: mxm_em_loop_coded, the whole loop in one persistent "
-                              "launch (em_fused_coded_kernel; round 4), wall time of %d iterations incl. launch and state "
-                              "read-back" % max(steps, 50),
+    # "ms_per_step" keeps ONE meaning across rounds -- HIP events over the per-iteration kernels, rounds 2-3's
+    # quantity and what a multi-GPU step runs around its all-reduce; the one-launch loop run_em takes on one GPU has a key
+    # of its own (round 4 reported it AS ms_per_step: "schema" tells the two layouts apart)
+    return {"schema": 5, "ms_per_step": ms, "value": float(n_rows) * n_haps / (ms * 1e-3), "unit": "cells/s",
+            "ms_per_step_is": "the separate-launch path (em_iter_coded_kernel -> column reduce + finalize), HIP events over "
+                              "%d steps: rounds 2-3's quantity (round 4 printed it as per_iteration_kernels_ms_per_step)" % steps,
+            "one_launch_loop_ms_per_iteration": loop_ms,
+            "one_launch_loop_value": float(n_rows) * n_haps / (loop_ms * 1e-3),
+            "one_launch_loop_note": "what run_em itself iterates over records on one GPU: mxm_em_loop_coded, the whole loop in "
+                                    "one persistent launch (em_fused_coded_kernel), wall time of %d iterations incl. launch "
+                                    "and state read-back (round 4 printed it as ms_per_step)" % max(steps, 50),
             "per_iteration_kernels_ms_per_step": ms,
-            "per_iteration_kernels_note": "the separate-launch path (em_iter_coded_kernel -> column reduce -> finalize: what "
-                                          "a multi-GPU step runs around its all-reduce, and rounds 2-3's ms_per_step), HIP "
-                                          "events over %d steps" % steps,
             "rows_with_16bit_codes": int(cplan.coded_wide),
             "kernel": "em_iter_coded_kernel", "kernel_ms": kernel_ms,
             "bytes_per_iteration": float(cplan.coded_bytes),
@@ -659,7 +663,7 @@ def bench_rows(opts, env):
             coded_info = coded_leg(em, torch, lib, plan, mat, wts, props_cur, ln_cur, opts.steps)
             log("row dictionaries: %.3f ms per iteration in the one-launch loop, %.3f through the per-iteration kernels "
                 "(%.2f GB read), encode %.1f ms, column sums within %.1e"
-                % (coded_info["ms_per_step"], coded_info["per_iteration_kernels_ms_per_step"],
+                % (coded_info["one_launch_loop_ms_per_iteration"], coded_info["per_iteration_kernels_ms_per_step"],
                    coded_info["bytes_per_iteration"] / 1e9, coded_info["encode_ms"], coded_info["max_rel_dcolsum"]))
         except Exception as exc:
             log("coded-storage leg skipped: %s" % exc)

@@ -462,19 +462,39 @@ __global__ __launch_bounds__(256) void votes_from_best_kernel(const int32_t *__r
     // round 4: the one thread that adds in row order adds into LDS (a 30 ns round trip; the workgroup's row of
     // `vote_part` in global memory cost ~0.7 us per row: 1.4 ms at 10^6 rows, 14 ms at 10^7), then all threads write
     // the row out.  Same order, same bits.
+    // Round 5: INTEGER weights (the reference's only case: fragments per signature, preprocess.py:220) need no order --
+    // sums of whole numbers below 2^53 are exact however they are formed -- so all 256 threads add (LDS atomics) and
+    // watch for a weight that is not a whole number; only then is the range redone by one thread in row order.  The
+    // serial walk was 0.26 ms at 10^6 rows but linear in R (2.6 ms at 10^7).
     extern __shared__ double s_votes[];
+    __shared__ int s_fractional;
+    const int64_t per = (R + gridDim.x - 1) / gridDim.x;
+    const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < R) ? lo + per : R;
     for (int h = threadIdx.x; h < H; h += 256) s_votes[h] = 0.0;
+    if (threadIdx.x == 0) s_fractional = 0;
     __syncthreads();
-    if (threadIdx.x == 0) {
-        const int64_t per = (R + gridDim.x - 1) / gridDim.x;
-        const int64_t lo = (int64_t)blockIdx.x * per, hi = (lo + per < R) ? lo + per : R;
-        for (int64_t r = lo; r < hi; ++r) {
-            const int b = best[r];
-            if ((unsigned)b >= (unsigned)H) continue;        // -1: a row without a record that nobody supplied densely
-            s_votes[b] += (w != nullptr ? w[r] : 1.0);
-        }
+    bool frac = false;
+    for (int64_t r = lo + threadIdx.x; r < hi; r += 256) {
+        const int b = best[r];
+        if ((unsigned)b >= (unsigned)H) continue;            // -1: a row without a record that nobody supplied densely
+        const double wr = (w != nullptr) ? w[r] : 1.0;
+        frac = frac || !(wr == floor(wr)) || !(fabs(wr) < 4503599627370496.0);     // (NaN and infinities count as fractional)
+        atomicAdd(&s_votes[b], wr);
     }
+    if (frac) s_fractional = 1;
     __syncthreads();
+    if (s_fractional != 0) {                                 // uniform: fractional weights -> the fixed row order
+        for (int h = threadIdx.x; h < H; h += 256) s_votes[h] = 0.0;
+        __syncthreads();
+        if (threadIdx.x == 0) {
+            for (int64_t r = lo; r < hi; ++r) {
+                const int b = best[r];
+                if ((unsigned)b >= (unsigned)H) continue;
+                s_votes[b] += (w != nullptr ? w[r] : 1.0);
+            }
+        }
+        __syncthreads();
+    }
     double *mine = vote_part + (int64_t)blockIdx.x * ldpart;
     for (int h = threadIdx.x; h < H; h += 256) mine[h] = s_votes[h];
 }

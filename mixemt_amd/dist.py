@@ -109,7 +109,9 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     graph: replay each burst of `check_every` iterations -- streaming kernel, column reduce, all-reduce,
     finalize -- from ONE captured hipGraph instead of enqueueing 4 x check_every operations from Python, for shards so
     small that the host would otherwise be what a step waits for.  "auto" (default) decides by a rule the loop applies
-    itself: the first burst always runs eagerly and is timed -- how long the host took to ENQUEUE it against how long
+    itself: the first TWO bursts run eagerly and the SECOND is timed (the first is cold: lazy code-object loading of the
+    kernels and, without a broadcast before the loop, RCCL's communicator set-up sit inside it and say nothing about the
+    steady state) -- how long the host took to ENQUEUE it against how long
     it took until its state came back; above GRAPH_AUTO_ISSUE_SHARE (bench.py: ~40 us of issue per step against
     0.83 ms at 125 000 dense rows per GPU -> eager; against 0.27 ms of a records shard it is close) the next bursts are
     captured.  Every rank must take the same decision (a captured collective and an eager one do not pair up), so the
@@ -134,8 +136,11 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     if max_iter <= 0:
         return ln_cur, ln_new, states
     first = True
+    eager_bursts = 0                                   # graph="auto" takes its decision from the second eager burst
     captured = None                                    # None: nothing captured yet; False: capture refused; (lead, graph)
     graph_bursts = 0
+    sharded_em_loop.last_issue_share = None
+    sharded_em_loop.last_issue_burst = None
     # The loop ends when `finalize` has marked every restart done (converged, or at its own max_iter).  A plan whose
     # finalize never does that must not spin for ever: a restart needs at most ceil(max_iter / check_every) bursts, and
     # at most ceil(n_runs / window) groups of restarts take turns.
@@ -191,7 +196,7 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
                 torch.cuda.synchronize()
                 warnings.warn("sharded EM loop: hipGraph capture of a burst was refused (%s); staying eager" % (exc,),
                               RuntimeWarning, stacklevel=2)
-        was_first, first = first, False
+        first = False
         if use_graph and captured:
             # a captured burst replays raw pointers: the loop vectors and the plan's buffers must still be the ones
             # it recorded (they are never reallocated inside this loop; this makes the convention a check)
@@ -206,7 +211,8 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
             t_issue = time.perf_counter() - t_burst
             states = plan.read_state(state)                  # (synchronises: the burst's state is back)
             t_wall = time.perf_counter() - t_burst
-            if was_first and graph == "auto":
+            eager_bursts += 1
+            if eager_bursts == 2 and graph == "auto":
                 share = t_issue / max(t_wall, 1e-9)
                 if exchange:                                 # one decision for all ranks
                     agreed = torch.tensor([share], dtype=torch.float64, device=props_cur.device)
@@ -215,6 +221,7 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
                 graph = bool(share > GRAPH_AUTO_ISSUE_SHARE and props_cur.is_cuda
                              and (not exchange or dist.get_backend(group) == "nccl"))
                 sharded_em_loop.last_issue_share = share
+                sharded_em_loop.last_issue_burst = eager_bursts
         if exchange and verify:
             _assert_ranks_agree(states, props_cur.device, group)
     if slot_run != list(range(n_runs)):                        # back to the caller's run order
@@ -230,7 +237,8 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
 
 
 sharded_em_loop.last_graph_bursts = 0        # bursts the last call replayed from a captured graph (diagnostic)
-sharded_em_loop.last_issue_share = None      # graph="auto": host enqueue time / wall time of the first burst (max over ranks)
+sharded_em_loop.last_issue_share = None      # graph="auto": host enqueue time / wall time of the burst it decided on (max over ranks)
+sharded_em_loop.last_issue_burst = None      # ... which eager burst that was (2: the first warm one); None = the loop ended before
 
 
 def _burst_ptrs(vectors, plan):

@@ -109,6 +109,9 @@ AUTO_CODED_MIN_CELLS = 1.5e7        # storage="auto": measured break-even of the
                                     # one-launch loops over the dense matrix (profiles/r04/small_runs_breakeven.txt: 26 vs 26 us
                                     # per iteration at 2400 x 5408, 31 vs 41 at 4600, 36 vs 58 at 7000; round 3, with the
                                     # records' iteration still four launches: 5e7)
+AUTO_CODED_MIN_CELLS_MULTI = 5e7    # ... with SEVERAL restarts: the one-launch records loop runs them one after
+                                    # another while the dense path shares each pass of the matrix among up to four, so the
+                                    # records only pay where an iteration is bound by the matrix's bytes (round 3's break-even)
 AUTO_CODED_MAX_REST = 0.25          # ... and at most this share of the rows may stay dense
 
 
@@ -160,7 +163,8 @@ class EmPlan(object):
         self.coded = None
         auto = storage == "auto"
         if auto:
-            storage = "coded" if (float(self.n_rows) * self.n_haps > AUTO_CODED_MIN_CELLS) else "f64"
+            floor = AUTO_CODED_MIN_CELLS if n_runs <= 1 else AUTO_CODED_MIN_CELLS_MULTI
+            storage = "coded" if (float(self.n_rows) * self.n_haps > floor) else "f64"
             self.storage = storage
         if storage == "coded":
             # (round 5: any width the linear kernels take, odd included, and any row stride -- an odd H, e.g. Build 17 plus
@@ -564,37 +568,41 @@ def run_em_ex(read_hap_mat, weights, args, inits=None, want_read_mix=True, stora
     verbose = getattr(args, "verbose", False)
     t_loop = time.perf_counter()
     if verbose:
-        # the reference's own progress text WHILE the loop runs (em.py:119-135): "Starting EM run i...", a dot per 10
-        # iterations, "Converged! (n)".  With several restarts that text is sequential by nature, so -v runs them one
-        # after another (each restart's result does not depend on when it is scheduled: it counts its own iterations);
-        # without -v they advance together and share the passes over the matrix.
-        parts = []
-        try:
-            for run in range(n_multi):
-                sys.stderr.write("Starting EM run %d...\n" % (run + 1))
-                shown = [0]
+        # The reference's own progress text (em.py:119-135): "Starting EM run i...", a dot per 10 iterations, "Converged! (n)",
+        # run after run.  The restarts still advance TOGETHER in one batched loop -- the same kernels, summation orders and
+        # bits as without -v (a logging flag must not change the arithmetic, nor cost n_multi times the passes
+        # over the matrix) -- and the text follows the lowest run that is not fully reported yet: live for that run, caught
+        # up at once for the runs that finished in its shadow.
+        report = {"run": 0, "dots": 0, "open": False}
 
-                def on_state(state_host, n_runs, _user, shown=shown):
-                    dots = state_host[0].iters // 10 - shown[0]
-                    if dots > 0:
-                        sys.stderr.write("." * dots)
-                        sys.stderr.flush()
-                        shown[0] += dots
-                hook = _lib.PROGRESS_FN(on_state)
-                plan.lib.mxm_set_progress_callback(ctypes.cast(hook, ctypes.c_void_p), None, 10)
-                lc, ln, st = em_loop(plan, inits[run:run + 1], args.tolerance, args.max_iter)
-                plan.lib.mxm_set_progress_callback(None, None, 10)
-                missing = st[0][1] // 10 - shown[0]          # (a loop that ended between two read-backs)
-                if missing > 0:
-                    sys.stderr.write("." * missing)
-                if st[0][0] == 1:
-                    sys.stderr.write("\nConverged! (%d)\n" % st[0][1])
-                parts.append((lc, ln, st[0]))
+        def tell(iters_done, n_runs):
+            """iters_done[i] = (iterations so far, done code) of run i"""
+            while report["run"] < n_runs:
+                run = report["run"]
+                iters, done = iters_done[run]
+                if not report["open"]:
+                    sys.stderr.write("Starting EM run %d...\n" % (run + 1))
+                    report["open"], report["dots"] = True, 0
+                dots = iters // 10 - report["dots"]
+                if dots > 0:
+                    sys.stderr.write("." * dots)
+                    report["dots"] += dots
+                if done == 0:
+                    break
+                if done == 1:
+                    sys.stderr.write("\nConverged! (%d)\n" % iters)
+                report["run"], report["open"] = run + 1, False
+            sys.stderr.flush()
+
+        def on_state(state_host, n_runs, _user):
+            tell([(state_host[i].iters, state_host[i].done) for i in range(n_runs)], n_runs)
+        hook = _lib.PROGRESS_FN(on_state)
+        try:
+            plan.lib.mxm_set_progress_callback(ctypes.cast(hook, ctypes.c_void_p), None, 10)
+            ln_cur, ln_new, states = em_loop(plan, inits, args.tolerance, args.max_iter)
         finally:
             plan.lib.mxm_set_progress_callback(None, None, 10)
-        ln_cur = torch.cat([part[0] for part in parts], dim=0)
-        ln_new = torch.cat([part[1] for part in parts], dim=0)
-        states = [part[2] for part in parts]
+        tell([(st[1], st[0]) for st in states], n_multi)               # whatever the last read-back did not show yet
     else:
         ln_cur, ln_new, states = em_loop(plan, inits, args.tolerance, args.max_iter)
     t_loop = time.perf_counter() - t_loop

@@ -641,7 +641,8 @@ def test_single_contributor_refinement_golden(b17):
 
 def test_verbose_progress_text_of_a_multi_run_is_live_and_the_references(capsys):
     """-v with n_multi = 3: 'Starting EM run i...', dots, 'Converged! (n)' per run, in run order, written while
-    that run's loop is going on (em.py:119-135) -- the restarts then run one after another, with the same results."""
+    the loop is going on (em.py:119-135).  Round 5: the restarts still advance in ONE batched loop, so -v changes
+    no bit of the result -- checked on the toy tree and on a Build-17 matrix of the size real inputs have."""
     from mixemt_amd import em
     g = golden("g1_toy")
     key = "m3_s2"
@@ -654,8 +655,22 @@ def test_verbose_progress_text_of_a_multi_run_is_live_and_the_references(capsys)
     want = "".join("Starting EM run %d...\n" % (i + 1) + "." * (n // 10) + "\nConverged! (%d)\n" % n
                    for i, n in enumerate(loud["iters"]))
     assert capsys.readouterr().err == want
-    assert loud["iters"] == quiet["iters"] and numpy.abs(loud["props"] - quiet["props"]).max() < 1e-12
+    assert loud["iters"] == quiet["iters"] and numpy.array_equal(loud["props"], quiet["props"])
     assert loud["iters"] == list(g[key + "_iters"]) and numpy.abs(loud["props"] - g[key + "_props"]).max() < PROPS_ATOL
+    # the same at a realistic size (2400 x 5408, two restarts): identical bits, the reference's text
+    g9 = golden("g9_run_em_2400")
+    from mixemt_amd import phylotree, preprocess
+    refseq = phylotree.load_rsrs()
+    phy = phylotree.load_build17(refseq)
+    tables = preprocess.HapVarTables.build(refseq, phy, sorted(phy.hap_var))
+    big = preprocess.build_em_matrix_device(tables, g9["row_ptr"], g9["site"], g9["obs"])
+    runs = []
+    for verbose in (False, True):
+        numpy.random.seed(5)
+        runs.append(em.run_em_ex(big, g9["wts"], em_args(n_multi=2, max_iter=60, verbose=verbose), want_read_mix=False))
+    text = capsys.readouterr().err
+    assert runs[0]["iters"] == runs[1]["iters"] == [60, 60] and numpy.array_equal(runs[0]["props"], runs[1]["props"])
+    assert text == "".join("Starting EM run %d...\n" % (i + 1) + "." * 6 for i in range(2))
 
 
 @pytest.mark.parametrize("fused", [1, 2, 0])
