@@ -2,7 +2,7 @@
 # Copy the summaries of a tools/profile_round.sh run from gpurun_out/<round>/ (scratch) into
 # profiles/<round>/ (tracked).  usage: bash tools/collect_profiles.sh r02
 set -u
-round=${1:-r04}
+round=${1:-r05}
 src=gpurun_out/$round
 dst=profiles/$round
 mkdir -p $dst
@@ -15,7 +15,8 @@ for f in bench_1m.json bench_1m_under_rocprof.json bench_1m_10restarts.json benc
          pmc_traffic_coded_1m.json coded_pmc_sq_summary.txt coded_storage_1m.txt pipeline_1m.txt pipeline_1m_coded.txt \
          bench_1m_records.json bench_10m_records_one_gpu.json bench_10m_records_one_gpu.log \
          bench_125k_records_one_rank_rccl.json pipeline_1m_records.txt pipeline_10m_records_one_gpu.txt \
-         pmc_calibration_coded.json coded_parts.txt records_read_ceiling.txt; do
+         pmc_calibration_coded.json coded_parts.txt records_read_ceiling.txt \
+         frontend_1m.txt pipeline_1m_alignments.txt row_pass_experiments.txt; do
   [ -f $src/$f ] && cp $src/$f $dst/$f
 done
 [ -f $src/bench_1m.log ] && cp $src/bench_1m.log $dst/bench_1m.log

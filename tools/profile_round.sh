@@ -5,7 +5,7 @@
 # rocprofv3 gets the program itself after `--` (python3 <script>), never a shell or env hop, and
 # counter passes (--pmc) are separate runs with --kernel-trace only.
 set -u
-round=${1:-r04}
+round=${1:-r05}
 part=${2:-all}        # a: headline + counters + row dictionaries; b: pipelines, other configurations, small runs, build; all: both
 repo=$PWD
 out=$repo/gpurun_out/$round
@@ -106,5 +106,12 @@ python3 $repo/tools/time_restarts.py > $out/restart_schedules.txt 2>&1
 echo "[profile_round] step 40 done"
 python3 $repo/tools/time_dropin_build.py > $out/dropin_build.txt 2>&1
 echo "[profile_round] step 41 done"
+# --- round 5: the front end (host threads of the box), the pipeline from alignments, the row-pass experiments ----------
+python3 $repo/tools/time_frontend.py > $out/frontend_1m.txt 2>&1
+echo "[profile_round] step 42 done"
+python3 $repo/tools/run_pipeline.py --reads 1000000 --alignments > $out/pipeline_1m_alignments.txt 2>&1
+echo "[profile_round] step 43 done"
+python3 $repo/tools/experiments/time_coded3.py 1000000 > $out/row_pass_experiments.txt 2>&1
+echo "[profile_round] step 44 done"
 fi
 find $out -name "*.csv" | head -60
