@@ -689,8 +689,12 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
         }
     }
     bool meta_ready = false;
-    int chk[2];
-    coded_row_pass<THREADS, NCH, NBUF, true, false, true, true>(rec, rec_off, ndist, ldc, w, wide_rows, n_wide, R, p, acc, meta_ready, chk);
+    int chk[2] = {(int)n_wide, 0};                       // (MXM_CODED_CHECK=0, A/B builds only: "the list is right")
+#ifndef MXM_CODED_CHECK
+#define MXM_CODED_CHECK 1
+#endif
+    coded_row_pass<THREADS, NCH, NBUF, true, false, true, MXM_CODED_CHECK != 0>(rec, rec_off, ndist, ldc, w, wide_rows, n_wide, R, p, acc,
+                                                                                 meta_ready, chk);
     if (t == 0) {                                        // {wide rows met, list fault}: behind the partial rows this path can use
         int *out = reinterpret_cast<int *>(partial + (int64_t)MXM_MAX_WG * ldpart) + 2 * blockIdx.x;
         out[0] = chk[0];
