@@ -44,7 +44,8 @@ extern "C" {
  * 400 round 4: mxm_coded gained wide_rows / n_wide (records with 16-bit codes for rows of 257..1024 distinct values),
  * mxm_record_bytes / mxm_coded_bytes grew with them, mxm_workspace_bytes covers the one-launch loops' layouts,
  * mxm_em_state gained `ticket` (24 bytes: mxm_m_finalize runs on several workgroups, the last arriver finishes);
- * 500 round 5: mxm_aln_* (the batched alignment front end) added; mxm_em_state.reserved_ became .error and
+ * 500 round 5: mxm_aln_* (the batched alignment front end), mxm_preload, mxm_build_em_matrix_lut_rows and
+ * mxm_scatter_records added; mxm_em_state.reserved_ became .error and
  * mxm_em_iter_coded's state lost its const (the wide-rows list is checked where it is used). */
 #define MXM_VERSION 500
 
@@ -61,6 +62,10 @@ typedef struct mxm_em_state {
 
 int         mxm_version(void);
 const char *mxm_last_error(void);
+/* HIP loads a library's code object lazily, on its first kernel launch (~18 ms for this one); mxm_preload() does it now, on
+ * the calling thread's current device, and returns when it is loaded (blocking).  Optional: a binding calls it when it loads
+ * the library so that the cost does not land in the first stage that happens to launch. */
+int         mxm_preload(void);
 
 /* Largest haplogroup count the linear-space streaming kernel accepts; above it
  * (and below MXM_LINEAR_MIN_H) mxm_em_iter runs the generic log-space kernel. */
@@ -109,6 +114,13 @@ int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const double *lhi
                             const uint8_t *obsmap, const int64_t *row_ptr, const uint16_t *site,
                             const uint8_t *obs, const int64_t *order, int64_t R, int32_t H, int32_t S,
                             double *M, int64_t ldm, void *stream);
+
+/* The same for a LIST of rows into a compact matrix: row rows[i] of the CSR -> row i of M_out[n_rows][ldm] (the rows the
+ * marker kernel hands back, built a slab at a time instead of inside the whole matrix). */
+int mxm_build_em_matrix_lut_rows(const uint8_t *Ecode, int64_t lde, const double *lhit, const double *lmiss,
+                                 const uint8_t *obsmap, const int64_t *row_ptr, const uint16_t *site,
+                                 const uint8_t *obs, const int64_t *rows, int64_t n_rows, int32_t H, int32_t S,
+                                 double *M_out, int64_t ldm, void *stream);
 
 /*
  * build_em_matrix from the haplogroups' MARKERS -- preprocess.py:177-198, the same bits as the kernels
@@ -259,6 +271,10 @@ size_t mxm_coded_bytes(int64_t R, int32_t H);
 int mxm_encode_rows(const double *M, int64_t ldm, int64_t R, int32_t H, uint8_t *rec, size_t rec_bytes,
                     int64_t *rec_off, int32_t *ndist, double *rowmax, int64_t *stats, void *stream);
 int mxm_decode_rows(const mxm_coded *c, int32_t H, double *P, int64_t ldp, void *stream);
+/* Records that mxm_encode_rows made from a compact side matrix of the rows rows[0 .. n) take their place in the matrix's
+ * record arrays: where sub_nd[i] > 0, rec_off[rows[i]] = sub_off[i] + base, ndist[rows[i]] = sub_nd[i], rowmax[rows[i]] = sub_rm[i]. */
+int mxm_scatter_records(const int64_t *rows, int64_t n, const int64_t *sub_off, const int32_t *sub_nd, const double *sub_rm,
+                        int64_t base, int64_t *rec_off, int32_t *ndist, double *rowmax, void *stream);
 /* The contributor vote straight from records -- assemble.py:115-123 / stats.py:39-40 over run_em's returned posterior
  * (em.py:145-161), for ALL rows, without a dense matrix or a posterior matrix:
  *   best[r] = first index of max_h  fold_k logaddexp( ln_props[k][h] + M[r][h] - lse_k[r] )     k = 0 .. n_runs-1 in run order

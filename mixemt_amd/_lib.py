@@ -55,6 +55,10 @@ SIGNATURES = {
                                                c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     "mxm_build_em_matrix_sparse": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                                   c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_ptr, c_ptr]),
+    "mxm_build_em_matrix_lut_rows": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
+                                                    c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
+    "mxm_scatter_records": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mxm_preload": (ctypes.c_int, []),
     "mxm_record_bytes": (c_size, [c_i64, c_i32]),
     "mxm_build_em_records": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                             c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr, c_size, c_ptr, c_ptr, c_ptr,
@@ -169,6 +173,13 @@ def load():
         fn.restype = restype
         fn.argtypes = argtypes
     _lib = lib
+    # the library's code object is loaded onto the device now rather than by the first kernel launch (18 ms that would land
+    # in whatever stage happens to launch first); nothing to do without a GPU (the host functions work there)
+    try:
+        if _dev.torch is not None and _dev.torch.cuda.is_available():
+            lib.mxm_preload()
+    except Exception:        # pragma: no cover - a preload that fails only moves the cost back
+        pass
     return lib
 
 

@@ -53,7 +53,9 @@ __global__ __launch_bounds__(LUT_THREADS) void build_lut_kernel(
     const uint8_t *__restrict__ E, int64_t lde, int64_t e_bytes, const double *__restrict__ lhit,
     const double *__restrict__ lmiss, const uint8_t *__restrict__ obsmap, const int64_t *__restrict__ row_ptr,
     const uint16_t *__restrict__ site, const uint8_t *__restrict__ obs, const int64_t *__restrict__ order,
-    int64_t R, int H, double *__restrict__ M, int64_t ldm, int vec_ok) {
+    int64_t R, int H, double *__restrict__ M, int64_t ldm, int vec_ok, int compact) {
+    // compact (with `order`): row order[i] is written to row i of M -- a compact side matrix of the listed rows (the
+    // rows the marker kernel hands back, built a slab at a time: mxm_build_em_matrix_lut_rows) -- instead of to its own row
     static_assert(CPL == 4 || CPL == 8, "one 4- or 8-byte table load per lane, site and tile");
     constexpr int EW = CPL / 4;                         // dwords per table load
     __shared__ double s_lut[2][LUT_CAP][16];            // per observation: [0] = log hit, [1..15] = log miss
@@ -174,7 +176,7 @@ __global__ __launch_bounds__(LUT_THREADS) void build_lut_kernel(
                 ncode = obsmap[nobs];
             }
             if (h < H) {
-                double *dst = M + r * ldm + h;
+                double *dst = M + (compact ? i : r) * ldm + h;
                 if (vec_ok && h + CPL <= H) {
 #pragma unroll
                     for (int c = 0; c < CPL; c += 2)

@@ -214,9 +214,9 @@ extern "C" int mxm_build_em_matrix(const uint8_t *E, int64_t lde, const double *
 static int launch_build_lut(int nt, int grid, hipStream_t s, const uint8_t *E, int64_t lde, int64_t e_bytes,
                             const double *lhit, const double *lmiss, const uint8_t *obsmap, const int64_t *row_ptr,
                             const uint16_t *site, const uint8_t *obs, const int64_t *order, int64_t R, int H, double *M,
-                            int64_t ldm, int vec_ok) {
+                            int64_t ldm, int vec_ok, int compact = 0) {
     switch (nt) {
-#define BL_CASE(n) case n: hipLaunchKernelGGL((build_lut_kernel<n, LUT_CPL>), dim3(grid), dim3(LUT_THREADS), 0, s, E, lde, e_bytes, lhit, lmiss, obsmap, row_ptr, site, obs, order, R, H, M, ldm, vec_ok); break;
+#define BL_CASE(n) case n: hipLaunchKernelGGL((build_lut_kernel<n, LUT_CPL>), dim3(grid), dim3(LUT_THREADS), 0, s, E, lde, e_bytes, lhit, lmiss, obsmap, row_ptr, site, obs, order, R, H, M, ldm, vec_ok, compact); break;
         BL_CASE(1) BL_CASE(2) BL_CASE(3) BL_CASE(4) BL_CASE(5) BL_CASE(6) BL_CASE(7) BL_CASE(8)
 #undef BL_CASE
         default: return 1;
@@ -243,6 +243,64 @@ extern "C" int mxm_build_em_matrix_lut(const uint8_t *Ecode, int64_t lde, const 
                          order, R, (int)H, M, ldm, vec_ok) != 0)
         return fail(-1, "mxm_build_em_matrix_lut: H=%s%lld outside the kernel's range", "", H);
     HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// the listed rows into a COMPACT matrix: row rows[i] of the input -> row i of M_out (build_em_records_device's slabs)
+extern "C" int mxm_build_em_matrix_lut_rows(const uint8_t *Ecode, int64_t lde, const double *lhit, const double *lmiss,
+                                            const uint8_t *obsmap, const int64_t *row_ptr, const uint16_t *site,
+                                            const uint8_t *obs, const int64_t *rows, int64_t n_rows, int32_t H, int32_t S,
+                                            double *M_out, int64_t ldm, void *stream) {
+    if (n_rows < 0 || H <= 0 || S <= 0 || rows == nullptr) return fail(-1, "mxm_build_em_matrix_lut_rows: bad arguments%s", "");
+    if (H > 8192) return fail(-1, "mxm_build_em_matrix_lut_rows: more than 8192 haplogroups%s (H=%lld)", "", H);
+    if (lde < (((int64_t)H + 7) & ~(int64_t)7) || (lde & 7) != 0 || (reinterpret_cast<uintptr_t>(Ecode) & 7) != 0)
+        return fail(-1, "mxm_build_em_matrix_lut_rows: Ecode must be 8-byte aligned with lde a multiple of 8 and >= H rounded up to 8%s (lde=%lld)", "", lde);
+    if (ldm < H) return fail(-1, "mxm_build_em_matrix_lut_rows: ldm < H%s", "");
+    if (S > 65536 || (int64_t)S * lde >= ((int64_t)1 << 31))
+        return fail(-1, "mxm_build_em_matrix_lut_rows: table of %s%lld x %lld bytes exceeds one buffer descriptor", "", S, lde);
+    if (n_rows == 0) return 0;
+    const int grid = clamp_grid(n_rows, num_cu() * 8);
+    const int nt = (H + LUT_THREADS * LUT_CPL - 1) / (LUT_THREADS * LUT_CPL);
+    const int vec_ok = ((ldm & 1) == 0) && ((reinterpret_cast<uintptr_t>(M_out) & 15) == 0);
+    if (launch_build_lut(nt, grid, (hipStream_t)stream, Ecode, lde, (int64_t)S * lde, lhit, lmiss, obsmap, row_ptr, site, obs, rows,
+                         n_rows, (int)H, M_out, ldm, vec_ok, 1) != 0)
+        return fail(-1, "mxm_build_em_matrix_lut_rows: H=%s%lld outside the kernel's range", "", H);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// The records of a slab of rows that were coded from their dense form (mxm_encode_rows over a compact side matrix) take
+// their place in the matrix's record arrays: row rows[i] gets sub_off[i] + base, sub_nd[i], sub_rm[i] where sub_nd[i] > 0.
+__global__ __launch_bounds__(256) void scatter_records_kernel(const int64_t *__restrict__ rows, int64_t n, const int64_t *__restrict__ sub_off,
+                                                             const int32_t *__restrict__ sub_nd, const double *__restrict__ sub_rm,
+                                                             int64_t base, int64_t *__restrict__ rec_off, int32_t *__restrict__ ndist,
+                                                             double *__restrict__ rowmax) {
+    const int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    if (i >= n || sub_nd[i] <= 0) return;
+    const int64_t r = rows[i];
+    rec_off[r] = sub_off[i] + base;
+    ndist[r] = sub_nd[i];
+    rowmax[r] = sub_rm[i];
+}
+extern "C" int mxm_scatter_records(const int64_t *rows, int64_t n, const int64_t *sub_off, const int32_t *sub_nd, const double *sub_rm,
+                                   int64_t base, int64_t *rec_off, int32_t *ndist, double *rowmax, void *stream) {
+    if (n < 0 || (n > 0 && (rows == nullptr || sub_off == nullptr || sub_nd == nullptr || sub_rm == nullptr || rec_off == nullptr ||
+                            ndist == nullptr || rowmax == nullptr)))
+        return fail(-1, "mxm_scatter_records: bad arguments%s", "");
+    if (n == 0) return 0;
+    hipLaunchKernelGGL(scatter_records_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rows, n, sub_off,
+                       sub_nd, sub_rm, base, rec_off, ndist, rowmax);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+// Loads the library's code object onto the calling thread's device (HIP does that lazily, on the first launch: ~18 ms that
+// would otherwise land in whatever stage launches first) and returns once it is there.
+__global__ void preload_kernel() {}
+extern "C" int mxm_preload(void) {
+    hipLaunchKernelGGL(preload_kernel, dim3(1), dim3(64), 0, (hipStream_t)nullptr);
+    HIP_TRY(hipGetLastError());
+    HIP_TRY(hipDeviceSynchronize());
     return 0;
 }
 

@@ -225,7 +225,7 @@ class EmPlan(object):
                                               p_rest.data_ptr(), p_rest.stride(0), rm.data_ptr(), current_stream()),
                        "mxm_linearize")
             w_rest = self.wts.index_select(0, cm.rest_rows).contiguous()
-        self.coded_record_bytes = cm.used - 8 * int(cm.ndist.sum().item())     # codes + P tables: the loop's read
+        self.coded_record_bytes = cm.used - 8 * int(cm.ndist_host().sum(dtype=numpy.int64))     # codes + P tables: the loop's read
         self.coded_bytes = self.coded_record_bytes + n_rest * self.n_haps * 8
         self.coded_rest = n_rest
         self.coded_ndist = cm.ndist

@@ -506,10 +506,17 @@ class CodedMatrix(object):
         self.rec, self.rec_off, self.ndist, self.rowmax = rec, rec_off, ndist, rowmax
         self.used, self.rest_rows, self.m_rest = used, rest_rows, m_rest
 
+    def ndist_host(self):
+        """ndist on the host (4 bytes per row, fetched once): the list of wide rows and the byte counts are formed from it with
+        numpy -- the first torch.nonzero / sum of a process loads their code objects (10-15 ms in a 20 ms plan)."""
+        if getattr(self, "_ndist_host", None) is None:
+            self._ndist_host = self.ndist.cpu().numpy()
+        return self._ndist_host
+
     def wide_rows(self):
         """Rows whose record has 16-bit codes (257..1024 distinct values), in row order (device int64)."""
         if getattr(self, "_wide", None) is None:
-            self._wide = torch.nonzero(self.ndist > 256).flatten()
+            self._wide = torch.from_numpy(numpy.flatnonzero(self.ndist_host() > 256)).to(self.rec.device)
         return self._wide
 
     def rows(self, lo, hi):
@@ -580,46 +587,6 @@ def record_buffer_bytes(n_rows, n_haps):
     return max(one, min(worst, int(n_rows) * (ldc + RECORD_BYTES_GUESS) + (1 << 20)))
 
 
-class RecordBufferReservation(object):
-    """
-    The record buffer, allocated on a helper thread while the host does something else (round 5).  A fresh device
-    allocation of this size is not free -- the driver hands out cleared pages: 0.11-0.36 s for the 7 GB of 10^6 rows
-    (profiles/r04/pipeline_1m_records.txt), 6-20 x the 18 ms the build's kernels take -- and nothing it has to wait for
-    exists before the rows are counted.  build_em_input starts it as soon as the front end knows the number of rows, so
-    it runs under HapVarTables.build / the CSR upload; a caller with a row count of its own can start it earlier still:
-        res = preprocess.reserve_record_buffer(n_rows, n_haps)
-        ... host work ...
-        cm = preprocess.build_em_records_device(tables, row_ptr, site, obs, rec=res)
-    """
-
-    def __init__(self, nbytes, dev):
-        import threading
-        self.nbytes, self._dev, self._buf, self._exc = int(nbytes), dev, None, None
-        self._thread = threading.Thread(target=self._run, daemon=True)
-        self._thread.start()
-
-    def _run(self):
-        try:
-            torch.cuda.set_device(self._dev)
-            self._buf = torch.empty((self.nbytes,), dtype=torch.uint8, device=self._dev)
-        except Exception as exc:       # (surfaced by get(): an allocation failure becomes the caller's ValueError)
-            self._exc = exc
-
-    def get(self):
-        self._thread.join()
-        if self._exc is not None:
-            if isinstance(self._exc, torch.cuda.OutOfMemoryError):
-                raise ValueError("not enough device memory for the coded matrix (%.1f GB): %s" % (self.nbytes / 1e9, self._exc))
-            raise self._exc
-        return self._buf
-
-
-def reserve_record_buffer(n_rows, n_haps, nbytes=None):
-    """Start allocating build_em_records_device's record buffer in the background (RecordBufferReservation)."""
-    dev = require_gpu()
-    return RecordBufferReservation(record_buffer_bytes(n_rows, n_haps) if nbytes is None else nbytes, dev)
-
-
 def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, rec=None):
     """
     CSR observations -> CodedMatrix: the marker kernel writes each row as a row-dictionary record
@@ -634,8 +601,9 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
     cap: bytes of the record buffer.  Default: room for RECORD_BYTES_GUESS table bytes per row instead of the
     worst case mxm_record_bytes (27 KB per row: a 27 GB hipMalloc at 10^6 rows for 6 GB of records); the kernels
     count what they would have needed, and an overflow repeats the build once with exactly that much.
-    rec: a buffer to build into -- a uint8 device tensor or a RecordBufferReservation (reserve_record_buffer: the
-    allocation then ran beside the caller's host work); too small a one is only the first attempt.
+    rec: a uint8 device tensor to build into (a buffer the caller already holds); too small a one is only the first attempt.
+    (The allocation itself is not what a cold call costs -- torch.empty of 7 GB takes 0.3 ms, profiles/r05/alloc_cost.txt;
+    what round 4 read as "the hipMalloc" was code objects being loaded: see the comment in the loop below.)
     """
     lib = _lib.load()
     dev = require_gpu()
@@ -652,8 +620,6 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
     ldc = (n_haps + 7) // 8 * 8
     worst = lib.mxm_record_bytes(n_rows, n_haps)
     one = 2 * ldc + 16 * 1024                       # a full wide record: the smallest buffer the library accepts
-    if isinstance(rec, RecordBufferReservation):
-        rec = rec.get()
     if rec is not None and (rec.dtype != torch.uint8 or not rec.is_cuda or rec.numel() < one or rec.data_ptr() % 16):
         rec = None
     if rec is not None:
@@ -665,16 +631,23 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
     rec_off = torch.empty(n_rows, dtype=torch.int64, device=dev)
     ndist = torch.empty(n_rows, dtype=torch.int32, device=dev)
     rowmax = torch.empty(n_rows, dtype=torch.float64, device=dev)
-    stats = torch.zeros(2, dtype=torch.int64, device=dev)
+    counters = torch.zeros(5, dtype=torch.int64, device=dev)        # [0:2] the build's stats, [2] n_fallback, [3:5] a slab's stats
+    stats, n_fallback, sub_stats = counters[0:2], counters[2:3], counters[3:5]
     fallback = torch.empty(n_rows, dtype=torch.int64, device=dev)
-    n_fallback = torch.zeros(1, dtype=torch.int64, device=dev)
+    stream = current_stream()
 
-    def lut_rows(rp, si, ob, order, count, out):
-        _lib.check(lib.mxm_build_em_matrix_lut(
+    def lut_rows(rows_d, count, out):
+        """rows rows_d[0 .. count) of the CSR, cell by cell, into the COMPACT matrix out[count][H]"""
+        _lib.check(lib.mxm_build_em_matrix_lut_rows(
             lut["ecode"].data_ptr(), lut["ecode"].stride(0), lut["lhit"].data_ptr(), lut["lmiss"].data_ptr(),
-            lut["obsmap"].data_ptr(), rp.data_ptr(), si.data_ptr(), ob.data_ptr(), order, count, n_haps, n_sites,
-            out.data_ptr(), out.stride(0), current_stream()), "mxm_build_em_matrix_lut")
+            lut["obsmap"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(), rows_d.data_ptr(), count,
+            n_haps, n_sites, out.data_ptr(), out.stride(0), stream), "mxm_build_em_matrix_lut_rows")
 
+    # Everything between the kernels below is pointer arithmetic and three small copies.  HIP loads code objects lazily:
+    # the first launch of this library costs 18 ms (profiles/r05/first_launch.txt; _lib.load() now does it: mxm_preload)
+    # and the first use of EVERY torch operator loads that operator's module (5-20 ms each).  A version of this function
+    # that compacted lists, gathered the long rows' observations and scattered results with torch spent ~60 ms of a cold
+    # 105 ms call there -- round 4 took it for the buffer's hipMalloc (profiles/r05/experiments.md section 3).
     for attempt in (0, 1):
         if rec is None:
             rec = device_empty((cap,), torch.uint8, dev, "the coded matrix")
@@ -683,19 +656,25 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
             enc["mk_hap"].data_ptr(), enc["mk_base"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(),
             0, n_rows, n_haps, n_sites, mat.data_ptr() if dense else 0, mat.stride(0) if dense else 0,
             rec.data_ptr(), cap, rec_off.data_ptr(), ndist.data_ptr(), rowmax.data_ptr(), stats.data_ptr(),
-            fallback.data_ptr(), n_fallback.data_ptr(), current_stream()), "mxm_build_em_records")
-        counts = torch.cat([stats, n_fallback]).cpu()
-        used, n_rest, left = (int(v) for v in counts)
+            fallback.data_ptr(), n_fallback.data_ptr(), stream), "mxm_build_em_records")
+        used, n_rest, left = (int(v) for v in counters[:3].cpu())
         need = used
         m_rest = None
+        rest_rows = fallback[:0]
         if used <= cap:
-            rest_rows = torch.nonzero(ndist == 0).flatten()
-            assert rest_rows.numel() == n_rest
-            if dense and left:
-                rows = fallback[:left].sort().values
-                lut_rows(row_ptr_d, site_d, obs_d, rows.data_ptr(), left, mat)
-            if not dense:
+            if dense:
+                if left:
+                    rows = fallback[:left].sort().values
+                    _lib.check(lib.mxm_build_em_matrix_lut(
+                        lut["ecode"].data_ptr(), lut["ecode"].stride(0), lut["lhit"].data_ptr(), lut["lmiss"].data_ptr(),
+                        lut["obsmap"].data_ptr(), row_ptr_d.data_ptr(), site_d.data_ptr(), obs_d.data_ptr(), rows.data_ptr(), left,
+                        n_haps, n_sites, mat.data_ptr(), mat.stride(0), stream), "mxm_build_em_matrix_lut")
+                rest_rows = torch.nonzero(ndist == 0).flatten()      # (also the rows of more than 256 values: dense above)
+                assert rest_rows.numel() == n_rest
+            else:
                 assert left == n_rest             # without a dense matrix every row without a record is on the list
+                if n_rest:                        # the list as the kernel appended it -> ascending (host: 8 bytes per row)
+                    rest_rows = torch.from_numpy(numpy.sort(fallback[:left].cpu().numpy())).to(dev)
             if n_rest:
                 # the dense rows of long reads mostly hold few distinct values too: built (or taken from the dense matrix)
                 # a slab at a time and coded from their dense form (mxm_encode_rows: bytes, then 16-bit codes) into the
@@ -705,7 +684,6 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
                 sub_off = torch.empty(slab, dtype=torch.int64, device=dev)
                 sub_nd = torch.empty(slab, dtype=torch.int32, device=dev)
                 sub_rm = torch.empty(slab, dtype=torch.float64, device=dev)
-                sub_stats = torch.zeros(2, dtype=torch.int64, device=dev)
                 kept_rows, kept_dense = [], []
                 for lo in range(0, n_rest, slab):
                     rows_s = rest_rows[lo:lo + slab]
@@ -713,24 +691,23 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
                     if dense:
                         m_s = mat.index_select(0, rows_s)
                     else:
-                        sub_ptr, sub_site, sub_obs = _gather_csr(row_ptr_d, site_d, obs_d, rows_s)
                         m_s = m_slab[:n_s]
-                        lut_rows(sub_ptr, sub_site, sub_obs, 0, n_s, m_s)
+                        lut_rows(rows_s, n_s, m_s)
                     base = (need + 15) // 16 * 16
-                    if cap - base >= one:
+                    room = cap - base >= one
+                    if room:
                         _lib.check(lib.mxm_encode_rows(m_s.data_ptr(), m_s.stride(0), n_s, n_haps, rec.data_ptr() + base,
                                                        cap - base, sub_off.data_ptr(), sub_nd.data_ptr(), sub_rm.data_ptr(),
-                                                       sub_stats.data_ptr(), current_stream()), "mxm_encode_rows")
-                        sub_used = int(sub_stats[0].item())
+                                                       sub_stats.data_ptr(), stream), "mxm_encode_rows")
+                        sub_used, sub_left = (int(v) for v in sub_stats.cpu())
                     else:
-                        sub_used = n_s * one              # no room left at all: ask for the worst case of these rows
-                    if base + sub_used <= cap and cap - base >= one:
-                        got = sub_nd[:n_s] > 0
-                        rows_c = rows_s[got]
-                        rec_off[rows_c] = sub_off[:n_s][got] + base
-                        ndist[rows_c] = sub_nd[:n_s][got]
-                        rowmax[rows_c] = sub_rm[:n_s][got]
-                        if not bool(got.all()):
+                        sub_used, sub_left = n_s * one, 0     # no room left at all: ask for the worst case of these rows
+                    if room and base + sub_used <= cap:
+                        _lib.check(lib.mxm_scatter_records(rows_s.data_ptr(), n_s, sub_off.data_ptr(), sub_nd.data_ptr(),
+                                                           sub_rm.data_ptr(), base, rec_off.data_ptr(), ndist.data_ptr(),
+                                                           rowmax.data_ptr(), stream), "mxm_scatter_records")
+                        if sub_left:                          # more than 1024 values (random matrices): stays dense
+                            got = sub_nd[:n_s] > 0
                             kept_rows.append(rows_s[~got])
                             kept_dense.append(m_s[~got].clone())
                     need = base + sub_used
@@ -806,15 +783,13 @@ def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False, as_reco
         if verbose:
             sys.stderr.write("Using %d aligned fragments (MQ>=%d) (%d distinct sub-haplotypes)\n\n"
                              % (enc.n_fragments - len(dropped), args.min_mq, enc.n_rows))
-        # the record buffer's allocation runs beside the table set-up (RecordBufferReservation)
-        reservation = reserve_record_buffer(enc.n_rows, len(haplogroups)) if (as_records and enc.n_rows > 0) else None
         tables = HapVarTables.build(refseq, phylo, haplogroups)
         if not numpy.array_equal(tables.sites, numpy.asarray(var_pos, dtype=numpy.int64)):
             raise ValueError("build_em_input: the tables' sites are not phylo.get_variant_pos()")
         if verbose:
             sys.stderr.write("Building EM input matrix...\n")
         if as_records:
-            em_matrix = build_em_records_device(tables, enc.row_ptr, enc.site, enc.obs, rec=reservation)
+            em_matrix = build_em_records_device(tables, enc.row_ptr, enc.site, enc.obs)
         else:
             em_matrix = build_em_matrix_device(tables, enc.row_ptr, enc.site, enc.obs)
             if not as_device_tensor:

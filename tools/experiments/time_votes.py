@@ -9,8 +9,7 @@ refseq = phylotree.load_rsrs(); phy = phylotree.load_build17(refseq); haps = sor
 tables = preprocess.HapVarTables.build(refseq, phy, haps)
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 row_ptr, site, obs, _ = synth.synth_rows(tables, len(refseq), 0, rows, seed=1)
-res0 = preprocess.reserve_record_buffer(rows, len(haps))
-cm = preprocess.build_em_records_device(tables, row_ptr, site, obs, rec=res0)
+cm = preprocess.build_em_records_device(tables, row_ptr, site, obs)
 wts = torch.ones(rows, dtype=torch.float64, device="cuda")
 args = argparse.Namespace(init_alpha=1.0, tolerance=1e-4, max_iter=30, n_multi=1, verbose=False)
 numpy.random.seed(7)

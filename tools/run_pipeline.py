@@ -88,9 +88,6 @@ def main():
 
     # one-time table set-up (the reference's HapVarBaseMatrix.__init__, preprocess.py:39-67): marker lists and lookup
     # tables encoded on the host and uploaded
-    # the record buffer's allocation (the driver hands out cleared pages: 0.1-0.4 s for 7 GB) runs on a helper thread
-    # beside the table set-up -- as build_em_input starts it beside HapVarTables.build
-    reservation = preprocess.reserve_record_buffer(opts.reads, len(haps)) if opts.records else None
     t0 = time.perf_counter()
     tables.sparse_device()
     tables.lut_device()
@@ -102,9 +99,9 @@ def main():
            else torch.from_numpy(weights_host).to(device="cuda", dtype=torch.float64))
     if opts.records:
         em_mat = None
-        cm = preprocess.build_em_records_device(tables, row_ptr, site, obs, rec=reservation)
+        cm = preprocess.build_em_records_device(tables, row_ptr, site, obs)
         torch.cuda.synchronize()
-        sys.stderr.write("EM input %d x %d built on the device as records in %.1f ms (incl. waiting for the buffer's allocation): %.2f GB, %d rows dense beside them "
+        sys.stderr.write("EM input %d x %d built on the device as records in %.1f ms: %.2f GB, %d rows dense beside them "
                          "(a dense matrix would be %.1f GB)\n"
                          % (cm.n_rows, cm.n_haps, (time.perf_counter() - t0) * 1e3, cm.used / 1e9,
                             cm.rest_rows.numel(), cm.n_rows * cm.n_haps * 8 / 1e9))
