@@ -38,7 +38,8 @@ def ns(**kw):
 
 widths = [1, 1, 2, 3, 4, 5, 8, 9, 16, 17, 31, 32, 33, 63, 64,        # the narrow (log-space) kernels: the refinement EM's shapes
           65, 66, 67, 127, 128, 129, 255, 256, 511, 512, 513, 1000, 1023, 1024, 1025, 2047, 2048, 2049,
-          3000, 4095, 4096, 4097, 5407, 5408, 5409, 6143, 6144, 6145, 7000, 8191, 8192]
+          3000, 4095, 4096, 4097, 5407, 5408, 5409, 6143, 6144, 6145, 7000, 8191, 8192,
+          8193, 9001, 9600, 9601, 10241, 12000]                    # round 5: beyond the streaming / log-space / finalize kernels' tables
 for case in range(opts.cases):
     if time.time() - t_start > opts.budget:
         print("budget used up after %d cases" % case)
