@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-/* 0.5.0.  Bumped whenever a signature or a documented default of this header changes; mxm_version() returns
+/* 0.5.1.  Bumped whenever a signature or a documented default of this header changes; mxm_version() returns
  * the value the loaded library was built with, and a binding must refuse a library whose value differs from the
  * header it was written against (mixemt_amd/_lib.py does).  History: 100 rounds 1-2 (mxm_row_argmax_votes gained
  * ws / ws_bytes and mxm_set_compact_restarts became 0/1/2 inside that number -- the reason for this rule);
@@ -46,8 +46,9 @@ extern "C" {
  * mxm_em_state gained `ticket` (24 bytes: mxm_m_finalize runs on several workgroups, the last arriver finishes);
  * 500 round 5: mxm_aln_* (the batched alignment front end), mxm_preload, mxm_build_em_matrix_lut_rows and
  * mxm_scatter_records added; mxm_em_state.reserved_ became .error and
- * mxm_em_iter_coded's state lost its const (the wide-rows list is checked where it is used). */
-#define MXM_VERSION 500
+ * mxm_em_iter_coded's state lost its const (the wide-rows list is checked where it is used);
+ * 501: mxm_bam_* (a BAM file into the front end's columns; the library now links zlib). */
+#define MXM_VERSION 501
 
 /* per-restart loop state, written by mxm_m_finalize (24 bytes); allocate it ZEROED */
 typedef struct mxm_em_state {
@@ -473,6 +474,32 @@ int  mxm_aln_fetch(const mxm_aln_enc *enc, int64_t *row_ptr, uint16_t *site, uin
                    int64_t *group_ptr, int64_t *group_frag, int64_t *dropped, char *text, int64_t *text_off);
 int  mxm_aln_fetch_fragments(const mxm_aln_enc *enc, int64_t *frag_id, int64_t *frag_ptr, uint16_t *site, uint8_t *obs);
 void mxm_aln_free(mxm_aln_enc *enc);
+
+/*
+ * HOST functions (no device work): a BAM file straight into those columns -- what the reference gets from pysam
+ * (bin/mixemt:139-147 opens the file; preprocess.py:209 iterates bamfile.fetch(); :118-132 read mapping_quality,
+ * query_name, query_sequence, query_qualities and the aligned pairs of every AlignedSegment).  The BGZF members are
+ * inflated on `n_threads` host threads (zlib), the records decoded into columns, equal read names given one fragment
+ * index by first appearance.  Like fetch() without a region: every record placed on a reference (refID >= 0) in file
+ * order, no flag filtering (the reference filters by mapping quality only, :119); records without a reference are
+ * skipped and counted.
+ *   mxm_bam_read      0, -1 (bad arguments), -6 (cannot open / read), -4 (not BGZF / BAM, truncated, or a CIGAR kept in
+ *                     a CG tag: more than 65535 operations), -5 (out of memory)
+ *   mxm_bam_columns   fills `cols` with pointers INTO the handle (valid until mxm_bam_free): mxm_aln_encode reads them
+ *                     in place
+ *   mxm_bam_fetch_names  names[names_bytes] / name_off[n_frag+1]: the fragments' read names back to back;
+ *                     ref_id[n_aln], flag[n_aln]: the records' reference index and FLAG (not used by the encoder);
+ *                     NULL = not wanted
+ */
+typedef struct mxm_bam_sizes {
+    int64_t n_aln, n_frag, n_cigar, n_bases, names_bytes, n_ref, n_records_total, n_skipped_unplaced;
+} mxm_bam_sizes;
+typedef struct mxm_bam mxm_bam;
+int  mxm_bam_read(const char *path, int32_t n_threads, mxm_bam **out);
+int  mxm_bam_sizes_of(const mxm_bam *bam, mxm_bam_sizes *sizes);
+int  mxm_bam_columns(const mxm_bam *bam, mxm_aln_columns *cols);
+int  mxm_bam_fetch_names(const mxm_bam *bam, char *names, int64_t *name_off, int32_t *ref_id, uint16_t *flag);
+void mxm_bam_free(mxm_bam *bam);
 
 #ifdef __cplusplus
 }

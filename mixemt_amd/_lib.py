@@ -41,6 +41,12 @@ class AlnSizes(ctypes.Structure):
                 ("n_frag_seen", c_i64), ("frag_nnz", c_i64)]
 
 
+class BamSizes(ctypes.Structure):
+    """mxm_bam_sizes (include/mixemt_hip.h)."""
+    _fields_ = [("n_aln", c_i64), ("n_frag", c_i64), ("n_cigar", c_i64), ("n_bases", c_i64), ("names_bytes", c_i64),
+                ("n_ref", c_i64), ("n_records_total", c_i64), ("n_skipped_unplaced", c_i64)]
+
+
 # name -> (restype, argtypes); must list every symbol the two headers declare
 # (include/mixemt_hip.h: the boundary; include/mixemt_hip_tuning.h: measurement / shape knobs)
 SIGNATURES = {
@@ -112,6 +118,11 @@ SIGNATURES = {
     "mxm_aln_fetch": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mxm_aln_fetch_fragments": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mxm_aln_free": (None, [c_ptr]),
+    "mxm_bam_read": (ctypes.c_int, [ctypes.c_char_p, c_i32, ctypes.POINTER(c_ptr)]),
+    "mxm_bam_sizes_of": (ctypes.c_int, [c_ptr, ctypes.POINTER(BamSizes)]),
+    "mxm_bam_columns": (ctypes.c_int, [c_ptr, ctypes.POINTER(AlnColumns)]),
+    "mxm_bam_fetch_names": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
+    "mxm_bam_free": (None, [c_ptr]),
     "mxm_set_compact_restarts": (ctypes.c_int, [c_i32]),
     "mxm_set_loop_graph": (ctypes.c_int, [c_i32]),
     "mxm_set_loop_fused": (ctypes.c_int, [c_i32, c_i32]),
@@ -129,7 +140,7 @@ SIGNATURES = {
 }
 
 # the MXM_VERSION of include/mixemt_hip.h these signatures were written for; load() refuses any other
-ABI_VERSION = 500
+ABI_VERSION = 501
 
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.POINTER(EmState), c_i32, c_ptr)
 

@@ -7,6 +7,7 @@ the library's host encoder (mxm_aln_encode, csrc/aln_encode.hpp) instead of one 
     build_em_input  :218-220, :225                                 rows = sorted(signatures), weights, id lists
 
     cols = AlignmentColumns.from_alignments(bam.fetch())       # pysam.AlignedSegment-like objects, read in bulk
+    cols = read_bam("sample.bam")                              # or: the file itself, through the library's BAM reader
     enc  = encode_alignments(cols, tables.sites, ref_len, min_mq, min_bq)
     enc.row_ptr, enc.site, enc.obs      the CSR observations build_em_matrix_device / build_em_records_device take
     enc.weights                         fragments per signature (int64)
@@ -140,6 +141,94 @@ class AlignmentColumns(object):
         cols = _lib.AlnColumns(len(self), self.n_frag, p(self.ref_start), p(self.mapq), p(self.frag), self.cig_ptr.ctypes.data,
                                p(self.cigar), self.seq_ptr.ctypes.data, p(self.seq), p(self.qual), p(self.has_qual))
         return cols, keep
+
+
+class FragmentNames(object):
+    """The fragments' read names as one byte string + offsets (read_bam): a sequence of str, decoded when looked at."""
+
+    def __init__(self, data, off):
+        self.data, self.off = data, off
+
+    def __len__(self):
+        return len(self.off) - 1
+
+    def __getitem__(self, i):
+        if isinstance(i, slice):
+            return [self[k] for k in range(*i.indices(len(self)))]
+        i = int(i)
+        if i < 0:
+            i += len(self)
+        if not 0 <= i < len(self):
+            raise IndexError("fragment index out of range")
+        return self.data[self.off[i]:self.off[i + 1]].tobytes().decode("ascii", "replace")
+
+    def __iter__(self):
+        return (self[i] for i in range(len(self)))
+
+
+def read_bam(path, n_threads=0):
+    """
+    A BAM file -> AlignmentColumns through the library's reader (mxm_bam_read, csrc/bam_reader.hpp): what the reference
+    gets from `pysam.AlignmentFile(path).fetch()` (bin/mixemt:139-147, preprocess.py:209) -- every record placed on a
+    reference, in file order -- without a Python object per alignment.  The columns carry `.ref_id`, `.flag` (per
+    alignment, not used by the encoder) and `.bam_counts` = (records in the file, skipped because unplaced).
+    Raises OSError when the file cannot be read, ValueError when it is not a BAM file the reader takes.
+    """
+    import ctypes
+    import os
+    lib = _lib.load()
+    handle = ctypes.c_void_p()
+    rc = lib.mxm_bam_read(os.fsencode(path), int(n_threads), ctypes.byref(handle))
+    if rc == -6:
+        raise OSError(lib.mxm_last_error().decode("utf-8", "replace"))
+    if rc == -4:
+        raise ValueError(lib.mxm_last_error().decode("utf-8", "replace"))
+    _lib.check(rc, "mxm_bam_read")
+    owner = _BamHandle(lib, handle)
+    sz = _lib.BamSizes()
+    _lib.check(lib.mxm_bam_sizes_of(handle, ctypes.byref(sz)), "mxm_bam_sizes_of")
+    st = _lib.AlnColumns()
+    _lib.check(lib.mxm_bam_columns(handle, ctypes.byref(st)), "mxm_bam_columns")
+
+    def view(ptr, n, dtype):
+        # the library's own arrays, not copies (the two big ones are a byte per base each); every view keeps the
+        # handle alive through the ctypes block it is made from
+        n = int(n)
+        if not n or not ptr:
+            return numpy.empty(0, dtype=dtype)
+        block = (ctypes.c_uint8 * (n * numpy.dtype(dtype).itemsize)).from_address(ptr)
+        block._owner = owner
+        out = numpy.frombuffer(block, dtype=dtype)
+        out.flags.writeable = False
+        return out
+
+    n = int(sz.n_aln)
+    names = numpy.empty(int(sz.names_bytes), dtype=numpy.uint8)
+    name_off = numpy.empty(int(sz.n_frag) + 1, dtype=numpy.int64)
+    ref_id = numpy.empty(n, dtype=numpy.int32)
+    flag = numpy.empty(n, dtype=numpy.uint16)
+    _lib.check(lib.mxm_bam_fetch_names(handle, names.ctypes.data, name_off.ctypes.data, ref_id.ctypes.data,
+                                       flag.ctypes.data), "mxm_bam_fetch_names")
+    cols = AlignmentColumns(view(st.ref_start, n, numpy.int64), view(st.mapq, n, numpy.int32), view(st.frag, n, numpy.int64),
+                            view(st.cig_ptr, n + 1, numpy.int64), view(st.cigar, sz.n_cigar, numpy.uint32),
+                            view(st.seq_ptr, n + 1, numpy.int64), view(st.seq, sz.n_bases, numpy.uint8),
+                            view(st.qual, sz.n_bases, numpy.uint8) if st.qual else None,
+                            view(st.has_qual, n, numpy.uint8), FragmentNames(names, name_off))
+    cols.ref_id, cols.flag = ref_id, flag
+    cols.bam_counts = (int(sz.n_records_total), int(sz.n_skipped_unplaced))
+    return cols
+
+
+class _BamHandle(object):
+    """Owns an mxm_bam: freed when the last array viewing it goes."""
+
+    def __init__(self, lib, handle):
+        self._free, self._handle = lib.mxm_bam_free, handle
+
+    def __del__(self):
+        handle, self._handle = self._handle, None
+        if handle and self._free is not None:
+            self._free(handle)
 
 
 class ReadIdGroups(object):

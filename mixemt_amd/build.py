@@ -59,7 +59,7 @@ def build(force=False, defines=(), verbose=False, out=None):
             if fin.read().strip() == want:
                 return LIB
     os.makedirs(os.path.dirname(LIB), exist_ok=True)
-    cmd = [_hipcc()] + flags + [SRC, "-o", LIB]
+    cmd = [_hipcc()] + flags + [SRC, "-o", LIB, "-lz"]          # zlib: the BGZF members of csrc/bam_reader.hpp
     if verbose:
         sys.stderr.write(" ".join(cmd) + "\n")
     proc = subprocess.run(cmd, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)

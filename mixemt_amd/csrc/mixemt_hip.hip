@@ -46,6 +46,7 @@
 
 #include "common.hpp"
 #include "aln_encode.hpp"
+#include "bam_reader.hpp"
 #include "coded_kernels.hpp"
 #include "build_kernels.hpp"
 #include "build_lut_kernels.hpp"

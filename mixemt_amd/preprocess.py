@@ -19,6 +19,7 @@ exactly the reference's string comparison, for any alphabet ('N' included).
 
 import collections
 import math
+import os
 import sys
 
 import numpy
@@ -754,7 +755,8 @@ def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False, as_reco
     alignments.ReadIdGroups -- the reference's list of lists, materialised row by row on demand); "python" = the
     reference's own object-by-object walk (process_reads / reduce_reads below); "auto" = batched, falling back to
     python for input the encoder hands back (so that the exception raised is the reference's).
-    `bamfile` may also be an alignments.AlignmentColumns (a columnar reader's output).
+    `bamfile` may also be an alignments.AlignmentColumns (a columnar reader's output) or the PATH of a BAM file, which
+    the library's own reader turns into columns (alignments.read_bam: no pysam, no object per alignment; batched only).
     """
     from . import alignments
     if frontend not in ("auto", "batched", "python"):
@@ -764,6 +766,10 @@ def build_em_input(bamfile, refseq, phylo, args, as_device_tensor=False, as_reco
     verbose = getattr(args, "verbose", False)
     enc = None
     columns = bamfile if isinstance(bamfile, alignments.AlignmentColumns) else None
+    if isinstance(bamfile, (str, bytes, os.PathLike)):
+        if frontend == "python":
+            raise ValueError("build_em_input: a BAM path goes through the batched front end (open it with pysam for 'python')")
+        columns = alignments.read_bam(bamfile)
     if frontend != "python":
         alns = None
         try:

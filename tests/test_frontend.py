@@ -159,6 +159,31 @@ def test_build_em_input_equals_the_reference_run(b17, as_records, frontend, caps
     assert numpy.array_equal(host[:3], g["mat_rows"])
 
 
+@pytest.mark.gpu
+def test_build_em_input_from_a_bam_file_equals_the_reference_run(b17, tmp_path, capsys):
+    """The same run started from a BAM FILE (golden g11's alignments written by tests/_bam_writer.py): the library's reader
+    in front of the encoder gives the reference's matrix, weights and read-id lists."""
+    import argparse
+    import hashlib
+    import json
+    import _bam_writer
+    from mixemt_amd import alignments
+    refseq, phy, haps, tables = b17
+    g, alns = _g11()
+    path = str(tmp_path / "g11.bam")
+    _bam_writer.write_bam(path, alignments.AlignmentColumns.from_alignments(alns), block_bytes=5000)
+    args = argparse.Namespace(min_mq=int(g["min_mq"]), min_bq=int(g["min_bq"]), verbose=False)
+    mat, wts, hap_order, read_ids = preprocess.build_em_input(path, refseq, phy, args)
+    assert preprocess.build_em_input.last_frontend == "batched"
+    assert preprocess.build_em_input.last_dropped == [str(g["empty_name"])]
+    assert "skipped 1 fragment" in capsys.readouterr().err
+    assert numpy.array_equal(wts, g["weights"])
+    assert read_ids == json.loads(str(g["read_ids"]))
+    assert hashlib.sha256(numpy.ascontiguousarray(mat).tobytes()).hexdigest() == str(g["mat_sha256"])
+    with pytest.raises(ValueError, match="batched front end"):
+        preprocess.build_em_input(path, refseq, phy, args, frontend="python")
+
+
 # ---- g12: the -s / -l files as the reference's own dump_all writes them and its load_prev reads them ----------------
 def _g12():
     import json

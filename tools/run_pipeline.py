@@ -40,6 +40,9 @@ def main():
     ap.add_argument("--records", action="store_true", help="(the default since round 3; kept for old command lines)")
     ap.add_argument("--alignments", action="store_true",
                     help="input = synthetic alignments as columns through the batched front end (instead of ready-made rows)")
+    ap.add_argument("--bam", action="store_true",
+                    help="with --alignments: write them as a BAM file first (tests/_bam_writer.py, untimed) and start from "
+                         "the FILE: the library's reader (alignments.read_bam) in front of the encoder")
     ap.add_argument("--threads", type=int, default=0, help="with --alignments: host threads of the encoder (0 = its default)")
     ap.add_argument("--storage", default="auto", choices=["f64", "f32", "coded", "auto"],
                     help="with --dense: form of the matrix the EM loop streams (EmPlan): coded = lossless row dictionaries, "
@@ -61,6 +64,26 @@ def main():
         cols = synth.synth_alignments(tables, refseq, opts.reads, seed=1)
         sys.stderr.write("%d synthetic alignments of %d fragments as columns (%.1f s of generation, not part of the pipeline)\n"
                          % (len(cols), cols.n_frag, time.perf_counter() - t0))
+        if opts.bam:
+            import tempfile
+            sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+            import _bam_writer
+            t0 = time.perf_counter()
+            tmp = tempfile.TemporaryDirectory()
+            bam_path = os.path.join(tmp.name, "synth.bam")
+            _bam_writer.write_bam(bam_path, cols)
+            n_written = len(cols)
+            sys.stderr.write("written as %s (%.1f MB) in %.1f s (not part of the pipeline)\n"
+                             % (bam_path, os.path.getsize(bam_path) / 1e6, time.perf_counter() - t0))
+            alignments.read_bam(bam_path, n_threads=opts.threads)                 # (page cache warm, as a file just written is)
+            t0 = time.perf_counter()
+            cols = alignments.read_bam(bam_path, n_threads=opts.threads)
+            t_bam = time.perf_counter() - t0
+            assert len(cols) == n_written
+            sys.stderr.write("BAM reader (BGZF inflate -> records -> columns, names -> fragment indices): %.1f ms for %d alignments "
+                             "(%.2f s per 10^6, %.0f MB/s of file)\n"
+                             % (t_bam * 1e3, len(cols), t_bam / max(1, len(cols)) * 1e6, os.path.getsize(bam_path) / 1e6 / t_bam))
+            tmp.cleanup()
         t0 = time.perf_counter()
         enc = alignments.encode_alignments(cols, tables.sites, len(refseq), 30, 30, n_threads=opts.threads)
         t_enc = time.perf_counter() - t0
