@@ -301,7 +301,9 @@ __global__ __launch_bounds__(ENC_THREADS) void encode_wide_rows_kernel(
 // step's metadata read from LDS ahead of the lookups (-3 %): 1.63 -> 1.45-1.48 ms.  Lost: the wave sum on the matrix pipe (two v_mfma_f64_16x16x4 with B = 1 + three adds instead of the
 // 22-instruction ladder: +8 %, the MFMA's result latency is longer than the ladder it replaces), a branch-free
 // quotient, 5 or 6 rows in flight, 16-byte code loads (a thread owning 24 consecutive bytes), other cache policies
-// on the record loads: all within noise.  With the chain knocked out the kernel takes 1.19 ms, of which the record
+// on the record loads: all within noise (round 5 adds: ONE s_waitcnt for the row's 24 lookups instead of the compiler's
+// countdown in front of the dot product's FMAs -- 11 instructions fewer per step, 1.4435 against 1.4500 ms:
+// profiles/r05/ab_onewait.txt).  With the chain knocked out the kernel takes 1.19 ms, of which the record
 // loads are 0.40 (0.79 without them) and the 48 FMAs per thread 0.08: what is left is neither arithmetic nor HBM
 // bandwidth (5 of 8 TB/s) but two waves per SIMD overlapping their loads, LDS traffic and issue imperfectly.
 // The row pass is a device function so that the per-iteration kernel (em_iter_coded_kernel) and the one-launch loop

@@ -21,6 +21,7 @@ import collections
 import math
 import os
 import sys
+import time
 
 import numpy
 
@@ -636,6 +637,14 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
     stats, n_fallback, sub_stats = counters[0:2], counters[2:3], counters[3:5]
     fallback = torch.empty(n_rows, dtype=torch.int64, device=dev)
     stream = current_stream()
+    timing = {} if os.environ.get("MXM_PIPELINE_TIMING") else None     # (synchronises: measurement only)
+    build_em_records_device.last_timing = timing
+
+    def lap(name, t0):
+        if timing is not None:
+            torch.cuda.synchronize()
+            timing[name] = round(timing.get(name, 0.0) + (time.perf_counter() - t0) * 1e3, 2)
+        return time.perf_counter()
 
     def lut_rows(rows_d, count, out):
         """rows rows_d[0 .. count) of the CSR, cell by cell, into the COMPACT matrix out[count][H]"""
@@ -650,6 +659,7 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
     # that compacted lists, gathered the long rows' observations and scattered results with torch spent ~60 ms of a cold
     # 105 ms call there -- round 4 took it for the buffer's hipMalloc (profiles/r05/experiments.md section 3).
     for attempt in (0, 1):
+        t_lap = lap("uploads", time.perf_counter()) if attempt == 0 and timing is not None else time.perf_counter()
         if rec is None:
             rec = device_empty((cap,), torch.uint8, dev, "the coded matrix")
         _lib.check(lib.mxm_build_em_records(
@@ -659,6 +669,7 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
             rec.data_ptr(), cap, rec_off.data_ptr(), ndist.data_ptr(), rowmax.data_ptr(), stats.data_ptr(),
             fallback.data_ptr(), n_fallback.data_ptr(), stream), "mxm_build_em_records")
         used, n_rest, left = (int(v) for v in counters[:3].cpu())
+        t_lap = lap("marker kernel", t_lap)
         need = used
         m_rest = None
         rest_rows = fallback[:0]
@@ -675,7 +686,9 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
             else:
                 assert left == n_rest             # without a dense matrix every row without a record is on the list
                 if n_rest:                        # the list as the kernel appended it -> ascending (host: 8 bytes per row)
-                    rest_rows = torch.from_numpy(numpy.sort(fallback[:left].cpu().numpy())).to(dev)
+                    rest_host = numpy.sort(fallback[:left].cpu().numpy())
+                    rest_rows = torch.from_numpy(rest_host).to(dev)
+                    t_lap = lap("list sort", t_lap)
             if n_rest:
                 # the dense rows of long reads mostly hold few distinct values too: built (or taken from the dense matrix)
                 # a slab at a time and coded from their dense form (mxm_encode_rows: bytes, then 16-bit codes) into the
@@ -685,7 +698,7 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
                 sub_off = torch.empty(slab, dtype=torch.int64, device=dev)
                 sub_nd = torch.empty(slab, dtype=torch.int32, device=dev)
                 sub_rm = torch.empty(slab, dtype=torch.float64, device=dev)
-                kept_rows, kept_dense = [], []
+                kept_rows, kept_dense, kept_host = [], [], []
                 for lo in range(0, n_rest, slab):
                     rows_s = rest_rows[lo:lo + slab]
                     n_s = int(rows_s.numel())
@@ -694,6 +707,7 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
                     else:
                         m_s = m_slab[:n_s]
                         lut_rows(rows_s, n_s, m_s)
+                        t_lap = lap("slab build", t_lap)
                     base = (need + 15) // 16 * 16
                     room = cap - base >= one
                     if room:
@@ -701,21 +715,35 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
                                                        cap - base, sub_off.data_ptr(), sub_nd.data_ptr(), sub_rm.data_ptr(),
                                                        sub_stats.data_ptr(), stream), "mxm_encode_rows")
                         sub_used, sub_left = (int(v) for v in sub_stats.cpu())
+                        t_lap = lap("slab encode", t_lap)
                     else:
                         sub_used, sub_left = n_s * one, 0     # no room left at all: ask for the worst case of these rows
                     if room and base + sub_used <= cap:
                         _lib.check(lib.mxm_scatter_records(rows_s.data_ptr(), n_s, sub_off.data_ptr(), sub_nd.data_ptr(),
                                                            sub_rm.data_ptr(), base, rec_off.data_ptr(), ndist.data_ptr(),
                                                            rowmax.data_ptr(), stream), "mxm_scatter_records")
-                        if sub_left:                          # more than 1024 values (random matrices): stays dense
-                            got = sub_nd[:n_s] > 0
-                            kept_rows.append(rows_s[~got])
-                            kept_dense.append(m_s[~got].clone())
+                        if sub_left:                          # more than 1024 values (long reads, random matrices): stays dense
+                            if dense:
+                                got = sub_nd[:n_s] > 0
+                                kept_rows.append(rows_s[~got])
+                                kept_dense.append(m_s[~got].clone())
+                            else:                             # which ones: on the host (a copy, no torch operator -- see above)
+                                kept_host.append(rest_host[lo:lo + n_s][sub_nd[:n_s].cpu().numpy() == 0])
+                        t_lap = lap("slab scatter / keep", t_lap)
                     need = base + sub_used
                 if need <= cap:
                     used = need
-                    rest_rows = torch.cat(kept_rows) if kept_rows else rest_rows[:0]
-                    m_rest = torch.cat(kept_dense) if kept_dense else None
+                    if dense:
+                        rest_rows = torch.cat(kept_rows) if kept_rows else rest_rows[:0]
+                        m_rest = torch.cat(kept_dense) if kept_dense else None
+                    elif kept_host:                           # built once more, compactly, straight into their final place
+                        kept = numpy.concatenate(kept_host)
+                        rest_rows = torch.from_numpy(kept).to(dev)
+                        m_rest = torch.empty((len(kept), n_haps), dtype=torch.float64, device=dev)
+                        lut_rows(rest_rows, len(kept), m_rest)
+                        t_lap = lap("kept rows", t_lap)
+                    else:
+                        rest_rows = rest_rows[:0]
                     n_rest = int(rest_rows.numel())
         if need <= cap:
             break

@@ -371,6 +371,36 @@ def test_records_straight_from_the_build(b17, name, read_len):
     assert numpy.array_equal(cm2.m_rest.cpu().numpy(), want[cm2.rest_rows.cpu().numpy()])
 
 
+def test_rows_from_alignments_keep_their_dense_rows(b17):
+    """Rows made of two mates carry up to ~170 observations: past the marker kernel (built a slab at a time, coded from
+    there) and, some of them, past 1024 distinct values -- those stay dense beside the records (`rest_rows` ascending,
+    `m_rest` the reference's bits), found without a dense matrix anywhere."""
+    import torch
+    from mixemt_amd import alignments, preprocess, synth
+    refseq, phy, haps, tables = b17
+    cols = synth.synth_alignments(tables, refseq, 6000, seed=21, mate_share=0.9)
+    enc = alignments.encode_alignments(cols, tables.sites, len(refseq), 30, 30)
+    want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, enc.row_ptr, enc.site, enc.obs, len(haps))
+    old = preprocess.REST_SLAB_ROWS
+    preprocess.REST_SLAB_ROWS = 150                                            # several slabs
+    try:
+        cm = preprocess.build_em_records_device(tables, enc.row_ptr, enc.site, enc.obs)
+    finally:
+        preprocess.REST_SLAB_ROWS = old
+    nd = cm.ndist.cpu().numpy()
+    rest = cm.rest_rows.cpu().numpy()
+    assert preprocess.build_em_matrix_device.last_fallback > 300               # (three slabs at least)
+    assert len(rest) >= 5 and numpy.array_equal(rest, numpy.flatnonzero(nd == 0))
+    assert all(len(numpy.unique(want[r])) > 1024 for r in rest)
+    assert numpy.array_equal(cm.m_rest.cpu().numpy(), want[rest])
+    dec = _decode_cm(cm)
+    rows = torch.from_numpy(nd > 0).to(dec.device)
+    lin = numpy.exp(want - want.max(axis=1, keepdims=True))
+    got = dec[rows].cpu().numpy()
+    assert numpy.allclose(got, lin[nd > 0], rtol=1e-15, atol=0)
+    assert numpy.array_equal(cm.rowmax.cpu().numpy()[nd > 0], want.max(axis=1)[nd > 0])
+
+
 def test_run_em_from_build_records_reproduces_the_reference(b17):
     """g9 (2400 rows, repeat weights, 1209 iterations): CSR -> records -> EM, no dense matrix anywhere."""
     from mixemt_amd import em, preprocess
