@@ -262,6 +262,33 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
     ms = beg.elapsed_time(end) / steps
     kernel_ms = kev[0].elapsed_time(kev[1])
     loop_ms = loop_ms_per_iteration(em, torch, cplan, props[0], max(steps, 50))
+    # the same step with a quad dictionary beside the records (EmPlan.attach_quads: built by default for several restarts)
+    quads = None
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    if cplan.attach_quads(True):
+        torch.cuda.synchronize()
+        quad_build_ms = (time.perf_counter() - t0) * 1e3
+        cs_quad = torch.zeros_like(props)
+        cplan.em_iter(props, ln_props, state, cs_quad)
+        qrel = float(((cs_quad - cs_dense).abs() / cs_dense.abs().clamp_min(1e-300)).max().item())
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        beg.record()
+        for _ in range(steps):
+            one()
+        end.record()
+        one(timed=True)
+        torch.cuda.synchronize()
+        qms, qkernel = beg.elapsed_time(end) / steps, kev[0].elapsed_time(kev[1])
+        quads = {"ms_per_step": qms, "value": float(n_rows) * n_haps / (qms * 1e-3), "kernel": "em_iter_quad_coded_kernel",
+                 "kernel_ms": qkernel, "kernel_bytes": float(cplan.coded_record_bytes),
+                 "hbm_frac": cplan.coded_record_bytes / (qkernel * 1e-3) / HBM_PEAK_BYTES_PER_S,
+                 "quad_rows": int(cplan.quad_rows_n), "quad_bytes": float(cplan.quad_bytes), "build_ms": quad_build_ms,
+                 "max_rel_dcolsum": qrel,
+                 "note": "one code byte per FOUR columns for the rows with at most 256 distinct value quadruples, beside the "
+                         "records (csrc/quad_kernels.hpp); the rows without quads share the grid; same timing as ms_per_step"}
     # "ms_per_step" keeps ONE meaning across rounds -- HIP events over the per-iteration kernels, rounds 2-3's
     # quantity and what a multi-GPU step runs around its all-reduce; the one-launch loop run_em takes on one GPU has a key
     # of its own (round 4 reported it AS ms_per_step: "schema" tells the two layouts apart)
@@ -279,7 +306,7 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
             "bytes_per_iteration": float(cplan.coded_bytes),
             "kernel_bytes": float(cplan.coded_record_bytes),
             "hbm_frac": cplan.coded_record_bytes / (kernel_ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
-            "rows_left_dense": int(cplan.coded_rest), "encode_ms": encode_ms, "max_rel_dcolsum": rel,
+            "rows_left_dense": int(cplan.coded_rest), "encode_ms": encode_ms, "max_rel_dcolsum": rel, "quads": quads,
             "note": "same iteration, matrix stored as one byte per cell + each row's distinct fp64 values "
                     "(decodes to the dense matrix bit for bit); not the headline value"}
 

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-/* 0.5.1.  Bumped whenever a signature or a documented default of this header changes; mxm_version() returns
+/* 0.5.2.  Bumped whenever a signature or a documented default of this header changes; mxm_version() returns
  * the value the loaded library was built with, and a binding must refuse a library whose value differs from the
  * header it was written against (mixemt_amd/_lib.py does).  History: 100 rounds 1-2 (mxm_row_argmax_votes gained
  * ws / ws_bytes and mxm_set_compact_restarts became 0/1/2 inside that number -- the reason for this rule);
@@ -47,8 +47,9 @@ extern "C" {
  * 500 round 5: mxm_aln_* (the batched alignment front end), mxm_preload, mxm_build_em_matrix_lut_rows and
  * mxm_scatter_records added; mxm_em_state.reserved_ became .error and
  * mxm_em_iter_coded's state lost its const (the wide-rows list is checked where it is used);
- * 501: mxm_bam_* (a BAM file into the front end's columns; the library now links zlib). */
-#define MXM_VERSION 501
+ * 501: mxm_bam_* (a BAM file into the front end's columns; the library now links zlib);
+ * 502: mxm_coded gained the quad dictionary's fields (qrec .. n_byte_rows), mxm_build_quads, mxm_quad_bytes. */
+#define MXM_VERSION 502
 
 /* per-restart loop state, written by mxm_m_finalize (24 bytes); allocate it ZEROED */
 typedef struct mxm_em_state {
@@ -267,8 +268,35 @@ typedef struct mxm_coded {
                                     Nothing else reads it: the vote, the posterior, the gathers and the decoder find
                                     the wide rows from ndist themselves. */
     int64_t        n_wide;
+    /* QUAD dictionary beside the records (round 5, optional: all NULL / 0 = none) -- an acceleration structure for
+     * mxm_em_iter_coded / mxm_em_loop_coded alone, made by mxm_build_quads; every other consumer reads the records,
+     * which stay complete.  A quad record names FOUR consecutive columns' values with one code byte (256 x 8 code
+     * bytes, thread-contiguous, then nquad[r] x 32 bytes of table: csrc/quad_kernels.hpp): 1.27 against 1.41 ms per
+     * pass at 10^6 x 5408.  With quads the iteration takes the rows of `quad_rows` from `qrec`, the rows of `byte_rows`
+     * and `wide_rows` from `rec`, the dense rest from P_rest; the lists are checked where they are used (in range,
+     * ascending, of their class: a fault poisons colsum with NaN and raises state[b].error, as for wide_rows), and
+     * n_quad_rows + n_byte_rows + n_wide + R_rest must be R. */
+    const uint8_t *qrec;         /* quad records */
+    const int64_t *qoff;         /* [R] byte offset of row r's quad record */
+    const int32_t *nquad;        /* [R] distinct quads of row r: 1..256, 0 = the row has no quad record */
+    const int64_t *quad_rows;    /* [n_quad_rows] the rows with nquad > 0, ASCENDING */
+    int64_t        n_quad_rows;
+    const int64_t *byte_rows;    /* [n_byte_rows] the rows with 0 < ndist <= 256 and nquad == 0, ASCENDING */
+    int64_t        n_byte_rows;
 } mxm_coded;
 size_t mxm_coded_bytes(int64_t R, int32_t H);
+/*
+ * mxm_build_quads    records -> quad records (device work on `stream`, no allocation): qoff[R] / nquad[R] for EVERY row
+ *                    (0 for rows without a byte-coded record and for rows with more than 256 distinct quads); the
+ *                    records go to qrec[0 .. qrec_bytes) by a bump allocator, stats[0] = bytes asked for (a record that
+ *                    no longer fits is not written and its row keeps nquad = 0: repeat with stats[0] bytes),
+ *                    stats[1] = byte-coded rows left without quads (device uint64[2], zeroed by the call).  qrec must be
+ *                    32-byte aligned.  The caller forms quad_rows / byte_rows from nquad and ndist.
+ * mxm_quad_bytes     a buffer size that can never overflow: R * (2048 + 256 * 32)
+ */
+size_t mxm_quad_bytes(int64_t R, int32_t H);
+int mxm_build_quads(const mxm_coded *c, int32_t H, uint8_t *qrec, size_t qrec_bytes, int64_t *qoff, int32_t *nquad,
+                    uint64_t *stats, void *stream);
 int mxm_encode_rows(const double *M, int64_t ldm, int64_t R, int32_t H, uint8_t *rec, size_t rec_bytes,
                     int64_t *rec_off, int32_t *ndist, double *rowmax, int64_t *stats, void *stream);
 int mxm_decode_rows(const mxm_coded *c, int32_t H, double *P, int64_t ldp, void *stream);

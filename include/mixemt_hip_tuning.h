@@ -98,6 +98,13 @@ int mxm_set_loop_fused(int32_t mode, int32_t chunk);
 int mxm_set_fused_coded_grid(int32_t nwg);
 
 /*
+ * Workgroups of the leftover pass (byte-coded rows without quads, wide rows) inside the grid it shares with the quad pass
+ * (em_iter_quad_coded_kernel; at most half the grid): 0 = by the rows' measured cost, so that both passes finish together.
+ * Results differ by the rounding of another summation order only.
+ */
+int mxm_set_quad_left_grid(int32_t nwg);
+
+/*
  * Test hook: the next one-launch loops start with their abort flag already raised, i.e. behave as if a workgroup had
  * waited in vain at the first grid barrier (the situation a second process holding CUs creates).  mxm_em_loop must then
  * undo the launch and finish through the per-iteration kernels (mode -1), or return -3 (mode 1).

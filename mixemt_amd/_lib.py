@@ -25,7 +25,10 @@ class Coded(ctypes.Structure):
     """mxm_coded (include/mixemt_hip.h): a matrix in row-dictionary storage."""
     _fields_ = [("rec", c_ptr), ("rec_off", c_ptr), ("ndist", c_ptr), ("R", c_i64),
                 ("P_rest", c_ptr), ("ldp_rest", c_i64), ("w_rest", c_ptr), ("R_rest", c_i64),
-                ("wide_rows", c_ptr), ("n_wide", c_i64)]
+                ("wide_rows", c_ptr), ("n_wide", c_i64),
+                # the quad dictionary beside the records (round 5; all NULL / 0 = none)
+                ("qrec", c_ptr), ("qoff", c_ptr), ("nquad", c_ptr), ("quad_rows", c_ptr), ("n_quad_rows", c_i64),
+                ("byte_rows", c_ptr), ("n_byte_rows", c_i64)]
 
 
 class AlnColumns(ctypes.Structure):
@@ -84,6 +87,8 @@ SIGNATURES = {
                                        c_ptr, c_f64, c_i32, c_i32, c_ptr, c_size, c_ptr,
                                        ctypes.POINTER(EmState)]),
     "mxm_coded_bytes": (c_size, [c_i64, c_i32]),
+    "mxm_quad_bytes": (c_size, [c_i64, c_i32]),
+    "mxm_build_quads": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_ptr, c_size, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mxm_encode_rows": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_size, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mxm_decode_rows": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_ptr, c_i64, c_ptr]),
     "mxm_row_argmax_votes_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_i32, c_ptr, c_ptr, c_ptr, c_ptr, c_i64,
@@ -107,6 +112,7 @@ SIGNATURES = {
     "mxm_diag_stream_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_i32, c_ptr, c_ptr]),
     "mxm_diag_fused_force_abort": (ctypes.c_int, [c_i32]),
     "mxm_set_fused_coded_grid": (ctypes.c_int, [c_i32]),
+    "mxm_set_quad_left_grid": (ctypes.c_int, [c_i32]),
     "mxm_diag_fused_stamps": (ctypes.c_int, [c_ptr, ctypes.POINTER(ctypes.c_ulonglong)]),
     "mxm_set_timing_events": (ctypes.c_int, [c_ptr, c_ptr]),
     "mxm_set_batch_tile": (ctypes.c_int, [c_i32]),
@@ -140,7 +146,7 @@ SIGNATURES = {
 }
 
 # the MXM_VERSION of include/mixemt_hip.h these signatures were written for; load() refuses any other
-ABI_VERSION = 501
+ABI_VERSION = 502
 
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.POINTER(EmState), c_i32, c_ptr)
 

@@ -334,7 +334,9 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
                                                const int32_t *__restrict__ ndist, int ldc, const double *__restrict__ w,
                                                const int64_t *__restrict__ wide_rows, int64_t n_wide, int64_t R,
                                                const double (&p)[NCH][4], double (&acc)[NCH][4], bool &meta_ready,
-                                               int *chk_result = nullptr) {
+                                               int *chk_result = nullptr, const int64_t *__restrict__ row_list = nullptr,
+                                               int64_t n_list = 0, const int32_t *__restrict__ nquad = nullptr, int vbid = -1,
+                                               int vgrid = 0) {
     static_assert(NBUF >= 3, "codes NBUF - 1 rows ahead, tables NBUF - 2");
     constexpr int NW = THREADS / 64;
     constexpr int AUX = NT ? 2 : 0;
@@ -342,7 +344,12 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
     __shared__ __attribute__((aligned(16))) double red[NBUF][NW];
     const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
     const int nword = ldc >> 2;
-    const row_deal deal(R);
+    // row_list (the per-iteration kernel beside a quad dictionary, quad_kernels.hpp): the main loop takes ONLY the listed
+    // rows -- the byte-coded rows that have no quads, ascending -- instead of every row
+    // (vbid / vgrid: the workgroup's place among the workgroups that do THIS pass, where a kernel's grid is shared with
+    // another pass -- em_iter_quad_coded_kernel; otherwise the block index and the grid's size)
+    const int64_t bid = vbid >= 0 ? (int64_t)vbid : (int64_t)blockIdx.x, grid = vbid >= 0 ? (int64_t)vgrid : (int64_t)gridDim.x;
+    const row_deal deal(row_list != nullptr ? n_list : R, bid, grid);
     const int voff = t * 4;
     int last_w = t + (NCH - 1) * THREADS;               // words past the row are clamped: their columns have p = 0
     if (last_w > nword - 1) last_w = nword - 1;
@@ -387,14 +394,34 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
     __shared__ int s_nd[2][THREADS];
     auto fetch_meta = [&](int half, int64_t q0) {       // steps q0 .. q0 + THREADS - 1, thread t takes step q0 + t
         const int64_t q = q0 + t;
-        const int64_t r = deal.row(q);
+        int64_t r = deal.row(q);
+        bool struck = false;
+        if (row_list != nullptr) {                       // (uniform) entry r of the list; CHECK: in range, ascending
+            const int64_t e = r;
+            r = row_list[e];
+            if constexpr (CHECK) {
+                if (r < 0 || r >= R || (e > 0 && row_list[e - 1] >= r)) {
+                    s_chk[1] = 1;
+                    r = 0;                               // (some row; the entry gets an empty table and weight 0)
+                    struck = true;
+                }
+            }
+        }
         int nd = ndist[r];
         if (nd > ENC_MAX_CODES) {                        // a wide row: the second loop's (empty table here, weight 0)
             if constexpr (CHECK) {
-                if (deal.live(q)) atomicAdd(&s_chk[0], 1);
+                if (row_list != nullptr) s_chk[1] = 1;   // a listed row must be byte-coded
+                else if (deal.live(q)) atomicAdd(&s_chk[0], 1);
             }
             nd = 0;
         }
+        if constexpr (CHECK) {                           // a listed row is byte-coded and has no quads (or the quad pass
+            if (row_list != nullptr && !struck && (nd <= 0 || nquad[r] != 0)) {     // takes it too)
+                s_chk[1] = 1;
+                struck = true;
+            }
+        }
+        if (struck) nd = 0;
         s_off[half][t] = rec_off[r];
         s_nd[half][t] = nd;
         s_wr[half][t] = (deal.live(q) && nd > 0) ? (w != nullptr ? w[r] : 1.0) : 0.0;   // dense rows are not ours
@@ -516,12 +543,12 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
     // The wide rows' metadata (second loop below) is asked for HERE, ahead of the main loop, and parked in registers:
     // two dependent gathers (list -> record offset) that cost ~3 us when they were issued after the main loop --
     // 27 us of a 238 us pass at 125 000 rows, more than the dense launch they replace.
-    const int64_t nq_w = (n_wide > (int64_t)blockIdx.x) ? (n_wide - blockIdx.x + gridDim.x - 1) / gridDim.x : 0;
+    const int64_t nq_w = (n_wide > bid) ? (n_wide - bid + grid - 1) / grid : 0;
     // (WIDE_PREFETCH: the per-iteration kernel only -- the one-launch loop has no five registers to spare across its
     // row loop, and its metadata is mostly resident anyway)
     const bool wide_fetch = WIDE_PREFETCH && nq_w > 0 && (!RESIDENT || !meta_ready);
     int64_t w_row = -1;
-    if (wide_fetch && t < nq_w) w_row = list_row((int64_t)blockIdx.x + (int64_t)t * (int64_t)gridDim.x);
+    if (wide_fetch && t < nq_w) w_row = list_row(bid + (int64_t)t * grid);
     long long w_off = 0;
     int w_nd = CHECK ? -1 : 0;
     double w_wr = 0.0;
@@ -564,7 +591,7 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
         w_wr = (w != nullptr) ? w[w_row] : 1.0;
     }
 
-    // ---- the wide rows of this workgroup: wide_rows[blockIdx.x + i * grid] ----------------------------------------
+    // ---- the wide rows of this workgroup: wide_rows[bid + i * grid] ----------------------------------------
     if (nq_w > 0) {                                      // workgroup uniform
         __shared__ double s_wide[ENC_MAX_WIDE];
         __shared__ long long s_woff[THREADS];
@@ -590,7 +617,7 @@ __device__ __forceinline__ void coded_row_pass(const uint8_t *__restrict__ rec, 
                 __syncthreads();                         // the previous batch's entries have been read
                 const int64_t q = q0 + t;
                 if (q < nq_w) {
-                    const int64_t r = list_row((int64_t)blockIdx.x + q * (int64_t)gridDim.x);
+                    const int64_t r = list_row(bid + q * grid);
                     const int nd = list_nd(r);
                     s_woff[t] = (r >= 0) ? rec_off[r] : 0;
                     s_wnd[t] = nd;
@@ -675,7 +702,8 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
     const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off, const int32_t *__restrict__ ndist, int ldc,
     const double *__restrict__ w, const int64_t *__restrict__ wide_rows, int64_t n_wide,
     const double *__restrict__ props, int64_t R, int H, double *__restrict__ partial,
-    int64_t ldpart, const mxm_em_state *__restrict__ state, int run) {
+    int64_t ldpart, const mxm_em_state *__restrict__ state, int run, const int64_t *__restrict__ row_list, int64_t n_list,
+    const int32_t *__restrict__ nquad, int part_row0) {
     if (state != nullptr && state[run].done != 0) return;
     const int t = threadIdx.x;
     props += (int64_t)run * H;
@@ -696,14 +724,15 @@ __global__ __launch_bounds__(THREADS, MINWG *THREADS / 256) void em_iter_coded_k
 #define MXM_CODED_CHECK 1
 #endif
     coded_row_pass<THREADS, NCH, NBUF, true, false, true, MXM_CODED_CHECK != 0>(rec, rec_off, ndist, ldc, w, wide_rows, n_wide, R, p, acc,
-                                                                                 meta_ready, chk);
+                                                                                 meta_ready, chk, row_list, n_list, nquad);
+    const int64_t prow = (int64_t)part_row0 + blockIdx.x;   // (beside a quad dictionary the quad kernel's rows come first)
     if (t == 0) {                                        // {wide rows met, list fault}: behind the partial rows this path can use
-        int *out = reinterpret_cast<int *>(partial + (int64_t)MXM_MAX_WG * ldpart) + 2 * blockIdx.x;
+        int *out = reinterpret_cast<int *>(partial + (int64_t)MXM_MAX_WG * ldpart) + 2 * prow;
         out[0] = chk[0];
         out[1] = chk[1];
     }
 
-    double *dst = partial + (int64_t)blockIdx.x * ldpart;
+    double *dst = partial + prow * ldpart;
 #pragma unroll
     for (int k = 0; k < NCH; ++k) {
         const int c = 4 * (t + k * THREADS);

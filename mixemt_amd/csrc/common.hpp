@@ -210,12 +210,13 @@ __device__ __forceinline__ unsigned int code_byte_x8(unsigned int word) {
 
 struct row_deal {
     int64_t nq;                                     // steps (rows) of this workgroup
-    __device__ explicit row_deal(int64_t R) : nq((R - blockIdx.x + gridDim.x - 1) / gridDim.x) {}
+    int64_t bid, grid;                              // the workgroup's place in the dealing (its block index and the grid's
+                                                    // size, or virtual ones: a kernel whose workgroups do two jobs)
+    __device__ explicit row_deal(int64_t R) : row_deal(R, blockIdx.x, gridDim.x) {}
+    __device__ row_deal(int64_t R, int64_t b, int64_t g) : nq((R - b + g - 1) / g), bid(b), grid(g) {}
     __device__ bool live(int64_t q) const { return q < nq; }
     // steps past the end re-read the workgroup's last row (their result is discarded)
-    __device__ int64_t row(int64_t q) const {
-        return (int64_t)blockIdx.x + (q < nq ? q : nq - 1) * (int64_t)gridDim.x;
-    }
+    __device__ int64_t row(int64_t q) const { return bid + (q < nq ? q : nq - 1) * grid; }
 };
 
 #endif  // MIXEMT_COMMON_HPP

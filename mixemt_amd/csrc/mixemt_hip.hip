@@ -48,6 +48,7 @@
 #include "aln_encode.hpp"
 #include "bam_reader.hpp"
 #include "coded_kernels.hpp"
+#include "quad_kernels.hpp"
 #include "build_kernels.hpp"
 #include "build_lut_kernels.hpp"
 #include "build_sparse_kernels.hpp"
@@ -80,6 +81,7 @@ struct mxm_tuning {
     int fused_chunk = 0;            // iterations per launch of the one-launch loop (0 = run to the end)
     int fused_cols = 1;             // matrices of up to 1536 rows take the transposed form (columns split)
     int fused_coded_wg = 0;         // workgroups of the one-launch loop over records (0 = by size)
+    int quad_left_wg = 0;           // workgroups of the leftover pass beside the quad pass (0 = by the rows' measured cost)
     int fused_force_abort = 0;      // test hook: the one-launch loop starts with its abort flag raised (as if starved)
     double fused_cells = 1.0e8;     // ~18 000 rows at H = 5408: measured break-even is ~30 000 rows (profiles/r02/small_runs.txt)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;     // timing hook around the dominant kernel
@@ -457,6 +459,10 @@ extern "C" int mxm_set_batch_tile(int32_t bt) {
 
 extern "C" int mxm_set_fused_coded_grid(int32_t nwg) {
     return tune_set([nwg](mxm_tuning &t) { t.fused_coded_wg = nwg > 0 ? nwg : 0; });
+}
+
+extern "C" int mxm_set_quad_left_grid(int32_t nwg) {
+    return tune_set([nwg](mxm_tuning &t) { t.quad_left_wg = nwg > 0 ? nwg : 0; });
 }
 
 extern "C" int mxm_diag_fused_force_abort(int32_t on) {
@@ -874,6 +880,37 @@ static int coded_check(const mxm_coded *c, int32_t H, const char *who) {
                                             (reinterpret_cast<uintptr_t>(c->P_rest) & 15))))
         return fail(-1, "%s: the dense rest needs 16-byte aligned rows with an even ld >= H", who);
     if (c->n_wide < 0 || (c->n_wide > 0 && c->wide_rows == nullptr)) return fail(-1, "%s: n_wide > 0 needs wide_rows", who);
+    if (c->qrec != nullptr) {                            // a quad dictionary beside the records
+        if (c->qoff == nullptr || c->nquad == nullptr || c->n_quad_rows < 0 || c->n_byte_rows < 0 ||
+            (c->n_quad_rows > 0 && c->quad_rows == nullptr) || (c->n_byte_rows > 0 && c->byte_rows == nullptr) ||
+            (reinterpret_cast<uintptr_t>(c->qrec) & 31))
+            return fail(-1, "%s: quad dictionary arrays missing (or qrec not 32-byte aligned)", who);
+        if (c->n_quad_rows + c->n_byte_rows + c->n_wide + c->R_rest != c->R)
+            return fail(-1, "%s: quad_rows + byte_rows + wide_rows + the dense rest must be all %lld rows", who, c->R);
+    }
+    return 0;
+}
+
+extern "C" size_t mxm_quad_bytes(int64_t R, int32_t H) {
+    (void)H;
+    return R > 0 ? (size_t)R * (size_t)(QUAD_CODE_BYTES + QUAD_MAX * 32) : 0;
+}
+
+extern "C" int mxm_build_quads(const mxm_coded *c, int32_t H, uint8_t *qrec, size_t qrec_bytes, int64_t *qoff, int32_t *nquad,
+                               uint64_t *stats, void *stream) {
+    MXM_ENTER();
+    if (c == nullptr || c->R <= 0 || c->rec == nullptr || c->rec_off == nullptr || c->ndist == nullptr || !mxm_linear_supported(H))
+        return fail(-1, "mxm_build_quads: bad coded matrix (rows %s%lld, H %lld)", "", c ? c->R : 0, H);
+    if (qoff == nullptr || nquad == nullptr || stats == nullptr || (qrec == nullptr && qrec_bytes > 0) ||
+        (reinterpret_cast<uintptr_t>(qrec) & 31))
+        return fail(-1, "mxm_build_quads: qoff, nquad, stats and a 32-byte aligned qrec required%s", "");
+    const int ldc = coded_ld(H);
+    if (ldc / 4 > 8 * QUAD_THREADS) return fail(-1, "mxm_build_quads: H=%s%lld beyond eight quads per thread", "", H);
+    HIP_TRY(hipMemsetAsync(stats, 0, 2 * sizeof(uint64_t), (hipStream_t)stream));
+    hipLaunchKernelGGL(quad_encode_kernel, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(QUAD_THREADS), 0, (hipStream_t)stream,
+                       c->rec, c->rec_off, c->ndist, ldc, (int)H, c->R, qrec, (unsigned long long)qrec_bytes, qoff, nquad,
+                       reinterpret_cast<unsigned long long *>(stats));
+    HIP_TRY(hipGetLastError());
     return 0;
 }
 
@@ -1005,14 +1042,36 @@ static const coded_shape g_coded_shapes[] = {{256, 4, 2}};
 static const int g_coded_shape = 0;
 template <int THREADS, int NBUF, int MINWG>
 static int launch_coded(int nch, int nwg, hipStream_t stream, const mxm_coded *c, int ldc, const double *w, const double *props,
-                        int H, double *partial, int64_t ldpart, const mxm_em_state *state, int run) {
+                        int H, double *partial, int64_t ldpart, const mxm_em_state *state, int run,
+                        const int64_t *row_list = nullptr, int64_t n_list = 0, int part_row0 = 0) {
     switch (nch) {
-#define COD_CASE(n) case n: if constexpr (n * THREADS <= 2048) { hipLaunchKernelGGL((em_iter_coded_kernel<THREADS, n, NBUF, MINWG>), dim3(nwg), dim3(THREADS), 0, stream, c->rec, c->rec_off, c->ndist, ldc, w, c->wide_rows, c->n_wide, props, c->R, H, partial, ldpart, state, run); return 0; } break;
+#define COD_CASE(n) case n: if constexpr (n * THREADS <= 2048) { hipLaunchKernelGGL((em_iter_coded_kernel<THREADS, n, NBUF, MINWG>), dim3(nwg), dim3(THREADS), 0, stream, c->rec, c->rec_off, c->ndist, ldc, w, c->wide_rows, c->n_wide, props, c->R, H, partial, ldpart, state, run, row_list, n_list, c->nquad, part_row0); return 0; } break;
         COD_CASE(1) COD_CASE(2) COD_CASE(3) COD_CASE(4) COD_CASE(5) COD_CASE(6) COD_CASE(7) COD_CASE(8)
 #undef COD_CASE
         default: break;
     }
     return fail(-1, "mxm_em_iter_coded: H=%s%lld outside the kernel's range", "", H);
+}
+#define QUAD_MAX_NCH 6              // H <= 6144: the instances of the quad pass that compile without scratch
+static int launch_quad(int nch, int nwg, hipStream_t stream, const mxm_coded *c, const double *w, const double *props, int H,
+                       double *partial, int64_t ldpart, const mxm_em_state *state, int run) {
+    switch (nch) {
+#define QUAD_CASE(n) case n: hipLaunchKernelGGL((em_iter_quad_kernel<n, 4>), dim3(nwg), dim3(QUAD_THREADS), 0, stream, c->qrec, c->qoff, c->nquad, c->quad_rows, c->n_quad_rows, c->R, w, props, H, partial, ldpart, 0, state, run); return 0;
+        QUAD_CASE(1) QUAD_CASE(2) QUAD_CASE(3) QUAD_CASE(4) QUAD_CASE(5) QUAD_CASE(6)      // (7, 8: 35 registers spilled)
+#undef QUAD_CASE
+        default: break;
+    }
+    return fail(-1, "mxm_em_iter_coded: H=%s%lld outside the quad kernel's range", "", H);
+}
+static int launch_quad_coded(int nch, int nwg, int nwg_left, hipStream_t stream, const mxm_coded *c, int ldc, const double *w,
+                             const double *props, int H, double *partial, int64_t ldpart, const mxm_em_state *state, int run) {
+    switch (nch) {
+#define QC_CASE(n) case n: hipLaunchKernelGGL((em_iter_quad_coded_kernel<n, 4>), dim3(nwg), dim3(QUAD_THREADS), 0, stream, c->rec, c->rec_off, c->ndist, ldc, c->wide_rows, c->n_wide, c->byte_rows, c->n_byte_rows, c->qrec, c->qoff, c->nquad, c->quad_rows, c->n_quad_rows, c->R, w, props, H, partial, ldpart, nwg_left, state, run); return 0;
+        QC_CASE(1) QC_CASE(2) QC_CASE(3) QC_CASE(4) QC_CASE(5) QC_CASE(6)
+#undef QC_CASE
+        default: break;
+    }
+    return fail(-1, "mxm_em_iter_coded: H=%s%lld outside the quad kernel's range", "", H);
 }
 
 // One restart's pass over a coded matrix: dictionary rows through em_iter_coded_kernel, the dense rest
@@ -1027,14 +1086,46 @@ static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *
     int cap = num_cu() * sh.wg_per_cu;
     if (cap > MXM_MAX_WG - num_cu()) cap = MXM_MAX_WG - num_cu();             // the dense rest's rows come behind
     if (cap < 1) cap = 1;
-    const int nwg = clamp_grid((c->R + sh.nbuf - 1) / sh.nbuf, cap);
+    const bool quads = c->qrec != nullptr && c->n_quad_rows > 0 && nch <= QUAD_MAX_NCH;   // (wider: the records alone)
+    // beside a quad dictionary: the quad rows' pass (partial rows 0 .. nwg_q) and the pass over the byte-coded rows without
+    // quads and the wide rows (rows nwg_q .. nwg) share ONE grid (em_iter_quad_coded_kernel)
+    int nwg_q = 0, nwg = 0;
+    if (quads) {
+        // the leftover pass's share of the CUs' slots, by the measured cost of a row in each pass (us per row and
+        // workgroup: quad 0.67; byte 1.0 and wide 1.5 where only a few workgroups run that pass -- a sweep of the share at
+        // 10^6 rows, profiles/r05/quads_product_1m.txt: 22 workgroups 1.56 ms, 32 1.33, 48 1.36, 64 1.40, 128 1.62)
+        const int slots = cap < 2 * num_cu() ? cap : 2 * num_cu();
+        const double left_cost = 1.0 * (double)c->n_byte_rows + 1.5 * (double)c->n_wide;
+        const double quad_cost = 0.67 * (double)c->n_quad_rows;
+        int nwg_b = 0;
+        if (c->n_byte_rows > 0 || c->n_wide > 0) {
+            nwg_b = (int)((double)slots * left_cost / (left_cost + quad_cost) + 0.5);
+            if (T.quad_left_wg > 0) nwg_b = T.quad_left_wg;
+            if (nwg_b < 4) nwg_b = 4;
+            if (nwg_b > slots / 2) nwg_b = slots / 2;
+            const int64_t left = c->n_byte_rows > c->n_wide ? c->n_byte_rows : c->n_wide;
+            nwg_b = clamp_grid(left, nwg_b);
+        }
+        nwg_q = clamp_grid((c->n_quad_rows + sh.nbuf - 1) / sh.nbuf, slots - nwg_b < 1 ? 1 : slots - nwg_b);
+        nwg = nwg_q + nwg_b;
+    } else {
+        nwg = clamp_grid((c->R + sh.nbuf - 1) / sh.nbuf, cap);
+    }
     if (timed && T.ev_start != nullptr) HIP_TRY(hipEventRecord(T.ev_start, stream));
     // {wide rows met, list fault} per workgroup: the kernel leaves them behind the partial rows this path can use
     // (coded_row_pass, CHECK; em_iter_coded_kernel forms the same address)
     int *chk = reinterpret_cast<int *>(partial + (int64_t)MXM_MAX_WG * ldpart);
     int lrc;
-    lrc = launch_coded<256, 4, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run);
-    if (lrc != 0) return lrc;
+    if (quads) {
+        // one grid: the leftover pass on its first nwg - nwg_q workgroups beside the quad pass on the others
+        // (em_iter_quad_coded_kernel); no leftover rows at all: the quad kernel alone
+        if (nwg > nwg_q) lrc = launch_quad_coded(nch, nwg, nwg - nwg_q, stream, c, ldc, w, props, H, partial, ldpart, state, run);
+        else lrc = launch_quad(nch, nwg_q, stream, c, w, props, H, partial, ldpart, state, run);
+        if (lrc != 0) return lrc;
+    } else {
+        lrc = launch_coded<256, 4, 2>(nch, nwg, stream, c, ldc, w, props, H, partial, ldpart, state, run);
+        if (lrc != 0) return lrc;
+    }
     HIP_TRY(hipGetLastError());
     if (timed && T.ev_stop != nullptr) HIP_TRY(hipEventRecord(T.ev_stop, stream));
     int nwg_rest = 0;
@@ -1047,7 +1138,8 @@ static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *
                                                name of their own in a trace, apart from the dense matrix's passes */);
         if (rc != 0) return rc;
     }
-    return reduce_tile(partial, nwg + nwg_rest, 1, H, colsum, state, sl, fin, stream, wide_check{chk, nwg, (long long)c->n_wide});
+    // (with a row list the byte pass meets no wide row in its main loop: the lists are checked entry by entry instead)
+    return reduce_tile(partial, nwg + nwg_rest, 1, H, colsum, state, sl, fin, stream, wide_check{chk, nwg, quads ? 0ll : (long long)c->n_wide});
 }
 
 extern "C" int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, int32_t H, int32_t B,
@@ -1163,8 +1255,15 @@ static int fused_coded_grid(int64_t R) {
     if ((int64_t)nwg > R) nwg = (int)R;
     return nwg < 1 ? 1 : nwg;
 }
+#define QUAD_PER_ITER_MIN_ROWS 300000
 static bool fused_coded_eligible(const mxm_coded *c, int H, int B, size_t ws_bytes) {
     if (T.loop_fused == 0 || c == nullptr || c->R_rest > 0 || !mxm_linear_supported(H) || (H & 1)) return false;
+    // beside a quad dictionary the per-iteration kernels are the faster loop from a few 10^5 rows (the quad pass saves 10 %
+    // of the row pass, the one-launch loop ~40 us of launches and tail per iteration): the one-launch loop, which reads
+    // the records only, keeps the small matrices (mxm_set_loop_fused(1, ...) still forces it)
+    if (c->qrec != nullptr && c->n_quad_rows >= QUAD_PER_ITER_MIN_ROWS && T.loop_fused != 1 &&
+        (coded_ld(H) / 4 + QUAD_THREADS - 1) / QUAD_THREADS <= QUAD_MAX_NCH)
+        return false;
     const int nwg = fused_coded_grid(c->R);
     const int ncol2 = H / 2;
     if ((ncol2 + nwg - 1) / nwg > 16 * FCODED_MAX_M) return false;           // slice wider than the column reduce covers

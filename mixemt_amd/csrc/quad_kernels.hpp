@@ -1,0 +1,471 @@
+// quad_kernels.hpp -- part of libmixemt_hip.so (gfx950); included by mixemt_hip.hip only.
+// A QUAD dictionary beside the row-dictionary records, for the EM iteration alone (round 5).
+#ifndef MIXEMT_QUAD_KERNELS_HPP
+#define MIXEMT_QUAD_KERNELS_HPP
+
+// ------------------------------------------------------------------------------------------
+// Why.  The records pass (coded_row_pass) spends, per cell, a shift (code byte -> table offset), a ds_read_b64 and two
+// fp64 FMAs, and runs at 0.65 of what its loads alone reach: VALU cycles, the LDS pipe and HBM are each a bit over half
+// used by two waves per SIMD that wait on each other's barrier (profiles/r05/experiments.md, 1b-1e).  A row holds few
+// distinct values (median 25) and they come in runs, so the row's 1352 aligned GROUPS OF FOUR columns hold few distinct
+// value quadruples too: median 93, at most 256 for 98.8 % of the byte-coded rows of a build_em_matrix matrix.  A quad
+// record names four columns' values with ONE code byte:
+//     codes   QUAD_CODE_BYTES = 256 threads x 8 bytes, thread-contiguous: byte j of thread t is the code of the quad
+//             t + 256 j (columns 4 (t + 256 j) .. + 3) -- the columns thread t of the pass owns; one 8-byte load per
+//             thread and row instead of six dword loads
+//     table   nq x 32 bytes: the four values (the record's own P table entries, the same bits) of each distinct quad
+// Per four cells: one shift and two ds_read_b128 instead of four shifts and four ds_read_b64; 4.8 KB per row instead of
+// 5.7.  Measured as an experiment on the real records first (tools/experiments/quad_experiment.hip, quad_1m.txt): 1.27 ms
+// per pass over 10^6 rows against 1.41-1.45, column sums within 2.5e-16 (same values, same thread-to-column map, same
+// order of the per-thread sums).
+// The quads are an ACCELERATION STRUCTURE for mxm_em_iter_coded / mxm_em_loop_coded: every other consumer (votes,
+// posterior, gathers, decode, the save files) keeps reading the records, which stay complete.  Rows without quads
+// (more than 256 distinct quads: 1.2 %; wide rows: 2 %) are taken from the records by the byte pass through a row list.
+// ------------------------------------------------------------------------------------------
+#define QUAD_MAX 256
+#define QUAD_CODE_BYTES 2048
+#define QUAD_HASH 1024
+#define QUAD_THREADS 256
+
+typedef unsigned int quad_u2 __attribute__((ext_vector_type(2)));
+typedef unsigned int quad_u4 __attribute__((ext_vector_type(4)));
+typedef double quad_d2 __attribute__((ext_vector_type(2)));
+
+// ------------------------------------------------------------------------------------------
+// K3q-enc  quad_encode_kernel: one workgroup per byte-coded row.  The row's quads (4 code bytes = one dword; code bytes
+// of columns past H are cleared so that equal quads compare equal) are de-duplicated in an LDS hash table (64-bit slots:
+// a tag bit + the quad, so that the quad 0xFFFFFFFF is an ordinary key), the distinct ones sorted (bitonic, 256 slots)
+// -- the codes are the ranks in that order, so a record's bytes do not depend on which thread won a slot -- and the
+// record goes to a bump-allocated place in `qrec` (stats[0] += its size; a record that does not fit any more is not
+// written and the row keeps nquad = 0: the caller sees stats[0] > capacity and may repeat with that much).
+// stats[1] counts the byte-coded rows left without quads.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t *__restrict__ rec,
+                                                                   const int64_t *__restrict__ rec_off,
+                                                                   const int32_t *__restrict__ ndist, int ldc, int H, int64_t R,
+                                                                   uint8_t *__restrict__ qrec, unsigned long long qcap,
+                                                                   int64_t *__restrict__ qoff, int32_t *__restrict__ nquad,
+                                                                   unsigned long long *__restrict__ stats) {
+    __shared__ unsigned long long s_tab[QUAD_HASH];
+    __shared__ unsigned int s_keys[QUAD_MAX];
+    __shared__ int s_n, s_n2;
+    __shared__ unsigned long long s_base;
+    const int t = threadIdx.x;
+    const int nqc = ldc >> 2;                              // quads per row
+    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
+        const int nd = ndist[r];
+        if (nd <= 0 || nd > ENC_MAX_CODES) {               // uniform: wide rows and rows without a record have no quads
+            if (t == 0) {
+                nquad[r] = 0;
+                qoff[r] = 0;
+            }
+            continue;
+        }
+        for (int i = t; i < QUAD_HASH; i += QUAD_THREADS) s_tab[i] = 0ull;
+        if (t == 0) s_n = s_n2 = 0;
+        __syncthreads();
+        const uint8_t *base = rec + rec_off[r];
+        const unsigned int *codes = reinterpret_cast<const unsigned int *>(base);
+        unsigned int q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = t + QUAD_THREADS * j;
+            unsigned int key = 0;
+            if (idx < nqc) {
+                key = codes[idx];
+                const int c0 = idx * 4;                    // columns past H (ldc - H <= 7 of them): code 0
+                if (c0 + 3 >= H) {
+                    if (c0 + 0 >= H) key &= ~0x000000ffu;
+                    if (c0 + 1 >= H) key &= ~0x0000ff00u;
+                    if (c0 + 2 >= H) key &= ~0x00ff0000u;
+                    if (c0 + 3 >= H) key &= ~0xff000000u;
+                }
+                const unsigned long long tagged = (1ull << 32) | key;
+                unsigned int slot = (key * 2654435761u) >> 22;               // 10 bits
+                bool placed = false;
+                for (int probe = 0; probe < QUAD_HASH && s_n <= QUAD_MAX; ++probe) {
+                    // most of a row's quads are ONE quad (the row's majority value four times): look before the atomic, or
+                    // a thousand compare-and-swaps queue up on one LDS word
+                    unsigned long long old = *reinterpret_cast<volatile unsigned long long *>(&s_tab[slot]);
+                    if (old == 0ull) old = atomicCAS(&s_tab[slot], 0ull, tagged);
+                    if (old == 0ull) {
+                        atomicAdd(&s_n, 1);
+                        placed = true;
+                        break;
+                    }
+                    if (old == tagged) {
+                        placed = true;
+                        break;
+                    }
+                    slot = (slot + 1) & (QUAD_HASH - 1);
+                }
+                if (!placed) atomicAdd(&s_n, QUAD_MAX + 1);                  // too many distinct quads (or a full table)
+            }
+            q[j] = key;
+        }
+        __syncthreads();
+        const int n = s_n;                                 // uniform
+        if (n > QUAD_MAX) {
+            if (t == 0) {
+                nquad[r] = 0;
+                qoff[r] = 0;
+                atomicAdd(&stats[1], 1ull);
+            }
+            __syncthreads();
+            continue;
+        }
+        s_keys[t] = 0xffffffffu;
+        __syncthreads();
+        for (int i = t; i < QUAD_HASH; i += QUAD_THREADS) {
+            const unsigned long long v = s_tab[i];
+            if (v != 0ull) s_keys[atomicAdd(&s_n2, 1)] = (unsigned int)v;
+        }
+        __syncthreads();
+        for (int k = 2; k <= QUAD_MAX; k <<= 1) {          // bitonic sort, ascending; the pads (0xFFFFFFFF) end up last
+            for (int j = k >> 1; j > 0; j >>= 1) {
+                const int ixj = t ^ j;
+                if (ixj > t) {
+                    const unsigned int a = s_keys[t], b = s_keys[ixj];
+                    const bool up = (t & k) == 0;
+                    if ((a > b) == up) {
+                        s_keys[t] = b;
+                        s_keys[ixj] = a;
+                    }
+                }
+                __syncthreads();
+            }
+        }
+        unsigned long long word = 0ull;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = t + QUAD_THREADS * j;
+            if (idx < nqc) {
+                int lo = 0, hi = n - 1;
+                while (lo < hi) {
+                    const int mid = (lo + hi) >> 1;
+                    if (s_keys[mid] < q[j]) lo = mid + 1;
+                    else hi = mid;
+                }
+                word |= (unsigned long long)lo << (8 * j);
+            }
+        }
+        const unsigned long long bytes = QUAD_CODE_BYTES + 32ull * (unsigned long long)n;
+        if (t == 0) s_base = atomicAdd(&stats[0], bytes);
+        __syncthreads();
+        const unsigned long long at = s_base;
+        const bool fits = at + bytes <= qcap;              // uniform
+        if (fits) {
+            *reinterpret_cast<unsigned long long *>(qrec + at + (unsigned long long)t * 8ull) = word;
+            if (t < n) {
+                const double *tbl = reinterpret_cast<const double *>(base + ldc);
+                const unsigned int key = s_keys[t];
+                quad_d2 *dst = reinterpret_cast<quad_d2 *>(qrec + at + QUAD_CODE_BYTES + (unsigned long long)t * 32ull);
+                dst[0] = quad_d2{tbl[key & 255u], tbl[(key >> 8) & 255u]};
+                dst[1] = quad_d2{tbl[(key >> 16) & 255u], tbl[key >> 24]};
+            }
+        }
+        if (t == 0) {
+            nquad[r] = fits ? n : 0;
+            qoff[r] = fits ? (int64_t)at : 0;
+            if (!fits) atomicAdd(&stats[1], 1ull);
+        }
+        __syncthreads();
+    }
+}
+
+// code byte B of a word x 32 = the byte offset of the quad's table entry: one SDWA shift
+template <int B>
+__device__ __forceinline__ unsigned int quad_byte_x32(unsigned int word) {
+    const unsigned int five = 5;
+    unsigned int r;
+    if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(five), "v"(word));
+    else if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(five), "v"(word));
+    else if constexpr (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(five), "v"(word));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(five), "v"(word));
+    return r;
+}
+
+// ------------------------------------------------------------------------------------------
+// K3q  quad_row_pass: coded_row_pass's main loop over quad records -- the same decomposition (the rows of `quad_rows`
+// dealt round-robin, thread t owns the columns 4 (t + 256 k) + e, the row's values wait in VGPRs between the dot product
+// and the accumulation, lookups one row ahead, the next step's metadata read under the division), so that the per-thread
+// sums are formed from the same values in the same order as the byte pass forms them.
+//   quad_rows[n_rows]  the rows that have quads, ASCENDING; qoff / nquad / w are indexed by ROW
+//   fault              set to 1 when a list entry is out of range, not above its predecessor or has no quads (the entry
+//                      is then skipped, never dereferenced): the column reduce poisons the sums, as for the wide list
+// ------------------------------------------------------------------------------------------
+template <int NCH, int NBUF, bool NT>
+__device__ __forceinline__ void quad_row_pass(const uint8_t *__restrict__ qrec, const int64_t *__restrict__ qoff,
+                                              const int32_t *__restrict__ nquad, const int64_t *__restrict__ quad_rows,
+                                              int64_t n_rows, int64_t R, const double *__restrict__ w,
+                                              const double (&p)[NCH][4], double (&acc)[NCH][4], int *fault, int vbid = -1,
+                                              int vgrid = 0) {
+    static_assert(NBUF >= 3 && NBUF <= 6, "codes NBUF - 1 rows ahead; unrolled by hand");
+    static_assert(NCH >= 1 && NCH <= 8, "eight code bytes per thread");
+    constexpr int THREADS = QUAD_THREADS, NW = THREADS / 64, AUX = NT ? 2 : 0;
+    __shared__ __attribute__((aligned(16))) double s_tbl[NBUF][QUAD_MAX * 4];
+    __shared__ __attribute__((aligned(16))) double red[NBUF][NW];
+    __shared__ long long s_off[2][THREADS];
+    __shared__ double s_wr[2][THREADS];
+    __shared__ int s_nd[2][THREADS];
+    __shared__ int s_fault;
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6;
+    const row_deal deal(n_rows, vbid >= 0 ? (int64_t)vbid : (int64_t)blockIdx.x, vbid >= 0 ? (int64_t)vgrid : (int64_t)gridDim.x);
+    if (t == 0) s_fault = 0;
+
+    auto fetch_meta = [&](int half, int64_t q0) {       // steps q0 .. q0 + THREADS - 1, thread t takes step q0 + t
+        const int64_t q = q0 + t;
+        const int64_t e = deal.row(q);                   // list index
+        int64_t r = quad_rows[e];
+        int nd = 0;
+        if (r < 0 || r >= R || (e > 0 && quad_rows[e - 1] >= r)) {
+            s_fault = 1;
+            r = -1;
+        } else {
+            nd = nquad[r];
+            if (nd <= 0 || nd > QUAD_MAX) {
+                s_fault = 1;
+                nd = 0;
+            }
+        }
+        s_off[half][t] = (nd > 0) ? qoff[r] : 0;
+        s_nd[half][t] = nd;
+        s_wr[half][t] = (deal.live(q) && nd > 0) ? (w != nullptr ? w[r] : 1.0) : 0.0;
+    };
+    quad_u2 cw[NBUF];
+    double tring[NBUF][4];
+    int pre_off_lo, pre_off_hi, pre_nd;                  // uniform (SGPRs)
+    double pre_wr;
+    auto read_meta = [&](int64_t q_load, int64_t q_weight) {
+        const int half = (int)((q_load / THREADS) & 1), idx = (int)(q_load % THREADS);
+        const long long off = s_off[half][idx];
+        pre_nd = __builtin_amdgcn_readfirstlane(s_nd[half][idx]);
+        pre_off_hi = __builtin_amdgcn_readfirstlane((int)(off >> 32));
+        pre_off_lo = __builtin_amdgcn_readfirstlane((int)off);
+        pre_wr = s_wr[(q_weight / THREADS) & 1][q_weight % THREADS];
+    };
+    // a row's record: this thread's eight code bytes, entry t of its table (lanes past the table read 0; a row with
+    // nd = 0 -- a faulty entry, a step past the end -- reads nothing: descriptors of 0 bytes)
+    auto load_row = [&](auto SLOT) {
+        constexpr int slot = decltype(SLOT)::value;
+        const int nd = pre_nd;
+        const uint8_t *base = qrec + (((long long)pre_off_hi << 32) | (unsigned int)pre_off_lo);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, nd > 0 ? QUAD_CODE_BYTES : 0, 0x00020000);
+        cw[slot] = __builtin_amdgcn_raw_buffer_load_b64(rs, t * 8, 0, AUX);
+        const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base + QUAD_CODE_BYTES), 0, nd * 32, 0x00020000);
+        const quad_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rt, t * 32, 0, AUX);
+        const quad_u4 b = __builtin_amdgcn_raw_buffer_load_b128(rt, t * 32, 16, AUX);
+        tring[slot][0] = __hiloint2double((int)a.y, (int)a.x);
+        tring[slot][1] = __hiloint2double((int)a.w, (int)a.z);
+        tring[slot][2] = __hiloint2double((int)b.y, (int)b.x);
+        tring[slot][3] = __hiloint2double((int)b.w, (int)b.z);
+    };
+    auto publish = [&](auto SLOT) {
+        constexpr int slot = decltype(SLOT)::value;
+        quad_d2 *dst = reinterpret_cast<quad_d2 *>(&s_tbl[slot][t * 4]);
+        dst[0] = quad_d2{tring[slot][0], tring[slot][1]};
+        dst[1] = quad_d2{tring[slot][2], tring[slot][3]};
+    };
+    double v[NCH][4];
+    auto lookup_quad = [&](const char *tb, auto K, const quad_u2 &c) {
+        constexpr int k = decltype(K)::value;
+        unsigned int off;
+        if constexpr (k < 4) off = quad_byte_x32<k>(c.x);
+        else off = quad_byte_x32<k - 4>(c.y);
+        const quad_d2 a = *reinterpret_cast<const quad_d2 *>(tb + off), b = *reinterpret_cast<const quad_d2 *>(tb + off + 16);
+        v[k][0] = a.x;
+        v[k][1] = a.y;
+        v[k][2] = b.x;
+        v[k][3] = b.y;
+    };
+    auto lookup_row = [&](const char *tb, const quad_u2 &c) {
+        lookup_quad(tb, std::integral_constant<int, 0>{}, c);
+        if constexpr (NCH > 1) lookup_quad(tb, std::integral_constant<int, 1>{}, c);
+        if constexpr (NCH > 2) lookup_quad(tb, std::integral_constant<int, 2>{}, c);
+        if constexpr (NCH > 3) lookup_quad(tb, std::integral_constant<int, 3>{}, c);
+        if constexpr (NCH > 4) lookup_quad(tb, std::integral_constant<int, 4>{}, c);
+        if constexpr (NCH > 5) lookup_quad(tb, std::integral_constant<int, 5>{}, c);
+        if constexpr (NCH > 6) lookup_quad(tb, std::integral_constant<int, 6>{}, c);
+        if constexpr (NCH > 7) lookup_quad(tb, std::integral_constant<int, 7>{}, c);
+    };
+
+    auto step = [&](auto J, int64_t q) {
+        constexpr int j = decltype(J)::value;
+        constexpr int jn = (j + 1) % NBUF, jl = (j + NBUF - 1) % NBUF;
+        if ((q % THREADS) == 0) fetch_meta((int)((q / THREADS + 1) & 1), q + THREADS);   // the block after this one
+        load_row(std::integral_constant<int, jl>{});     // row q + NBUF - 1; slot jl held row q - 1: consumed
+        const double wr = pre_wr;
+        double s4[4] = {0.0, 0.0, 0.0, 0.0};             // four independent chains, as the byte pass
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) s4[e] = fma(v[k][e], p[k][e], s4[e]);
+        double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
+        __builtin_amdgcn_s_setprio(1);
+        s = wave_sum_lane63(s);
+        if (lane == 63) red[j][wv] = s;
+        publish(std::integral_constant<int, jn>{});      // row q + 1's table, published by the same barrier
+        __syncthreads();
+        read_meta(q + NBUF, q + 1);                      // for the next step; returns under the division
+        static_assert(NW == 4, "four wave sums");
+        const quad_d2 ra = *reinterpret_cast<const quad_d2 *>(&red[j][0]), rb = *reinterpret_cast<const quad_d2 *>(&red[j][2]);
+        const double cf = readlane_f64(weight_over_norm(wr, (ra.x + ra.y) + (rb.x + rb.y)), 0);
+        __builtin_amdgcn_s_setprio(0);
+        const char *tbn = reinterpret_cast<const char *>(&s_tbl[jn][0]);
+        auto upd = [&](auto K) {
+            constexpr int k = decltype(K)::value;
+            if constexpr (k < NCH) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    acc[k][e] = fma(cf, v[k][e], acc[k][e]);
+                    asm volatile("" : "+v"(acc[k][e]));  // (pinned, as in the byte pass)
+                }
+                lookup_quad(tbn, K, cw[jn]);
+            }
+        };
+        upd(std::integral_constant<int, 0>{});
+        upd(std::integral_constant<int, 1>{});
+        upd(std::integral_constant<int, 2>{});
+        upd(std::integral_constant<int, 3>{});
+        upd(std::integral_constant<int, 4>{});
+        upd(std::integral_constant<int, 5>{});
+        upd(std::integral_constant<int, 6>{});
+        upd(std::integral_constant<int, 7>{});
+    };
+
+    if (deal.nq > 0) {
+        __syncthreads();
+        fetch_meta(0, 0);
+        __syncthreads();
+        read_meta(0, 0);
+        load_row(std::integral_constant<int, 0>{});
+        read_meta(1, 0);
+        load_row(std::integral_constant<int, 1>{});
+        if constexpr (NBUF > 3) {
+            read_meta(2, 0);
+            load_row(std::integral_constant<int, 2>{});
+        }
+        if constexpr (NBUF > 4) {
+            read_meta(3, 0);
+            load_row(std::integral_constant<int, 3>{});
+        }
+        if constexpr (NBUF > 5) {
+            read_meta(4, 0);
+            load_row(std::integral_constant<int, 4>{});
+        }
+        publish(std::integral_constant<int, 0>{});
+        __syncthreads();
+        read_meta(NBUF - 1, 0);
+        lookup_row(reinterpret_cast<const char *>(&s_tbl[0][0]), cw[0]);
+        for (int64_t q = 0; q < deal.nq; q += NBUF) {
+            step(std::integral_constant<int, 0>{}, q);
+            step(std::integral_constant<int, 1>{}, q + 1);
+            step(std::integral_constant<int, 2>{}, q + 2);
+            if constexpr (NBUF > 3) step(std::integral_constant<int, 3>{}, q + 3);
+            if constexpr (NBUF > 4) step(std::integral_constant<int, 4>{}, q + 4);
+            if constexpr (NBUF > 5) step(std::integral_constant<int, 5>{}, q + 5);
+        }
+    }
+    __syncthreads();
+    *fault = s_fault;
+}
+
+// K3q  em_iter_quad_kernel: the quad rows' share of one restart's pass; partial row part_row0 + blockIdx.x, and
+// {0, list fault} where the byte pass leaves {wide rows met, list fault} (coded_kernels.hpp, CHECK) for the column reduce.
+template <int NCH, int NBUF>
+__global__ __launch_bounds__(QUAD_THREADS, 2) void em_iter_quad_kernel(
+    const uint8_t *__restrict__ qrec, const int64_t *__restrict__ qoff, const int32_t *__restrict__ nquad,
+    const int64_t *__restrict__ quad_rows, int64_t n_rows, int64_t R, const double *__restrict__ w,
+    const double *__restrict__ props, int H, double *__restrict__ partial, int64_t ldpart, int part_row0,
+    const mxm_em_state *__restrict__ state, int run) {
+    if (state != nullptr && state[run].done != 0) return;
+    const int t = threadIdx.x;
+    props += (int64_t)run * H;
+    double p[NCH][4], acc[NCH][4];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (t + k * QUAD_THREADS) + e;
+            p[k][e] = (c < H) ? props[c] : 0.0;
+            acc[k][e] = 0.0;
+        }
+    }
+    int fault = 0;
+    quad_row_pass<NCH, NBUF, true>(qrec, qoff, nquad, quad_rows, n_rows, R, w, p, acc, &fault);
+    const int64_t row = (int64_t)part_row0 + blockIdx.x;
+    if (t == 0) {
+        int *out = reinterpret_cast<int *>(partial + (int64_t)MXM_MAX_WG * ldpart) + 2 * row;
+        out[0] = 0;
+        out[1] = fault;
+    }
+    double *dst = partial + row * ldpart;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = 4 * (t + k * QUAD_THREADS);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < H) dst[c + e] = acc[k][e];
+    }
+}
+
+// K3q+  em_iter_quad_coded_kernel: BOTH row passes of an iteration beside a quad dictionary in one grid.  One after the
+// other the leftover pass (the byte-coded rows without quads, the wide rows: 3 % of the rows) is a tail of its own --
+// a few thousand rows cannot fill a launch, and a launch that is sized to run beside the quad pass takes as long as it
+// (measured: 1.22 + 0.45 ms, and 2.6 ms per iteration where a second stream did not overlap at all).  Here the first
+// `nwg_left` workgroups of the grid do the leftover pass and the others the quad pass, each dealt its rows among its
+// own kind; the host sizes the two shares by the measured cost of a row so that they finish together, and the whole
+// grid is resident at once (two workgroups per CU: 76 KB of LDS each, the two passes' buffers side by side).
+// Partial rows: quad workgroup i -> i, leftover workgroup i -> nwg_quad + i (the column reduce's order is the same as
+// with two launches).
+template <int NCH, int NBUF>
+__global__ __launch_bounds__(QUAD_THREADS, 2) void em_iter_quad_coded_kernel(
+    const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off, const int32_t *__restrict__ ndist, int ldc,
+    const int64_t *__restrict__ wide_rows, int64_t n_wide, const int64_t *__restrict__ byte_rows, int64_t n_byte_rows,
+    const uint8_t *__restrict__ qrec, const int64_t *__restrict__ qoff, const int32_t *__restrict__ nquad,
+    const int64_t *__restrict__ quad_rows, int64_t n_quad_rows, int64_t R, const double *__restrict__ w,
+    const double *__restrict__ props, int H, double *__restrict__ partial, int64_t ldpart, int nwg_left,
+    const mxm_em_state *__restrict__ state, int run) {
+    if (state != nullptr && state[run].done != 0) return;
+    const int t = threadIdx.x;
+    props += (int64_t)run * H;
+    double p[NCH][4], acc[NCH][4];
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int c = 4 * (t + k * QUAD_THREADS) + e;
+            p[k][e] = (c < H) ? props[c] : 0.0;
+            acc[k][e] = 0.0;
+        }
+    }
+    const int nwg_quad = (int)gridDim.x - nwg_left;
+    int chk[2] = {0, 0};
+    int64_t prow;
+    if ((int)blockIdx.x < nwg_left) {                    // workgroup uniform
+        bool meta_ready = false;
+        coded_row_pass<QUAD_THREADS, NCH, NBUF, true, false, true, true>(rec, rec_off, ndist, ldc, w, wide_rows, n_wide, R, p, acc,
+                                                                         meta_ready, chk, byte_rows, n_byte_rows, nquad,
+                                                                         (int)blockIdx.x, nwg_left);
+        prow = (int64_t)nwg_quad + blockIdx.x;
+    } else {
+        quad_row_pass<NCH, NBUF, true>(qrec, qoff, nquad, quad_rows, n_quad_rows, R, w, p, acc, &chk[1],
+                                       (int)blockIdx.x - nwg_left, nwg_quad);
+        prow = (int64_t)blockIdx.x - nwg_left;
+    }
+    if (t == 0) {
+        int *out = reinterpret_cast<int *>(partial + (int64_t)MXM_MAX_WG * ldpart) + 2 * prow;
+        out[0] = chk[0];
+        out[1] = chk[1];
+    }
+    double *dst = partial + prow * ldpart;
+#pragma unroll
+    for (int k = 0; k < NCH; ++k) {
+        const int c = 4 * (t + k * QUAD_THREADS);
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+            if (c + e < H) dst[c + e] = acc[k][e];
+    }
+}
+
+#endif  // MIXEMT_QUAD_KERNELS_HPP

@@ -25,6 +25,7 @@ legacy RNG exactly as the reference does (em.py:36, :123).
 
 import ctypes
 import math
+import os
 import sys
 import time
 
@@ -109,6 +110,9 @@ AUTO_CODED_MIN_CELLS = 1.5e7        # storage="auto": measured break-even of the
                                     # one-launch loops over the dense matrix (profiles/r04/small_runs_breakeven.txt: 26 vs 26 us
                                     # per iteration at 2400 x 5408, 31 vs 41 at 4600, 36 vs 58 at 7000; round 3, with the
                                     # records' iteration still four launches: 5e7)
+QUADS = "auto"                      # EmPlan.attach_quads: a quad dictionary beside the records ("auto" / True / False)
+QUADS_MIN_ROWS = 300000             # ... "auto": several restarts over this many byte-coded rows (below, the one-launch loop over
+                                    # the records is faster; one restart barely earns the build back)
 AUTO_CODED_MIN_CELLS_MULTI = 5e7    # ... with SEVERAL restarts: the one-launch records loop runs them one after
                                     # another while the dense path shares each pass of the matrix among up to four, so the
                                     # records only pay where an iteration is bound by the matrix's bytes (round 3's break-even)
@@ -237,6 +241,93 @@ class EmPlan(object):
                                 p_rest.data_ptr() if n_rest else None, p_rest.stride(0) if n_rest else 0,
                                 w_rest.data_ptr() if n_rest else None, n_rest,
                                 wide.data_ptr() if self.coded_wide else None, self.coded_wide)
+        self._quad_keep = None
+        self.attach_quads()
+
+    def attach_quads(self, mode=None, cap=None):
+        """
+        A quad dictionary beside the records, for the loop alone (include/mixemt_hip.h, mxm_build_quads;
+        csrc/quad_kernels.hpp): one code byte per FOUR columns for the rows with at most 256 distinct value quadruples
+        (98.8 % of build_em_matrix's byte-coded rows), 1.27 against 1.41 ms per pass at 10^6 x 5408.  The records stay
+        complete -- every other consumer reads them -- so this costs memory: ~4.8 KB per row beside the records' 5.9.
+        mode: True / False / "auto" (None = QUADS): auto builds them for SEVERAL restarts over at least QUADS_MIN_ROWS
+        byte-coded rows, if they fit a quarter of the card's memory.  Measured at 10^6 x 5408 (profiles/r05/
+        quads_product_1m.txt): the step 1.46 -> 1.32 ms, run_em's loop 1.44 (one-launch loop over the records) -> 1.35 ms per
+        iteration (the per-iteration kernels), the build 22 ms warm / 40 cold: one restart of ~400 iterations gains about
+        what the build costs, every further restart 35 ms.
+        cap: bytes of the first buffer (default: room for 112 quads per row; the kernel counts what it needs and an
+        overflow repeats the build once with exactly that much).
+        """
+        mode = QUADS if mode is None else mode
+        if self.coded is None or mode is False or self._quad_keep is not None:
+            return self._quad_keep is not None
+        lib, dev = self.lib, self.dev
+        rec, rec_off, ndist = self._coded_keep[:3]
+        nd_h = self.records.ndist_host() if getattr(self, "records", None) is not None else ndist.cpu().numpy()
+        byte_coded = (nd_h > 0) & (nd_h <= 256)
+        n_byte = int(byte_coded.sum())
+        ldc = (self.n_haps + 7) // 8 * 8
+        if n_byte == 0 or ldc // 4 > 6 * 256:         # (the quad pass is instantiated up to H = 6144)
+            return False
+        guess = n_byte * (2048 + 32 * 112) + (1 << 20)
+        if mode == "auto":
+            # by the card's TOTAL memory, not by what happens to be free: which loop runs decides the last bits of the sums
+            # (fixed orders, but different ones), and the same call must take the same route every time
+            if self.n_runs < 2 or n_byte < QUADS_MIN_ROWS or guess > torch.cuda.mem_get_info(dev)[1] // 4:
+                return False
+        n_rows = self.n_rows
+        laps = {} if os.environ.get("MXM_PIPELINE_TIMING") else None          # (synchronises: measurement only)
+        self.quad_laps = laps
+        t_lap = [time.perf_counter()]
+
+        def lap(name):
+            if laps is not None:
+                torch.cuda.synchronize()
+                laps[name] = round(laps.get(name, 0.0) + (time.perf_counter() - t_lap[0]) * 1e3, 2)
+                t_lap[0] = time.perf_counter()
+
+        qoff = torch.empty(n_rows, dtype=torch.int64, device=dev)
+        nquad = torch.empty(n_rows, dtype=torch.int32, device=dev)
+        stats = torch.empty(2, dtype=torch.int64, device=dev)
+        cap = guess if cap is None else max(32, int(cap) // 32 * 32)
+        for attempt in (0, 1):
+            try:
+                qrec = device_empty((cap,), torch.uint8, dev, "the quad dictionary")
+            except ValueError:
+                if mode == "auto":                    # no room beside the records: the records alone
+                    return False
+                raise
+            _lib.check(lib.mxm_build_quads(ctypes.byref(self.coded), self.n_haps, qrec.data_ptr(), qrec.numel(), qoff.data_ptr(),
+                                           nquad.data_ptr(), stats.data_ptr(), current_stream()), "mxm_build_quads")
+            used, n_left = (int(v) for v in stats.cpu())
+            lap("allocation + quad_encode_kernel")
+            if used <= cap:
+                break
+            if attempt == 1:
+                raise ValueError("mxm_build_quads: buffer of %d bytes overflowed (%d needed)" % (cap, used))
+            del qrec
+            cap = (used + 31) // 32 * 32
+        nq_h = nquad.cpu().numpy()
+        quad_rows = numpy.flatnonzero(nq_h > 0)
+        byte_rows = numpy.flatnonzero(byte_coded & (nq_h == 0))
+        if len(quad_rows) == 0:
+            return False
+        quad_rows_d = torch.from_numpy(quad_rows).to(dev)
+        byte_rows_d = torch.from_numpy(byte_rows).to(dev)
+        lap("row lists (host)")
+        self._quad_keep = (qrec, qoff, nquad, quad_rows_d, byte_rows_d)
+        self.coded.qrec, self.coded.qoff, self.coded.nquad = qrec.data_ptr(), qoff.data_ptr(), nquad.data_ptr()
+        self.coded.quad_rows, self.coded.n_quad_rows = quad_rows_d.data_ptr(), len(quad_rows)
+        self.coded.byte_rows, self.coded.n_byte_rows = (byte_rows_d.data_ptr() if len(byte_rows) else None), len(byte_rows)
+        # what an iteration reads now: the quad records, and of the records only the rows without quads (codes + P table)
+        wide_h = nd_h > 256
+        left = numpy.zeros(n_rows, dtype=bool)
+        left[byte_rows] = True
+        rec_left = int((ldc + 8 * nd_h[left].astype(numpy.int64)).sum() + (2 * ldc + 8 * nd_h[wide_h].astype(numpy.int64)).sum())
+        self.quad_rows_n, self.quad_bytes = len(quad_rows), used
+        self.coded_record_bytes = used + rec_left
+        self.coded_bytes = self.coded_record_bytes + self.coded_rest * self.n_haps * 8
+        return True
 
     def encode(self):
         """Row-dictionary form of this plan's matrix (mxm_encode_rows) + the dense rest."""
@@ -292,6 +383,8 @@ class EmPlan(object):
                                 p_rest.data_ptr() if n_rest else None, p_rest.stride(0) if n_rest else 0,
                                 w_rest.data_ptr() if n_rest else None, n_rest,
                                 wide.data_ptr() if self.coded_wide else None, self.coded_wide)
+        self._quad_keep = None                        # (a second encode(): the quads are made again from the new records)
+        self.attach_quads()
 
     # pointers for the C ABI ------------------------------------------------
     def mat_args(self):
