@@ -46,6 +46,10 @@ struct fcoded_args {
     int max_iter, H;
 };
 
+// (Round 5: a variant whose phase A is shared out between the quad pass and the records' pass, as in
+// em_iter_quad_coded_kernel, was built and measured: 1.41 ms per iteration at 10^6 rows against 1.45 for this kernel and
+// 1.35 for the per-iteration kernels with quads -- both passes' scalar state beside phases B / C spilled 77 SGPRs.  Not
+// kept; beside a quad dictionary mxm_em_loop_coded takes the per-iteration kernels.  profiles/r05/quads_product_fused_1m.txt)
 template <int NCH, int NBUF, bool RESIDENT>
 __global__ __launch_bounds__(FCODED_THREADS, 2) void em_fused_coded_kernel(
     const uint8_t *__restrict__ rec, const int64_t *__restrict__ rec_off, const int32_t *__restrict__ ndist, int ldc,

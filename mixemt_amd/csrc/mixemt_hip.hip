@@ -1053,6 +1053,22 @@ static int launch_coded(int nch, int nwg, hipStream_t stream, const mxm_coded *c
     return fail(-1, "mxm_em_iter_coded: H=%s%lld outside the kernel's range", "", H);
 }
 #define QUAD_MAX_NCH 6              // H <= 6144: the instances of the quad pass that compile without scratch
+// The leftover pass's share of a grid of `slots` workgroups it shares with the quad pass, by the measured cost of a row in
+// each pass (us per row and workgroup: quad 0.67; byte 1.0 and wide 1.5 where only a few workgroups run that pass -- a
+// sweep of the share at 10^6 rows, profiles/r05/quads_product_1m.txt: 22 workgroups 1.56 ms, 32 1.33, 48 1.36, 64 1.40,
+// 128 1.62), so that both finish together; 0 when there is nothing left over.
+static int quad_left_share(const mxm_coded *c, int slots) {
+    if (c->n_byte_rows <= 0 && c->n_wide <= 0) return 0;
+    const double left_cost = 1.0 * (double)c->n_byte_rows + 1.5 * (double)c->n_wide;
+    const double quad_cost = 0.67 * (double)c->n_quad_rows;
+    int n = (int)((double)slots * left_cost / (left_cost + quad_cost) + 0.5);
+    if (T.quad_left_wg > 0) n = T.quad_left_wg;
+    if (n < 4) n = 4;
+    if (n > slots / 2) n = slots / 2;
+    const int64_t left = c->n_byte_rows > c->n_wide ? c->n_byte_rows : c->n_wide;
+    n = clamp_grid(left, n);
+    return n < 1 ? 1 : n;
+}
 static int launch_quad(int nch, int nwg, hipStream_t stream, const mxm_coded *c, const double *w, const double *props, int H,
                        double *partial, int64_t ldpart, const mxm_em_state *state, int run) {
     switch (nch) {
@@ -1091,21 +1107,8 @@ static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *
     // quads and the wide rows (rows nwg_q .. nwg) share ONE grid (em_iter_quad_coded_kernel)
     int nwg_q = 0, nwg = 0;
     if (quads) {
-        // the leftover pass's share of the CUs' slots, by the measured cost of a row in each pass (us per row and
-        // workgroup: quad 0.67; byte 1.0 and wide 1.5 where only a few workgroups run that pass -- a sweep of the share at
-        // 10^6 rows, profiles/r05/quads_product_1m.txt: 22 workgroups 1.56 ms, 32 1.33, 48 1.36, 64 1.40, 128 1.62)
         const int slots = cap < 2 * num_cu() ? cap : 2 * num_cu();
-        const double left_cost = 1.0 * (double)c->n_byte_rows + 1.5 * (double)c->n_wide;
-        const double quad_cost = 0.67 * (double)c->n_quad_rows;
-        int nwg_b = 0;
-        if (c->n_byte_rows > 0 || c->n_wide > 0) {
-            nwg_b = (int)((double)slots * left_cost / (left_cost + quad_cost) + 0.5);
-            if (T.quad_left_wg > 0) nwg_b = T.quad_left_wg;
-            if (nwg_b < 4) nwg_b = 4;
-            if (nwg_b > slots / 2) nwg_b = slots / 2;
-            const int64_t left = c->n_byte_rows > c->n_wide ? c->n_byte_rows : c->n_wide;
-            nwg_b = clamp_grid(left, nwg_b);
-        }
+        const int nwg_b = quad_left_share(c, slots);
         nwg_q = clamp_grid((c->n_quad_rows + sh.nbuf - 1) / sh.nbuf, slots - nwg_b < 1 ? 1 : slots - nwg_b);
         nwg = nwg_q + nwg_b;
     } else {
@@ -1258,9 +1261,10 @@ static int fused_coded_grid(int64_t R) {
 #define QUAD_PER_ITER_MIN_ROWS 300000
 static bool fused_coded_eligible(const mxm_coded *c, int H, int B, size_t ws_bytes) {
     if (T.loop_fused == 0 || c == nullptr || c->R_rest > 0 || !mxm_linear_supported(H) || (H & 1)) return false;
-    // beside a quad dictionary the per-iteration kernels are the faster loop from a few 10^5 rows (the quad pass saves 10 %
-    // of the row pass, the one-launch loop ~40 us of launches and tail per iteration): the one-launch loop, which reads
-    // the records only, keeps the small matrices (mxm_set_loop_fused(1, ...) still forces it)
+    // beside a quad dictionary the per-iteration kernels are the faster loop from a few 10^5 rows (1.35 against 1.45 ms per
+    // iteration at 10^6: the quad pass saves 0.13 ms of the row pass, the one-launch loop ~0.04 ms of launches and tail;
+    // a one-launch loop with the quad pass inside ran 1.41): the one-launch loop, which reads the records only, keeps
+    // the small matrices (mxm_set_loop_fused(1, ...) still forces it)
     if (c->qrec != nullptr && c->n_quad_rows >= QUAD_PER_ITER_MIN_ROWS && T.loop_fused != 1 &&
         (coded_ld(H) / 4 + QUAD_THREADS - 1) / QUAD_THREADS <= QUAD_MAX_NCH)
         return false;
@@ -1756,6 +1760,17 @@ extern "C" int mxm_em_loop_coded(const mxm_coded *c, const double *w, int32_t H,
         HIP_TRY(hipGetLastError());
         HIP_TRY(hipMemcpyAsync(host, chk, sizeof(host), hipMemcpyDeviceToHost, s));
         HIP_TRY(hipStreamSynchronize(s));
+        if (c->qrec != nullptr && host[1] == 0 && (long long)host[0] == (long long)c->n_wide) {   // ... and the quad dictionary's lists
+            unsigned long long qhost[2] = {0, 0};
+            HIP_TRY(hipMemsetAsync(chk, 0, 2 * sizeof(unsigned long long), s));
+            hipLaunchKernelGGL(quad_validate_kernel, dim3(clamp_grid((c->R + 255) / 256, num_cu() * 4)), dim3(256), 0, s, c->ndist,
+                               c->nquad, c->R, c->quad_rows, c->n_quad_rows, c->byte_rows, c->n_byte_rows, chk);
+            HIP_TRY(hipGetLastError());
+            HIP_TRY(hipMemcpyAsync(qhost, chk, sizeof(qhost), hipMemcpyDeviceToHost, s));
+            HIP_TRY(hipStreamSynchronize(s));
+            if (qhost[1] != 0)
+                return fail(-1, "mxm_em_loop_coded: quad_rows / byte_rows must list the rows with / without quads, ascending%s", "");
+        }
         if (host[1] != 0 || (long long)host[0] != (long long)c->n_wide)
             return fail(-1, "mxm_em_loop_coded: wide_rows must list exactly the rows with more than 256 values, ascending "
                             "%s(%lld such rows, n_wide = %lld)", "", (long long)host[0], (long long)c->n_wide);

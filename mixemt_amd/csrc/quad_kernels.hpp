@@ -173,6 +173,29 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
     }
 }
 
+// The two row lists of a quad dictionary against ndist / nquad, for the blocking entry point (mxm_em_loop_coded validates
+// once, on entry; the per-iteration kernels check their entries where they use them): out[1] = 1 if an entry is out of
+// range, not above its predecessor or not of its class (quad_rows: 1 <= nquad <= 256; byte_rows: 0 < ndist <= 256 and
+// nquad == 0).  With the counts adding up to R (coded_check) that makes the lists the partition they must be.
+__global__ __launch_bounds__(256) void quad_validate_kernel(const int32_t *__restrict__ ndist, const int32_t *__restrict__ nquad,
+                                                           int64_t R, const int64_t *__restrict__ quad_rows, int64_t n_quad,
+                                                           const int64_t *__restrict__ byte_rows, int64_t n_byte,
+                                                           unsigned long long *__restrict__ out) {
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    bool bad = false;
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_quad; e += stride) {
+        const int64_t r = quad_rows[e];
+        if (r < 0 || r >= R || (e > 0 && quad_rows[e - 1] >= r)) bad = true;
+        else bad = bad || nquad[r] < 1 || nquad[r] > QUAD_MAX || ndist[r] < 1 || ndist[r] > ENC_MAX_CODES;
+    }
+    for (int64_t e = (int64_t)blockIdx.x * 256 + threadIdx.x; e < n_byte; e += stride) {
+        const int64_t r = byte_rows[e];
+        if (r < 0 || r >= R || (e > 0 && byte_rows[e - 1] >= r)) bad = true;
+        else bad = bad || nquad[r] != 0 || ndist[r] < 1 || ndist[r] > ENC_MAX_CODES;
+    }
+    if (bad) out[1] = 1ull;
+}
+
 // code byte B of a word x 32 = the byte offset of the quad's table entry: one SDWA shift
 template <int B>
 __device__ __forceinline__ unsigned int quad_byte_x32(unsigned int word) {
