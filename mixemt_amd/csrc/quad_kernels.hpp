@@ -34,8 +34,8 @@ typedef double quad_d2 __attribute__((ext_vector_type(2)));
 // ------------------------------------------------------------------------------------------
 // K3q-enc  quad_encode_kernel: one workgroup per byte-coded row.  The row's quads (4 code bytes = one dword; code bytes
 // of columns past H are cleared so that equal quads compare equal) are de-duplicated in an LDS hash table (64-bit slots:
-// a tag bit + the quad, so that the quad 0xFFFFFFFF is an ordinary key), the distinct ones sorted (bitonic, 256 slots)
-// -- the codes are the ranks in that order, so a record's bytes do not depend on which thread won a slot -- and the
+// a tag bit + the quad, so that the quad 0xFFFFFFFF is an ordinary key), the distinct ones ranked by value (each counts
+// the smaller ones) -- the codes are those ranks, so a record's bytes do not depend on which thread won a slot -- and the
 // record goes to a bump-allocated place in `qrec` (stats[0] += its size; a record that does not fit any more is not
 // written and the row keeps nquad = 0: the caller sees stats[0] > capacity and may repeat with that much).
 // stats[1] counts the byte-coded rows left without quads.
@@ -47,7 +47,9 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
                                                                    int64_t *__restrict__ qoff, int32_t *__restrict__ nquad,
                                                                    unsigned long long *__restrict__ stats) {
     __shared__ unsigned long long s_tab[QUAD_HASH];
-    __shared__ unsigned int s_keys[QUAD_MAX];
+    __shared__ unsigned int s_keys[QUAD_MAX], s_sorted[QUAD_MAX];
+    __shared__ unsigned short s_slot[QUAD_MAX];
+    __shared__ unsigned char s_rank[QUAD_HASH];
     __shared__ int s_n, s_n2;
     __shared__ unsigned long long s_base;
     const int t = threadIdx.x;
@@ -114,39 +116,36 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
             __syncthreads();
             continue;
         }
-        s_keys[t] = 0xffffffffu;
-        __syncthreads();
+        // the distinct quads, numbered by RANK (ascending quad): compact them, count for each how many are smaller (n
+        // broadcast reads), and leave the rank in the quad's hash slot for the threads' own quads to pick up -- no sort,
+        // four barriers per row
         for (int i = t; i < QUAD_HASH; i += QUAD_THREADS) {
             const unsigned long long v = s_tab[i];
-            if (v != 0ull) s_keys[atomicAdd(&s_n2, 1)] = (unsigned int)v;
-        }
-        __syncthreads();
-        for (int k = 2; k <= QUAD_MAX; k <<= 1) {          // bitonic sort, ascending; the pads (0xFFFFFFFF) end up last
-            for (int j = k >> 1; j > 0; j >>= 1) {
-                const int ixj = t ^ j;
-                if (ixj > t) {
-                    const unsigned int a = s_keys[t], b = s_keys[ixj];
-                    const bool up = (t & k) == 0;
-                    if ((a > b) == up) {
-                        s_keys[t] = b;
-                        s_keys[ixj] = a;
-                    }
-                }
-                __syncthreads();
+            if (v != 0ull) {
+                const int at_i = atomicAdd(&s_n2, 1);
+                s_keys[at_i] = (unsigned int)v;
+                s_slot[at_i] = (unsigned short)i;
             }
         }
+        __syncthreads();
+        unsigned int my_key = 0;
+        if (t < n) {
+            my_key = s_keys[t];
+            int rank = 0;
+            for (int j = 0; j < n; ++j) rank += (s_keys[j] < my_key) ? 1 : 0;
+            s_rank[s_slot[t]] = (unsigned char)rank;
+            s_sorted[rank] = my_key;
+        }
+        __syncthreads();
         unsigned long long word = 0ull;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int idx = t + QUAD_THREADS * j;
             if (idx < nqc) {
-                int lo = 0, hi = n - 1;
-                while (lo < hi) {
-                    const int mid = (lo + hi) >> 1;
-                    if (s_keys[mid] < q[j]) lo = mid + 1;
-                    else hi = mid;
-                }
-                word |= (unsigned long long)lo << (8 * j);
+                const unsigned long long tagged = (1ull << 32) | q[j];
+                unsigned int slot = (q[j] * 2654435761u) >> 22;
+                while (s_tab[slot] != tagged) slot = (slot + 1) & (QUAD_HASH - 1);      // it is there: inserted above
+                word |= (unsigned long long)s_rank[slot] << (8 * j);
             }
         }
         const unsigned long long bytes = QUAD_CODE_BYTES + 32ull * (unsigned long long)n;
@@ -158,7 +157,7 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
             *reinterpret_cast<unsigned long long *>(qrec + at + (unsigned long long)t * 8ull) = word;
             if (t < n) {
                 const double *tbl = reinterpret_cast<const double *>(base + ldc);
-                const unsigned int key = s_keys[t];
+                const unsigned int key = s_sorted[t];
                 quad_d2 *dst = reinterpret_cast<quad_d2 *>(qrec + at + QUAD_CODE_BYTES + (unsigned long long)t * 32ull);
                 dst[0] = quad_d2{tbl[key & 255u], tbl[(key >> 8) & 255u]};
                 dst[1] = quad_d2{tbl[(key >> 16) & 255u], tbl[key >> 24]};

@@ -253,8 +253,8 @@ class EmPlan(object):
         mode: True / False / "auto" (None = QUADS): auto builds them for SEVERAL restarts over at least QUADS_MIN_ROWS
         byte-coded rows, if they fit a quarter of the card's memory.  Measured at 10^6 x 5408 (profiles/r05/
         quads_product_1m.txt): the step 1.46 -> 1.32 ms, run_em's loop 1.44 (one-launch loop over the records) -> 1.35 ms per
-        iteration (the per-iteration kernels), the build 22 ms warm / 40 cold: one restart of ~400 iterations gains about
-        what the build costs, every further restart 35 ms.
+        iteration (the per-iteration kernels), the build 18 ms warm (more in a cold process: its first pageable uploads): one
+        restart of ~400 iterations gains about what the build costs, every further restart 35 ms.
         cap: bytes of the first buffer (default: room for 112 quads per row; the kernel counts what it needs and an
         overflow repeats the build once with exactly that much).
         """
@@ -297,10 +297,11 @@ class EmPlan(object):
                 if mode == "auto":                    # no room beside the records: the records alone
                     return False
                 raise
+            lap("buffers")
             _lib.check(lib.mxm_build_quads(ctypes.byref(self.coded), self.n_haps, qrec.data_ptr(), qrec.numel(), qoff.data_ptr(),
                                            nquad.data_ptr(), stats.data_ptr(), current_stream()), "mxm_build_quads")
             used, n_left = (int(v) for v in stats.cpu())
-            lap("allocation + quad_encode_kernel")
+            lap("quad_encode_kernel")
             if used <= cap:
                 break
             if attempt == 1:
@@ -312,9 +313,10 @@ class EmPlan(object):
         byte_rows = numpy.flatnonzero(byte_coded & (nq_h == 0))
         if len(quad_rows) == 0:
             return False
+        lap("row lists (host)")
         quad_rows_d = torch.from_numpy(quad_rows).to(dev)
         byte_rows_d = torch.from_numpy(byte_rows).to(dev)
-        lap("row lists (host)")
+        lap("row lists to the device")
         self._quad_keep = (qrec, qoff, nquad, quad_rows_d, byte_rows_d)
         self.coded.qrec, self.coded.qoff, self.coded.nquad = qrec.data_ptr(), qoff.data_ptr(), nquad.data_ptr()
         self.coded.quad_rows, self.coded.n_quad_rows = quad_rows_d.data_ptr(), len(quad_rows)
