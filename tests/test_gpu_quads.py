@@ -166,6 +166,28 @@ def test_run_em_with_quads_reproduces_the_reference(b17, name, seed, monkeypatch
     assert numpy.abs(res["props"] - g["props"]).max() < 1e-12
 
 
+def test_three_restarts_with_quads_reproduce_the_reference(b17, monkeypatch):
+    """g5 (three restarts, the fold over runs, em.py:145-165) through records + quads: what `"auto"` attaches for several
+    restarts over many rows, here forced at the golden's size, with the per-iteration kernels that serve it."""
+    from mixemt_amd import _lib, em, preprocess
+    refseq, phy, haps, tables = b17
+    g = golden("g5_run_em_multi")
+    cm = preprocess.build_em_records_device(tables, g["row_ptr"], g["site"], g["obs"])
+    monkeypatch.setattr(em, "QUADS", True)
+    lib = _lib.load()
+    lib.mxm_set_loop_fused(0, 0)
+    try:
+        numpy.random.seed(11)
+        res = em.run_em_ex(None, g["wts"], em_args(n_multi=3), records=cm)
+    finally:
+        lib.mxm_reset_tuning()
+    assert numpy.array_equal(res["inits"], g["inits"])
+    assert res["iters"] == list(g["iters"]) and numpy.abs(res["props"] - g["props"]).max() < 1e-12
+    mix = res["read_mix"].cpu().numpy()
+    assert numpy.array_equal(mix.argmax(axis=1), g["mix_argmax"])
+    assert numpy.allclose(mix[:16], g["mix_rows"], rtol=0, atol=1e-8)
+
+
 def test_faulty_lists_poison_the_sums(b17):
     import torch
     from mixemt_amd import em
