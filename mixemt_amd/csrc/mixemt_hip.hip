@@ -1082,7 +1082,7 @@ static int launch_quad(int nch, int nwg, hipStream_t stream, const mxm_coded *c,
 static int launch_quad_coded(int nch, int nwg, int nwg_left, hipStream_t stream, const mxm_coded *c, int ldc, const double *w,
                              const double *props, int H, double *partial, int64_t ldpart, const mxm_em_state *state, int run) {
     switch (nch) {
-#define QC_CASE(n) case n: hipLaunchKernelGGL((em_iter_quad_coded_kernel<n, 4>), dim3(nwg), dim3(QUAD_THREADS), 0, stream, c->rec, c->rec_off, c->ndist, ldc, c->wide_rows, c->n_wide, c->byte_rows, c->n_byte_rows, c->qrec, c->qoff, c->nquad, c->quad_rows, c->n_quad_rows, c->R, w, props, H, partial, ldpart, nwg_left, state, run); return 0;
+#define QC_CASE(n) case n: hipLaunchKernelGGL((em_iter_quad_coded_kernel<n, 4>), dim3(nwg), dim3(QUAD_THREADS), 0, stream, c->rec, c->rec_off, c->ndist, ldc, c->wide_rows, c->n_wide, c->byte_rows != nullptr ? c->byte_rows : c->quad_rows /* an EMPTY list is still a list: a null pointer would mean "every row" to the pass */, c->n_byte_rows, c->qrec, c->qoff, c->nquad, c->quad_rows, c->n_quad_rows, c->R, w, props, H, partial, ldpart, nwg_left, state, run); return 0;
         QC_CASE(1) QC_CASE(2) QC_CASE(3) QC_CASE(4) QC_CASE(5) QC_CASE(6)
 #undef QC_CASE
         default: break;

@@ -129,6 +129,65 @@ def test_iteration_with_quads_equals_the_iteration_without(b17, n_rows, seed, re
     assert numpy.abs(t - want).max() < 1e-9 * wts.sum()
 
 
+@pytest.mark.parametrize("n_cols,n_rows,read_len", [(2050, 3000, 150), (2050, 600, 3000), (130, 900, 600), (1024, 2000, 150)])
+def test_narrower_tables_and_no_byte_rows_left(n_cols, n_rows, read_len):
+    """Sub-trees of Build 17 (two to three code words per thread instead of six): among them matrices where EVERY byte-coded
+    row gets quads and only wide rows are left to the records' pass -- its row list is then EMPTY, which is not the same
+    as "no list" (found by tools/stress_parity.py: the pass took every row a second time, and the in-kernel check said so)."""
+    from mixemt_amd import em, phylotree, preprocess, synth
+    refseq = phylotree.load_rsrs()
+    phy = phylotree.load_build17(refseq)
+    haps = sorted(phy.hap_var)
+    sub = haps[700:700 + n_cols]
+    tables = preprocess.HapVarTables.build(refseq, phy, sub)
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=n_cols + n_rows, read_len=read_len,
+                                              contrib=(0, n_cols // 2, n_cols - 1))
+    cm = preprocess.build_em_records_device(tables, row_ptr, site, obs)
+    rng = numpy.random.default_rng(n_cols)
+    wts = rng.integers(1, 4, size=n_rows).astype(numpy.float64)
+    props = rng.dirichlet([1.0] * n_cols)
+    base = _iterate(em.EmPlan(None, wts, records=cm), props)[0][0]
+    plan = em.EmPlan(None, wts, records=cm)
+    if not plan.attach_quads(True):                                  # long reads: no row with at most 256 quads -- nothing attached
+        assert read_len >= 3000 and plan.coded.qrec is None and plan._quad_keep is None
+        assert numpy.array_equal(_iterate(plan, props)[0][0], base)
+        return
+    got = _iterate(plan, props, reps=2)
+    assert numpy.isfinite(got[0][0]).all() and numpy.array_equal(got[0][0], got[1][0])
+    assert (numpy.abs(got[0][0] - base) / numpy.abs(base).max()).max() < 3e-15
+
+
+def test_an_empty_byte_list_is_still_a_list(b17):
+    """Only quad rows and wide rows: the records' pass has wide rows to do and an EMPTY list of byte-coded rows -- a null
+    list pointer would mean "every row" to it (tools/stress_parity.py found exactly that; the in-kernel check caught it)."""
+    from mixemt_amd import em, preprocess, synth
+    refseq, phy, haps, tables = b17
+    n_rows = 3000
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=77, read_len=260)
+    cm0 = preprocess.build_em_records_device(tables, row_ptr, site, obs)
+    plan0 = em.EmPlan(None, numpy.ones(n_rows), records=cm0)
+    assert plan0.attach_quads(True)
+    nquad = plan0._quad_keep[2].cpu().numpy()
+    nd = cm0.ndist_host()
+    keep = numpy.flatnonzero((nquad > 0) | (nd > 256))
+    assert (nd[keep] > 256).sum() > 10 and len(keep) < n_rows
+    lens = numpy.diff(row_ptr)[keep]
+    new_ptr = numpy.zeros(len(keep) + 1, dtype=numpy.int64)
+    numpy.cumsum(lens, out=new_ptr[1:])
+    idx = numpy.concatenate([numpy.arange(row_ptr[r], row_ptr[r + 1]) for r in keep])
+    cm = preprocess.build_em_records_device(tables, new_ptr, site[idx], obs[idx])
+    rng = numpy.random.default_rng(5)
+    wts = rng.integers(1, 4, size=len(keep)).astype(numpy.float64)
+    props = rng.dirichlet([1.0] * len(haps))
+    base = _iterate(em.EmPlan(None, wts, records=cm), props)[0][0]
+    plan = em.EmPlan(None, wts, records=cm)
+    assert plan.attach_quads(True)
+    assert int(plan.coded.n_byte_rows) == 0 and int(plan.coded_wide) > 10 and not plan.coded.byte_rows
+    got = _iterate(plan, props, reps=2)
+    assert numpy.isfinite(got[0][0]).all() and numpy.array_equal(got[0][0], got[1][0])
+    assert (numpy.abs(got[0][0] - base) / numpy.abs(base).max()).max() < 3e-15
+
+
 @pytest.mark.parametrize("name,seed", [("g9_run_em_2400", 17), ("g10_run_em_20k", 23)])
 def test_run_em_with_quads_reproduces_the_reference(b17, name, seed, monkeypatch):
     """Goldens through records + quads (the per-iteration kernels and the batched loop around them): the reference's

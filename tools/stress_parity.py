@@ -155,9 +155,17 @@ for case in range(20):
         numpy.random.seed(seed)
         want_props, want_mix = em_oracle.run_em(want, wts, args, trace=trace)
         cm = preprocess.build_em_records_device(tables, row_ptr, site, obs)
-        for label, kw in (("coded", dict(read_hap_mat=want, storage="coded")), ("records", dict(read_hap_mat=None, records=cm))):
+        for label, kw in (("coded", dict(read_hap_mat=want, storage="coded")), ("records", dict(read_hap_mat=None, records=cm)),
+                          ("records+quads", dict(read_hap_mat=None, records=cm))):
+            # round 5: the same from records with a quad dictionary beside them, through the per-iteration kernels that
+            # read it (forced: at these sizes "auto" builds none and the one-launch loop would run)
+            quads = label.endswith("quads")
+            em.QUADS = True if quads else False
+            lib.mxm_set_loop_fused(0 if quads else -1, 0)
             numpy.random.seed(seed)
             res = em.run_em_ex(kw.pop("read_hap_mat"), wts, args, **kw)
+            em.QUADS = "auto"
+            lib.mxm_reset_tuning()
             got_mix = res["read_mix"].cpu().numpy()
             ok = res["iters"] == [t["iters"] for t in trace] and res["storage"] == "coded"
             ok = ok and float(numpy.abs(res["props"] - want_props).max()) < 1e-9
@@ -166,7 +174,7 @@ for case in range(20):
             if not ok:
                 fails += 1
                 line += "  %s MISMATCH" % label
-        line += "  [coded + records EM, %d rows dense]" % int(cm.rest_rows.numel())
+        line += "  [coded + records (+ quads) EM, %d rows dense]" % int(cm.rest_rows.numel())
     print(line + ("" if "MISMATCH" in line else "  bit-exact"))
     sys.stdout.flush()
 print("%d mismatches" % fails)
