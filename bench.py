@@ -515,6 +515,10 @@ def bench_rows(opts, env):
         _lib.check(lin_fn(mat.data_ptr(), mat.stride(0), n_rows, n_haps, plan.lin.data_ptr(),
                           plan.lin.stride(0), plan.rowmax.data_ptr(),
                           torch.cuda.current_stream().cuda_stream), "mxm_linearize")
+    if use_dist and plan.coded is not None and em.QUADS == "auto":
+        # what dist.sharded_em_loop does on entry: over several ranks the per-iteration kernels are the only loop, and a
+        # records shard gets its quad dictionary from SHARD_QUADS_MIN_ROWS rows (the timed step below runs them)
+        plan.attach_quads("auto", min_rows=mdist.SHARD_QUADS_MIN_ROWS)
     torch.cuda.synchronize()
     linearize_s = time.perf_counter() - t0
     if rank == 0:
@@ -714,6 +718,9 @@ def bench_rows(opts, env):
             kernel_name = name_buf.value.decode()
         if n_runs == 1:
             traffic = pmc_traffic(n_rows, n_haps, "f64", kernel_name, algo_bytes)
+    has_quads = plan.coded is not None and getattr(plan, "_quad_keep", None) is not None
+    if has_quads:                                     # both row passes in one grid, most rows from the quad records
+        kernel_name = "em_iter_quad_coded_kernel"
     elif plan.storage == "coded" and n_runs == 1:
         # the records' kernel: counter bytes calibrated against a bare reader of exactly the same records in the same
         # counter pass (tools/pmc_calibrate_coded.py -> tools/pmc_summary.py); same [0.9, 1.5] x rule as the dense line

@@ -85,6 +85,9 @@ GRAPH_AUTO_ISSUE_SHARE = 0.5       # graph="auto": replay bursts from a hipGraph
                                    # of a burst's wall time just to ENQUEUE it (the device would otherwise wait for Python)
 
 
+SHARD_QUADS_MIN_ROWS = 60000        # sharded_em_loop: attach a quad dictionary to a records shard of at least this many rows
+
+
 def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8, compact=True,
                     window=None, verify=True, graph="auto"):
     """
@@ -120,6 +123,11 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     under capture) the loop logs once and stays eager.  Results are bit-identical either way (same kernels, same order).
     """
     exchange = _collective(group)
+    # This loop always runs the per-iteration kernels (the exchange sits between the row pass and the finalize), so over
+    # records a quad dictionary has no one-launch loop to beat and pays from far fewer rows than in run_em's own loop
+    # (em.EmPlan.attach_quads; SHARD_QUADS_MIN_ROWS byte-coded rows in the shard)
+    if getattr(plan, "coded", None) is not None and hasattr(plan, "attach_quads") and _em.QUADS == "auto":
+        plan.attach_quads("auto", min_rows=SHARD_QUADS_MIN_ROWS)
     ln0, p0 = _em.log_inits(inits)
     n_runs = ln0.shape[0]
     if window is None:

@@ -110,7 +110,9 @@ AUTO_CODED_MIN_CELLS = 1.5e7        # storage="auto": measured break-even of the
                                     # one-launch loops over the dense matrix (profiles/r04/small_runs_breakeven.txt: 26 vs 26 us
                                     # per iteration at 2400 x 5408, 31 vs 41 at 4600, 36 vs 58 at 7000; round 3, with the
                                     # records' iteration still four launches: 5e7)
-QUADS = "auto"                      # EmPlan.attach_quads: a quad dictionary beside the records ("auto" / True / False)
+# EmPlan.attach_quads: a quad dictionary beside the records ("auto" / True / False; the environment's MXM_QUADS = on / off / auto
+# sets the start value: A/B runs of the tools without editing them)
+QUADS = {"off": False, "0": False, "on": True, "1": True}.get(os.environ.get("MXM_QUADS", "auto").strip().lower(), "auto")
 QUADS_MIN_ROWS = 300000             # ... "auto": several restarts over this many byte-coded rows (below, the one-launch loop over
                                     # the records is faster; one restart barely earns the build back)
 AUTO_CODED_MIN_CELLS_MULTI = 5e7    # ... with SEVERAL restarts: the one-launch records loop runs them one after
@@ -244,7 +246,7 @@ class EmPlan(object):
         self._quad_keep = None
         self.attach_quads()
 
-    def attach_quads(self, mode=None, cap=None):
+    def attach_quads(self, mode=None, cap=None, min_rows=None):
         """
         A quad dictionary beside the records, for the loop alone (include/mixemt_hip.h, mxm_build_quads;
         csrc/quad_kernels.hpp): one code byte per FOUR columns for the rows with at most 256 distinct value quadruples
@@ -273,7 +275,10 @@ class EmPlan(object):
         if mode == "auto":
             # by the card's TOTAL memory, not by what happens to be free: which loop runs decides the last bits of the sums
             # (fixed orders, but different ones), and the same call must take the same route every time
-            if self.n_runs < 2 or n_byte < QUADS_MIN_ROWS or guess > torch.cuda.mem_get_info(dev)[1] // 4:
+            # (min_rows: a caller whose loop runs the per-iteration kernels anyway -- dist.sharded_em_loop -- names its own
+            # floor, and one restart is reason enough there)
+            floor_ok = (n_byte >= min_rows) if min_rows is not None else (self.n_runs >= 2 and n_byte >= QUADS_MIN_ROWS)
+            if not floor_ok or guess > torch.cuda.mem_get_info(dev)[1] // 4:
                 return False
         n_rows = self.n_rows
         laps = {} if os.environ.get("MXM_PIPELINE_TIMING") else None          # (synchronises: measurement only)

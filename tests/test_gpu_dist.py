@@ -249,7 +249,7 @@ def test_bench_four_ranks_over_records_dry_run():
     assert line["config"]["total_rows"] == 1000000 and line["config"]["rows_per_gpu"] == 250000
     assert len(line["kernel_ms_per_rank"]) == 4 and min(line["kernel_ms_per_rank"]) > 0
     assert len(line["all_reduce_us_per_rank"]) == 4
-    assert line["roofline"]["kernel"] == "em_iter_coded_kernel"
+    assert line["roofline"]["kernel"] == "em_iter_quad_coded_kernel"        # 250 000-row records shards: quads attached (round 5)
     cap = line["projected_scaling_ceiling"]
     assert cap["n_gpus"] == 4 and 1.0 < cap["speedup_at_most"] <= 4.0 + 1e-9
     assert abs(cap["kernel_ms"] - max(line["kernel_ms_per_rank"])) < 1e-9
