@@ -223,13 +223,17 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
     """
     n_rows, n_haps = mat.shape
     torch.cuda.synchronize()
-    cplan = em.EmPlan(mat, wts, n_runs=1, storage="coded")
-    if cplan.coded is None:
-        return None
-    t0 = time.perf_counter()
-    cplan.encode()
-    torch.cuda.synchronize()
-    encode_ms = (time.perf_counter() - t0) * 1e3
+    quads_mode, em.QUADS = em.QUADS, False            # first the records alone; the quad dictionary is attached below
+    try:
+        cplan = em.EmPlan(mat, wts, n_runs=1, storage="coded")
+        if cplan.coded is None:
+            return None
+        t0 = time.perf_counter()
+        cplan.encode()
+        torch.cuda.synchronize()
+        encode_ms = (time.perf_counter() - t0) * 1e3
+    finally:
+        em.QUADS = quads_mode
     state = em.new_state(1, mat.device)
     cs_dense = torch.zeros_like(props)
     cs_coded = torch.zeros_like(props)
@@ -262,7 +266,7 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
     ms = beg.elapsed_time(end) / steps
     kernel_ms = kev[0].elapsed_time(kev[1])
     loop_ms = loop_ms_per_iteration(em, torch, cplan, props[0], max(steps, 50))
-    # the same step with a quad dictionary beside the records (EmPlan.attach_quads: built by default for several restarts)
+    # the same step with a quad dictionary beside the records (EmPlan.attach_quads: what "auto" does from 3e5 rows)
     quads = None
     torch.cuda.synchronize()
     t0 = time.perf_counter()

@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-/* 0.5.2.  Bumped whenever a signature or a documented default of this header changes; mxm_version() returns
+/* 0.5.3.  Bumped whenever a signature or a documented default of this header changes; mxm_version() returns
  * the value the loaded library was built with, and a binding must refuse a library whose value differs from the
  * header it was written against (mixemt_amd/_lib.py does).  History: 100 rounds 1-2 (mxm_row_argmax_votes gained
  * ws / ws_bytes and mxm_set_compact_restarts became 0/1/2 inside that number -- the reason for this rule);
@@ -48,8 +48,9 @@ extern "C" {
  * mxm_scatter_records added; mxm_em_state.reserved_ became .error and
  * mxm_em_iter_coded's state lost its const (the wide-rows list is checked where it is used);
  * 501: mxm_bam_* (a BAM file into the front end's columns; the library now links zlib);
- * 502: mxm_coded gained the quad dictionary's fields (qrec .. n_byte_rows), mxm_build_quads, mxm_quad_bytes. */
-#define MXM_VERSION 502
+ * 502: mxm_coded gained the quad dictionary's fields (qrec .. n_byte_rows), mxm_build_quads, mxm_quad_bytes;
+ * 503: mxm_quad_lists, mxm_quad_lists_scratch_bytes. */
+#define MXM_VERSION 503
 
 /* per-restart loop state, written by mxm_m_finalize (24 bytes); allocate it ZEROED */
 typedef struct mxm_em_state {
@@ -295,6 +296,13 @@ size_t mxm_coded_bytes(int64_t R, int32_t H);
  * mxm_quad_bytes     a buffer size that can never overflow: R * (2048 + 256 * 32)
  */
 size_t mxm_quad_bytes(int64_t R, int32_t H);
+/* mxm_quad_lists     the two row lists from ndist / nquad, on the device, ASCENDING: quad_rows[R] / byte_rows[R] (room for
+ *                    every row), counts[2] = {n_quad_rows, n_byte_rows} (device int64); scratch of
+ *                    mxm_quad_lists_scratch_bytes(R) bytes.  (Forming them on the host is as valid; this saves the round
+ *                    trip: 4 bytes per row down, 8 bytes per row up.) */
+size_t mxm_quad_lists_scratch_bytes(int64_t R);
+int mxm_quad_lists(const int32_t *ndist, const int32_t *nquad, int64_t R, int64_t *quad_rows, int64_t *byte_rows,
+                   int64_t *counts, void *scratch, size_t scratch_bytes, void *stream);
 int mxm_build_quads(const mxm_coded *c, int32_t H, uint8_t *qrec, size_t qrec_bytes, int64_t *qoff, int32_t *nquad,
                     uint64_t *stats, void *stream);
 int mxm_encode_rows(const double *M, int64_t ldm, int64_t R, int32_t H, uint8_t *rec, size_t rec_bytes,

@@ -88,6 +88,8 @@ SIGNATURES = {
                                        ctypes.POINTER(EmState)]),
     "mxm_coded_bytes": (c_size, [c_i64, c_i32]),
     "mxm_quad_bytes": (c_size, [c_i64, c_i32]),
+    "mxm_quad_lists_scratch_bytes": (c_size, [c_i64]),
+    "mxm_quad_lists": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
     "mxm_build_quads": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_ptr, c_size, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mxm_encode_rows": (ctypes.c_int, [c_ptr, c_i64, c_i64, c_i32, c_ptr, c_size, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr]),
     "mxm_decode_rows": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_ptr, c_i64, c_ptr]),
@@ -146,7 +148,7 @@ SIGNATURES = {
 }
 
 # the MXM_VERSION of include/mixemt_hip.h these signatures were written for; load() refuses any other
-ABI_VERSION = 502
+ABI_VERSION = 503
 
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.POINTER(EmState), c_i32, c_ptr)
 

@@ -896,6 +896,27 @@ extern "C" size_t mxm_quad_bytes(int64_t R, int32_t H) {
     return R > 0 ? (size_t)R * (size_t)(QUAD_CODE_BYTES + QUAD_MAX * 32) : 0;
 }
 
+extern "C" size_t mxm_quad_lists_scratch_bytes(int64_t R) {
+    return R > 0 ? (size_t)((R + QLIST_CHUNK - 1) / QLIST_CHUNK) * 2 * sizeof(long long) : 0;
+}
+
+extern "C" int mxm_quad_lists(const int32_t *ndist, const int32_t *nquad, int64_t R, int64_t *quad_rows, int64_t *byte_rows,
+                              int64_t *counts, void *scratch, size_t scratch_bytes, void *stream) {
+    MXM_ENTER();
+    if (ndist == nullptr || nquad == nullptr || R <= 0 || quad_rows == nullptr || byte_rows == nullptr || counts == nullptr)
+        return fail(-1, "mxm_quad_lists: bad arguments%s", "");
+    if (scratch == nullptr || scratch_bytes < mxm_quad_lists_scratch_bytes(R)) return fail(-1, "mxm_quad_lists: scratch too small%s", "");
+    const int64_t nchunk = (R + QLIST_CHUNK - 1) / QLIST_CHUNK;
+    if (nchunk > 0x7fffffff) return fail(-1, "mxm_quad_lists: too many rows%s", "");
+    hipStream_t s = (hipStream_t)stream;
+    long long *cc = static_cast<long long *>(scratch);
+    hipLaunchKernelGGL(quad_list_count_kernel, dim3((unsigned)nchunk), dim3(QLIST_THREADS), 0, s, ndist, nquad, R, cc);
+    hipLaunchKernelGGL(quad_list_scan_kernel, dim3(1), dim3(QLIST_THREADS), 0, s, cc, nchunk, reinterpret_cast<long long *>(counts));
+    hipLaunchKernelGGL(quad_list_fill_kernel, dim3((unsigned)nchunk), dim3(QLIST_THREADS), 0, s, ndist, nquad, R, cc, quad_rows, byte_rows);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int mxm_build_quads(const mxm_coded *c, int32_t H, uint8_t *qrec, size_t qrec_bytes, int64_t *qoff, int32_t *nquad,
                                uint64_t *stats, void *stream) {
     MXM_ENTER();

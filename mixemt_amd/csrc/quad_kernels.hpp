@@ -195,6 +195,119 @@ __global__ __launch_bounds__(256) void quad_validate_kernel(const int32_t *__res
     if (bad) out[1] = 1ull;
 }
 
+// ------------------------------------------------------------------------------------------
+// The row lists of a quad dictionary, formed ON THE DEVICE in ascending order (mxm_quad_lists): rows with quads ->
+// quad_rows, byte-coded rows without -> byte_rows.  Three small launches -- per-chunk counts, one workgroup's scan over
+// the chunks, per-chunk ordered scatter -- instead of a round trip through the host (4 bytes per row down, numpy, 8
+// bytes per row up: a process's first uploads from fresh pageable memory cost 20-30 ms each, more than the encoder).
+// Class of row r: 1 = quads (nquad > 0), 2 = byte-coded without quads (0 < ndist <= 256), 0 = neither.
+// ------------------------------------------------------------------------------------------
+#define QLIST_THREADS 256
+#define QLIST_PER_THREAD 16
+#define QLIST_CHUNK (QLIST_THREADS * QLIST_PER_THREAD)
+__device__ __forceinline__ int quad_row_class(const int32_t *__restrict__ ndist, const int32_t *__restrict__ nquad, int64_t r) {
+    if (nquad[r] > 0) return 1;
+    const int nd = ndist[r];
+    return (nd > 0 && nd <= ENC_MAX_CODES) ? 2 : 0;
+}
+__global__ __launch_bounds__(QLIST_THREADS) void quad_list_count_kernel(const int32_t *__restrict__ ndist,
+                                                                       const int32_t *__restrict__ nquad, int64_t R,
+                                                                       long long *__restrict__ chunk_counts /* [nchunk][2] */) {
+    __shared__ int s_c[2];
+    if (threadIdx.x < 2) s_c[threadIdx.x] = 0;
+    __syncthreads();
+    const int64_t r0 = (int64_t)blockIdx.x * QLIST_CHUNK + (int64_t)threadIdx.x * QLIST_PER_THREAD;
+    int nq = 0, nb = 0;
+    for (int i = 0; i < QLIST_PER_THREAD; ++i) {
+        const int64_t r = r0 + i;
+        if (r < R) {
+            const int c = quad_row_class(ndist, nquad, r);
+            nq += (c == 1);
+            nb += (c == 2);
+        }
+    }
+    if (nq) atomicAdd(&s_c[0], nq);
+    if (nb) atomicAdd(&s_c[1], nb);
+    __syncthreads();
+    if (threadIdx.x < 2) chunk_counts[2 * blockIdx.x + threadIdx.x] = s_c[threadIdx.x];
+}
+// exclusive scan of the chunk counts in place (one workgroup; the chunks number R / 4096); totals -> counts[0..1]
+__global__ __launch_bounds__(QLIST_THREADS) void quad_list_scan_kernel(long long *__restrict__ chunk_counts, int64_t nchunk,
+                                                                      long long *__restrict__ counts) {
+    __shared__ long long s_sum[2][QLIST_THREADS];
+    const int t = threadIdx.x;
+    const int64_t per = (nchunk + QLIST_THREADS - 1) / QLIST_THREADS;
+    const int64_t lo = (int64_t)t * per, hi = (lo + per < nchunk) ? lo + per : nchunk;
+    long long a = 0, b = 0;
+    for (int64_t i = lo; i < hi; ++i) {
+        a += chunk_counts[2 * i];
+        b += chunk_counts[2 * i + 1];
+    }
+    s_sum[0][t] = a;
+    s_sum[1][t] = b;
+    __syncthreads();
+    if (t == 0) {                                        // 256 partial sums: serial, in order
+        long long ra = 0, rb = 0;
+        for (int i = 0; i < QLIST_THREADS; ++i) {
+            const long long xa = s_sum[0][i], xb = s_sum[1][i];
+            s_sum[0][i] = ra;
+            s_sum[1][i] = rb;
+            ra += xa;
+            rb += xb;
+        }
+        counts[0] = ra;
+        counts[1] = rb;
+    }
+    __syncthreads();
+    a = s_sum[0][t];
+    b = s_sum[1][t];
+    for (int64_t i = lo; i < hi; ++i) {
+        const long long xa = chunk_counts[2 * i], xb = chunk_counts[2 * i + 1];
+        chunk_counts[2 * i] = a;
+        chunk_counts[2 * i + 1] = b;
+        a += xa;
+        b += xb;
+    }
+}
+__global__ __launch_bounds__(QLIST_THREADS) void quad_list_fill_kernel(const int32_t *__restrict__ ndist,
+                                                                      const int32_t *__restrict__ nquad, int64_t R,
+                                                                      const long long *__restrict__ chunk_base,
+                                                                      int64_t *__restrict__ quad_rows,
+                                                                      int64_t *__restrict__ byte_rows) {
+    __shared__ int s_q[QLIST_THREADS], s_b[QLIST_THREADS];
+    const int t = threadIdx.x;
+    const int64_t r0 = (int64_t)blockIdx.x * QLIST_CHUNK + (int64_t)t * QLIST_PER_THREAD;
+    int cls[QLIST_PER_THREAD];
+    int nq = 0, nb = 0;
+#pragma unroll
+    for (int i = 0; i < QLIST_PER_THREAD; ++i) {
+        const int64_t r = r0 + i;
+        cls[i] = (r < R) ? quad_row_class(ndist, nquad, r) : 0;
+        nq += (cls[i] == 1);
+        nb += (cls[i] == 2);
+    }
+    s_q[t] = nq;
+    s_b[t] = nb;
+    __syncthreads();
+    if (t == 0) {                                        // exclusive scan over the 256 threads, in order
+        int rq = 0, rb = 0;
+        for (int i = 0; i < QLIST_THREADS; ++i) {
+            const int xq = s_q[i], xb = s_b[i];
+            s_q[i] = rq;
+            s_b[i] = rb;
+            rq += xq;
+            rb += xb;
+        }
+    }
+    __syncthreads();
+    long long oq = chunk_base[2 * blockIdx.x] + s_q[t], ob = chunk_base[2 * blockIdx.x + 1] + s_b[t];
+#pragma unroll
+    for (int i = 0; i < QLIST_PER_THREAD; ++i) {
+        if (cls[i] == 1) quad_rows[oq++] = r0 + i;
+        else if (cls[i] == 2) byte_rows[ob++] = r0 + i;
+    }
+}
+
 // code byte B of a word x 32 = the byte offset of the quad's table entry: one SDWA shift
 template <int B>
 __device__ __forceinline__ unsigned int quad_byte_x32(unsigned int word) {

@@ -113,8 +113,8 @@ AUTO_CODED_MIN_CELLS = 1.5e7        # storage="auto": measured break-even of the
 # EmPlan.attach_quads: a quad dictionary beside the records ("auto" / True / False; the environment's MXM_QUADS = on / off / auto
 # sets the start value: A/B runs of the tools without editing them)
 QUADS = {"off": False, "0": False, "on": True, "1": True}.get(os.environ.get("MXM_QUADS", "auto").strip().lower(), "auto")
-QUADS_MIN_ROWS = 300000             # ... "auto": several restarts over this many byte-coded rows (below, the one-launch loop over
-                                    # the records is faster; one restart barely earns the build back)
+QUADS_MIN_ROWS = 300000             # ... "auto": from this many byte-coded rows (below, the one-launch loop over the records is faster)
+QUADS_MAX_FOOTPRINT = 60e9          # ... and only while records + dictionary stay under this many bytes
 AUTO_CODED_MIN_CELLS_MULTI = 5e7    # ... with SEVERAL restarts: the one-launch records loop runs them one after
                                     # another while the dense path shares each pass of the matrix among up to four, so the
                                     # records only pay where an iteration is bound by the matrix's bytes (round 3's break-even)
@@ -252,11 +252,11 @@ class EmPlan(object):
         csrc/quad_kernels.hpp): one code byte per FOUR columns for the rows with at most 256 distinct value quadruples
         (98.8 % of build_em_matrix's byte-coded rows), 1.27 against 1.41 ms per pass at 10^6 x 5408.  The records stay
         complete -- every other consumer reads them -- so this costs memory: ~4.8 KB per row beside the records' 5.9.
-        mode: True / False / "auto" (None = QUADS): auto builds them for SEVERAL restarts over at least QUADS_MIN_ROWS
-        byte-coded rows, if they fit a quarter of the card's memory.  Measured at 10^6 x 5408 (profiles/r05/
-        quads_product_1m.txt): the step 1.46 -> 1.32 ms, run_em's loop 1.44 (one-launch loop over the records) -> 1.35 ms per
-        iteration (the per-iteration kernels), the build 18 ms warm (more in a cold process: its first pageable uploads): one
-        restart of ~400 iterations gains about what the build costs, every further restart 35 ms.
+        mode: True / False / "auto" (None = QUADS): auto builds them from QUADS_MIN_ROWS byte-coded rows while records +
+        dictionary stay under QUADS_MAX_FOOTPRINT.  Measured at 10^6 x 5408 (profiles/r05/quads_product_1m.txt,
+        pipeline_1m_records_quads.txt): the step 1.46 -> 1.32 ms, run_em's loop 1.44 (one-launch loop over the records) ->
+        1.35 ms per iteration (the per-iteration kernels), the build 17 ms cold or warm (encoder 14.7 ms; the row lists are
+        formed on the device): a restart of ~400 iterations gains 35 ms for it.
         cap: bytes of the first buffer (default: room for 112 quads per row; the kernel counts what it needs and an
         overflow repeats the build once with exactly that much).
         """
@@ -277,8 +277,10 @@ class EmPlan(object):
             # (fixed orders, but different ones), and the same call must take the same route every time
             # (min_rows: a caller whose loop runs the per-iteration kernels anyway -- dist.sharded_em_loop -- names its own
             # floor, and one restart is reason enough there)
-            floor_ok = (n_byte >= min_rows) if min_rows is not None else (self.n_runs >= 2 and n_byte >= QUADS_MIN_ROWS)
-            if not floor_ok or guess > torch.cuda.mem_get_info(dev)[1] // 4:
+            floor_ok = n_byte >= (min_rows if min_rows is not None else QUADS_MIN_ROWS)
+            # ... and not where it would take the process's device footprint past ~64 GB: the driver charges a process's
+            # first growth past that mark with 2-6 s (profiles/r05/alloc_big.txt), more than the dictionary earns back
+            if not floor_ok or int(rec.numel()) + guess > QUADS_MAX_FOOTPRINT:
                 return False
         n_rows = self.n_rows
         laps = {} if os.environ.get("MXM_PIPELINE_TIMING") else None          # (synchronises: measurement only)
@@ -313,24 +315,33 @@ class EmPlan(object):
                 raise ValueError("mxm_build_quads: buffer of %d bytes overflowed (%d needed)" % (cap, used))
             del qrec
             cap = (used + 31) // 32 * 32
-        nq_h = nquad.cpu().numpy()
-        quad_rows = numpy.flatnonzero(nq_h > 0)
-        byte_rows = numpy.flatnonzero(byte_coded & (nq_h == 0))
-        if len(quad_rows) == 0:
+        # the row lists: formed on the device, ascending (mxm_quad_lists) -- their upload from the host was the build's
+        # largest cold cost (a process's first copies from fresh pageable memory: 20-30 ms each, profiles/r05/quad_build_1m.txt)
+        quad_rows_d = torch.empty(n_rows, dtype=torch.int64, device=dev)
+        byte_rows_d = torch.empty(n_rows, dtype=torch.int64, device=dev)
+        counts = torch.empty(2, dtype=torch.int64, device=dev)
+        sbytes = lib.mxm_quad_lists_scratch_bytes(n_rows)
+        scratch = torch.empty(max(1, (sbytes + 7) // 8), dtype=torch.int64, device=dev)
+        _lib.check(lib.mxm_quad_lists(ndist.data_ptr(), nquad.data_ptr(), n_rows, quad_rows_d.data_ptr(), byte_rows_d.data_ptr(),
+                                      counts.data_ptr(), scratch.data_ptr(), scratch.numel() * 8, current_stream()), "mxm_quad_lists")
+        n_quad, n_byte_left = (int(v) for v in counts.cpu())
+        lap("row lists (device)")
+        if n_quad == 0:
             return False
-        lap("row lists (host)")
-        quad_rows_d = torch.from_numpy(quad_rows).to(dev)
-        byte_rows_d = torch.from_numpy(byte_rows).to(dev)
-        lap("row lists to the device")
+        quad_rows_d, byte_rows_d = quad_rows_d[:n_quad], byte_rows_d[:n_byte_left]
         self._quad_keep = (qrec, qoff, nquad, quad_rows_d, byte_rows_d)
         self.coded.qrec, self.coded.qoff, self.coded.nquad = qrec.data_ptr(), qoff.data_ptr(), nquad.data_ptr()
-        self.coded.quad_rows, self.coded.n_quad_rows = quad_rows_d.data_ptr(), len(quad_rows)
-        self.coded.byte_rows, self.coded.n_byte_rows = (byte_rows_d.data_ptr() if len(byte_rows) else None), len(byte_rows)
+        self.coded.quad_rows, self.coded.n_quad_rows = quad_rows_d.data_ptr(), n_quad
+        self.coded.byte_rows, self.coded.n_byte_rows = (byte_rows_d.data_ptr() if n_byte_left else None), n_byte_left
         # what an iteration reads now: the quad records, and of the records only the rows without quads (codes + P table)
+        nq_h = nquad.cpu().numpy()
+        left = byte_coded & (nq_h == 0)
         wide_h = nd_h > 256
-        left = numpy.zeros(n_rows, dtype=bool)
-        left[byte_rows] = True
         rec_left = int((ldc + 8 * nd_h[left].astype(numpy.int64)).sum() + (2 * ldc + 8 * nd_h[wide_h].astype(numpy.int64)).sum())
+        lap("byte counts (host)")
+        quad_rows = quad_rows_d                       # (len() below)
+        if laps is not None:
+            sys.stderr.write("[attach_quads] %s\n" % laps)
         self.quad_rows_n, self.quad_bytes = len(quad_rows), used
         self.coded_record_bytes = used + rec_left
         self.coded_bytes = self.coded_record_bytes + self.coded_rest * self.n_haps * 8

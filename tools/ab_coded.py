@@ -15,6 +15,8 @@ import numpy
 import torch
 from mixemt_amd import _lib, em, phylotree, preprocess, synth
 
+em.QUADS = False        # this tool measures the records' own pass (em_iter_coded_kernel): no quad dictionary beside them
+
 
 def bind(path):
     lib = ctypes.CDLL(os.path.abspath(path))

@@ -21,6 +21,8 @@ import numpy
 import torch
 from mixemt_amd import _lib, em, phylotree, preprocess, synth
 
+em.QUADS = False        # this tool measures the records' own pass (em_iter_coded_kernel): no quad dictionary beside them
+
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 path = sys.argv[2] if len(sys.argv) > 2 else os.path.join(ROOT, "tools", "experiments", "_build", "libquad.so")
 x = ctypes.CDLL(path)

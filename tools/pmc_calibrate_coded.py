@@ -23,6 +23,8 @@ import numpy
 import torch
 from mixemt_amd import _lib, em, phylotree, preprocess, synth
 
+em.QUADS = False        # this tool measures the records' own pass (em_iter_coded_kernel): no quad dictionary beside them
+
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 lib = _lib.load()
 refseq = phylotree.load_rsrs()

@@ -15,6 +15,8 @@ import numpy
 import torch
 from mixemt_amd import _lib, em, phylotree, preprocess, synth
 
+em.QUADS = False        # this tool measures the records' own pass (em_iter_coded_kernel): no quad dictionary beside them
+
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 1000000
 reps = int(sys.argv[2]) if len(sys.argv) > 2 else 10
 only = [int(v) for v in sys.argv[3].split(",")] if len(sys.argv) > 3 else None     # shapes to time
