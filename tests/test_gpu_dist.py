@@ -386,6 +386,15 @@ def _graph_worker(rank, port, out_path):
     graphed = mdist.sharded_em_loop(plan, g["inits"], 1e-4, 10000, check_every=8, graph=True)
     out["local_bursts"] = mdist.sharded_em_loop.last_graph_bursts
     out["local_equal"] = int(torch.equal(eager[1], graphed[1]) and eager[2] == graphed[2])
+    # the same over records with a quad dictionary (round 5): both row passes in one launch inside the captured burst
+    cm = preprocess.build_em_records_device(tables, g["row_ptr"], g["site"], g["obs"])
+    qplan = em.EmPlan(None, torch.from_numpy(g["wts"]).cuda(), n_runs=3, records=cm)
+    assert qplan.attach_quads(True)
+    q_eager = mdist.sharded_em_loop(qplan, g["inits"], 1e-4, 10000, check_every=8)
+    q_graph = mdist.sharded_em_loop(qplan, g["inits"], 1e-4, 10000, check_every=8, graph=True)
+    out["quads_bursts"] = mdist.sharded_em_loop.last_graph_bursts
+    out["quads_equal"] = int(torch.equal(q_eager[1], q_graph[1]) and q_eager[2] == q_graph[2])
+    out["quads_iters"] = numpy.array([s[1] for s in q_graph[2]])
     # one-rank RCCL group: the all-reduce is inside the captured burst (if the backend allows it)
     dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
     try:
@@ -411,5 +420,6 @@ def test_sharded_loop_bursts_replayed_from_a_captured_graph(tmp_path):
     r = numpy.load(out_path)
     g = golden("g5_run_em_multi")
     assert int(r["local_equal"]) == 1 and int(r["local_bursts"]) > 10          # really replayed, really identical
+    assert int(r["quads_equal"]) == 1 and int(r["quads_bursts"]) > 10 and list(r["quads_iters"]) == list(g["iters"])
     assert int(r["rccl_equal"]) == 1 and list(r["iters"]) == list(g["iters"])
     print("bursts replayed with the RCCL all-reduce inside the graph: %d" % int(r["rccl_bursts"]))
