@@ -92,6 +92,9 @@ def parse_args(argv=None):
     ap.add_argument("--force-dist", action="store_true",
                     help="initialise the process group and issue the per-iteration all-reduce even with "
                          "one rank (exercises the RCCL path on a single-GPU box)")
+    ap.add_argument("--exchange", default="rccl", choices=["rccl", "oneshot"],
+                    help="the per-iteration exchange of a multi-rank step: torch.distributed's all-reduce (default) or the "
+                         "library's one-shot exchange (dist.OneShotExchange; unmeasured over xGMI)")
     ap.add_argument("--backend", default="nccl",
                     help="torch.distributed backend for N > 1 (nccl = RCCL; gloo only to test the "
                          "multi-process path on a single GPU)")
@@ -547,6 +550,8 @@ def bench_rows(opts, env):
         for ev in quad:
             ev.record()
 
+    oneshot = mdist.OneShotExchange(colsum.numel()) if (use_dist and opts.exchange == "oneshot") else None
+
     def step(quad=None):
         if quad is not None:
             lib.mxm_set_timing_events(quad[0].cuda_event, quad[1].cuda_event)
@@ -556,7 +561,10 @@ def bench_rows(opts, env):
         if use_dist:
             if quad is not None:
                 quad[2].record()
-            dist.all_reduce(colsum, op=dist.ReduceOp.SUM)
+            if oneshot is not None:
+                oneshot.reduce(colsum, state)
+            else:
+                dist.all_reduce(colsum, op=dist.ReduceOp.SUM)
             if quad is not None:
                 quad[3].record()
         plan.finalize(colsum, ln_cur, ln_new, props_cur, state, 0.0, total + 1)
@@ -571,7 +579,8 @@ def bench_rows(opts, env):
         rank, dist.sharded_em_loop over several): restarts advance in full tiles dealt round-robin, so
         a "step" of B restarts costs B / tile passes over the matrix, not ceil(B / tile)."""
         if use_dist:
-            _, _, sts = mdist.sharded_em_loop(plan, init, 0.0, n_iters, check_every=16)
+            _, _, sts = mdist.sharded_em_loop(plan, init, 0.0, n_iters, check_every=16,
+                                              exchange=oneshot if oneshot is not None else "rccl")
         else:
             _, _, sts = em.em_loop(plan, init, 0.0, n_iters)
         return sts
@@ -763,6 +772,7 @@ def bench_rows(opts, env):
         "parity_in_run": parity,
         "coded_storage": coded_info,
         "all_reduce_us": all_reduce_us,
+        "exchange": opts.exchange if use_dist else None,
         "all_reduce_us_per_rank": all_reduce_us_per_rank,
         "all_reduce_us_min_mean_max": (None if not all_reduce_us_per_rank else
                                        [min(all_reduce_us_per_rank), sum(all_reduce_us_per_rank) / len(all_reduce_us_per_rank),

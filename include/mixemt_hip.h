@@ -34,7 +34,7 @@
 extern "C" {
 #endif
 
-/* 0.5.3.  Bumped whenever a signature or a documented default of this header changes; mxm_version() returns
+/* 0.5.4.  Bumped whenever a signature or a documented default of this header changes; mxm_version() returns
  * the value the loaded library was built with, and a binding must refuse a library whose value differs from the
  * header it was written against (mixemt_amd/_lib.py does).  History: 100 rounds 1-2 (mxm_row_argmax_votes gained
  * ws / ws_bytes and mxm_set_compact_restarts became 0/1/2 inside that number -- the reason for this rule);
@@ -49,8 +49,9 @@ extern "C" {
  * mxm_em_iter_coded's state lost its const (the wide-rows list is checked where it is used);
  * 501: mxm_bam_* (a BAM file into the front end's columns; the library now links zlib);
  * 502: mxm_coded gained the quad dictionary's fields (qrec .. n_byte_rows), mxm_build_quads, mxm_quad_bytes;
- * 503: mxm_quad_lists, mxm_quad_lists_scratch_bytes. */
-#define MXM_VERSION 503
+ * 503: mxm_quad_lists, mxm_quad_lists_scratch_bytes;
+ * 504: mxm_exchange_* (the optional one-shot exchange of a row-sharded loop); mxm_em_state.error may be 2. */
+#define MXM_VERSION 504
 
 /* per-restart loop state, written by mxm_m_finalize (24 bytes); allocate it ZEROED */
 typedef struct mxm_em_state {
@@ -58,7 +59,7 @@ typedef struct mxm_em_state {
     int32_t iters;               /* EM steps executed so far ("Converged! (n)", em.py:135) */
     double  l1;                  /* last sum_h |p_new - p_cur|  (em.py:53-54) */
     uint32_t ticket;             /* scratch of mxm_m_finalize (arrival count of its workgroups): 0 between calls */
-    uint32_t error;              /* 0 = fine; 1 = mxm_em_iter_coded found that mxm_coded.wide_rows is not exactly the set of
+    uint32_t error;              /* 0 = fine; 2 = mxm_exchange_pull timed out waiting for a rank; 1 = mxm_em_iter_coded found that mxm_coded.wide_rows is not exactly the set of
                                     rows with more than 256 values (colsum is then NaN throughout); mxm_em_loop_coded
                                     returns -1 instead of iterating on */
 } mxm_em_state;
@@ -536,6 +537,29 @@ int  mxm_bam_sizes_of(const mxm_bam *bam, mxm_bam_sizes *sizes);
 int  mxm_bam_columns(const mxm_bam *bam, mxm_aln_columns *cols);
 int  mxm_bam_fetch_names(const mxm_bam *bam, char *names, int64_t *name_off, int32_t *ref_id, uint16_t *flag);
 void mxm_bam_free(mxm_bam *bam);
+
+/*
+ * One-shot exchange of the M-step sums between the ranks of a row-sharded loop -- OPTIONAL, instead of the all-reduce
+ * between mxm_em_iter and mxm_m_finalize (SURVEY.md section 8 e: "each GPU writes its 43 KB to its peers, sum in fixed
+ * rank order"; the reference has no counterpart: it is single-process).  Every rank owns one device buffer that all ranks
+ * map (hipIpc); mxm_exchange_push writes the rank's sums into its slot of EVERY rank's buffer and then raises that
+ * rank's flag there; mxm_exchange_pull waits (bounded: on a timeout colsum is NaN and state[0 .. nb).error = 2) until
+ * all ranks' flags of this exchange are up in its own buffer and forms colsum[i] = sum over the ranks' slots in RANK
+ * order -- the same bits on every rank.  Both only enqueue kernels on `stream` (the exchange count lives on the device:
+ * a burst of iterations is capturable in a hipGraph).  Exercised with several processes on ONE GPU; over xGMI UNMEASURED
+ * (csrc/exchange.hpp states the visibility rules it relies on).  mixemt_amd.dist.sharded_em_loop(exchange="oneshot").
+ *   mxm_exchange_create   HOST, blocking: allocates this rank's buffer for exchanges of at most n_doubles doubles on the
+ *                         current device and writes its IPC handle (mxm_exchange_handle_bytes() bytes) to handle_out
+ *   mxm_exchange_connect  HOST: handles[world][handle_bytes] of ALL ranks in rank order (the caller all-gathers them)
+ */
+typedef struct mxm_exchange mxm_exchange;
+size_t mxm_exchange_handle_bytes(void);
+int  mxm_exchange_create(int32_t world, int32_t rank, int64_t n_doubles, mxm_exchange **out, void *handle_out);
+int  mxm_exchange_connect(mxm_exchange *x, const void *handles);
+int  mxm_exchange_push(mxm_exchange *x, const double *colsum, int64_t n, void *stream);
+int  mxm_exchange_pull(mxm_exchange *x, double *colsum, int64_t n, mxm_em_state *state, int32_t nb, void *stream);
+int  mxm_exchange_info(const mxm_exchange *x, int32_t *fine_grained, int64_t *bytes);
+void mxm_exchange_destroy(mxm_exchange *x);
 
 #ifdef __cplusplus
 }

@@ -60,6 +60,7 @@
 #include "fused_cols_kernels.hpp"
 #include "fused_coded_kernels.hpp"
 #include "fused_narrow_kernels.hpp"
+#include "exchange.hpp"
 
 
 // ------------------------------------------------------------------------------------------

@@ -81,6 +81,58 @@ def broadcast_inits(n_runs, n_haps, alpha, device, group=None, src=0):
     return buf.cpu().numpy()
 
 
+class OneShotExchange(object):
+    """
+    The library's one-shot exchange (include/mixemt_hip.h, mxm_exchange_*; csrc/exchange.hpp) for a process group: every
+    rank's buffer mapped into every rank, the handles all-gathered over the group (any backend: 64 bytes per rank, once).
+    reduce(colsum, state): push + pull on the current stream -- colsum becomes the sum over the ranks in rank order, the
+    same bits everywhere.  Opt-in: sharded_em_loop(exchange="oneshot"); RCCL's all-reduce is the default.  Exercised with
+    several processes on one GPU; UNMEASURED over xGMI.
+    """
+
+    def __init__(self, n_doubles, group=None):
+        import ctypes
+        from . import _lib
+        self.lib = _lib.load()
+        rank, world = _world(group)
+        self.rank, self.world = rank, world
+        hb = int(self.lib.mxm_exchange_handle_bytes())
+        mine = ctypes.create_string_buffer(hb)
+        handle = ctypes.c_void_p()
+        _lib.check(self.lib.mxm_exchange_create(world, rank, int(n_doubles), ctypes.byref(handle), mine), "mxm_exchange_create")
+        self.handle = handle
+        every = [None] * world
+        if world > 1:
+            dist.all_gather_object(every, bytes(mine.raw), group=group)
+        else:
+            every = [bytes(mine.raw)]
+        blob = ctypes.create_string_buffer(b"".join(every), hb * world)
+        _lib.check(self.lib.mxm_exchange_connect(handle, blob), "mxm_exchange_connect")
+        if world > 1:
+            dist.barrier(group=group)                  # nobody pushes into a buffer its owner has not finished setting up
+        self.n_doubles = int(n_doubles)
+
+    def reduce(self, colsum, state=None):
+        from . import _lib
+        from ._dev import current_stream
+        n = colsum.numel()
+        nb = colsum.shape[0] if colsum.dim() > 1 else 1
+        if not colsum.is_contiguous() or n > self.n_doubles:
+            raise ValueError("one-shot exchange: a contiguous block of at most %d doubles" % self.n_doubles)
+        stream = current_stream()
+        _lib.check(self.lib.mxm_exchange_push(self.handle, colsum.data_ptr(), n, stream), "mxm_exchange_push")
+        _lib.check(self.lib.mxm_exchange_pull(self.handle, colsum.data_ptr(), n, state.data_ptr() if state is not None else None,
+                                              nb if state is not None else 0, stream), "mxm_exchange_pull")
+
+    def close(self):
+        handle, self.handle = getattr(self, "handle", None), None
+        if handle:
+            self.lib.mxm_exchange_destroy(handle)
+
+    def __del__(self):
+        self.close()
+
+
 GRAPH_AUTO_ISSUE_SHARE = 0.5       # graph="auto": replay bursts from a hipGraph once the host needs more than this share
                                    # of a burst's wall time just to ENQUEUE it (the device would otherwise wait for Python)
 
@@ -89,7 +141,7 @@ SHARD_QUADS_MIN_ROWS = 60000        # sharded_em_loop: attach a quad dictionary 
 
 
 def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8, compact=True,
-                    window=None, verify=True, graph="auto"):
+                    window=None, verify=True, graph="auto", exchange="rccl"):
     """
     The EM loop over a row-sharded matrix.  `plan` is the rank-local EmPlan (or
     any object with its em_iter / finalize / alloc / read_state surface -- the
@@ -121,8 +173,22 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     shares are max-reduced over the ranks first.  True / False force it.  A burst whose set of iterating restarts
     changed is re-captured; whenever capture is not possible (gloo, CPU tensors, a backend that refuses collectives
     under capture) the loop logs once and stays eager.  Results are bit-identical either way (same kernels, same order).
+    exchange: "rccl" (default) = torch.distributed's all-reduce of the iterating restarts' sums; "oneshot" = the library's
+    one-shot exchange (OneShotExchange: every rank writes its sums into every rank's buffer, each sums them in rank order;
+    kernels only, so a burst is capturable whatever the group's backend) -- an OneShotExchange may also be passed in, to be
+    reused over several loops.  Opt-in; exercised with several processes on one GPU, unmeasured over xGMI.
     """
-    exchange = _collective(group)
+    oneshot = None
+    if exchange == "oneshot":
+        if not hasattr(plan, "lib"):
+            raise ValueError("the one-shot exchange needs a device plan")
+        oneshot = OneShotExchange(int(numpy.asarray(inits).shape[0]) * int(numpy.asarray(inits).shape[1]), group)
+    elif isinstance(exchange, OneShotExchange):
+        oneshot = exchange
+    elif exchange != "rccl":
+        raise ValueError("exchange must be 'rccl', 'oneshot' or an OneShotExchange")
+    grouped = _collective(group)                       # a process group exists: decisions are agreed over it
+    exchange = grouped or oneshot is not None
     # This loop always runs the per-iteration kernels (the exchange sits between the row pass and the finalize), so over
     # records a quad dictionary has no one-launch loop to beat and pays from far fewer rows than in run_em's own loop
     # (em.EmPlan.attach_quads; SHARD_QUADS_MIN_ROWS byte-coded rows in the shard)
@@ -181,13 +247,15 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
         def burst():
             for _ in range(check_every):
                 plan.em_iter(props_cur[:lead], ln_cur[:lead], state[:lead], colsum[:lead])
-                if exchange:
+                if oneshot is not None:
+                    oneshot.reduce(colsum[:lead], state[:lead])
+                elif exchange:
                     dist.all_reduce(colsum[:lead], op=dist.ReduceOp.SUM, group=group)
                 plan.finalize(colsum[:lead], ln_cur[:lead], ln_new[:lead], props_cur[:lead], state[:lead],
                               tolerance, max_iter)
 
         use_graph = (graph is True and not first and captured is not False and props_cur.is_cuda
-                     and (not exchange or dist.get_backend(group) == "nccl"))
+                     and (not exchange or oneshot is not None or dist.get_backend(group) == "nccl"))
         if use_graph and (captured is None or captured[0] != lead):
             # (re)capture: the burst's launches are recorded, not run; a failure leaves the loop eager for good
             #  only what a refused CAPTURE raises is taken as "not capturable here" -- torch reports those as
@@ -222,15 +290,15 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
             eager_bursts += 1
             if eager_bursts == 2 and graph == "auto":
                 share = t_issue / max(t_wall, 1e-9)
-                if exchange:                                 # one decision for all ranks
+                if grouped:                                  # one decision for all ranks
                     agreed = torch.tensor([share], dtype=torch.float64, device=props_cur.device)
                     dist.all_reduce(agreed, op=dist.ReduceOp.MAX, group=group)
                     share = float(agreed.item())
                 graph = bool(share > GRAPH_AUTO_ISSUE_SHARE and props_cur.is_cuda
-                             and (not exchange or dist.get_backend(group) == "nccl"))
+                             and (not grouped or oneshot is not None or dist.get_backend(group) == "nccl"))
                 sharded_em_loop.last_issue_share = share
                 sharded_em_loop.last_issue_burst = eager_bursts
-        if exchange and verify:
+        if grouped and verify:
             _assert_ranks_agree(states, props_cur.device, group)
     if slot_run != list(range(n_runs)):                        # back to the caller's run order
         back = [0] * n_runs
@@ -272,13 +340,13 @@ def _assert_ranks_agree(states, device, group):
 
 
 def run_em_sharded(local_mat, local_weights, args, inits=None, group=None, want_read_mix=True,
-                   check_every=8, storage=None, records=None):
+                   check_every=8, storage=None, records=None, exchange="rccl"):
     """
     run_em (em.py:94-165) over a matrix whose rows are spread over the ranks of
     `group`; each rank passes ITS row block and gets back the global proportions
     plus ITS block of the posterior matrix.  Same dict as em.run_em_ex.
     records: the shard as a preprocess.CodedMatrix (build_em_records_device on the rank's own rows);
-    local_mat may then be None.
+    local_mat may then be None.  exchange: see sharded_em_loop ("rccl" | "oneshot").
     """
     n_multi = int(args.n_multi)
     plan = _em.EmPlan(local_mat, local_weights, n_runs=n_multi,
@@ -287,7 +355,7 @@ def run_em_sharded(local_mat, local_weights, args, inits=None, group=None, want_
         inits = broadcast_inits(n_multi, plan.n_haps, args.init_alpha, plan.dev, group)
     inits = numpy.ascontiguousarray(inits, dtype=numpy.float64)
     ln_cur, ln_new, states = sharded_em_loop(plan, inits, args.tolerance, args.max_iter,
-                                             group=group, check_every=check_every)
+                                             group=group, check_every=check_every, exchange=exchange)
     return _em.collect_result(plan, inits, ln_cur, ln_new, states, want_read_mix, reuse_linear=True)
 
 

@@ -489,6 +489,8 @@ def read_state(state):
     raw = state.cpu().numpy().tobytes()
     n = len(raw) // ctypes.sizeof(_lib.EmState)
     arr = (_lib.EmState * n).from_buffer_copy(raw)
+    if any(s.error == 2 for s in arr):
+        raise ValueError("EM loop state: the one-shot exchange timed out waiting for a rank (mxm_exchange_pull poisoned the sums)")
     if any(s.error for s in arr):
         raise ValueError("EM loop state: the records' wide_rows list does not match the rows with more than 256 values "
                          "(mxm_em_iter_coded poisoned the sums)")
