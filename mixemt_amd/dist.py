@@ -130,7 +130,10 @@ class OneShotExchange(object):
             self.lib.mxm_exchange_destroy(handle)
 
     def __del__(self):
-        self.close()
+        try:
+            self.close()
+        except Exception:                                  # (interpreter shutdown: the runtime may be gone already)
+            pass
 
 
 GRAPH_AUTO_ISSUE_SHARE = 0.5       # graph="auto": replay bursts from a hipGraph once the host needs more than this share
@@ -178,11 +181,12 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     kernels only, so a burst is capturable whatever the group's backend) -- an OneShotExchange may also be passed in, to be
     reused over several loops.  Opt-in; exercised with several processes on one GPU, unmeasured over xGMI.
     """
-    oneshot = None
+    oneshot, own_exchange = None, False
     if exchange == "oneshot":
         if not hasattr(plan, "lib"):
             raise ValueError("the one-shot exchange needs a device plan")
         oneshot = OneShotExchange(int(numpy.asarray(inits).shape[0]) * int(numpy.asarray(inits).shape[1]), group)
+        own_exchange = True
     elif isinstance(exchange, OneShotExchange):
         oneshot = exchange
     elif exchange != "rccl":
@@ -208,6 +212,8 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     slot_run = list(range(n_runs))                             # slot -> caller's run index
     states = plan.read_state(state)
     if max_iter <= 0:
+        if own_exchange:
+            oneshot.close()
         return ln_cur, ln_new, states
     first = True
     eager_bursts = 0                                   # graph="auto" takes its decision from the second eager burst
@@ -309,6 +315,11 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
             vec.copy_(vec[idx])
         states = [states[s] for s in back]
     sharded_em_loop.last_graph_bursts = graph_bursts
+    if own_exchange:                                   # made here: unmapped here, once every rank is through its last pull
+        torch.cuda.synchronize()
+        if grouped:
+            dist.barrier(group=group)
+        oneshot.close()
     return ln_cur, ln_new, states
 
 
