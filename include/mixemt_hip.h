@@ -50,8 +50,9 @@ extern "C" {
  * 501: mxm_bam_* (a BAM file into the front end's columns; the library now links zlib);
  * 502: mxm_coded gained the quad dictionary's fields (qrec .. n_byte_rows), mxm_build_quads, mxm_quad_bytes;
  * 503: mxm_quad_lists, mxm_quad_lists_scratch_bytes;
- * 504: mxm_exchange_* (the optional one-shot exchange of a row-sharded loop); mxm_em_state.error may be 2. */
-#define MXM_VERSION 504
+ * 504: mxm_exchange_* (the optional one-shot exchange of a row-sharded loop); mxm_em_state.error may be 2;
+ * 505: mxm_exchange_reduce. */
+#define MXM_VERSION 505
 
 /* per-restart loop state, written by mxm_m_finalize (24 bytes); allocate it ZEROED */
 typedef struct mxm_em_state {
@@ -558,6 +559,8 @@ int  mxm_exchange_create(int32_t world, int32_t rank, int64_t n_doubles, mxm_exc
 int  mxm_exchange_connect(mxm_exchange *x, const void *handles);
 int  mxm_exchange_push(mxm_exchange *x, const double *colsum, int64_t n, void *stream);
 int  mxm_exchange_pull(mxm_exchange *x, double *colsum, int64_t n, mxm_em_state *state, int32_t nb, void *stream);
+/* push + pull in ONE launch (in place: colsum in, the ranks' sum out) -- what the loop uses */
+int  mxm_exchange_reduce(mxm_exchange *x, double *colsum, int64_t n, mxm_em_state *state, int32_t nb, void *stream);
 int  mxm_exchange_info(const mxm_exchange *x, int32_t *fine_grained, int64_t *bytes);
 void mxm_exchange_destroy(mxm_exchange *x);
 

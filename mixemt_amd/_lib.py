@@ -92,6 +92,7 @@ SIGNATURES = {
     "mxm_exchange_connect": (ctypes.c_int, [c_ptr, c_ptr]),
     "mxm_exchange_push": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_ptr]),
     "mxm_exchange_pull": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr]),
+    "mxm_exchange_reduce": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr]),
     "mxm_exchange_info": (ctypes.c_int, [c_ptr, ctypes.POINTER(c_i32), ctypes.POINTER(c_i64)]),
     "mxm_exchange_destroy": (None, [c_ptr]),
     "mxm_quad_bytes": (c_size, [c_i64, c_i32]),
@@ -155,7 +156,7 @@ SIGNATURES = {
 }
 
 # the MXM_VERSION of include/mixemt_hip.h these signatures were written for; load() refuses any other
-ABI_VERSION = 504
+ABI_VERSION = 505
 
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.POINTER(EmState), c_i32, c_ptr)
 

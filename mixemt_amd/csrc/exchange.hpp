@@ -30,6 +30,7 @@
 // ------------------------------------------------------------------------------------------
 #define MXM_EXCHANGE_MAX_WORLD 16
 #define MXM_EXCHANGE_THREADS 256
+#define MXM_EXCHANGE_MAX_GRID 64          // workgroups of a launch that both pushes and waits: all resident at once
 
 struct exchange_header {
     unsigned long long epoch;
@@ -115,6 +116,60 @@ __global__ __launch_bounds__(MXM_EXCHANGE_THREADS) void exchange_pull_kernel(uns
     for (long long i = (long long)blockIdx.x * MXM_EXCHANGE_THREADS + threadIdx.x; i < n; i += stride) {
         double s = 0.0;
         for (int r = 0; r < world; ++r)                      // rank order: the same bits on every rank
+            s += __hip_atomic_load(exchange_slot(own_base, parity, r, world, cap) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        colsum[i] = late ? __longlong_as_double(0x7ff8000000000000ll) : s;
+    }
+    if (late && blockIdx.x == 0 && (int)threadIdx.x < nb && state != nullptr) state[threadIdx.x].error = 2u;
+}
+
+// push and pull in ONE launch (mxm_exchange_reduce): the workgroups push their parts, the last to arrive raises the flags,
+// and every workgroup then waits for all ranks' flags -- its own rank's among them -- and sums its part of the slots.
+// At most MXM_EXCHANGE_MAX_GRID workgroups, all resident at once, so the ones that wait cannot keep the ones that still
+// have to push off the chip.  One launch boundary (~4 us) less than push + pull.
+__global__ __launch_bounds__(MXM_EXCHANGE_THREADS) void exchange_reduce_kernel(exchange_peers peers, int world, int rank, long long cap,
+                                                                              double *__restrict__ colsum, long long n,
+                                                                              mxm_em_state *__restrict__ state, int nb) {
+    __shared__ int s_late;
+    unsigned char *own_base = peers.base[rank];
+    exchange_header *own = reinterpret_cast<exchange_header *>(own_base);
+    const unsigned long long e = __hip_atomic_load(&own->epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1ull;
+    const int parity = (int)(e & 1ull);
+    const long long stride = (long long)gridDim.x * MXM_EXCHANGE_THREADS;
+    for (long long i = (long long)blockIdx.x * MXM_EXCHANGE_THREADS + threadIdx.x; i < n; i += stride) {
+        const double v = colsum[i];
+        for (int p = 0; p < world; ++p)
+            __hip_atomic_store(exchange_slot(peers.base[p], parity, rank, world, cap) + i, v, __ATOMIC_RELAXED,
+                               __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+    __threadfence_system();
+    if (threadIdx.x == 0) s_late = 0;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned int arrived = __hip_atomic_fetch_add(&own->ticket, 1u, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+        if (arrived == gridDim.x - 1) {
+            __hip_atomic_store(&own->ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_store(&own->epoch, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+            __threadfence_system();
+            for (int p = 0; p < world; ++p)
+                __hip_atomic_store(&reinterpret_cast<exchange_header *>(peers.base[p])->flags[parity][rank], e,
+                                   __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+        }
+    }
+    if ((int)threadIdx.x < world) {
+        const unsigned long long t0 = wall_clock64();
+        while (__hip_atomic_load(&own->flags[parity][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
+            if (wall_clock64() - t0 > EXCHANGE_TIMEOUT_TICKS) {
+                s_late = 1;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+        }
+    }
+    __syncthreads();
+    const bool late = s_late != 0;
+    for (long long i = (long long)blockIdx.x * MXM_EXCHANGE_THREADS + threadIdx.x; i < n; i += stride) {
+        double s = 0.0;
+        for (int r = 0; r < world; ++r)
             s += __hip_atomic_load(exchange_slot(own_base, parity, r, world, cap) + i, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
         colsum[i] = late ? __longlong_as_double(0x7ff8000000000000ll) : s;
     }
@@ -207,6 +262,20 @@ extern "C" int mxm_exchange_pull(mxm_exchange *x, double *colsum, int64_t n, mxm
     if (grid > 64) grid = 64;
     hipLaunchKernelGGL(exchange_pull_kernel, dim3(grid), dim3(MXM_EXCHANGE_THREADS), 0, (hipStream_t)stream, x->own, x->world,
                        x->cap, colsum, (long long)n, state, (int)nb);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
+extern "C" int mxm_exchange_reduce(mxm_exchange *x, double *colsum, int64_t n, mxm_em_state *state, int32_t nb, void *stream) {
+    if (x == nullptr || colsum == nullptr || n < 1 || n > x->cap || nb < 0 || nb > MXM_EXCHANGE_THREADS)
+        return fail(-1, "mxm_exchange_reduce: bad arguments%s", "");
+    for (int p = 0; p < x->world; ++p)
+        if (x->peers.base[p] == nullptr) return fail(-1, "mxm_exchange_reduce: rank %s%lld is not connected", "", (long long)p);
+    int grid = (int)((n + MXM_EXCHANGE_THREADS * 4 - 1) / (MXM_EXCHANGE_THREADS * 4));
+    if (grid < 1) grid = 1;
+    if (grid > MXM_EXCHANGE_MAX_GRID) grid = MXM_EXCHANGE_MAX_GRID;
+    hipLaunchKernelGGL(exchange_reduce_kernel, dim3(grid), dim3(MXM_EXCHANGE_THREADS), 0, (hipStream_t)stream, x->peers, x->world,
+                       x->rank, x->cap, colsum, (long long)n, state, (int)nb);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -90,8 +90,9 @@ class OneShotExchange(object):
     several processes on one GPU; UNMEASURED over xGMI.
     """
 
-    def __init__(self, n_doubles, group=None):
+    def __init__(self, n_doubles, group=None, split=False):
         import ctypes
+        self.split = bool(split)
         from . import _lib
         self.lib = _lib.load()
         rank, world = _world(group)
@@ -120,9 +121,12 @@ class OneShotExchange(object):
         if not colsum.is_contiguous() or n > self.n_doubles:
             raise ValueError("one-shot exchange: a contiguous block of at most %d doubles" % self.n_doubles)
         stream = current_stream()
-        _lib.check(self.lib.mxm_exchange_push(self.handle, colsum.data_ptr(), n, stream), "mxm_exchange_push")
-        _lib.check(self.lib.mxm_exchange_pull(self.handle, colsum.data_ptr(), n, state.data_ptr() if state is not None else None,
-                                              nb if state is not None else 0, stream), "mxm_exchange_pull")
+        state_ptr, nb = (state.data_ptr(), nb) if state is not None else (None, 0)
+        if self.split:                                     # (two launches: kept for A/B and as the documented primitive pair)
+            _lib.check(self.lib.mxm_exchange_push(self.handle, colsum.data_ptr(), n, stream), "mxm_exchange_push")
+            _lib.check(self.lib.mxm_exchange_pull(self.handle, colsum.data_ptr(), n, state_ptr, nb, stream), "mxm_exchange_pull")
+        else:
+            _lib.check(self.lib.mxm_exchange_reduce(self.handle, colsum.data_ptr(), n, state_ptr, nb, stream), "mxm_exchange_reduce")
 
     def close(self):
         handle, self.handle = getattr(self, "handle", None), None
