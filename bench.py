@@ -224,6 +224,7 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
     (EmPlan(storage="coded")): same proportions in, column sums compared with the dense pass,
     `steps` iterations timed the same way (HIP events around the whole step).
     """
+    import numpy
     n_rows, n_haps = mat.shape
     torch.cuda.synchronize()
     quads_mode, em.QUADS = em.QUADS, False            # first the records alone; the quad dictionary is attached below
@@ -246,28 +247,35 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
     ln_a, ln_b = ln_props.clone(), ln_props.clone()
     p_cur = props.clone()
     beg, end = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    kev = [torch.cuda.Event(enable_timing=True) for _ in range(2)]
-    for ev in kev:
-        ev.record()
+    # the row-pass kernel of EVERY timed step by its own pair of events (the library records them around the launch): the
+    # mean is what a rocprofv3 average of the same run shows; the steps of a run's first iterations are the slow ones
+    # (profiles/r05/step_sequence.txt), so the last step alone would flatter the kernel
+    kevs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(steps)]
+    for a_ev, b_ev in kevs:
+        a_ev.record()
+        b_ev.record()
 
-    def one(timed=False):
-        if timed:
-            lib.mxm_set_timing_events(kev[0].cuda_event, kev[1].cuda_event)
+    def one(pair=None):
+        if pair is not None:
+            lib.mxm_set_timing_events(pair[0].cuda_event, pair[1].cuda_event)
         cplan.em_iter(p_cur, ln_a, state, cs_coded)
-        if timed:
+        if pair is not None:
             lib.mxm_set_timing_events(None, None)
         cplan.finalize(cs_coded, ln_a, ln_b, p_cur, state, 0.0, 1 << 30)
-    for _ in range(3):
-        one()
-    torch.cuda.synchronize()
-    beg.record()
-    for _ in range(steps):
-        one()
-    end.record()
-    one(timed=True)
-    torch.cuda.synchronize()
-    ms = beg.elapsed_time(end) / steps
-    kernel_ms = kev[0].elapsed_time(kev[1])
+
+    def timed_steps():
+        for _ in range(3):
+            one()
+        torch.cuda.synchronize()
+        beg.record()
+        for i in range(steps):
+            one(kevs[i])
+        end.record()
+        torch.cuda.synchronize()
+        each = [a_ev.elapsed_time(b_ev) for a_ev, b_ev in kevs]
+        return beg.elapsed_time(end) / steps, float(numpy.mean(each)), float(each[-1])
+
+    ms, kernel_ms, kernel_ms_last = timed_steps()
     loop_ms = loop_ms_per_iteration(em, torch, cplan, props[0], max(steps, 50))
     # the same step with a quad dictionary beside the records (EmPlan.attach_quads: what "auto" does from 3e5 rows)
     quads = None
@@ -279,18 +287,9 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
         cs_quad = torch.zeros_like(props)
         cplan.em_iter(props, ln_props, state, cs_quad)
         qrel = float(((cs_quad - cs_dense).abs() / cs_dense.abs().clamp_min(1e-300)).max().item())
-        for _ in range(3):
-            one()
-        torch.cuda.synchronize()
-        beg.record()
-        for _ in range(steps):
-            one()
-        end.record()
-        one(timed=True)
-        torch.cuda.synchronize()
-        qms, qkernel = beg.elapsed_time(end) / steps, kev[0].elapsed_time(kev[1])
+        qms, qkernel, qkernel_last = timed_steps()
         quads = {"ms_per_step": qms, "value": float(n_rows) * n_haps / (qms * 1e-3), "kernel": "em_iter_quad_coded_kernel",
-                 "kernel_ms": qkernel, "kernel_bytes": float(cplan.coded_record_bytes),
+                 "kernel_ms": qkernel, "kernel_ms_last_step": qkernel_last, "kernel_bytes": float(cplan.coded_record_bytes),
                  "hbm_frac": cplan.coded_record_bytes / (qkernel * 1e-3) / HBM_PEAK_BYTES_PER_S,
                  "quad_rows": int(cplan.quad_rows_n), "quad_bytes": float(cplan.quad_bytes), "build_ms": quad_build_ms,
                  "max_rel_dcolsum": qrel,
@@ -309,7 +308,9 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
                                     "and state read-back (round 4 printed it as ms_per_step)" % max(steps, 50),
             "per_iteration_kernels_ms_per_step": ms,
             "rows_with_16bit_codes": int(cplan.coded_wide),
-            "kernel": "em_iter_coded_kernel", "kernel_ms": kernel_ms,
+            "kernel": "em_iter_coded_kernel", "kernel_ms": kernel_ms, "kernel_ms_last_step": kernel_ms_last,
+            "kernel_ms_is": "mean over the %d timed steps (HIP events around each launch); the last step alone beside it: the first "
+                            "iterations of a run are the slow ones (profiles/r05/step_sequence.txt)" % steps,
             "bytes_per_iteration": float(cplan.coded_bytes),
             "kernel_bytes": float(cplan.coded_record_bytes),
             "hbm_frac": cplan.coded_record_bytes / (kernel_ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
