@@ -51,8 +51,8 @@ extern "C" {
  * 502: mxm_coded gained the quad dictionary's fields (qrec .. n_byte_rows), mxm_build_quads, mxm_quad_bytes;
  * 503: mxm_quad_lists, mxm_quad_lists_scratch_bytes;
  * 504: mxm_exchange_* (the optional one-shot exchange of a row-sharded loop); mxm_em_state.error may be 2;
- * 505: mxm_exchange_reduce. */
-#define MXM_VERSION 505
+ * 505: mxm_exchange_reduce; 506: mxm_expand_tables. */
+#define MXM_VERSION 506
 
 /* per-restart loop state, written by mxm_m_finalize (24 bytes); allocate it ZEROED */
 typedef struct mxm_em_state {
@@ -101,6 +101,16 @@ int mxm_build_em_matrix(const uint8_t *E, int64_t lde,
                         const uint8_t *obs,
                         int64_t R, int32_t H, int32_t S,
                         double *M, int64_t ldm, void *stream);
+
+/*
+ * The dense tables of the two cell-by-cell build kernels from the marker form, on the device (nothing of the reference: its
+ * HapVarBaseMatrix is a dict of dicts, preprocess.py:39-67): out[s][h] = map256[maj[s]] for every haplogroup h < H, then
+ * out[s][mk_hap[j]] = map256[mk_base[j]] for the markers j of site s; columns H .. lde are 0.  map256 NULL = identity:
+ * `E` of mxm_build_em_matrix; map256 = the 4-bit code table (<< 3): `Ecode` of mxm_build_em_matrix_lut.
+ * maj / mk_ptr / mk_hap / mk_base as for mxm_build_em_matrix_sparse.
+ */
+int mxm_expand_tables(const uint8_t *maj, const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
+                      const uint8_t *map256, int32_t S, int32_t H, int64_t lde, uint8_t *out, void *stream);
 
 /*
  * build_em_matrix, lookup-table fast path -- same arithmetic, same order, same bits as

@@ -95,6 +95,7 @@ SIGNATURES = {
     "mxm_exchange_reduce": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_i32, c_ptr]),
     "mxm_exchange_info": (ctypes.c_int, [c_ptr, ctypes.POINTER(c_i32), ctypes.POINTER(c_i64)]),
     "mxm_exchange_destroy": (None, [c_ptr]),
+    "mxm_expand_tables": (ctypes.c_int, [c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_i32, c_i32, c_i64, c_ptr, c_ptr]),
     "mxm_quad_bytes": (c_size, [c_i64, c_i32]),
     "mxm_quad_lists_scratch_bytes": (c_size, [c_i64]),
     "mxm_quad_lists": (ctypes.c_int, [c_ptr, c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_size, c_ptr]),
@@ -156,7 +157,7 @@ SIGNATURES = {
 }
 
 # the MXM_VERSION of include/mixemt_hip.h these signatures were written for; load() refuses any other
-ABI_VERSION = 505
+ABI_VERSION = 506
 
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.POINTER(EmState), c_i32, c_ptr)
 

@@ -470,4 +470,27 @@ __global__ __launch_bounds__(256, 2) void diag_stream_coded_kernel(const uint8_t
     if (acc == 0x9e3779b9u) sink[0] = acc;
 }
 
+// ------------------------------------------------------------------------------------------
+// expand_tables: the dense expected-base table E[S][lde] (or its 4-bit code form Ecode, through `map`) from the marker form
+// (maj + the (site, haplogroup, base) triples that differ from it: 0.4 MB) ON THE DEVICE -- the host used to upload the
+// 22 MB table and gather the codes with torch operators (a 176 MB index temporary; the operators' first uses were most of a
+// cold process's 118 ms "tables" stage).  One workgroup per site row: fill with the majority base, then the markers.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void expand_tables_kernel(const uint8_t *__restrict__ maj, const int32_t *__restrict__ mk_ptr,
+                                                           const uint16_t *__restrict__ mk_hap, const uint8_t *__restrict__ mk_base,
+                                                           const uint8_t *__restrict__ map, int S, int H, int64_t lde,
+                                                           uint8_t *__restrict__ out) {
+    for (int s = blockIdx.x; s < S; s += gridDim.x) {
+        uint8_t *row = out + (int64_t)s * lde;
+        const uint8_t fill = (map != nullptr) ? map[maj[s]] : maj[s];
+        for (int64_t h = threadIdx.x; h < lde; h += 256) row[h] = (h < H) ? fill : (uint8_t)0;
+        __syncthreads();
+        for (int j = mk_ptr[s] + (int)threadIdx.x; j < mk_ptr[s + 1]; j += 256) {
+            const int hap = mk_hap[j];
+            if (hap < H) row[hap] = (map != nullptr) ? map[mk_base[j]] : mk_base[j];
+        }
+        __syncthreads();
+    }
+}
+
 #endif  // MIXEMT_AUX_KERNELS_HPP

@@ -897,6 +897,16 @@ extern "C" size_t mxm_quad_bytes(int64_t R, int32_t H) {
     return R > 0 ? (size_t)R * (size_t)(QUAD_CODE_BYTES + QUAD_MAX * 32) : 0;
 }
 
+extern "C" int mxm_expand_tables(const uint8_t *maj, const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
+                                 const uint8_t *map256, int32_t S, int32_t H, int64_t lde, uint8_t *out, void *stream) {
+    if (maj == nullptr || mk_ptr == nullptr || mk_hap == nullptr || mk_base == nullptr || out == nullptr || S <= 0 || H <= 0 || lde < H)
+        return fail(-1, "mxm_expand_tables: bad arguments%s", "");
+    hipLaunchKernelGGL(expand_tables_kernel, dim3(clamp_grid(S, num_cu() * 8)), dim3(256), 0, (hipStream_t)stream, maj, mk_ptr, mk_hap,
+                       mk_base, map256, (int)S, (int)H, lde, out);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" size_t mxm_quad_lists_scratch_bytes(int64_t R) {
     return R > 0 ? (size_t)((R + QLIST_CHUNK - 1) / QLIST_CHUNK) * 2 * sizeof(long long) : 0;
 }

@@ -204,12 +204,19 @@ class HapVarTables(object):
                             "mk_base": numpy.ascontiguousarray(exp[site_i, hap_i])}
         return self._sparse
 
+    def _vectors_device(self):
+        """lhit / lmiss on the device (uploaded once)."""
+        if getattr(self, "_vec_dev", None) is None:
+            dev = require_gpu()
+            self._vec_dev = (torch.from_numpy(self.lhit).to(dev), torch.from_numpy(self.lmiss).to(dev))
+        return self._vec_dev
+
     def sparse_device(self):
         """Device copies of sparse() (plus lhit / lmiss), uploaded once."""
         if self._sparse_dev is None:
             dev = require_gpu()
             enc = self.sparse()
-            _, lhit_d, lmiss_d = self.device()
+            lhit_d, lmiss_d = self._vectors_device()
             self._sparse_dev = {key: torch.from_numpy(val).to(dev) for key, val in enc.items()}
             if self._sparse_dev["mk_hap"].numel() == 0:                  # keep the pointers valid
                 self._sparse_dev["mk_hap"] = torch.zeros(1, dtype=torch.uint16, device=dev)
@@ -217,29 +224,43 @@ class HapVarTables(object):
             self._sparse_dev["lhit"], self._sparse_dev["lmiss"] = lhit_d, lmiss_d
         return self._sparse_dev
 
+    def _expand_on_device(self, code_map):
+        """[S][lde] uint8 table from the marker form, on the device (mxm_expand_tables): the expected bases themselves
+        (code_map None) or their lookup codes.  0.4 MB of markers go up instead of the 22 MB table."""
+        lib = _lib.load()
+        dev = require_gpu()
+        sp = self.sparse_device()
+        out = torch.empty(self.expected.shape, dtype=torch.uint8, device=dev)
+        map_d = None if code_map is None else torch.from_numpy(numpy.ascontiguousarray(code_map, dtype=numpy.uint8)).to(dev)
+        _lib.check(lib.mxm_expand_tables(sp["maj"].data_ptr(), sp["mk_ptr"].data_ptr(), sp["mk_hap"].data_ptr(),
+                                         sp["mk_base"].data_ptr(), map_d.data_ptr() if map_d is not None else None,
+                                         len(self.sites), self.n_haps, self.expected.shape[1], out.data_ptr(), current_stream()),
+                   "mxm_expand_tables")
+        return out
+
     def lut_device(self):
-        """Device copies of lut() (plus lhit / lmiss), uploaded once; None if the tables do not qualify."""
+        """Device form of lut() (plus lhit / lmiss), made once; None if the tables do not qualify."""
         enc = self.lut()
         if enc is None:
             return None
         if self._lut_dev is None:
             dev = require_gpu()
-            exp_d, lhit_d, lmiss_d = self.device()
-            # the code table from the expected-base table on the device: a 22 MB gather there instead of on the host
-            code_d = torch.from_numpy(enc.code_of).to(dev)
-            ecode_d = code_d[exp_d.reshape(-1).to(torch.int64)].reshape(exp_d.shape).contiguous()
-            ecode_d[:, self.n_haps:] = 0
+            lhit_d, lmiss_d = self._vectors_device()
+            # the code table straight from the marker form on the device (round 5: it used to be a torch gather over the
+            # uploaded 22 MB table -- most of a cold process's "tables" stage was those operators' first uses)
+            ecode_d = self._expand_on_device(enc.code_of) if len(self.sites) else torch.zeros(self.expected.shape, dtype=torch.uint8, device=dev)
             self._lut_dev = {"ecode": ecode_d, "obsmap": torch.from_numpy(enc["obsmap"]).to(dev),
                              "lhit": lhit_d, "lmiss": lmiss_d}
         return self._lut_dev
 
     def device(self):
-        """Upload once; returns (expected, lhit, lmiss) as device tensors."""
+        """(expected, lhit, lmiss) as device tensors, made once: the table is expanded from the marker form on the device
+        (mxm_expand_tables) rather than uploaded."""
         if self._dev is None:
             dev = require_gpu()
-            self._dev = (torch.from_numpy(self.expected).to(dev),
-                         torch.from_numpy(self.lhit).to(dev),
-                         torch.from_numpy(self.lmiss).to(dev))
+            lhit_d, lmiss_d = self._vectors_device()
+            exp_d = self._expand_on_device(None) if (len(self.sites) and self.n_haps <= 65535) else torch.from_numpy(self.expected).to(dev)
+            self._dev = (exp_d, lhit_d, lmiss_d)
         return self._dev
 
 

@@ -278,3 +278,21 @@ def test_sparse_kernel_full_table_fallback(b17, n_cols):
     got = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="sparse").cpu().numpy()
     assert numpy.array_equal(got, want)
     assert plain + 50 < preprocess.build_em_matrix_device.last_fallback < 700      # both paths, many rows each
+
+
+def test_dense_tables_expanded_on_the_device_equal_the_hosts(b17):
+    """mxm_expand_tables: E and Ecode from the marker form (0.4 MB) on the device, bit for bit the host's 22 MB tables --
+    Build 17, a sub-tree with an odd width, and a table whose majority base is NOT the reference base at some sites."""
+    import torch
+    from mixemt_amd import phylotree, preprocess
+    refseq, phy, haps, tables = b17
+    cases = [tables, preprocess.HapVarTables.build(refseq, phy, haps[100:1137])]
+    few = [h for h in haps if h.startswith("L0")][:40] or haps[:40]          # a clade: many sites where most carry the marker
+    cases.append(preprocess.HapVarTables.build(refseq, phy, few))
+    for t in cases:
+        exp_d, lhit_d, lmiss_d = t.device()
+        assert numpy.array_equal(exp_d.cpu().numpy(), t.expected)
+        assert numpy.array_equal(lhit_d.cpu().numpy(), t.lhit) and numpy.array_equal(lmiss_d.cpu().numpy(), t.lmiss)
+        lut = t.lut()
+        if lut is not None:
+            assert numpy.array_equal(t.lut_device()["ecode"].cpu().numpy(), lut["ecode"])
