@@ -25,6 +25,7 @@
 #include <stdio.h>
 #include <string.h>
 #include <zlib.h>
+#include <functional>
 #include <fcntl.h>
 #include <sys/mman.h>
 #include <sys/stat.h>
@@ -316,33 +317,82 @@ static int bam_read_impl(const char *path, int n_threads, mxm_bam *out) {
     for (int64_t i = 0; i < n; ++i) out->any_qual = out->any_qual || out->has_qual[i] != 0;
     stamp("columns");
     // ---- fragments: equal read names share an index, numbered by first appearance ---------------------------
-    // (open addressing over the records' own name bytes; the hashes were taken by the threads above)
+    // Partitioned by the top bits of the names' hashes (taken by the threads above): every partition de-duplicates its own
+    // records in a table of its own (open addressing over the records' name bytes), in ascending record order, so that
+    // each name's representative is its FIRST record; the numbering by first appearance and the name bytes follow from
+    // one prefix pass.  (As one table on one thread this was 106 ms of a 300 ms read at 1.4 * 10^6 records.)
     {
-        size_t cap = 16;
-        while (cap < (size_t)n * 2) cap <<= 1;
-        std::vector<int64_t> slot(cap, -1);                  // record index of the name's first appearance
+        constexpr int NPART = 64;
+        const int nt = (n_threads > 1 && n >= 4096) ? n_threads : 1;
+        std::vector<int64_t> first((size_t)n);
+        // (1) per thread and partition: its records, ascending
+        std::vector<std::vector<int64_t>> lists((size_t)nt * NPART);
+        auto split = [&](int t) {
+            const int64_t per = (n + nt - 1) / nt, lo = t * per, hi = std::min(n, lo + per);
+            for (int64_t i = lo; i < hi; ++i) lists[(size_t)t * NPART + (size_t)(name_hash[i] >> 58)].push_back(i);
+        };
+        // (2) per partition: first[i] = the first record with i's name
+        auto dedup = [&](int t) {
+            std::vector<int64_t> slot;
+            for (int part = t; part < NPART; part += nt) {
+                size_t count = 0;
+                for (int u = 0; u < nt; ++u) count += lists[(size_t)u * NPART + part].size();
+                size_t cap = 16;
+                while (cap < count * 2) cap <<= 1;
+                slot.assign(cap, -1);
+                for (int u = 0; u < nt; ++u) {               // thread order = ascending record order
+                    for (const int64_t i : lists[(size_t)u * NPART + part]) {
+                        const uint8_t *name = recs[i] + 32;
+                        const size_t len = name_len[i];
+                        size_t at_slot = (size_t)(name_hash[i] * 0x9e3779b97f4a7c15ull >> 20) & (cap - 1);
+                        for (;;) {
+                            const int64_t j = slot[at_slot];
+                            if (j < 0) {
+                                slot[at_slot] = i;
+                                first[i] = i;
+                                break;
+                            }
+                            if (name_hash[j] == name_hash[i] && name_len[j] == len && memcmp(recs[j] + 32, name, len) == 0) {
+                                first[i] = j;
+                                break;
+                            }
+                            at_slot = (at_slot + 1) & (cap - 1);
+                        }
+                    }
+                }
+            }
+        };
+        auto run = [&](const std::function<void(int)> &body) {
+            if (nt == 1) {
+                body(0);
+                return;
+            }
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nt; ++t) pool.emplace_back(body, t);
+            for (auto &th : pool) th.join();
+        };
+        run(split);
+        run(dedup);
+        // (3) number the first records in file order; the names' offsets
         out->name_off.assign(1, 0);
-        out->names.reserve((size_t)n * 16);
+        int64_t n_frag = 0, bytes = 0;
         for (int64_t i = 0; i < n; ++i) {
-            const char *name = reinterpret_cast<const char *>(recs[i] + 32);
-            const size_t len = name_len[i];
-            size_t at_slot = (size_t)name_hash[i] & (cap - 1);
-            for (;;) {
-                const int64_t j = slot[at_slot];
-                if (j < 0) {
-                    slot[at_slot] = i;
-                    out->frag[i] = (int64_t)out->name_off.size() - 1;
-                    out->names.insert(out->names.end(), name, name + len);
-                    out->name_off.push_back((int64_t)out->names.size());
-                    break;
-                }
-                if (name_hash[j] == name_hash[i] && name_len[j] == len && memcmp(recs[j] + 32, name, len) == 0) {
-                    out->frag[i] = out->frag[j];
-                    break;
-                }
-                at_slot = (at_slot + 1) & (cap - 1);
+            if (first[i] == i) {
+                out->frag[i] = n_frag++;
+                bytes += name_len[i];
+                out->name_off.push_back(bytes);
             }
         }
+        out->names.resize((size_t)bytes);
+        // (4) every record's fragment; the name bytes
+        auto fill_frag = [&](int t) {
+            const int64_t per = (n + nt - 1) / nt, lo = t * per, hi = std::min(n, lo + per);
+            for (int64_t i = lo; i < hi; ++i) {
+                if (first[i] == i) memcpy(out->names.data() + out->name_off[(size_t)out->frag[i]], recs[i] + 32, name_len[i]);
+                else out->frag[i] = out->frag[first[i]];     // (its first record lies earlier in the file: numbered in (3))
+            }
+        };
+        run(fill_frag);
     }
     stamp("names");
     return 0;

@@ -211,6 +211,10 @@ def test_reader_under_address_sanitizer(tmp_path, b17):
     good = str(tmp_path / "good.bam")
     stream = bw.write_bam(good, cols, block_bytes=1500)
     files = [good]
+    big = str(tmp_path / "big.bam")                                # enough records for the reader's threaded stages
+    big_cols = synth.synth_alignments(tables, refseq, 3500, seed=16)
+    assert len(big_cols) >= 4096
+    bw.write_bam(big, big_cols, level=1)
     raw = open(good, "rb").read()
     rng = numpy.random.default_rng(15)
     head = len(bw.header([("chrM", 16569)]))
@@ -243,9 +247,11 @@ def test_reader_under_address_sanitizer(tmp_path, b17):
         files.append(name)
     open(str(tmp_path / "zero.bam"), "wb").close()
     files.append(str(tmp_path / "zero.bam"))
-    proc = subprocess.run([exe] + files, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
+    proc = subprocess.run([exe] + files + [big], stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=300)
     assert proc.returncode == 0, proc.stdout[-4000:]
     lines = proc.stdout.strip().split("\n")
-    assert len(lines) == 2 * len(files)
+    assert len(lines) == 2 * (len(files) + 1)
+    assert " rc=0 n_aln=%d n_frag=%d " % (len(big_cols), big_cols.n_frag) in lines[-1]          # three threads
+    assert lines[-1].split("check=")[1].strip() == lines[-2].split("check=")[1].strip()         # ... as one
     assert " rc=0 n_aln=%d " % len(cols) in lines[0] and lines[0].split("check=")[1] == lines[1].split("check=")[1]
     assert sum(" rc=-4 " in ln for ln in lines) > 20              # most damage is noticed; none of it crashes
