@@ -29,6 +29,8 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <chrono>
+#include <functional>
+#include <memory>
 #include <thread>
 #include <vector>
 
@@ -45,7 +47,8 @@ struct mxm_aln_enc {
     std::vector<int64_t> dropped;        // fragments whose every site was conflicted away (signature '')
     std::vector<int64_t> text_off;       // [n_rows + 1] into the text as fetched (rows in order)
     std::vector<int64_t> row_text;       // [n_rows] where row r's signature starts in `text`
-    std::vector<char> text;              // the signatures in the order they were first seen, one '\n' after each
+    std::unique_ptr<char[]> text;        // the signatures in the order they were first seen, one '\n' after each (not
+                                         // zero-filled first: 100 MB at 10^6 fragments, written once by the threads)
     // fragments in the reference's dict order (process_reads' result, for the callers that want it: formed on fetch)
     std::vector<int64_t> frag_id;        // [n_frag_seen]
     std::vector<int64_t> f_ptr, f_len;   // [n_frag]: fragment f keeps f_len[f] observations at o_site / o_base [f_ptr[f] ...)
@@ -273,47 +276,99 @@ static int aln_encode_impl(const mxm_aln_columns *c, const int32_t *site_of_pos,
     });
     stamp("resolve");
     // fragments in dict order
+    // (f_first = the fragment's first counted alignment: distinct per fragment, so the order is a scatter, not a sort)
     std::vector<int64_t> order;
     order.reserve((size_t)n_frag);
-    for (int64_t f = 0; f < n_frag; ++f)
-        if (f_first[f] >= 0) order.push_back(f);
-    std::sort(order.begin(), order.end(), [&](int64_t x, int64_t y) { return f_first[x] < f_first[y]; });
+    {
+        std::vector<int64_t> by_first((size_t)n_aln, -1);
+        for (int64_t f = 0; f < n_frag; ++f)
+            if (f_first[f] >= 0) by_first[(size_t)f_first[f]] = f;
+        for (int64_t i = 0; i < n_aln; ++i)
+            if (by_first[(size_t)i] >= 0) order.push_back(by_first[(size_t)i]);
+    }
     const int64_t n_seen = (int64_t)order.size();
     stamp("dict order");
     // ---- 4. de-dup -----------------------------------------------------------------------------------------
-    size_t cap = 16;
-    while (cap < (size_t)n_seen * 2 + 16) cap <<= 1;
-    std::vector<int64_t> slot(cap, -1);                      // -> signature id
+    // by 64-bit hash + exact compare, in 64 partitions of the hash on the threads (one table on one thread was 50 of the
+    // encoder's 180 ms at 16 threads): each partition walks ITS fragments in dict order, so a signature's representative
+    // is the first fragment that shows it; signature ids are then handed out in dict order of the representatives
     std::vector<int64_t> sig_rep;                            // representative fragment of each signature
     std::vector<int64_t> sig_of((size_t)n_frag, -1);
     std::vector<int64_t> sig_count;
     out->dropped.clear();
-    for (int64_t k = 0; k < n_seen; ++k) {
-        const int64_t f = order[k];
-        const int64_t m = f_len[f];
-        if (m == 0) {
-            out->dropped.push_back(f);
-            continue;
-        }
-        size_t h = (size_t)f_hash[f] & (cap - 1);
-        for (;;) {
-            const int64_t sg = slot[h];
-            if (sg < 0) {
-                slot[h] = (int64_t)sig_rep.size();
-                sig_of[f] = (int64_t)sig_rep.size();
+    {
+        constexpr int NPART = 64;
+        const int nt = (n_threads > 1 && n_seen >= 4096) ? n_threads : 1;
+        std::vector<int64_t> first_k((size_t)n_seen, -1), cnt_k((size_t)n_seen, 0);
+        std::vector<std::vector<int64_t>> lists((size_t)nt * NPART);
+        auto run = [&](const std::function<void(int)> &body) {
+            if (nt == 1) {
+                body(0);
+                return;
+            }
+            std::vector<std::thread> pool;
+            for (int t = 0; t < nt; ++t) pool.emplace_back(body, t);
+            for (auto &th : pool) th.join();
+        };
+        run([&](int t) {
+            const int64_t per = (n_seen + nt - 1) / nt, lo = t * per, hi = std::min(n_seen, lo + per);
+            for (int64_t k = lo; k < hi; ++k) {
+                const int64_t f = order[(size_t)k];
+                if (f_len[f] > 0) lists[(size_t)t * NPART + (size_t)(f_hash[f] >> 58)].push_back(k);
+            }
+        });
+        run([&](int t) {
+            std::vector<int64_t> slot;
+            for (int part = t; part < NPART; part += nt) {
+                size_t count = 0;
+                for (int u = 0; u < nt; ++u) count += lists[(size_t)u * NPART + part].size();
+                size_t cap = 16;
+                while (cap < count * 2) cap <<= 1;
+                slot.assign(cap, -1);                        // -> k of the signature's first fragment
+                for (int u = 0; u < nt; ++u) {               // thread order = ascending k = dict order
+                    for (const int64_t k : lists[(size_t)u * NPART + part]) {
+                        const int64_t f = order[(size_t)k], m = f_len[f];
+                        size_t h = (size_t)(f_hash[f] * 0x9e3779b97f4a7c15ull >> 20) & (cap - 1);
+                        for (;;) {
+                            const int64_t kr = slot[h];
+                            if (kr < 0) {
+                                slot[h] = k;
+                                first_k[(size_t)k] = k;
+                                cnt_k[(size_t)k] = 1;
+                                break;
+                            }
+                            const int64_t g = order[(size_t)kr];
+                            if (f_hash[g] == f_hash[f] && f_len[g] == m &&
+                                memcmp(&o_site[f_ptr[g]], &o_site[f_ptr[f]], (size_t)m * 2) == 0 &&
+                                memcmp(&o_base[f_ptr[g]], &o_base[f_ptr[f]], (size_t)m) == 0) {
+                                first_k[(size_t)k] = kr;
+                                ++cnt_k[(size_t)kr];
+                                break;
+                            }
+                            h = (h + 1) & (cap - 1);
+                        }
+                    }
+                }
+            }
+        });
+        std::vector<int64_t> id_of_k((size_t)n_seen, -1);
+        for (int64_t k = 0; k < n_seen; ++k) {               // ids (and the dropped fragments) in dict order
+            const int64_t f = order[(size_t)k];
+            if (f_len[f] == 0) {
+                out->dropped.push_back(f);
+            } else if (first_k[(size_t)k] == k) {
+                id_of_k[(size_t)k] = (int64_t)sig_rep.size();
                 sig_rep.push_back(f);
-                sig_count.push_back(1);
-                break;
+                sig_count.push_back(cnt_k[(size_t)k]);
             }
-            const int64_t g = sig_rep[sg];
-            if (f_hash[g] == f_hash[f] && f_len[g] == m && memcmp(&o_site[f_ptr[g]], &o_site[f_ptr[f]], (size_t)m * 2) == 0 &&
-                memcmp(&o_base[f_ptr[g]], &o_base[f_ptr[f]], (size_t)m) == 0) {
-                sig_of[f] = sg;
-                ++sig_count[sg];
-                break;
-            }
-            h = (h + 1) & (cap - 1);
         }
+        run([&](int t) {
+            const int64_t per = (n_seen + nt - 1) / nt, lo = t * per, hi = std::min(n_seen, lo + per);
+            for (int64_t k = lo; k < hi; ++k) {
+                const int64_t f = order[(size_t)k];
+                if (f_len[f] > 0) sig_of[f] = id_of_k[(size_t)first_k[(size_t)k]];
+            }
+        });
     }
     const int64_t n_sig = (int64_t)sig_rep.size();
     stamp("de-dup");
@@ -328,14 +383,17 @@ static int aln_encode_impl(const mxm_aln_columns *c, const int32_t *site_of_pos,
             for (int64_t v = site_pos[s]; v >= 10; v /= 10) ++d;
             digits[s] = (uint8_t)d;
         }
-        for (int64_t sg = 0; sg < n_sig; ++sg) {
-            const int64_t f = sig_rep[sg], a = f_ptr[f], m = f_len[f];
-            int64_t len = m * 2 + (m - 1);                   // ':' + base per item, ',' between items
-            for (int64_t i = 0; i < m; ++i) len += digits[o_site[a + i]];
-            t_off[sg + 1] = t_off[sg] + len + 1;
-        }
+        parallel_for(n_sig, n_threads, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t sg = lo; sg < hi; ++sg) {
+                const int64_t f = sig_rep[sg], a = f_ptr[f], m = f_len[f];
+                int64_t len = m * 2 + (m - 1);               // ':' + base per item, ',' between items
+                for (int64_t i = 0; i < m; ++i) len += digits[o_site[a + i]];
+                t_off[sg + 1] = len + 1;                     // (its own length: summed up below)
+            }
+        });
+        for (int64_t sg = 0; sg < n_sig; ++sg) t_off[sg + 1] += t_off[sg];
     }
-    std::vector<char> text((size_t)t_off[n_sig]);
+    std::unique_ptr<char[]> text(new char[(size_t)t_off[n_sig] + 1]);
     parallel_for(n_sig, n_threads, [&](int64_t lo, int64_t hi, int) {
         for (int64_t sg = lo; sg < hi; ++sg) {
             const int64_t f = sig_rep[sg], a = f_ptr[f], m = f_len[f];
@@ -377,22 +435,50 @@ static int aln_encode_impl(const mxm_aln_columns *c, const int32_t *site_of_pos,
         if (cmp != 0) return cmp < 0;
         return xl < yl;
     };
-    if (n_threads > 1 && n_sig >= 65536) {
-        // sorted runs on the threads, then pairwise merges
+    if (n_threads > 1 && n_sig >= 8192) {
+        // sample sort: splitters from a sorted sample, every thread counts and scatters its share of the keys into the
+        // splitters' buckets, then the buckets are sorted side by side -- no serial merge at the end (the pairwise merges
+        // of sorted runs this replaces spent their last pass, all n_sig keys, on one thread)
         const int parts = n_threads;
-        std::vector<int64_t> cut((size_t)parts + 1);
-        for (int t = 0; t <= parts; ++t) cut[t] = n_sig * t / parts;
+        const int64_t step = std::max<int64_t>(1, n_sig / ((int64_t)parts * 64));
+        std::vector<key> sample;
+        for (int64_t i = step / 2; i < n_sig; i += step) sample.push_back(keys[(size_t)i]);
+        std::sort(sample.begin(), sample.end(), less);
+        std::vector<key> split;
+        for (int b = 1; b < parts; ++b) split.push_back(sample[(size_t)((int64_t)sample.size() * b / parts)]);
+        auto bucket_of = [&](const key &x) -> int {
+            return (int)(std::upper_bound(split.begin(), split.end(), x, less) - split.begin());
+        };
+        std::vector<int64_t> bcnt((size_t)parts * parts, 0);    // [thread][bucket]
+        std::vector<int32_t> bkt((size_t)n_sig);
         parallel_for(parts, parts, [&](int64_t lo, int64_t hi, int) {
-            for (int64_t t = lo; t < hi; ++t) std::sort(keys.begin() + cut[t], keys.begin() + cut[t + 1], less);
+            for (int64_t t = lo; t < hi; ++t)
+                for (int64_t i = n_sig * t / parts; i < n_sig * (t + 1) / parts; ++i) {
+                    bkt[(size_t)i] = bucket_of(keys[(size_t)i]);
+                    ++bcnt[(size_t)t * parts + bkt[(size_t)i]];
+                }
         }, 2);
-        for (int width = 1; width < parts; width *= 2) {
-            std::vector<std::thread> pool;
-            for (int t = 0; t + width < parts; t += 2 * width) {
-                const int64_t a = cut[t], b = cut[t + width], e = cut[std::min(parts, t + 2 * width)];
-                pool.emplace_back([&keys, &less, a, b, e]() { std::inplace_merge(keys.begin() + a, keys.begin() + b, keys.begin() + e, less); });
+        std::vector<int64_t> start((size_t)parts * parts), bstart((size_t)parts + 1, 0);
+        int64_t run = 0;
+        for (int b = 0; b < parts; ++b) {
+            bstart[b] = run;
+            for (int t = 0; t < parts; ++t) {
+                start[(size_t)t * parts + b] = run;
+                run += bcnt[(size_t)t * parts + b];
             }
-            for (auto &th : pool) th.join();
         }
+        bstart[parts] = run;
+        std::vector<key> tmp((size_t)n_sig);
+        parallel_for(parts, parts, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t t = lo; t < hi; ++t) {
+                std::vector<int64_t> at(start.begin() + t * parts, start.begin() + (t + 1) * parts);
+                for (int64_t i = n_sig * t / parts; i < n_sig * (t + 1) / parts; ++i) tmp[(size_t)at[bkt[(size_t)i]]++] = keys[(size_t)i];
+            }
+        }, 2);
+        parallel_for(parts, parts, [&](int64_t lo, int64_t hi, int) {
+            for (int64_t b = lo; b < hi; ++b) std::sort(tmp.begin() + bstart[b], tmp.begin() + bstart[b + 1], less);
+        }, 2);
+        keys.swap(tmp);
     } else {
         std::sort(keys.begin(), keys.end(), less);
     }
@@ -430,7 +516,7 @@ static int aln_encode_impl(const mxm_aln_columns *c, const int32_t *site_of_pos,
     out->f_len.swap(f_len);
     out->o_site.swap(o_site);
     out->o_base.swap(o_base);
-    out->text.swap(text);
+    out->text = std::move(text);
     stamp("outputs");
     return 0;
 }
