@@ -435,7 +435,7 @@ static int aln_encode_impl(const mxm_aln_columns *c, const int32_t *site_of_pos,
         if (cmp != 0) return cmp < 0;
         return xl < yl;
     };
-    if (n_threads > 1 && n_sig >= 8192) {
+    if (n_threads > 1 && n_sig >= 4096) {
         // sample sort: splitters from a sorted sample, every thread counts and scatters its share of the keys into the
         // splitters' buckets, then the buckets are sorted side by side -- no serial merge at the end (the pairwise merges
         // of sorted runs this replaces spent their last pass, all n_sig keys, on one thread)

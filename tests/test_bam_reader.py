@@ -212,7 +212,7 @@ def test_reader_under_address_sanitizer(tmp_path, b17):
     stream = bw.write_bam(good, cols, block_bytes=1500)
     files = [good]
     big = str(tmp_path / "big.bam")                                # enough records for the reader's threaded stages
-    big_cols = synth.synth_alignments(tables, refseq, 3500, seed=16)
+    big_cols = synth.synth_alignments(tables, refseq, 20000, seed=16)   # (enough for every threaded stage of reader and encoder)
     assert len(big_cols) >= 4096
     bw.write_bam(big, big_cols, level=1)
     raw = open(good, "rb").read()
