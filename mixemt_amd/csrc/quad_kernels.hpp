@@ -149,7 +149,11 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
             }
         }
         const unsigned long long bytes = QUAD_CODE_BYTES + 32ull * (unsigned long long)n;
+#ifdef QUAD_FIXED_SLOTS                                     // (timing experiment: no shared bump pointer)
+        if (t == 0) s_base = (unsigned long long)r * (QUAD_CODE_BYTES + 32ull * QUAD_MAX);
+#else
         if (t == 0) s_base = atomicAdd(&stats[0], bytes);
+#endif
         __syncthreads();
         const unsigned long long at = s_base;
         const bool fits = at + bytes <= qcap;              // uniform
