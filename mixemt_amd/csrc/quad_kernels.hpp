@@ -26,6 +26,7 @@
 #define QUAD_CODE_BYTES 2048
 #define QUAD_HASH 1024
 #define QUAD_THREADS 256
+#define QUAD_CHUNK 65536ull               // bytes a workgroup of the encoder reserves at a time
 
 typedef unsigned int quad_u2 __attribute__((ext_vector_type(2)));
 typedef unsigned int quad_u4 __attribute__((ext_vector_type(4)));
@@ -36,8 +37,9 @@ typedef double quad_d2 __attribute__((ext_vector_type(2)));
 // of columns past H are cleared so that equal quads compare equal) are de-duplicated in an LDS hash table (64-bit slots:
 // a tag bit + the quad, so that the quad 0xFFFFFFFF is an ordinary key), the distinct ones ranked by value (each counts
 // the smaller ones) -- the codes are those ranks, so a record's bytes do not depend on which thread won a slot -- and the
-// record goes to a bump-allocated place in `qrec` (stats[0] += its size; a record that does not fit any more is not
-// written and the row keeps nquad = 0: the caller sees stats[0] > capacity and may repeat with that much).
+// record goes to a bump-allocated place in `qrec` (a workgroup reserves 64 KB at a time: stats[0] = bytes RESERVED, an upper
+// bound of what is in use; a record that does not fit any more is not written and the row keeps nquad = 0: the caller sees
+// stats[0] > capacity and may repeat with that much and a chunk per workgroup to spare).
 // stats[1] counts the byte-coded rows left without quads.
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t *__restrict__ rec,
@@ -51,9 +53,10 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
     __shared__ unsigned short s_slot[QUAD_MAX];
     __shared__ unsigned char s_rank[QUAD_HASH];
     __shared__ int s_n, s_n2;
-    __shared__ unsigned long long s_base;
+    __shared__ unsigned long long s_base, s_chunk_at, s_chunk_left;
     const int t = threadIdx.x;
     const int nqc = ldc >> 2;                              // quads per row
+    if (t == 0) s_chunk_at = s_chunk_left = 0ull;          // (ordered before its first use by the row loop's barriers)
     for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
         const int nd = ndist[r];
         if (nd <= 0 || nd > ENC_MAX_CODES) {               // uniform: wide rows and rows without a record have no quads
@@ -152,7 +155,20 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
 #ifdef QUAD_FIXED_SLOTS                                     // (timing experiment: no shared bump pointer)
         if (t == 0) s_base = (unsigned long long)r * (QUAD_CODE_BYTES + 32ull * QUAD_MAX);
 #else
-        if (t == 0) s_base = atomicAdd(&stats[0], bytes);
+        // The bump pointer is shared by every workgroup of the grid: one atomic add per ROW on one address was 6 of the
+        // kernel's 14.6 ms at 10^6 rows (a fixed-slot timing build ran 8.4).  A workgroup therefore reserves QUAD_CHUNK
+        // bytes at a time and hands its rows out of that: one global atomic per dozen rows; what a chunk's tail cannot hold
+        // is left unused (< one record per chunk, + at most one chunk per workgroup at the end: ~5 % at 10^6 rows).
+        if (t == 0) {
+            if (s_chunk_left < bytes) {
+                const unsigned long long grab = bytes > QUAD_CHUNK ? bytes : QUAD_CHUNK;
+                s_chunk_at = atomicAdd(&stats[0], grab);
+                s_chunk_left = grab;
+            }
+            s_base = s_chunk_at;
+            s_chunk_at += bytes;
+            s_chunk_left -= bytes;
+        }
 #endif
         __syncthreads();
         const unsigned long long at = s_base;

@@ -255,7 +255,7 @@ class EmPlan(object):
         mode: True / False / "auto" (None = QUADS): auto builds them from QUADS_MIN_ROWS byte-coded rows while records +
         dictionary stay under QUADS_MAX_FOOTPRINT.  Measured at 10^6 x 5408 (profiles/r05/quads_product_1m.txt,
         pipeline_1m_records_quads.txt): the step 1.46 -> 1.32 ms, run_em's loop 1.44 (one-launch loop over the records) ->
-        1.35 ms per iteration (the per-iteration kernels), the build 17 ms cold or warm (encoder 14.7 ms; the row lists are
+        1.35 ms per iteration (the per-iteration kernels), the build 11 ms cold or warm (encoder 8.6 ms; the row lists are
         formed on the device): a restart of ~400 iterations gains 35 ms for it.
         cap: bytes of the first buffer (default: room for 112 quads per row; the kernel counts what it needs and an
         overflow repeats the build once with exactly that much).
@@ -271,7 +271,9 @@ class EmPlan(object):
         ldc = (self.n_haps + 7) // 8 * 8
         if n_byte == 0 or ldc // 4 > 6 * 256:         # (the quad pass is instantiated up to H = 6144)
             return False
-        guess = n_byte * (2048 + 32 * 112) + (1 << 20)
+        # room for 112 quads per row (mean on build_em_matrix rows: 93) + the 64 KB chunk every workgroup of the encoder may
+        # leave half empty at the end
+        guess = n_byte * (2048 + 32 * 112) + min(self.n_rows, 4096) * 65536 + (1 << 20)
         if mode == "auto":
             # by the card's TOTAL memory, not by what happens to be free: which loop runs decides the last bits of the sums
             # (fixed orders, but different ones), and the same call must take the same route every time
@@ -314,7 +316,7 @@ class EmPlan(object):
             if attempt == 1:
                 raise ValueError("mxm_build_quads: buffer of %d bytes overflowed (%d needed)" % (cap, used))
             del qrec
-            cap = (used + 31) // 32 * 32
+            cap = (used + (256 << 20) + 31) // 32 * 32    # (the encoder reserves in chunks: a second run lays them out anew)
         # the row lists: formed on the device, ascending (mxm_quad_lists) -- their upload from the host was the build's
         # largest cold cost (a process's first copies from fresh pageable memory: 20-30 ms each, profiles/r05/quad_build_1m.txt)
         quad_rows_d = torch.empty(n_rows, dtype=torch.int64, device=dev)
@@ -342,8 +344,9 @@ class EmPlan(object):
         quad_rows = quad_rows_d                       # (len() below)
         if laps is not None:
             sys.stderr.write("[attach_quads] %s\n" % laps)
-        self.quad_rows_n, self.quad_bytes = len(quad_rows), used
-        self.coded_record_bytes = used + rec_left
+        quad_exact = int((2048 + 32 * nq_h[nq_h > 0].astype(numpy.int64)).sum())       # (`used` includes the allocator's slack)
+        self.quad_rows_n, self.quad_bytes = len(quad_rows), quad_exact
+        self.coded_record_bytes = quad_exact + rec_left
         self.coded_bytes = self.coded_record_bytes + self.coded_rest * self.n_haps * 8
         return True
 
