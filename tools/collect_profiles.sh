@@ -16,7 +16,10 @@ for f in bench_1m.json bench_1m_under_rocprof.json bench_1m_10restarts.json benc
          bench_1m_records.json bench_10m_records_one_gpu.json bench_10m_records_one_gpu.log \
          bench_125k_records_one_rank_rccl.json pipeline_1m_records.txt pipeline_10m_records_one_gpu.txt \
          pmc_calibration_coded.json coded_parts.txt records_read_ceiling.txt \
-         frontend_1m.txt pipeline_1m_alignments.txt row_pass_experiments.txt; do
+         frontend_1m.txt pipeline_1m_alignments.txt row_pass_experiments.txt \
+         bam_reader_1m.txt pipeline_1m_bam.txt quad_1m.txt quads_product_1m.txt quad_build_1m.txt step_sequence.txt \
+         alloc_big.txt records_build_alignments.txt stress_parity_707.txt stress_parity_808.txt stress_parity_909.txt \
+         bench_125k_records_one_rank_rccl.json bench_125k_records_one_rank_oneshot.json exchange_tests.txt; do
   [ -f $src/$f ] && cp $src/$f $dst/$f
 done
 [ -f $src/bench_1m.log ] && cp $src/bench_1m.log $dst/bench_1m.log
