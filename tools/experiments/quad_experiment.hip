@@ -257,6 +257,8 @@ extern "C" float quad_time(int variant, const uint8_t *qrec, const int64_t *qoff
         case 4: grid = n_cu * 3; ms = time_launches(reps, QK(4, true, 3)); break;
         case 5: grid = n_cu * 2; ms = time_launches(reps, QK(4, false, 2, true)); break;
         case 6: grid = n_cu * 2; ms = time_launches(reps, QK(3, false, 2, true)); break;
+        case 7: grid = n_cu * 2; ms = time_launches(reps, QK(5, false, 2)); break;
+        case 8: grid = n_cu * 2; ms = time_launches(reps, QK(6, false, 2)); break;
         default: return -5.0f;
     }
 #undef QK

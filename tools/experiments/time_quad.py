@@ -138,7 +138,9 @@ names = {0: "quad records, table through registers, 2 rows in flight, 2 workgrou
          3: "... 5 rows in flight",
          4: "... 3 rows in flight, 3 workgroups per CU (spills)",
          5: "quad records, table through registers, 3 rows in flight, ONE wait for the row's lookups",
-         6: "... 2 rows in flight, one wait"}
+         6: "... 2 rows in flight, one wait",
+         7: "quad records, table through registers, 4 rows in flight",
+         8: "... 5 rows in flight"}
 for rep in range(2):
     for v in sorted(names):
         g = I(0)
