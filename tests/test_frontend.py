@@ -184,6 +184,42 @@ def test_build_em_input_from_a_bam_file_equals_the_reference_run(b17, tmp_path, 
         preprocess.build_em_input(path, refseq, phy, args, frontend="python")
 
 
+@pytest.mark.gpu
+def test_an_open_handle_that_names_its_file_is_read_by_the_library(b17, tmp_path, capsys):
+    """bin/mixemt:139-147 hands build_em_input an open pysam.AlignmentFile; it carries `.filename`, and the batched front end
+    reads that file itself instead of iterating fetch() -- same matrix, weights and ids; a handle whose file the reader does
+    not take (here: SAM text) still goes through its objects."""
+    import argparse
+    import hashlib
+    import json
+    import _bam_writer
+    from mixemt_amd import alignments
+    refseq, phy, haps, tables = b17
+    g, alns = _g11()
+    path = str(tmp_path / "g11.bam")
+    _bam_writer.write_bam(path, alignments.AlignmentColumns.from_alignments(alns))
+
+    class Handle(FakeBam):
+        def __init__(self, alns, filename):
+            FakeBam.__init__(self, alns)
+            self.filename, self.fetched = filename, 0
+
+        def fetch(self):
+            self.fetched += 1
+            return FakeBam.fetch(self)
+
+    args = argparse.Namespace(min_mq=int(g["min_mq"]), min_bq=int(g["min_bq"]), verbose=False)
+    for name, want_source, want_fetch in ((path.encode(), "file of the handle", 0), (str(tmp_path / "reads.sam"), "objects", 1)):
+        if want_fetch:
+            open(name, "w").write("@HD\tVN:1.6\n")
+        handle = Handle(alns, name)
+        mat, wts, hap_order, read_ids = preprocess.build_em_input(handle, refseq, phy, args)
+        assert preprocess.build_em_input.last_source == want_source and handle.fetched == want_fetch
+        assert numpy.array_equal(wts, g["weights"]) and read_ids == json.loads(str(g["read_ids"]))
+        assert hashlib.sha256(numpy.ascontiguousarray(mat).tobytes()).hexdigest() == str(g["mat_sha256"])
+    capsys.readouterr()
+
+
 # ---- g12: the -s / -l files as the reference's own dump_all writes them and its load_prev reads them ----------------
 def _g12():
     import json
