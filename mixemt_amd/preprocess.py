@@ -599,7 +599,10 @@ def _gather_csr(row_ptr_d, site_d, obs_d, rows):
 
 RECORD_BYTES_GUESS = 16 * 96          # table bytes per row the first record buffer allows for (synth-v1 needs 16 x 61 on average,
                                       # wide records included: 6.39 KB per row at H = 5408)
-REST_SLAB_ROWS = 8192                 # rows without a marker-kernel record are built densely and coded this many at a time
+REST_SLAB_ROWS = None                 # rows without a marker-kernel record are built densely and coded a slab at a time: this
+                                      # many rows (tests), or by default as many as REST_SLAB_BYTES of dense rows hold
+REST_SLAB_BYTES = 2 << 30             # (46 000 rows at 5408 columns: one slab at 10^6 reads, 8 at 10^7 -- a slab ends in a
+                                      # host read-back of its byte count, so fewer, larger slabs: 8192 rows cost 41 round trips at 10^7)
 
 
 def record_buffer_bytes(n_rows, n_haps):
@@ -617,7 +620,7 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
     makes from the dense matrix with a pass of its own.  dense=False: NO dense matrix is written (5.5 GB
     instead of 43 GB at 10^6 x 5408; 10^7 rows fit one GPU); rows the marker kernel cannot take (more than
     64 observations, more than 256 distinct values: ~3.5 %) are built densely by the lookup-table kernel and
-    coded from there (mxm_encode_rows: byte codes up to 256 values, 16-bit codes up to 1024) REST_SLAB_ROWS at a
+    coded from there (mxm_encode_rows: byte codes up to 256 values, 16-bit codes up to 1024) a slab (REST_SLAB_BYTES) at a
     time, so the detour never holds more than one slab of dense rows (round 4 built all of them at once: 1.4 GB at
     10^6 rows, 14 GB at 10^7); what remains (more than 1024 values: none on build_em_matrix's rows) stays dense in `m_rest`.
     dense=True: returns (CodedMatrix, M) with the full dense matrix as well.
@@ -714,7 +717,7 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
                 # the dense rows of long reads mostly hold few distinct values too: built (or taken from the dense matrix)
                 # a slab at a time and coded from their dense form (mxm_encode_rows: bytes, then 16-bit codes) into the
                 # tail of the same record buffer; what still has no record afterwards is kept, dense
-                slab = min(n_rest, REST_SLAB_ROWS)
+                slab = min(n_rest, REST_SLAB_ROWS if REST_SLAB_ROWS else max(1024, REST_SLAB_BYTES // (8 * n_haps)))
                 m_slab = None if dense else torch.empty((slab, n_haps), dtype=torch.float64, device=dev)
                 sub_off = torch.empty(slab, dtype=torch.int64, device=dev)
                 sub_nd = torch.empty(slab, dtype=torch.int32, device=dev)
