@@ -263,8 +263,18 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
             lib.mxm_set_timing_events(None, None)
         cplan.finalize(cs_coded, ln_a, ln_b, p_cur, state, 0.0, 1 << 30)
 
+    SETTLE = 30        # iterations of a run before the proportions have concentrated (profiles/r05/step_sequence.txt)
+
     def timed_steps():
-        for _ in range(3):
+        """-> (ms per step, kernel ms) once a run has settled, and the kernel ms over the run's FIRST `steps` iterations."""
+        p_cur.copy_(props)                                 # a fresh run: the same start for every leg
+        ln_a.copy_(ln_props)
+        state.zero_()
+        for i in range(steps):                             # the early phase, kernel by kernel
+            one(kevs[i])
+        torch.cuda.synchronize()
+        early = float(numpy.mean([a_ev.elapsed_time(b_ev) for a_ev, b_ev in kevs]))
+        for _ in range(max(0, SETTLE - steps)):
             one()
         torch.cuda.synchronize()
         beg.record()
@@ -273,10 +283,11 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
         end.record()
         torch.cuda.synchronize()
         each = [a_ev.elapsed_time(b_ev) for a_ev, b_ev in kevs]
-        return beg.elapsed_time(end) / steps, float(numpy.mean(each)), float(each[-1])
+        return beg.elapsed_time(end) / steps, float(numpy.mean(each)), early
 
-    ms, kernel_ms, kernel_ms_last = timed_steps()
+    ms, kernel_ms, kernel_ms_first = timed_steps()
     loop_ms = loop_ms_per_iteration(em, torch, cplan, props[0], max(steps, 50))
+    rec_kernel_bytes, rec_bytes_per_iteration = float(cplan.coded_record_bytes), float(cplan.coded_bytes)   # (the quads change them)
     # the same step with a quad dictionary beside the records (EmPlan.attach_quads: what "auto" does from 3e5 rows)
     quads = None
     torch.cuda.synchronize()
@@ -287,9 +298,9 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
         cs_quad = torch.zeros_like(props)
         cplan.em_iter(props, ln_props, state, cs_quad)
         qrel = float(((cs_quad - cs_dense).abs() / cs_dense.abs().clamp_min(1e-300)).max().item())
-        qms, qkernel, qkernel_last = timed_steps()
+        qms, qkernel, qkernel_first = timed_steps()
         quads = {"ms_per_step": qms, "value": float(n_rows) * n_haps / (qms * 1e-3), "kernel": "em_iter_quad_coded_kernel",
-                 "kernel_ms": qkernel, "kernel_ms_last_step": qkernel_last, "kernel_bytes": float(cplan.coded_record_bytes),
+                 "kernel_ms": qkernel, "kernel_ms_first_steps": qkernel_first, "kernel_bytes": float(cplan.coded_record_bytes),
                  "hbm_frac": cplan.coded_record_bytes / (qkernel * 1e-3) / HBM_PEAK_BYTES_PER_S,
                  "quad_rows": int(cplan.quad_rows_n), "quad_bytes": float(cplan.quad_bytes), "build_ms": quad_build_ms,
                  "max_rel_dcolsum": qrel,
@@ -308,12 +319,14 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
                                     "and state read-back (round 4 printed it as ms_per_step)" % max(steps, 50),
             "per_iteration_kernels_ms_per_step": ms,
             "rows_with_16bit_codes": int(cplan.coded_wide),
-            "kernel": "em_iter_coded_kernel", "kernel_ms": kernel_ms, "kernel_ms_last_step": kernel_ms_last,
-            "kernel_ms_is": "mean over the %d timed steps (HIP events around each launch); the last step alone beside it: the first "
-                            "iterations of a run are the slow ones (profiles/r05/step_sequence.txt)" % steps,
-            "bytes_per_iteration": float(cplan.coded_bytes),
-            "kernel_bytes": float(cplan.coded_record_bytes),
-            "hbm_frac": cplan.coded_record_bytes / (kernel_ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
+            "kernel": "em_iter_coded_kernel", "kernel_ms": kernel_ms, "kernel_ms_first_steps": kernel_ms_first,
+            "kernel_ms_is": "mean over %d timed steps (HIP events around each launch) AFTER the first %d iterations of a run; "
+                            "kernel_ms_first_steps is the same mean over the run's first %d iterations, where all proportions are "
+                            "of one magnitude and the card runs at lower clocks (profiles/r05/step_sequence.txt) -- a rocprofv3 "
+                            "average over all launches of the run lies between the two" % (steps, SETTLE, steps),
+            "bytes_per_iteration": rec_bytes_per_iteration,
+            "kernel_bytes": rec_kernel_bytes,
+            "hbm_frac": rec_kernel_bytes / (kernel_ms * 1e-3) / HBM_PEAK_BYTES_PER_S,
             "rows_left_dense": int(cplan.coded_rest), "encode_ms": encode_ms, "max_rel_dcolsum": rel, "quads": quads,
             "note": "same iteration, matrix stored as one byte per cell + each row's distinct fp64 values "
                     "(decodes to the dense matrix bit for bit); not the headline value"}
