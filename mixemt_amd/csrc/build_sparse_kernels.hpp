@@ -348,7 +348,11 @@ __global__ __launch_bounds__(SPB_THREADS, (EMIT ? SPB_WAVES_EMIT : SPB_WAVES)) v
                 if (lane == 0) s_wmax[wv] = wmax;
                 if (t == 0) {                               // the record: codes ++ P table ++ table of the sums
                     const long long bytes = (long long)out.ldc + 16ll * (D + 1);
+#ifdef RECORDS_FIXED_SLOTS                                  // (timing experiment: no shared bump pointer)
+                    long long off = (long long)r * ((long long)out.ldc + 16ll * (SPB_MAXD + 1));
+#else
                     long long off = (long long)atomicAdd(&out.stats[0], (unsigned long long)bytes);
+#endif
                     if (off + bytes > out.rec_cap) off = -1;
                     s_off = off;
                 }
