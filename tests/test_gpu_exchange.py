@@ -89,6 +89,15 @@ def _g10_worker(rank, world, port, out_dir):
             out[label + "_props"] = res["props"]
             out[label + "_iters"] = numpy.array(res["iters"])
             out[label + "_inits"] = res["inits"]
+        # the same loop with its bursts replayed from a captured hipGraph: kernels only, so capturable over a gloo group too;
+        # the exchange count lives on the device, so a replay pushes the right epoch
+        from mixemt_amd import em
+        plan = em.EmPlan(shard, w, n_runs=1, storage="f64")
+        eager = mdist.sharded_em_loop(plan, out["oneshot_inits"], 1e-4, 10000, check_every=8, exchange="oneshot", graph=False)
+        graphed = mdist.sharded_em_loop(plan, out["oneshot_inits"], 1e-4, 10000, check_every=8, exchange="oneshot", graph=True)
+        out["graph_bursts"] = mdist.sharded_em_loop.last_graph_bursts
+        out["graph_equal"] = int(torch.equal(eager[1], graphed[1]) and eager[2] == graphed[2])
+        out["graph_iters"] = numpy.array([st[1] for st in graphed[2]])
         numpy.savez(os.path.join(out_dir, "rank%d.npz" % rank), **out)
     finally:
         dist.destroy_process_group()
@@ -107,6 +116,7 @@ def test_g10_over_two_ranks_is_the_all_reduce_run_bit_for_bit(tmp_path):
         assert numpy.abs(r["oneshot_props"] - g["props"]).max() < 1e-12
         assert numpy.array_equal(r["oneshot_props"], r["rccl_props"])          # a + b in either order: the same bits
         assert numpy.array_equal(r["oneshot_props"], res[0]["oneshot_props"])
+        assert int(r["graph_equal"]) == 1 and int(r["graph_bursts"]) > 10 and list(r["graph_iters"]) == list(g["iters"])
 
 
 def _sum_worker(rank, world, port, out_dir, silent_rank):
