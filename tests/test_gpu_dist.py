@@ -229,6 +229,22 @@ def test_bench_four_ranks_on_the_metrics_own_problem():
     assert line["value"] > 0 and abs(line["value"] - 1e6 * 5408 * 6 / (line["ms_per_step"] * 6e-3)) < 1e-3 * line["value"]
 
 
+def test_bench_two_ranks_with_the_one_shot_exchange():
+    """`bench.py --gpus 2 --exchange oneshot` (gloo carries the handles; the exchange itself is the library's kernels): one
+    line, the sums sane, the exchange named -- and the same step with the default all-reduce beside it."""
+    import torch
+    torch.cuda.empty_cache()
+    lines = {}
+    for exch in ("oneshot", "rccl"):
+        proc, line = _run_bench(["--gpus", "2", "--backend", "gloo", "--total-rows", "60000", "--steps", "6", "--warmup", "2",
+                                 "--no-cpu-baseline", "--exchange", exch])
+        assert proc.returncode == 0, proc.stderr[-3000:]
+        assert line["n_gpus"] == 2 and line["sanity_ok"] and line["exchange"] == exch
+        assert len(line["all_reduce_us_per_rank"]) == 2 and min(line["all_reduce_us_per_rank"]) > 0
+        lines[exch] = line
+    assert lines["oneshot"]["all_reduce_us"] < 5000          # (two kernels sharing one GPU wait on each other: no more than that)
+
+
 def test_bench_four_ranks_over_records_dry_run():
     """
     VERDICT r3 #5: nothing may happen for the first time on the 8-GPU node.  `bench.py --gpus 4 --storage coded`
