@@ -332,7 +332,7 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
                     "(decodes to the dense matrix bit for bit); not the headline value"}
 
 
-def pmc_traffic(n_rows, n_haps, storage="f64", kernel=None, algo_bytes=None, root=None):
+def pmc_traffic(n_rows, n_haps, storage="f64", kernel=None, algo_bytes=None, root=None, matrix=None):
     """
     HBM bytes per launch of the streaming kernel from the committed rocprofv3 PMC passes
     (profiles/rNN/pmc_traffic_*.json, written by tools/pmc_summary.py from separate --pmc FETCH_SIZE /
@@ -342,7 +342,9 @@ def pmc_traffic(n_rows, n_haps, storage="f64", kernel=None, algo_bytes=None, roo
     "em_iter_wide_kernel<512, 6, 1, 3, 1>" from mxm_describe_stream_kernel) -- a plan in row-dictionary
     storage also launches em_iter_wide_kernel, on its few dense leftover rows, and that figure must never
     stand in for the dense matrix's.  A value outside [0.9, 1.5] x the algorithmic bytes is refused
-    (it would say the file is not about this kernel).  -> (bytes, path relative to the repo) or None.
+    (it would say the file is not about this kernel).  matrix ("records" | "encoded"): which records a coded file was
+    taken on -- the build's (--records) or the encoder's; files without the field are the encoder's.
+    -> (bytes, path relative to the repo) or None.
     """
     import glob
     import re
@@ -360,6 +362,8 @@ def pmc_traffic(n_rows, n_haps, storage="f64", kernel=None, algo_bytes=None, roo
         # files written before the field existed: the coded runs carry it in their name
         have = meta.get("storage") or ("coded" if "coded" in os.path.basename(path) else "f64")
         if have != storage:
+            continue
+        if matrix is not None and meta.get("matrix", "encoded") != matrix:
             continue
         for name, rec in data.items():
             if name.startswith("_") or (kernel is not None and not kernel.endswith("*") and name != kernel):
@@ -746,12 +750,15 @@ def bench_rows(opts, env):
         if n_runs == 1:
             traffic = pmc_traffic(n_rows, n_haps, "f64", kernel_name, algo_bytes)
     has_quads = plan.coded is not None and getattr(plan, "_quad_keep", None) is not None
+    rec_kind = "records" if records is not None else "encoded"
     if has_quads:                                     # both row passes in one grid, most rows from the quad records
         kernel_name = "em_iter_quad_coded_kernel"
+        if n_runs == 1:                               # calibrated like the records' kernel (pmc_calibrate_coded.py --quads)
+            traffic = pmc_traffic(n_rows, n_haps, "coded", "em_iter_quad_coded_kernel*", algo_bytes, matrix=rec_kind)
     elif plan.storage == "coded" and n_runs == 1:
         # the records' kernel: counter bytes calibrated against a bare reader of exactly the same records in the same
         # counter pass (tools/pmc_calibrate_coded.py -> tools/pmc_summary.py); same [0.9, 1.5] x rule as the dense line
-        traffic = pmc_traffic(n_rows, n_haps, "coded", "em_iter_coded_kernel*", algo_bytes)
+        traffic = pmc_traffic(n_rows, n_haps, "coded", "em_iter_coded_kernel*", algo_bytes, matrix=rec_kind)
     return {
         "metric": "read x hap cells/sec through the EM iteration (EM iters/sec reported beside it as "
                   "em_iters_per_s), %d reads x %d haps in total, whole job" % (total_rows, n_haps),

@@ -61,6 +61,13 @@ struct mxm_coded;
 int mxm_diag_stream_coded(const struct mxm_coded *c, int32_t H, int32_t wg_per_cu, void *sink, void *stream);
 
 /*
+ * Diagnostic: exactly the loads of em_iter_quad_coded_kernel's quad pass over the quad dictionary of `c` (2048 code
+ * bytes and the 32-byte table entries of every row of c->quad_rows) and nothing else: the counter calibration for that
+ * kernel (tools/pmc_calibrate_coded.py --quads). -1 when `c` carries no quad dictionary.
+ */
+int mxm_diag_stream_quads(const struct mxm_coded *c, int32_t H, int32_t wg_per_cu, void *sink, void *stream);
+
+/*
  * Progress hook for mxm_em_loop (the reference prints a dot every 10 iterations while it runs,
  * em.py:127-135): fn(state_host, B, user) is called on the calling host thread after every read-back
  * of the loop state, which then happens at least every `every` iterations.  NULL switches it off.

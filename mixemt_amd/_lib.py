@@ -121,6 +121,7 @@ SIGNATURES = {
     "mxm_assign_reads": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_i32, c_i64, c_i32, c_f64, c_ptr, c_ptr]),
     "mxm_diag_stream_read": (ctypes.c_int, [c_ptr, c_size, c_i32, c_i32, c_ptr, c_ptr]),
     "mxm_diag_stream_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_i32, c_ptr, c_ptr]),
+    "mxm_diag_stream_quads": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32, c_i32, c_ptr, c_ptr]),
     "mxm_diag_fused_force_abort": (ctypes.c_int, [c_i32]),
     "mxm_set_fused_coded_grid": (ctypes.c_int, [c_i32]),
     "mxm_set_quad_left_grid": (ctypes.c_int, [c_i32]),

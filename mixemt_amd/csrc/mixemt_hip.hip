@@ -1958,6 +1958,17 @@ extern "C" int mxm_diag_stream_coded(const mxm_coded *c, int32_t H, int32_t wg_p
     return 0;
 }
 
+extern "C" int mxm_diag_stream_quads(const mxm_coded *c, int32_t H, int32_t wg_per_cu, void *sink, void *stream) {
+    const int rc = coded_check(c, H, "mxm_diag_stream_quads");
+    if (rc != 0) return rc;
+    if (sink == nullptr || wg_per_cu < 1 || c->qrec == nullptr || c->n_quad_rows <= 0)
+        return fail(-1, "mxm_diag_stream_quads: a coded matrix with a quad dictionary required%s", "");
+    hipLaunchKernelGGL(diag_stream_quads_kernel, dim3(clamp_grid(c->n_quad_rows, num_cu() * wg_per_cu)), dim3(QUAD_THREADS), 0,
+                       (hipStream_t)stream, c->qrec, c->qoff, c->nquad, c->quad_rows, c->n_quad_rows, (unsigned int *)sink);
+    HIP_TRY(hipGetLastError());
+    return 0;
+}
+
 extern "C" int mxm_row_argmax_votes(const double *X, int64_t ldx, const double *w, int64_t R, int32_t H,
                                     int32_t *best, double *votes, void *ws, size_t ws_bytes, void *stream) {
     if (R <= 0 || H <= 0 || ldx < H) return fail(-1, "mxm_row_argmax_votes: bad shape%s", "");

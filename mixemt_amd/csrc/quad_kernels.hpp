@@ -623,4 +623,62 @@ __global__ __launch_bounds__(QUAD_THREADS, 2) void em_iter_quad_coded_kernel(
     }
 }
 
+// Diagnostic (tools/pmc_calibrate_coded.py --quads): the quad pass's loads and nothing else -- a thread's 8 code bytes and
+// its 32 bytes of the table, row after row of `quad_rows`, three rows ahead, the rows' offsets and sizes fetched 256 steps
+// at a time through LDS as the pass does -- so that a counter pass can state the quad kernel's traffic against a reader of
+// exactly its bytes through exactly its access widths, and its time against what those loads reach alone.
+__global__ __launch_bounds__(QUAD_THREADS, 2) void diag_stream_quads_kernel(const uint8_t *__restrict__ qrec,
+                                                                           const int64_t *__restrict__ qoff,
+                                                                           const int32_t *__restrict__ nquad,
+                                                                           const int64_t *__restrict__ quad_rows, int64_t n_rows,
+                                                                           unsigned int *__restrict__ sink) {
+    constexpr int NBUF = 4, THREADS = QUAD_THREADS;
+    static_assert(THREADS % NBUF == 0, "a block of steps is a whole number of rounds");
+    __shared__ long long s_off[2][THREADS];
+    __shared__ int s_nd[2][THREADS];
+    const int t = threadIdx.x;
+    const row_deal deal(n_rows);
+    if (deal.nq <= 0) return;
+    quad_u2 x[NBUF];
+    quad_u4 ya[NBUF], yb[NBUF];
+    unsigned int acc = 0;
+    auto fetch_meta = [&](int half, int64_t q0) {
+        const int64_t q = q0 + t;
+        const int64_t r = quad_rows[deal.row(q)];
+        const int nd = deal.live(q) ? nquad[r] : 0;        // a step past the end reads nothing
+        s_off[half][t] = nd > 0 ? qoff[r] : 0;
+        s_nd[half][t] = nd > 0 && nd <= QUAD_MAX ? nd : 0;
+    };
+    auto load_rec = [&](int slot, int64_t q) {
+        const int half = (int)((q / THREADS) & 1), idx = (int)(q % THREADS);
+        const long long off = s_off[half][idx];
+        const int nd = __builtin_amdgcn_readfirstlane(s_nd[half][idx]);
+        const int off_hi = __builtin_amdgcn_readfirstlane((int)(off >> 32)), off_lo = __builtin_amdgcn_readfirstlane((int)off);
+        const uint8_t *base = qrec + (((long long)off_hi << 32) | (unsigned int)off_lo);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, nd > 0 ? QUAD_CODE_BYTES : 0, 0x00020000);
+        x[slot] = __builtin_amdgcn_raw_buffer_load_b64(rs, t * 8, 0, 2);
+        const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base + QUAD_CODE_BYTES), 0, nd * 32, 0x00020000);
+        ya[slot] = __builtin_amdgcn_raw_buffer_load_b128(rt, t * 32, 0, 2);
+        yb[slot] = __builtin_amdgcn_raw_buffer_load_b128(rt, t * 32, 16, 2);
+    };
+    fetch_meta(0, 0);
+    __syncthreads();
+#pragma unroll
+    for (int j = 0; j < NBUF - 1; ++j) load_rec(j, j);
+    const int64_t nblk = (deal.nq + THREADS - 1) / THREADS;
+    for (int64_t b = 0; b < nblk; ++b) {
+        __syncthreads();                                   // (the half written next was read until the block before this one ended)
+        fetch_meta((int)((b + 1) & 1), (b + 1) * THREADS);
+        __syncthreads();
+        for (int i = 0; i < THREADS; i += NBUF) {
+#pragma unroll
+            for (int j = 0; j < NBUF; ++j) {
+                load_rec((j + NBUF - 1) % NBUF, b * THREADS + i + j + NBUF - 1);
+                acc ^= x[j].x ^ x[j].y ^ ya[j].x ^ ya[j].w ^ yb[j].y ^ yb[j].z;
+            }
+        }
+    }
+    if (acc == 0x9e3779b9u) sink[0] = acc;                 // (keeps the loads)
+}
+
 #endif  // MIXEMT_QUAD_KERNELS_HPP

@@ -349,3 +349,28 @@ def test_odd_width_and_a_buffer_that_overflows_once(monkeypatch):
     want = _decode(cm)
     for r in list(rows)[:200]:
         assert numpy.array_equal(rows[r].view(numpy.int64), want[r].view(numpy.int64))
+
+
+def test_the_bare_reader_of_the_quad_records(b17):
+    """mxm_diag_stream_quads (the counter calibration's reader, tools/pmc_calibrate_coded.py --quads): runs over a plan's
+    quad records and leaves everything as it was; without a quad dictionary it says so instead of reading."""
+    import torch
+    from mixemt_amd import _lib, em
+    from mixemt_amd._dev import current_stream
+    lib = _lib.load()
+    cm, _ = _records(b17, 3000, 21)
+    plan = em.EmPlan(None, numpy.ones(3000), records=cm)
+    sink = torch.zeros(4, dtype=torch.int32, device=plan.dev)
+    assert lib.mxm_diag_stream_quads(ctypes.byref(plan.coded), plan.n_haps, 2, sink.data_ptr(), current_stream()) == -1
+    assert b"quad dictionary" in lib.mxm_last_error()
+    assert plan.attach_quads(True)
+    props = numpy.random.default_rng(1).dirichlet([0.5] * plan.n_haps)
+    before = _iterate(plan, props)[0][0]
+    qrec = plan._quad_keep[0].clone()
+    for wg in (1, 2, 4):
+        _lib.check(lib.mxm_diag_stream_quads(ctypes.byref(plan.coded), plan.n_haps, wg, sink.data_ptr(), current_stream()),
+                   "mxm_diag_stream_quads")
+    torch.cuda.synchronize()
+    assert torch.equal(qrec, plan._quad_keep[0]) and int(sink.abs().sum()) == 0
+    assert numpy.array_equal(_iterate(plan, props)[0][0], before)
+    assert lib.mxm_diag_stream_quads(ctypes.byref(plan.coded), plan.n_haps, 0, sink.data_ptr(), current_stream()) == -1

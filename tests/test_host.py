@@ -303,6 +303,15 @@ def test_bench_quotes_calibrated_counter_traffic_for_the_records_kernel():
     assert "diag_stream_coded_kernel" in rec["fetch_correction_source"] and 1.0 < rec["fetch_correction"] <= 2.0
     # the dense matrix's figure is never taken for it, nor the other way round
     assert bench.pmc_traffic(10 ** 6, 5408, "f64", "em_iter_coded_kernel*", algo) is None
+    # the quad dictionary's kernel has a calibration of its own (a bare reader of the quad records: --quads), and neither
+    # kernel's figure answers for the other
+    calq = json.load(open(os.path.join(root, "profiles", "r05", "pmc_calibration_quads.json")))
+    algo_q = float(calq["kernel_bytes_per_pass"])
+    got_q = bench.pmc_traffic(10 ** 6, 5408, "coded", "em_iter_quad_coded_kernel*", algo_q)
+    assert got_q is not None and abs(got_q[0] - algo_q) < 0.05 * algo_q and got_q[1] != got[1], got_q
+    rec_q = next(v for k, v in json.load(open(os.path.join(root, got_q[1]))).items() if k.startswith("em_iter_quad_coded_kernel"))
+    assert "diag_stream_quads_kernel" in rec_q["fetch_correction_source"] and 1.0 < rec_q["fetch_correction"] <= 2.0
+    assert calq["bare_reader_covers"] > 0.9
 
 
 def test_committed_profiles_name_the_kernel_instances_this_source_builds():

@@ -29,7 +29,8 @@ WIDE_READERS = ("em_iter_wide_kernel", "em_iter_wide_f32_kernel", "estep_wide_ke
                 "encode_rows_kernel", "encode_wide_rows_kernel", "row_argmax_wide_kernel")
 # kernels calibrated against a bare reader of exactly their bytes in the SAME counter pass (tools/pmc_calibrate_coded.py):
 #   factor = known bytes / FETCH_SIZE of the bare reader
-CALIBRATED = {"em_iter_coded_kernel": "diag_stream_coded_kernel", "em_fused_coded_kernel": "diag_stream_coded_kernel"}
+CALIBRATED = {"em_iter_coded_kernel": "diag_stream_coded_kernel", "em_fused_coded_kernel": "diag_stream_coded_kernel",
+              "em_iter_quad_coded_kernel": "diag_stream_quads_kernel"}
 
 
 def per_kernel(path):
@@ -68,6 +69,7 @@ def main():
     haps = int(sys.argv[4]) if len(sys.argv) > 4 else 5408
     storage = sys.argv[5] if len(sys.argv) > 5 else "f64"
     out["_workload"] = {"rows_per_gpu": rows, "haps": haps, "storage": storage,
+                        **({"matrix": calib.get("matrix", "encoded")} if calib is not None else {}),
                         "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py "
                                    "--steps 4 --warmup 1 --no-cpu-baseline (tools/profile_round.sh)"}
     json.dump(out, sys.stdout, indent=1)

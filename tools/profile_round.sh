@@ -42,6 +42,14 @@ rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write_
 echo "[profile_round] step 11 done"
 python3 $repo/tools/pmc_summary.py $out/pmc_fetch_coded/f_counter_collection.csv $out/pmc_write_coded/w_counter_collection.csv 1000000 5408 coded $out/pmc_calibration_coded.json > $out/pmc_traffic_coded_1m.json
 echo "[profile_round] step 12 done"
+# ... and of the kernel a plan of this size runs with the quad dictionary beside the records (em_iter_quad_coded_kernel)
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch_quads -o f -- python3 $repo/tools/pmc_calibrate_coded.py 1000000 --quads > $out/pmc_calibration_quads.json 2> $out/pmc_fetch_quads.log
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write_quads -o w -- python3 $repo/tools/pmc_calibrate_coded.py 1000000 --quads > /dev/null 2> $out/pmc_write_quads.log
+python3 $repo/tools/pmc_summary.py $out/pmc_fetch_quads/f_counter_collection.csv $out/pmc_write_quads/w_counter_collection.csv 1000000 5408 coded $out/pmc_calibration_quads.json > $out/pmc_traffic_quads_1m.json
+rocprofv3 --output-format csv --kernel-trace --pmc FETCH_SIZE -d $out/pmc_fetch_quads_records -o f -- python3 $repo/tools/pmc_calibrate_coded.py 1000000 --quads --records > $out/pmc_calibration_quads_records.json 2> $out/pmc_fetch_quads_records.log
+rocprofv3 --output-format csv --kernel-trace --pmc WRITE_SIZE -d $out/pmc_write_quads_records -o w -- python3 $repo/tools/pmc_calibrate_coded.py 1000000 --quads --records > /dev/null 2> $out/pmc_write_quads_records.log
+python3 $repo/tools/pmc_summary.py $out/pmc_fetch_quads_records/f_counter_collection.csv $out/pmc_write_quads_records/w_counter_collection.csv 1000000 5408 coded $out/pmc_calibration_quads_records.json > $out/pmc_traffic_quads_records_1m.json
+echo "[profile_round] step 12q done"
 rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $out/pmc_sq_coded -o sq -- python3 $repo/bench.py --storage coded --steps 4 --warmup 1 --no-cpu-baseline > /dev/null 2> $out/pmc_sq_coded.log
 echo "[profile_round] step 13 done"
 python3 $repo/tools/sq_summary.py $out/pmc_sq_coded/sq_counter_collection.csv > $out/coded_pmc_sq_summary.txt 2>&1
