@@ -70,8 +70,12 @@ def main():
     storage = sys.argv[5] if len(sys.argv) > 5 else "f64"
     out["_workload"] = {"rows_per_gpu": rows, "haps": haps, "storage": storage,
                         **({"matrix": calib.get("matrix", "encoded")} if calib is not None else {}),
-                        "command": "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py "
-                                   "--steps 4 --warmup 1 --no-cpu-baseline (tools/profile_round.sh)"}
+                        "command": ("rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 tools/pmc_calibrate_coded.py "
+                                    "%d%s%s (tools/profile_round.sh)" % (rows, " --quads" if str(calib.get("kernel", "")).startswith("em_iter_quad") else "",
+                                                                         " --records" if calib.get("matrix") == "records" else "")
+                                    if calib is not None else
+                                    "rocprofv3 --pmc FETCH_SIZE|WRITE_SIZE --kernel-trace -- python3 bench.py "
+                                    "--steps 4 --warmup 1 --no-cpu-baseline (tools/profile_round.sh)")}
     json.dump(out, sys.stdout, indent=1)
     sys.stdout.write("\n")
 
