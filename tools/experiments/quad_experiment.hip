@@ -226,6 +226,162 @@ __global__ __launch_bounds__(256, WG_PER_CU) void quad_kernel(const uint8_t *__r
     }
 }
 
+// ---- B restarts through ONE pass over the quad records (config 3: ten restarts on one matrix) -------------------------
+// A workgroup of 512 threads takes a row (3 quads = 12 columns per thread: thread t' owns the quads tl + 256 (2 k + half),
+// tl = t' & 255, half = t' >> 8 -- the odd or the even code bytes of the word thread tl of the product kernel loads) and
+// keeps the proportions and the column sums of B restarts in registers (B x 48 VGPRs each); a row's codes, table and LDS
+// lookups are fetched once for all B, the dot products / wave sums / updates run B times.  One workgroup per CU (two waves
+// per SIMD, 256 registers each).
+template <int B, int NBUF>
+__global__ __launch_bounds__(512, 1) void quadB_kernel(const uint8_t *__restrict__ qrec, const int64_t *__restrict__ qoff,
+                                                       const int32_t *__restrict__ nquad, const double *__restrict__ w,
+                                                       const double *__restrict__ props, int64_t ldp, int64_t R, int H,
+                                                       double *__restrict__ partial, int64_t ldpart) {
+    constexpr int THREADS = 512, NW = 8, NCH = 3, AUX = 2;
+    static_assert(NBUF >= 3 && NBUF <= 4, "codes NBUF - 1 rows ahead");
+    static_assert(B * NW <= 64, "one partial per lane in the ratio");
+    __shared__ __attribute__((aligned(16))) double s_tbl[NBUF][Q_MAX * 4];
+    __shared__ __attribute__((aligned(16))) double red[NBUF][B * NW];
+    __shared__ long long s_off[2][THREADS];
+    __shared__ double s_wr[2][THREADS];
+    __shared__ int s_nd[2][THREADS];
+    const int t = threadIdx.x, lane = t & 63, wv = t >> 6, half = t >> 8, tl = t & 255;
+    const row_deal deal(R);
+
+    double p[B][NCH][4], acc[B][NCH][4];
+#pragma unroll
+    for (int b = 0; b < B; ++b)
+#pragma unroll
+        for (int k = 0; k < NCH; ++k)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int c = 4 * (tl + 256 * (2 * k + half)) + e;
+                p[b][k][e] = (c < H) ? props[b * ldp + c] : 0.0;
+                acc[b][k][e] = 0.0;
+            }
+    auto fetch_meta = [&](int hf, int64_t q0) {
+        const int64_t q = q0 + t;
+        const int64_t r = deal.row(q);
+        int nd = nquad[r];
+        if (nd > Q_MAX || nd < 0) nd = 0;
+        s_off[hf][t] = nd > 0 ? qoff[r] : 0;
+        s_nd[hf][t] = nd;
+        s_wr[hf][t] = (deal.live(q) && nd > 0) ? (w != nullptr ? w[r] : 1.0) : 0.0;
+    };
+    q_u2 cw[NBUF];
+    q_d2 tring[NBUF];
+    int pre_off_lo, pre_off_hi, pre_nd;
+    double pre_wr;
+    auto read_meta = [&](int64_t q_load, int64_t q_weight) {
+        const int hf = (int)((q_load / THREADS) & 1), idx = (int)(q_load % THREADS);
+        const long long off = s_off[hf][idx];
+        pre_nd = __builtin_amdgcn_readfirstlane(s_nd[hf][idx]);
+        pre_off_hi = __builtin_amdgcn_readfirstlane((int)(off >> 32));
+        pre_off_lo = __builtin_amdgcn_readfirstlane((int)off);
+        pre_wr = s_wr[(q_weight / THREADS) & 1][q_weight % THREADS];
+    };
+    auto load_row = [&](auto SLOT) {
+        constexpr int slot = decltype(SLOT)::value;
+        const int nd = pre_nd;
+        const uint8_t *base = qrec + (((long long)pre_off_hi << 32) | (unsigned int)pre_off_lo);
+        const auto rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base), 0, nd > 0 ? Q_CODE_BYTES : 0, 0x00020000);
+        cw[slot] = __builtin_amdgcn_raw_buffer_load_b64(rs, tl * 8, 0, AUX);
+        const auto rt = __builtin_amdgcn_make_buffer_rsrc(const_cast<uint8_t *>(base + Q_CODE_BYTES), 0, nd * 32, 0x00020000);
+        const q_u4 a = __builtin_amdgcn_raw_buffer_load_b128(rt, t * 16, 0, AUX);
+        tring[slot] = q_d2{__hiloint2double((int)a.y, (int)a.x), __hiloint2double((int)a.w, (int)a.z)};
+    };
+    auto publish = [&](auto SLOT) {
+        constexpr int slot = decltype(SLOT)::value;
+        *reinterpret_cast<q_d2 *>(&s_tbl[slot][t * 2]) = tring[slot];
+    };
+    double v[NCH][4];
+    // the thread's three code bytes: 0, 2, 4 of the word shifted down by `half` bytes
+    auto lookup_row = [&](const char *tb, const q_u2 &c) {
+        const unsigned long long word = (((unsigned long long)c.y << 32) | c.x) >> (8 * half);
+        const unsigned int lo = (unsigned int)word, hi = (unsigned int)(word >> 32);
+        const unsigned int off[NCH] = {quad_byte_x32<0>(lo), quad_byte_x32<2>(lo), quad_byte_x32<0>(hi)};
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const q_d2 a = *reinterpret_cast<const q_d2 *>(tb + off[k]), b = *reinterpret_cast<const q_d2 *>(tb + off[k] + 16);
+            v[k][0] = a.x;
+            v[k][1] = a.y;
+            v[k][2] = b.x;
+            v[k][3] = b.y;
+        }
+    };
+
+    auto step = [&](auto J, int64_t q) {
+        constexpr int j = decltype(J)::value;
+        constexpr int jn = (j + 1) % NBUF, jl = (j + NBUF - 1) % NBUF;
+        if ((q % THREADS) == 0) fetch_meta((int)((q / THREADS + 1) & 1), q + THREADS);
+        load_row(std::integral_constant<int, jl>{});     // row q + NBUF - 1
+        const double wr = pre_wr;
+        double s[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            double s2[2] = {0.0, 0.0};
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) s2[e & 1] = fma(v[k][e], p[b][k][e], s2[e & 1]);
+            s[b] = s2[0] + s2[1];
+        }
+        __builtin_amdgcn_s_setprio(1);
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            s[b] = wave_sum_lane63(s[b]);
+            if (lane == 63) red[j][b * NW + wv] = s[b];
+        }
+        publish(std::integral_constant<int, jn>{});      // row q + 1's table, published by the same barrier
+        __syncthreads();
+        read_meta(q + NBUF, q + 1);
+        double cf[B];
+        group_ratio_to_sgpr<NW, B>(&red[j][0], lane, wr, cf);
+        __builtin_amdgcn_s_setprio(0);
+#pragma unroll
+        for (int b = 0; b < B; ++b)
+#pragma unroll
+            for (int k = 0; k < NCH; ++k)
+#pragma unroll
+                for (int e = 0; e < 4; ++e) acc[b][k][e] = fma(cf[b], v[k][e], acc[b][k][e]);
+        lookup_row(reinterpret_cast<const char *>(&s_tbl[jn][0]), cw[jn]);
+    };
+
+    if (deal.nq > 0) {
+        fetch_meta(0, 0);
+        __syncthreads();
+        read_meta(0, 0);
+        load_row(std::integral_constant<int, 0>{});
+        read_meta(1, 0);
+        load_row(std::integral_constant<int, 1>{});
+        if constexpr (NBUF > 3) {
+            read_meta(2, 0);
+            load_row(std::integral_constant<int, 2>{});
+        }
+        publish(std::integral_constant<int, 0>{});
+        __syncthreads();
+        read_meta(NBUF - 1, 0);
+        lookup_row(reinterpret_cast<const char *>(&s_tbl[0][0]), cw[0]);
+        for (int64_t q = 0; q < deal.nq; q += NBUF) {
+            step(std::integral_constant<int, 0>{}, q);
+            step(std::integral_constant<int, 1>{}, q + 1);
+            step(std::integral_constant<int, 2>{}, q + 2);
+            if constexpr (NBUF > 3) step(std::integral_constant<int, 3>{}, q + 3);
+        }
+    }
+#pragma unroll
+    for (int b = 0; b < B; ++b) {
+        double *dst = partial + ((int64_t)b * gridDim.x + blockIdx.x) * ldpart;
+#pragma unroll
+        for (int k = 0; k < NCH; ++k) {
+            const int c = 4 * (tl + 256 * (2 * k + half));
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+                if (c + e < H) dst[c + e] = acc[b][k][e];
+        }
+    }
+}
+
 static float time_launches(int reps, const std::function<void()> &launch) {
     hipEvent_t a, b;
     if (hipEventCreate(&a) != hipSuccess || hipEventCreate(&b) != hipSuccess) return -1.0f;
@@ -264,4 +420,25 @@ extern "C" float quad_time(int variant, const uint8_t *qrec, const int64_t *qoff
 #undef QK
     *grid_out = grid;
     return ms;
+}
+
+// B restarts in one pass: props [B][ldp], partial [B][grid][ldpart]; -> ms per launch (all B restarts)
+extern "C" float quadB_time(int B, int nbuf, const uint8_t *qrec, const int64_t *qoff, const int32_t *nquad, const double *w,
+                            const double *props, int64_t ldp, int64_t R, int H, double *partial, int64_t ldpart, int n_cu,
+                            int reps, int *grid_out) {
+    if (H > 4 * 256 * 6) return -2.0f;
+    const int grid = n_cu;
+    *grid_out = grid;
+#define QB(b, nb) [&]() { hipLaunchKernelGGL((quadB_kernel<b, nb>), dim3(grid), dim3(512), 0, 0, qrec, qoff, nquad, w, props, ldp, R, H, partial, ldpart); }
+    switch (B * 10 + nbuf) {
+        case 13: return time_launches(reps, QB(1, 3));
+        case 23: return time_launches(reps, QB(2, 3));
+        case 33: return time_launches(reps, QB(3, 3));
+        case 43: return time_launches(reps, QB(4, 3));
+        case 24: return time_launches(reps, QB(2, 4));
+        case 34: return time_launches(reps, QB(3, 4));
+        case 44: return time_launches(reps, QB(4, 4));
+        default: return -5.0f;
+    }
+#undef QB
 }
