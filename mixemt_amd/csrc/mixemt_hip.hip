@@ -1964,7 +1964,7 @@ extern "C" int mxm_diag_stream_quads(const mxm_coded *c, int32_t H, int32_t wg_p
     if (sink == nullptr || wg_per_cu < 1 || c->qrec == nullptr || c->n_quad_rows <= 0)
         return fail(-1, "mxm_diag_stream_quads: a coded matrix with a quad dictionary required%s", "");
     hipLaunchKernelGGL(diag_stream_quads_kernel, dim3(clamp_grid(c->n_quad_rows, num_cu() * wg_per_cu)), dim3(QUAD_THREADS), 0,
-                       (hipStream_t)stream, c->qrec, c->qoff, c->nquad, c->quad_rows, c->n_quad_rows, (unsigned int *)sink);
+                       (hipStream_t)stream, c->qrec, c->qoff, c->nquad, c->quad_rows, c->n_quad_rows, c->R, (unsigned int *)sink);
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -631,7 +631,7 @@ __global__ __launch_bounds__(QUAD_THREADS, 2) void diag_stream_quads_kernel(cons
                                                                            const int64_t *__restrict__ qoff,
                                                                            const int32_t *__restrict__ nquad,
                                                                            const int64_t *__restrict__ quad_rows, int64_t n_rows,
-                                                                           unsigned int *__restrict__ sink) {
+                                                                           int64_t R, unsigned int *__restrict__ sink) {
     constexpr int NBUF = 4, THREADS = QUAD_THREADS;
     static_assert(THREADS % NBUF == 0, "a block of steps is a whole number of rounds");
     __shared__ long long s_off[2][THREADS];
@@ -645,8 +645,9 @@ __global__ __launch_bounds__(QUAD_THREADS, 2) void diag_stream_quads_kernel(cons
     auto fetch_meta = [&](int half, int64_t q0) {
         const int64_t q = q0 + t;
         const int64_t r = quad_rows[deal.row(q)];
-        const int nd = deal.live(q) ? nquad[r] : 0;        // a step past the end reads nothing
-        s_off[half][t] = nd > 0 ? qoff[r] : 0;
+        const bool ok = deal.live(q) && r >= 0 && r < R;   // a step past the end, an entry that names no row: nothing is read
+        const int nd = ok ? nquad[r] : 0;
+        s_off[half][t] = nd > 0 && nd <= QUAD_MAX ? qoff[r] : 0;
         s_nd[half][t] = nd > 0 && nd <= QUAD_MAX ? nd : 0;
     };
     auto load_rec = [&](int slot, int64_t q) {
