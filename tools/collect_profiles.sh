@@ -15,7 +15,7 @@ for f in bench_1m.json bench_1m_under_rocprof.json bench_1m_10restarts.json benc
          pmc_traffic_coded_1m.json coded_pmc_sq_summary.txt coded_storage_1m.txt pipeline_1m.txt pipeline_1m_coded.txt \
          bench_1m_records.json bench_10m_records_one_gpu.json bench_10m_records_one_gpu.log \
          bench_125k_records_one_rank_rccl.json pipeline_1m_records.txt pipeline_10m_records_one_gpu.txt \
-         pmc_calibration_coded.json pmc_calibration_quads.json pmc_traffic_quads_1m.json pmc_calibration_quads_records.json pmc_traffic_quads_records_1m.json quad_bare_reader_1m.txt quad_batched_1m.txt coded_parts.txt records_read_ceiling.txt \
+         pmc_calibration_coded.json pmc_calibration_quads.json pmc_traffic_quads_1m.json pmc_calibration_quads_records.json pmc_traffic_quads_records_1m.json quad_bare_reader_1m.txt quad_batched_1m.txt quad_mfma_sum_1m.txt coded_parts.txt records_read_ceiling.txt \
          frontend_1m.txt pipeline_1m_alignments.txt row_pass_experiments.txt \
          bam_reader_1m.txt pipeline_1m_bam.txt quad_1m.txt quads_product_1m.txt quad_build_1m.txt step_sequence.txt \
          alloc_big.txt records_build_alignments.txt stress_parity_707.txt stress_parity_808.txt stress_parity_909.txt stress_parity_1111.txt \

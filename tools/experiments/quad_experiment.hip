@@ -35,8 +35,20 @@ __device__ __forceinline__ unsigned int quad_byte_x32(unsigned int word) {
     return r;
 }
 
+// The wave's sum on the matrix core: D = A x ones gives every lane of a 16-lane group the sums over the four lanes
+// {i, i + 16, i + 32, i + 48} of four i; folding the four registers and a second product leaves the total in EVERY lane --
+// two v_mfma_f64_16x16x4_f64 and three v_add_f64 instead of twelve v_mov_dpp, six v_add_f64 and the DPP hazard nops.
+typedef double q_d4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ double wave_sum_mfma(double v) {
+    const q_d4 zero = {0.0, 0.0, 0.0, 0.0};
+    const q_d4 a = __builtin_amdgcn_mfma_f64_16x16x4f64(v, 1.0, zero, 0, 0, 0);
+    const double t = (a.x + a.y) + (a.z + a.w);
+    const q_d4 b = __builtin_amdgcn_mfma_f64_16x16x4f64(t, 1.0, zero, 0, 0, 0);
+    return b.x;
+}
+
 // DMA: the table goes global -> LDS directly (buffer_load_dwordx4 ... lds, gfx950), no registers, no ds_write
-template <int NBUF, bool DMA, int WG_PER_CU, bool ONEWAIT = false>
+template <int NBUF, bool DMA, int WG_PER_CU, bool ONEWAIT = false, bool MFMA_SUM = false>
 __global__ __launch_bounds__(256, WG_PER_CU) void quad_kernel(const uint8_t *__restrict__ qrec, const int64_t *__restrict__ qoff,
                                                               const int32_t *__restrict__ nquad, const double *__restrict__ w,
                                                               const double *__restrict__ props, int64_t R, int H,
@@ -148,7 +160,8 @@ __global__ __launch_bounds__(256, WG_PER_CU) void quad_kernel(const uint8_t *__r
             for (int e = 0; e < 4; ++e) s4[e] = fma(v[k][e], p[k][e], s4[e]);
         double s = (s4[0] + s4[1]) + (s4[2] + s4[3]);
         __builtin_amdgcn_s_setprio(1);
-        s = wave_sum_lane63(s);
+        if constexpr (MFMA_SUM) s = wave_sum_mfma(s);
+        else s = wave_sum_lane63(s);
         if (lane == 63) red[j][wv] = s;
         publish(std::integral_constant<int, jn>{});      // row q + 1's table, published by the same barrier
         __syncthreads();
@@ -415,6 +428,8 @@ extern "C" float quad_time(int variant, const uint8_t *qrec, const int64_t *qoff
         case 6: grid = n_cu * 2; ms = time_launches(reps, QK(3, false, 2, true)); break;
         case 7: grid = n_cu * 2; ms = time_launches(reps, QK(5, false, 2)); break;
         case 8: grid = n_cu * 2; ms = time_launches(reps, QK(6, false, 2)); break;
+        case 9: grid = n_cu * 2; ms = time_launches(reps, QK(4, false, 2, false, true)); break;
+        case 10: grid = n_cu * 2; ms = time_launches(reps, QK(3, false, 2, false, true)); break;
         default: return -5.0f;
     }
 #undef QK

@@ -140,7 +140,9 @@ names = {0: "quad records, table through registers, 2 rows in flight, 2 workgrou
          5: "quad records, table through registers, 3 rows in flight, ONE wait for the row's lookups",
          6: "... 2 rows in flight, one wait",
          7: "quad records, table through registers, 4 rows in flight",
-         8: "... 5 rows in flight"}
+         8: "... 5 rows in flight",
+         9: "... 3 rows in flight, the wave's sum on the matrix core (2 v_mfma_f64_16x16x4 + 3 adds instead of the DPP ladder)",
+         10: "... 2 rows in flight, the wave's sum on the matrix core"}
 for rep in range(2):
     for v in sorted(names):
         g = I(0)
