@@ -218,6 +218,61 @@ def loop_ms_per_iteration(em, torch, plan, props_row, n_iter):
     return best
 
 
+RESTARTS10 = 10                  # BASELINE config 3: ten restarts on one matrix
+RESTARTS10_ITERS = 48            # iterations of every restart in the timed run (whole bursts of the loop driver's 16)
+
+
+def restarts10_leg(em, torch, lib, cplan, n_rows, n_haps):
+    """
+    BASELINE config 3 on the default route (records + quad dictionary): ten restarts through the product's own loop driver
+    (em.em_loop -> mxm_em_loop_coded), tolerance 0 so that every restart runs exactly RESTARTS10_ITERS iterations.  Full
+    tiles of three restarts share a pass over the records (em_iter_quad_batched_kernel, round 6); the same run with one
+    restart per pass (round 5's schedule) is timed beside it, and one iteration's per-restart column sums are compared.
+    """
+    import numpy
+    inits = numpy.random.RandomState(7).dirichlet([1.0] * n_haps, size=RESTARTS10)
+    out = {"restarts": RESTARTS10, "iterations_each": RESTARTS10_ITERS, "tile": int(cplan.restart_tile())}
+
+    def run(tile):
+        lib.mxm_set_coded_batch_tile(tile)
+        try:
+            em.em_loop(cplan, inits, 0.0, 3)                               # warm
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            _, _, states = em.em_loop(cplan, inits, 0.0, RESTARTS10_ITERS)
+            torch.cuda.synchronize()
+            dt = time.perf_counter() - t0
+        finally:
+            lib.mxm_set_coded_batch_tile(3)
+        done = sum(s[1] for s in states)
+        return dt, done
+
+    def sums(tile):
+        lib.mxm_set_coded_batch_tile(tile)
+        try:
+            p = torch.from_numpy(inits[:3].copy()).to(cplan.dev)
+            cs = torch.zeros_like(p)
+            cplan.em_iter(p, p.log(), em.new_state(3, cplan.dev), cs)
+            torch.cuda.synchronize()
+            return cs
+        finally:
+            lib.mxm_set_coded_batch_tile(3)
+
+    dt3, done3 = run(3)
+    dt1, done1 = run(1)
+    a, b = sums(3), sums(1)
+    out.update({"restart_iterations_per_s": done3 / dt3, "ms_per_restart_iteration": dt3 * 1e3 / max(done3, 1),
+                "restart_iterations": int(done3), "value": float(n_rows) * n_haps * done3 / dt3, "unit": "cells/s",
+                "one_per_pass_restart_iterations_per_s": done1 / dt1,
+                "one_per_pass_ms_per_restart_iteration": dt1 * 1e3 / max(done1, 1),
+                "max_rel_dcolsum_vs_one_per_pass": float(((a - b).abs() / b.abs().amax(dim=1, keepdim=True)).max().item()),
+                "kernel": "em_iter_quad_batched_kernel<3, %d, 1> + <3, %d, 6>" % (((n_haps + 7) // 8 * 2 + 255) // 256 + 1 >> 1,) * 2,
+                "note": "wall time of mxm_em_loop_coded over %d iterations of each of %d restarts (launches, state read-backs "
+                        "and the single pass of the tenth restart included); three restarts share the row loads, the tables "
+                        "in LDS and the lookups of one pass" % (RESTARTS10_ITERS, RESTARTS10)})
+    return out
+
+
 def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
     """
     The EM iteration of the default line over the SAME matrix in row-dictionary storage
@@ -229,7 +284,7 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
     torch.cuda.synchronize()
     quads_mode, em.QUADS = em.QUADS, False            # first the records alone; the quad dictionary is attached below
     try:
-        cplan = em.EmPlan(mat, wts, n_runs=1, storage="coded")
+        cplan = em.EmPlan(mat, wts, n_runs=RESTARTS10, storage="coded")     # (workspace for the restarts10 sub-leg below)
         if cplan.coded is None:
             return None
         t0 = time.perf_counter()
@@ -305,7 +360,8 @@ def coded_leg(em, torch, lib, plan, mat, wts, props, ln_props, steps):
                  "quad_rows": int(cplan.quad_rows_n), "quad_bytes": float(cplan.quad_bytes), "build_ms": quad_build_ms,
                  "max_rel_dcolsum": qrel,
                  "note": "one code byte per FOUR columns for the rows with at most 256 distinct value quadruples, beside the "
-                         "records (csrc/quad_kernels.hpp); the rows without quads share the grid; same timing as ms_per_step"}
+                         "records (csrc/quad_kernels.hpp); the rows without quads share the grid; same timing as ms_per_step",
+                 "restarts10": restarts10_leg(em, torch, lib, cplan, n_rows, n_haps)}
     # "ms_per_step" keeps ONE meaning across rounds -- HIP events over the per-iteration kernels, rounds 2-3's
     # quantity and what a multi-GPU step runs around its all-reduce; the one-launch loop run_em takes on one GPU has a key
     # of its own (round 4 reported it AS ms_per_step: "schema" tells the two layouts apart)
@@ -752,7 +808,7 @@ def bench_rows(opts, env):
     has_quads = plan.coded is not None and getattr(plan, "_quad_keep", None) is not None
     rec_kind = "records" if records is not None else "encoded"
     if has_quads:                                     # both row passes in one grid, most rows from the quad records
-        kernel_name = "em_iter_quad_coded_kernel"
+        kernel_name = "em_iter_quad_coded_kernel" if min(n_runs, plan.restart_tile()) < 3 else "em_iter_quad_batched_kernel (a tile of 3 restarts)"
         if n_runs == 1:                               # calibrated like the records' kernel (pmc_calibrate_coded.py --quads)
             traffic = pmc_traffic(n_rows, n_haps, "coded", "em_iter_quad_coded_kernel*", algo_bytes, matrix=rec_kind)
     elif plan.storage == "coded" and n_runs == 1:
@@ -774,7 +830,7 @@ def bench_rows(opts, env):
         "config": {"workload": "%d reads x %d haplogroups in total (Phylotree B17 + RSRS), %d per rank, "
                                "%d EM restart(s) advanced together (tile %d; several restarts: full tiles "
                                "dealt round-robin by the loop driver), %s matrix"
-                               % (total_rows, n_haps, n_rows, n_runs, opts.batch_tile,
+                               % (total_rows, n_haps, n_rows, n_runs, opts.batch_tile if plan.storage != "coded" else plan.restart_tile(),
                                   {"f64": "fp64", "f32": "fp32-stored", "coded": "row-dictionary (lossless fp64)"}[plan.storage]
                                   + (", records straight from the build, no dense matrix on the device" if records is not None else "")),
                    "total_rows": total_rows, "rows_per_gpu": n_rows, "haps": n_haps, "restarts": n_runs,

@@ -51,8 +51,10 @@ extern "C" {
  * 502: mxm_coded gained the quad dictionary's fields (qrec .. n_byte_rows), mxm_build_quads, mxm_quad_bytes;
  * 503: mxm_quad_lists, mxm_quad_lists_scratch_bytes;
  * 504: mxm_exchange_* (the optional one-shot exchange of a row-sharded loop); mxm_em_state.error may be 2;
- * 505: mxm_exchange_reduce; 506: mxm_expand_tables. */
-#define MXM_VERSION 506
+ * 505: mxm_exchange_reduce; 506: mxm_expand_tables;
+ * 600 round 6: mxm_restart_tile_coded (three restarts share a pass over records beside a quad dictionary:
+ * mxm_em_iter_coded / mxm_em_loop_coded take full tiles of three through em_iter_quad_batched_kernel). */
+#define MXM_VERSION 600
 
 /* per-restart loop state, written by mxm_m_finalize (24 bytes); allocate it ZEROED */
 typedef struct mxm_em_state {
@@ -261,7 +263,9 @@ int mxm_em_loop_f32(const float *P, int64_t ldp, const double *w, int64_t R, int
  *                           needs an even H in [66, 8192], even ldm, 16-byte aligned M and rec
  *   mxm_decode_rows         P[r][:] = row r decoded, coded rows only (tests; posterior passes)
  *   mxm_em_iter_coded / mxm_em_loop_coded   = mxm_em_iter / mxm_em_loop over a coded matrix
- *                           (one restart per pass; w[R] indexes all rows, coded or not)
+ *                           (w[R] indexes all rows, coded or not; one restart per pass -- beside a quad dictionary
+ *                           full tiles of mxm_restart_tile_coded() = 3 restarts share a pass, em.py:117-161 runs them
+ *                           one after another over the same matrix)
  */
 typedef struct mxm_coded {
     const uint8_t *rec;          /* records */
@@ -355,6 +359,10 @@ int mxm_gather_columns_coded(const mxm_coded *c, int32_t H, const int32_t *cols,
 int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, int32_t H, int32_t B,
                       mxm_em_state *state /* nullable; only .error is ever written */, double *colsum, void *ws,
                       size_t ws_bytes, void *stream);
+/* Restarts that share one pass over THIS coded matrix in mxm_em_iter_coded / mxm_em_loop_coded: 3 beside a quad dictionary
+ * (width within the quad pass's range, no dense leftover rows), else 1.  B restarts take floor(B / 3) shared passes and
+ * B mod 3 single ones; per-restart sums differ from the one-per-pass kernel's by the rounding of another order only. */
+int mxm_restart_tile_coded(const mxm_coded *c, int32_t H);
 int mxm_em_loop_coded(const mxm_coded *c, const double *w, int32_t H, int32_t B,
                       double *props_cur, double *ln_cur, double *ln_new, double *colsum,
                       mxm_em_state *state, double tol, int32_t max_iter, int32_t check_every,

@@ -112,6 +112,13 @@ int mxm_set_fused_coded_grid(int32_t nwg);
 int mxm_set_quad_left_grid(int32_t nwg);
 
 /*
+ * Restarts per pass over records beside a quad dictionary: 3 (default; em_iter_quad_batched_kernel takes full tiles of
+ * three) or 1 (every restart its own pass, as before round 6).  Results differ by the rounding of another summation
+ * order only.
+ */
+int mxm_set_coded_batch_tile(int32_t bt);
+
+/*
  * Test hook: the next one-launch loops start with their abort flag already raised, i.e. behave as if a workgroup had
  * waited in vain at the first grid barrier (the situation a second process holding CUs creates).  mxm_em_loop must then
  * undo the launch and finish through the per-iteration kernels (mode -1), or return -3 (mode 1).

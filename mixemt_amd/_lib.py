@@ -58,6 +58,7 @@ SIGNATURES = {
     "mxm_linear_supported": (ctypes.c_int, [c_i32]),
     "mxm_workspace_bytes": (c_size, [c_i64, c_i32, c_i32]),
     "mxm_restart_tile": (ctypes.c_int, [c_i32]),
+    "mxm_restart_tile_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32]),
     "mxm_build_em_matrix": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                            c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     "mxm_build_em_matrix_lut": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
@@ -125,6 +126,7 @@ SIGNATURES = {
     "mxm_diag_fused_force_abort": (ctypes.c_int, [c_i32]),
     "mxm_set_fused_coded_grid": (ctypes.c_int, [c_i32]),
     "mxm_set_quad_left_grid": (ctypes.c_int, [c_i32]),
+    "mxm_set_coded_batch_tile": (ctypes.c_int, [c_i32]),
     "mxm_diag_fused_stamps": (ctypes.c_int, [c_ptr, ctypes.POINTER(ctypes.c_ulonglong)]),
     "mxm_set_timing_events": (ctypes.c_int, [c_ptr, c_ptr]),
     "mxm_set_batch_tile": (ctypes.c_int, [c_i32]),
@@ -158,7 +160,7 @@ SIGNATURES = {
 }
 
 # the MXM_VERSION of include/mixemt_hip.h these signatures were written for; load() refuses any other
-ABI_VERSION = 506
+ABI_VERSION = 600
 
 PROGRESS_FN = ctypes.CFUNCTYPE(None, ctypes.POINTER(EmState), c_i32, c_ptr)
 

@@ -118,6 +118,34 @@ __device__ __forceinline__ double wave_sum_lane63(double v) {
     v += dpp_mov_old_f64<0x143, 0xC>(0.0, v);       // row_bcast:31 into rows 2 and 3
     return v;
 }
+// Three wave-wide sums for the price of one and a half (round 6; the batched quad pass reduces three restarts' dot
+// products per row): gfx950's v_permlane32_swap / v_permlane16_swap exchange HALVES / ROWS of two registers, so each
+// folding step also sorts the values apart -- afterwards the 16 lanes of a row hold one value's partial sums, and the four
+// in-row DPP steps finish all three at once.  23 VALU instructions instead of 54 (three DPP ladders) and a third of the
+// DPP hazard nops.  Returns z with EVERY lane of row 0 = sum(a), row 1 = sum(c), row 2 = sum(b), row 3 = sum(c).
+// Fixed order: ((x[l] + x[l+32]) + (x[l+16] + x[l+48])) over l < 16, then the in-row tree.  Needs the full wave active.
+__device__ __forceinline__ double swap32_add(double x, double y) {   // lanes < 32: x[l] + x[l+32]; lanes >= 32: y[l-32] + y[l]
+    typedef unsigned int u2s __attribute__((ext_vector_type(2)));
+    const u2s lo = __builtin_amdgcn_permlane32_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const u2s hi = __builtin_amdgcn_permlane32_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double swap16_add(double x, double y) {   // rows: x.r0 + x.r1 | y.r0 + y.r1 | x.r2 + x.r3 | y.r2 + y.r3
+    typedef unsigned int u2s __attribute__((ext_vector_type(2)));
+    const u2s lo = __builtin_amdgcn_permlane16_swap((unsigned)__double2loint(x), (unsigned)__double2loint(y), false, false);
+    const u2s hi = __builtin_amdgcn_permlane16_swap((unsigned)__double2hiint(x), (unsigned)__double2hiint(y), false, false);
+    return __hiloint2double((int)hi.x, (int)lo.x) + __hiloint2double((int)hi.y, (int)lo.y);
+}
+__device__ __forceinline__ double wave_sum3_by_row(double a, double b, double c) {
+    const double ab = swap32_add(a, b);             // lanes < 32: a over {l, l+32}; lanes >= 32: b
+    const double cc = swap32_add(c, c);             // every lane: c over {l mod 32, l mod 32 + 32}
+    double v = swap16_add(ab, cc);                  // rows: a | c | b | c, 16 partial sums each
+    v += dpp_mov_f64<0xB1>(v);                      // lane ^ 1
+    v += dpp_mov_f64<0x4E>(v);                      // lane ^ 2
+    v += dpp_mov_f64<0x141>(v);                     // row_half_mirror
+    v += dpp_mov_f64<0x140>(v);                     // row_mirror: every lane = its row's sum
+    return v;
+}
 __device__ __forceinline__ double wave_max_lane63(double v) {
     v = fmax(v, dpp_mov_f64<0xB1>(v));
     v = fmax(v, dpp_mov_f64<0x4E>(v));

@@ -49,6 +49,7 @@
 #include "bam_reader.hpp"
 #include "coded_kernels.hpp"
 #include "quad_kernels.hpp"
+#include "quad_batched_kernels.hpp"
 #include "build_kernels.hpp"
 #include "build_lut_kernels.hpp"
 #include "build_sparse_kernels.hpp"
@@ -83,6 +84,7 @@ struct mxm_tuning {
     int fused_cols = 1;             // matrices of up to 1536 rows take the transposed form (columns split)
     int fused_coded_wg = 0;         // workgroups of the one-launch loop over records (0 = by size)
     int quad_left_wg = 0;           // workgroups of the leftover pass beside the quad pass (0 = by the rows' measured cost)
+    int coded_bt = 3;               // restarts per pass over records beside a quad dictionary (1 = one per pass, 3 = the batched kernel)
     int fused_force_abort = 0;      // test hook: the one-launch loop starts with its abort flag raised (as if starved)
     double fused_cells = 1.0e8;     // ~18 000 rows at H = 5408: measured break-even is ~30 000 rows (profiles/r02/small_runs.txt)
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;     // timing hook around the dominant kernel
@@ -462,6 +464,10 @@ extern "C" int mxm_set_fused_coded_grid(int32_t nwg) {
     return tune_set([nwg](mxm_tuning &t) { t.fused_coded_wg = nwg > 0 ? nwg : 0; });
 }
 
+extern "C" int mxm_set_coded_batch_tile(int32_t bt) {
+    if (bt != 1 && bt != 3) return fail(-1, "mxm_set_coded_batch_tile: 1 or 3, got %s%lld", "", bt);
+    return tune_set([bt](mxm_tuning &t) { t.coded_bt = bt; });
+}
 extern "C" int mxm_set_quad_left_grid(int32_t nwg) {
     return tune_set([nwg](mxm_tuning &t) { t.quad_left_wg = nwg > 0 ? nwg : 0; });
 }
@@ -1177,6 +1183,56 @@ static int em_iter_coded_one(const mxm_coded *c, const double *w, const double *
     return reduce_tile(partial, nwg + nwg_rest, 1, H, colsum, state, sl, fin, stream, wide_check{chk, nwg, quads ? 0ll : (long long)c->n_wide});
 }
 
+// ---- QB_BT restarts through one pass over the records beside a quad dictionary (quad_batched_kernels.hpp) ----------
+#define QB_BT 3
+// Can a tile of QB_BT restarts share one pass over this coded matrix?  It takes a quad dictionary (the kernel's first
+// and largest class of rows), a width the quad pass covers, and dense leftover rows (random matrices), if any, that
+// the dense kernel takes three restarts at a time too.
+static bool coded_batch_ok(const mxm_coded *c, int H) {
+    if (T.coded_bt < QB_BT || c == nullptr || c->qrec == nullptr || c->n_quad_rows <= 0) return false;
+    if (c->R_rest > 0 && !batch_fits(H, QB_BT)) return false;                // (the dense leftover rows' tile of three)
+    const int nch256 = (coded_ld(H) / 4 + QUAD_THREADS - 1) / QUAD_THREADS;
+    return nch256 <= QUAD_MAX_NCH && mxm_linear_supported(H);
+}
+static int em_iter_coded_batched(const mxm_coded *c, const double *w, const double *props, int H, const mxm_slots &tile,
+                                 const mxm_em_state *state, double *colsum, double *partial, hipStream_t stream, bool timed,
+                                 const fin_args *fin = nullptr) {
+    const int64_t ldpart = part_ld(H);
+    const int ldc = coded_ld(H);
+    const int nch = ((ldc / 4 + QUAD_THREADS - 1) / QUAD_THREADS + 1) / 2;      // code bytes per thread of 512
+    int cap = num_cu();
+    if (cap > MXM_MAX_WG / QB_BT - num_cu() / QB_BT) cap = MXM_MAX_WG / QB_BT - num_cu() / QB_BT;   // (the dense rest's rows come behind)
+    if (cap < 1) cap = 1;
+    const int nwg = clamp_grid((c->n_quad_rows + 2) / 3, cap);
+    mxm_slots sl = tile;
+    for (int i = QB_BT; i < MXM_MAX_BT; ++i) sl.s[i] = sl.s[0];
+    if (timed && T.ev_start != nullptr) HIP_TRY(hipEventRecord(T.ev_start, stream));
+    const int64_t *byte_rows = c->byte_rows != nullptr ? c->byte_rows : c->quad_rows;      // (an empty list is still a list)
+    const int64_t *wide_rows = c->wide_rows != nullptr ? c->wide_rows : c->quad_rows;
+    // two launches on the same grid: the quad rows start the partial sums, the leftover rows (byte-coded without quads,
+    // wide) are added to them (quad_batched_kernels.hpp: as one kernel the three row loops spill into the quad rows' loop)
+    const bool left = c->n_byte_rows > 0 || c->n_wide > 0;
+    switch (nch) {
+#define QB_ARGS c->rec, c->rec_off, c->ndist, ldc, wide_rows, c->n_wide, byte_rows, c->n_byte_rows, c->qrec, c->qoff, c->nquad, c->quad_rows, c->n_quad_rows, c->R, w, props, H, partial, ldpart, state, sl
+#define QB_CASE(n) case n: hipLaunchKernelGGL((em_iter_quad_batched_kernel<QB_BT, n, 1>), dim3(nwg), dim3(QB_THREADS), 0, stream, QB_ARGS); if (left) hipLaunchKernelGGL((em_iter_quad_batched_kernel<QB_BT, n, 6>), dim3(nwg), dim3(QB_THREADS), 0, stream, QB_ARGS); break;
+        QB_CASE(1) QB_CASE(2) QB_CASE(3)
+#undef QB_CASE
+#undef QB_ARGS
+        default: return fail(-1, "mxm_em_iter_coded: H=%s%lld outside the batched quad kernel's range", "", H);
+    }
+    HIP_TRY(hipGetLastError());
+    if (timed && T.ev_stop != nullptr) HIP_TRY(hipEventRecord(T.ev_stop, stream));
+    int nwg_rest = 0;
+    if (c->R_rest > 0) {
+        const int rc = stream_linear_tile(c->P_rest, c->ldp_rest, c->w_rest, props, c->R_rest, H, QB_BT, sl, state,
+                                          partial + (int64_t)nwg * QB_BT * ldpart, stream, false, &nwg_rest,
+                                          (MXM_MAX_WG - nwg * QB_BT) / QB_BT);
+        if (rc != 0) return rc;
+    }
+    int *chk = reinterpret_cast<int *>(partial + (int64_t)MXM_MAX_WG * ldpart);
+    return reduce_tile(partial, nwg + nwg_rest, QB_BT, H, colsum, state, sl, fin, stream, wide_check{chk, nwg, 0ll});
+}
+
 extern "C" int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, int32_t H, int32_t B,
                                  mxm_em_state *state, double *colsum, void *ws, size_t ws_bytes, void *stream) {
     MXM_ENTER();
@@ -1184,11 +1240,24 @@ extern "C" int mxm_em_iter_coded(const mxm_coded *c, const double *w, const doub
     if (rc != 0) return rc;
     if (B <= 0 || props == nullptr || colsum == nullptr) return fail(-1, "mxm_em_iter_coded: bad arguments%s", "");
     if (ws == nullptr || ws_bytes < mxm_workspace_bytes(c->R, H, B)) return fail(-1, "mxm_em_iter_coded: workspace too small%s", "");
-    for (int b = 0; b < B; ++b) {
+    // beside a quad dictionary full tiles of QB_BT restarts share a pass (the remainder: one per pass)
+    int b = 0;
+    if (coded_batch_ok(c, (int)H)) {
+        for (; b + QB_BT <= B; b += QB_BT) {
+            const int irc = em_iter_coded_batched(c, w, props, (int)H, slots_from(b), state, colsum, (double *)ws, (hipStream_t)stream, b == 0);
+            if (irc != 0) return irc;
+        }
+    }
+    for (; b < B; ++b) {
         const int irc = em_iter_coded_one(c, w, props, (int)H, b, state, colsum, (double *)ws, (hipStream_t)stream, b == 0);
         if (irc != 0) return irc;
     }
     return 0;
+}
+
+extern "C" int mxm_restart_tile_coded(const mxm_coded *c, int32_t H) {
+    MXM_ENTER();
+    return coded_batch_ok(c, (int)H) ? QB_BT : 1;
 }
 
 extern "C" int mxm_restart_tile(int32_t H) {
@@ -1552,6 +1621,8 @@ static int enqueue_tile_iteration(const double *M, int64_t ldm, const double *P,
     // records and the linear fp64 matrix: the finalize rides on the column reduce's launch (one ticket per restart)
     fin_args fin = {ln_cur, ln_new, props_cur, state, tol, (int)max_iter};
     if (coded != nullptr) {
+        if (nb == QB_BT && coded_batch_ok(coded, (int)H))
+            return em_iter_coded_batched(coded, w, props_cur, (int)H, tile, state, colsum, (double *)ws, s, timed, &fin);
         for (int i = 0; i < nb; ++i) {
             const int rc = em_iter_coded_one(coded, w, props_cur, (int)H, tile.s[i], state, colsum, (double *)ws, s, timed && i == 0, &fin);
             if (rc != 0) return rc;
@@ -1636,6 +1707,7 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     int window = T.max_bt;                             // the largest restart tile that fits (mxm_em_iter)
     if (p_is_f32 || P == nullptr || !mxm_linear_supported(H)) window = 1;
     while (window > 1 && !batch_fits((int)H, window)) --window;
+    if (coded != nullptr && coded_batch_ok(coded, (int)H)) window = QB_BT;     // records beside a quad dictionary: tiles of three
 
     // the loop runs on a private stream (the caller's may be the legacy default stream, which
     // cannot be captured); it is ordered after / before the caller's stream with events
@@ -1687,14 +1759,21 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
                 // the fewest passes that cover what is left, restarts spread evenly over them
                 const int left = (int)(all.size() - at);
                 const int passes = (left + window - 1) / window;
-                const int nb = (left + passes - 1) / passes;
+                // (records: only a FULL tile shares a pass -- 4 left are 3 + 1, not 2 + 2)
+                const int nb = coded != nullptr ? (left < window ? left : window) : (left + passes - 1) / passes;
                 members.insert(members.end(), all.begin() + at, all.begin() + at + nb);
                 sizes.push_back(nb);
                 at += nb;
             }
         }
-        const int64_t n = check_every;                 // finalize stops each restart at its own max_iter;
-                                                       // kernels of a stopped restart are no-ops
+        // finalize stops each restart at its own max_iter and kernels of a stopped restart are no-ops -- but a pass that
+        // several restarts share costs the same with a stopped member in it: a chunk ends where its first member reaches
+        // max_iter (what converges on the way cannot be known beforehand)
+        int64_t n = check_every;
+        for (int b : members) {
+            const int64_t left = (int64_t)max_iter - (int64_t)state_host[b].iters;
+            if (left > 0 && left < n) n = left;
+        }
         auto enqueue_chunk = [&]() -> int {
             for (int64_t it = 0; it < n; ++it) {
                 size_t at = 0;
@@ -1714,6 +1793,7 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
         if (want_graph && !rotating) {                 // a rotating tile list would be re-captured every chunk
             std::vector<int> key(members);
             key.insert(key.end(), sizes.begin(), sizes.end());
+            key.push_back((int)n);
             if (exec == nullptr || key != graph_key) {
                 if (exec != nullptr) { (void)hipGraphExecDestroy(exec); exec = nullptr; }
                 if (graph != nullptr) { (void)hipGraphDestroy(graph); graph = nullptr; }

@@ -433,8 +433,10 @@ class EmPlan(object):
         return lin
 
     def restart_tile(self):
-        """Restarts that share one pass over this plan's matrix (mxm_restart_tile; 1 for the
-        fp32-storage variant and for narrow matrices, which iterate one restart per pass)."""
+        """Restarts that share one pass over this plan's matrix (mxm_restart_tile / mxm_restart_tile_coded; 1 for the
+        fp32-storage variant, for narrow matrices and for records without a quad dictionary, which iterate one restart per pass)."""
+        if self.coded is not None:                    # records: three beside a quad dictionary (em_iter_quad_batched_kernel), else one
+            return int(self.lib.mxm_restart_tile_coded(ctypes.byref(self.coded), self.n_haps))
         if self.lin is None or self.storage != "f64":
             return 1
         return int(self.lib.mxm_restart_tile(self.n_haps))
