@@ -266,7 +266,7 @@ def restarts10_leg(em, torch, lib, cplan, n_rows, n_haps):
                 "one_per_pass_restart_iterations_per_s": done1 / dt1,
                 "one_per_pass_ms_per_restart_iteration": dt1 * 1e3 / max(done1, 1),
                 "max_rel_dcolsum_vs_one_per_pass": float(((a - b).abs() / b.abs().amax(dim=1, keepdim=True)).max().item()),
-                "kernel": "em_iter_quad_batched_kernel<3, %d, 1> + <3, %d, 6>" % (((n_haps + 7) // 8 * 2 + 255) // 256 + 1 >> 1,) * 2,
+                "kernel": "em_iter_quad_batched_kernel<3, %d, 1> + <3, %d, 6>" % (((((n_haps + 7) // 8 * 2 + 255) // 256 + 1) // 2,) * 2),
                 "note": "wall time of mxm_em_loop_coded over %d iterations of each of %d restarts (launches, state read-backs "
                         "and the single pass of the tenth restart included); three restarts share the row loads, the tables "
                         "in LDS and the lookups of one pass" % (RESTARTS10_ITERS, RESTARTS10)})
@@ -562,14 +562,53 @@ def main(argv=None):
 
     env = dict(lib=lib, dev=dev, rank=rank, world=world, use_dist=use_dist, mat=mat, wts=wts, n_rows=n_rows,
                n_haps=n_haps, total_rows=total_rows, scaling=scaling, build_s=build_s, records=records, slab=slab)
+    census = rank_census(torch, dist, dev, rank, world, use_dist, opts.backend, opts.gpus)
     line = bench_restarts(opts, env) if opts.mode == "restarts" else bench_rows(opts, env)
     if rank == 0:
+        # what the collective itself saw: a line that says "n_gpus: 8" must show eight ranks that answered a
+        # device-side all-reduce, each on a GPU of its own
+        line.update({k: census[k] for k in ("ranks_seen", "devices", "backend")})
+        if not census["ok"]:
+            line["sanity_ok"] = False
+            line["sanity_note"] = census["note"]
         os.write(json_fd, (json.dumps(line) + "\n").encode())
     if use_dist:
         dist.barrier()
         dist.destroy_process_group()
     if rank == 0 and not line.get("sanity_ok", False):
         raise SystemExit(3)
+
+
+def rank_census(torch, dist, dev, rank, world, use_dist, backend, gpus):
+    """
+    Who took part, as the collective saw it: `ranks_seen` = an all-reduce (SUM) of a one held on each rank's device (the
+    backend's own tensors: device memory under nccl = RCCL), `devices` = every rank's GPU name and PCI address, all-gathered.
+    ok is False when ranks_seen differs from --gpus, or when two ranks of an RCCL group sit on one PCI address -- a
+    multi-GPU line must not be taken on trust from WORLD_SIZE alone.
+    """
+    props = torch.cuda.get_device_properties(dev)
+    pci = tuple(getattr(props, k, None) for k in ("pci_domain_id", "pci_bus_id", "pci_device_id"))
+    mine = {"rank": rank, "device_index": dev.index, "name": props.name,
+            "pci": None if any(v is None for v in pci) else "%04x:%02x:%02x" % pci,
+            "uuid": str(getattr(props, "uuid", "")) or None}
+    if not use_dist:
+        return {"ranks_seen": 1, "devices": [mine], "backend": None, "ok": gpus == 1, "note": "--gpus %d without a process group" % gpus}
+    one = torch.ones(1, dtype=torch.float64, device=dev if backend == "nccl" else "cpu")
+    dist.all_reduce(one, op=dist.ReduceOp.SUM)
+    seen = int(round(float(one.item())))
+    every = [None] * world
+    dist.all_gather_object(every, mine)
+    note = None
+    ok = seen == gpus
+    if not ok:
+        note = "the all-reduce saw %d rank(s), --gpus says %d" % (seen, gpus)
+    if backend == "nccl":
+        addr = [d["pci"] or d["uuid"] for d in every]
+        known = [a for a in addr if a]
+        if len(set(known)) < len(known):
+            ok = False
+            note = "two ranks of the RCCL group share a GPU: %s" % (addr,)
+    return {"ranks_seen": seen, "devices": every, "backend": backend, "ok": ok, "note": note}
 
 
 def bench_rows(opts, env):

@@ -112,6 +112,13 @@ int mxm_set_fused_coded_grid(int32_t nwg);
 int mxm_set_quad_left_grid(int32_t nwg);
 
 /*
+ * The marker build's launch for rows of 65 .. 128 observations (mxm_build_em_matrix_sparse / mxm_build_em_records; round 6):
+ * 1 (default) = they are built by the 128-bit instance of the marker kernel, 0 = they go to the fallback list like every
+ * row beyond 64 observations did before.  The same bits either way.
+ */
+int mxm_set_sparse_long_rows(int32_t on);
+
+/*
  * Restarts per pass over records beside a quad dictionary: 3 (default; em_iter_quad_batched_kernel takes full tiles of
  * three) or 1 (every restart its own pass, as before round 6).  Results differ by the rounding of another summation
  * order only.

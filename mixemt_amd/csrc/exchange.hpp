@@ -32,6 +32,11 @@
 #define MXM_EXCHANGE_THREADS 256
 #define MXM_EXCHANGE_MAX_GRID 64          // workgroups of a launch that both pushes and waits: all resident at once
 
+// spins are bounded by the wall clock (100 MHz): 3 s by default -- far beyond a straggler, short of a hang; the
+// environment's MXM_EXCHANGE_TIMEOUT_MS (read when an exchange is created) sets another bound, e.g. for a rank that is
+// being debugged or a host that stalls in a graph instantiation
+#define EXCHANGE_TIMEOUT_TICKS_DEFAULT 300000000ull
+
 struct exchange_header {
     unsigned long long epoch;
     unsigned int ticket;
@@ -49,6 +54,7 @@ struct mxm_exchange {
     size_t bytes = 0;
     unsigned char *own = nullptr;
     bool fine_grained = false;
+    unsigned long long timeout_ticks = EXCHANGE_TIMEOUT_TICKS_DEFAULT;
     exchange_peers peers;
     bool opened[MXM_EXCHANGE_MAX_WORLD];
     hipIpcMemHandle_t handle;
@@ -87,12 +93,11 @@ __global__ __launch_bounds__(MXM_EXCHANGE_THREADS) void exchange_push_kernel(exc
     }
 }
 
-// spins are bounded by the wall clock (100 MHz): EXCHANGE_TIMEOUT_TICKS = 3 s -- far beyond a straggler, short of a hang
-#define EXCHANGE_TIMEOUT_TICKS 300000000ull
 
 __global__ __launch_bounds__(MXM_EXCHANGE_THREADS) void exchange_pull_kernel(unsigned char *own_base, int world, long long cap,
                                                                             double *__restrict__ colsum, long long n,
-                                                                            mxm_em_state *__restrict__ state, int nb) {
+                                                                            mxm_em_state *__restrict__ state, int nb,
+                                                                            unsigned long long timeout_ticks) {
     __shared__ int s_late;
     exchange_header *own = reinterpret_cast<exchange_header *>(own_base);
     // the push before this kernel on the same stream has published the epoch
@@ -103,7 +108,7 @@ __global__ __launch_bounds__(MXM_EXCHANGE_THREADS) void exchange_pull_kernel(uns
     if ((int)threadIdx.x < world) {
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(&own->flags[parity][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
-            if (wall_clock64() - t0 > EXCHANGE_TIMEOUT_TICKS) {
+            if (wall_clock64() - t0 > timeout_ticks) {
                 s_late = 1;
                 break;
             }
@@ -128,7 +133,8 @@ __global__ __launch_bounds__(MXM_EXCHANGE_THREADS) void exchange_pull_kernel(uns
 // have to push off the chip.  One launch boundary (~4 us) less than push + pull.
 __global__ __launch_bounds__(MXM_EXCHANGE_THREADS) void exchange_reduce_kernel(exchange_peers peers, int world, int rank, long long cap,
                                                                               double *__restrict__ colsum, long long n,
-                                                                              mxm_em_state *__restrict__ state, int nb) {
+                                                                              mxm_em_state *__restrict__ state, int nb,
+                                                                              unsigned long long timeout_ticks) {
     __shared__ int s_late;
     unsigned char *own_base = peers.base[rank];
     exchange_header *own = reinterpret_cast<exchange_header *>(own_base);
@@ -158,7 +164,7 @@ __global__ __launch_bounds__(MXM_EXCHANGE_THREADS) void exchange_reduce_kernel(e
     if ((int)threadIdx.x < world) {
         const unsigned long long t0 = wall_clock64();
         while (__hip_atomic_load(&own->flags[parity][threadIdx.x], __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) < e) {
-            if (wall_clock64() - t0 > EXCHANGE_TIMEOUT_TICKS) {
+            if (wall_clock64() - t0 > timeout_ticks) {
                 s_late = 1;
                 break;
             }
@@ -197,24 +203,49 @@ extern "C" int mxm_exchange_create(int32_t world, int32_t rank, int64_t n_double
         x->opened[p] = false;
     }
     if (hipGetDevice(&x->device) != hipSuccess) x->device = 0;
-    void *ptr = nullptr;
-    // fine-grained where the runtime has it: peers write into this buffer while its owner's kernel spins on it
-    if (hipExtMallocWithFlags(&ptr, x->bytes, hipDeviceMallocFinegrained) == hipSuccess && ptr != nullptr) {
-        x->fine_grained = true;
-    } else {
-        (void)hipGetLastError();
-        if (hipMalloc(&ptr, x->bytes) != hipSuccess) {
+    if (const char *ms = getenv("MXM_EXCHANGE_TIMEOUT_MS")) {
+        const long long v = atoll(ms);
+        if (v > 0) x->timeout_ticks = (unsigned long long)v * 100000ull;            // the wall clock counts at 100 MHz
+    }
+    // fault injection for the tests of the fall-back (dist.OneShotExchange): MXM_EXCHANGE_FAIL_RANK = k makes rank k's
+    // create fail; MXM_EXCHANGE_REFUSE_FINE = 1 behaves as if the runtime refused to export the fine-grained buffer
+    if (const char *fr = getenv("MXM_EXCHANGE_FAIL_RANK")) {
+        if (fr[0] != '\0' && atoi(fr) == rank) {
             delete x;
-            return fail(-2, "mxm_exchange_create: cannot allocate %s%lld bytes", "", (long long)x->bytes);
+            return fail(-2, "mxm_exchange_create: failure injected on rank %s%lld (MXM_EXCHANGE_FAIL_RANK)", "", (long long)rank);
         }
     }
-    x->own = static_cast<unsigned char *>(ptr);
-    if (hipMemset(x->own, 0, x->bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess ||
-        hipIpcGetMemHandle(&x->handle, x->own) != hipSuccess) {
-        const int rc = fail(-2, "mxm_exchange_create: %s", hipGetErrorString(hipGetLastError()));
-        (void)hipFree(x->own);
-        delete x;
-        return rc;
+    const char *rf = getenv("MXM_EXCHANGE_REFUSE_FINE");
+    const bool refuse_fine = rf != nullptr && rf[0] == '1';
+    // fine-grained where the runtime has it (peers write into this buffer while its owner's kernel spins on it) AND lets it
+    // be exported; otherwise ordinary device memory -- the kernels' system-scope stores / acquire loads are what the
+    // protocol rests on either way (mxm_exchange_info says which one it got)
+    const size_t bytes = x->bytes;
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        void *ptr = nullptr;
+        const bool fine = attempt == 0;
+        hipError_t e = fine ? hipExtMallocWithFlags(&ptr, bytes, hipDeviceMallocFinegrained) : hipMalloc(&ptr, bytes);
+        if (e != hipSuccess || ptr == nullptr) {
+            (void)hipGetLastError();
+            if (fine) continue;
+            delete x;
+            return fail(-2, "mxm_exchange_create: cannot allocate %s%lld bytes", "", (long long)bytes);
+        }
+        e = hipMemset(ptr, 0, bytes);
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        if (e == hipSuccess) e = (fine && refuse_fine) ? hipErrorInvalidValue : hipIpcGetMemHandle(&x->handle, ptr);
+        if (e == hipSuccess) {
+            x->own = static_cast<unsigned char *>(ptr);
+            x->fine_grained = fine;
+            break;
+        }
+        (void)hipGetLastError();
+        (void)hipFree(ptr);
+        if (!fine) {
+            const int rc = fail(-2, "mxm_exchange_create: %s", hipGetErrorString(e));
+            delete x;
+            return rc;
+        }
     }
     x->peers.base[rank] = x->own;
     memcpy(handle_out, &x->handle, sizeof(hipIpcMemHandle_t));
@@ -261,7 +292,7 @@ extern "C" int mxm_exchange_pull(mxm_exchange *x, double *colsum, int64_t n, mxm
     if (grid < 1) grid = 1;
     if (grid > 64) grid = 64;
     hipLaunchKernelGGL(exchange_pull_kernel, dim3(grid), dim3(MXM_EXCHANGE_THREADS), 0, (hipStream_t)stream, x->own, x->world,
-                       x->cap, colsum, (long long)n, state, (int)nb);
+                       x->cap, colsum, (long long)n, state, (int)nb, x->timeout_ticks);
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -275,7 +306,7 @@ extern "C" int mxm_exchange_reduce(mxm_exchange *x, double *colsum, int64_t n, m
     if (grid < 1) grid = 1;
     if (grid > MXM_EXCHANGE_MAX_GRID) grid = MXM_EXCHANGE_MAX_GRID;
     hipLaunchKernelGGL(exchange_reduce_kernel, dim3(grid), dim3(MXM_EXCHANGE_THREADS), 0, (hipStream_t)stream, x->peers, x->world,
-                       x->rank, x->cap, colsum, (long long)n, state, (int)nb);
+                       x->rank, x->cap, colsum, (long long)n, state, (int)nb, x->timeout_ticks);
     HIP_TRY(hipGetLastError());
     return 0;
 }

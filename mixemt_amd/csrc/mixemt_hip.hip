@@ -32,6 +32,7 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdio.h>
+#include <stdlib.h>
 #include <string.h>
 #include <math.h>
 #include <algorithm>
@@ -84,6 +85,7 @@ struct mxm_tuning {
     int fused_cols = 1;             // matrices of up to 1536 rows take the transposed form (columns split)
     int fused_coded_wg = 0;         // workgroups of the one-launch loop over records (0 = by size)
     int quad_left_wg = 0;           // workgroups of the leftover pass beside the quad pass (0 = by the rows' measured cost)
+    int sparse_long = 1;            // the marker build's second launch for rows of 65 .. 128 observations (0: they go to the fallback list)
     int coded_bt = 3;               // restarts per pass over records beside a quad dictionary (1 = one per pass, 3 = the batched kernel)
     int fused_force_abort = 0;      // test hook: the one-launch loop starts with its abort flag raised (as if starved)
     double fused_cells = 1.0e8;     // ~18 000 rows at H = 5408: measured break-even is ~30 000 rows (profiles/r02/small_runs.txt)
@@ -341,24 +343,51 @@ static int build_sparse_impl(const char *who, const uint8_t *maj, const double *
     // 3 ranges 10.5 ms (6 rows; 12.4 when compiled for 5), 4 ranges 11.2-12.4 ms (profiles/r03/build_kernel_experiments.txt)
     const int passes = SPB_PASSES;
     const int maxd = (T.sparse_maxd < 0 || T.sparse_maxd > SPB_MAXD) ? SPB_MAXD : T.sparse_maxd;
+    const int maxd_long = (T.sparse_maxd < 0 || T.sparse_maxd > SPB_MAXD_LONG) ? SPB_MAXD_LONG : T.sparse_maxd;
     const int kpp = (nch + passes - 1) / passes;
     const size_t lds = (size_t)kpp * 2 * SPB_THREADS * 8 + SPB_SLOTS * 8 + 6 * 1024;      // mask array + table + the kernel's other LDS
     int per_cu = (int)((160 * 1024) / lds);
     if (per_cu > 8) per_cu = 8;
     if (per_cu < 1) per_cu = 1;
     const int grid = clamp_grid(R, num_cu() * per_cu * 2);
+    const int long_too = T.sparse_long;                  // (0: rows beyond 64 observations go to the fallback list, as before round 6)
+    const int grid_long = clamp_grid((R + SPB_LONG_CHUNK - 1) / SPB_LONG_CHUNK, num_cu() * 4 * 2);
     spb_records none = {};
     const spb_records rec = out != nullptr ? *out : none;
-#define SPB_LAUNCH(n, p) do { if (out != nullptr) hipLaunchKernelGGL((build_sparse_kernel<n, p, true>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), maxd, rec); \
-                          else hipLaunchKernelGGL((build_sparse_kernel<n, p, false>), dim3(grid), dim3(SPB_THREADS), 0, s, maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), maxd, rec); } while (0)
-#define SPB_CASE(n) case n: if (passes == 1) { if constexpr (n <= 7) SPB_LAUNCH(n, 1); else return fail(-1, "%s: one pass covers H <= 3584", who); } else if (passes == 2) SPB_LAUNCH(n, 2); else if (passes == 3) SPB_LAUNCH(n, 3); else SPB_LAUNCH(n, 4); break;
+#define SPB_ARGS maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), maxd, rec
+#define SPB_LAUNCH(n, p) do { if (out != nullptr) hipLaunchKernelGGL((build_sparse_kernel<n, p, true, 1>), dim3(grid), dim3(SPB_THREADS), 0, s, SPB_ARGS, long_too); \
+                          else hipLaunchKernelGGL((build_sparse_kernel<n, p, false, 1>), dim3(grid), dim3(SPB_THREADS), 0, s, SPB_ARGS, long_too); } while (0)
+    // (only the instances of the column-range count this build runs with are compiled: the other three quarters of them
+    // were a third of the library's build time)
+#define SPB_CASE(n) case n: if constexpr (SPB_PASSES == 1) { if constexpr (n <= 7) SPB_LAUNCH(n, 1); else return fail(-1, "%s: one pass covers H <= 3584", who); } else if constexpr (SPB_PASSES == 2) SPB_LAUNCH(n, 2); else if constexpr (SPB_PASSES == 3) SPB_LAUNCH(n, 3); else SPB_LAUNCH(n, 4); break;
     switch (nch) {
         SPB_CASE(1) SPB_CASE(2) SPB_CASE(3) SPB_CASE(4) SPB_CASE(5) SPB_CASE(6) SPB_CASE(7) SPB_CASE(8)
         SPB_CASE(9) SPB_CASE(10) SPB_CASE(11) SPB_CASE(12) SPB_CASE(13) SPB_CASE(14) SPB_CASE(15) SPB_CASE(16)
         default: return fail(-1, "%s: H=%lld outside the kernel's range", who, H);
     }
+    HIP_TRY(hipGetLastError());
+    if (long_too != 0) {
+        // the rows of 65 .. 128 observations (merged mates, long reads): 128-bit masks, one column range per 512 haplogroups
+        // and a table of 1024 slots (build_sparse_kernels.hpp, W = 2); its grid looks at the rows 64 at a time
+#define SPB_ARGS_LONG maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), maxd_long, rec
+#define SPB_LONG(n, p) case n: if (out != nullptr) hipLaunchKernelGGL((build_sparse_kernel<n, p, true, 2>), dim3(grid_long), dim3(SPB_THREADS), 0, s, SPB_ARGS_LONG, 0); \
+                               else hipLaunchKernelGGL((build_sparse_kernel<n, p, false, 2>), dim3(grid_long), dim3(SPB_THREADS), 0, s, SPB_ARGS_LONG, 0); break;
+        switch (nch) {
+#ifndef SPB_LONG_KPP
+#define SPB_LONG_KPP 1                // 512-haplogroup chunks per column range of the long rows' instance
+#endif
+#define SPB_LP(n) SPB_LONG(n, ((n + SPB_LONG_KPP - 1) / SPB_LONG_KPP))
+            SPB_LP(1) SPB_LP(2) SPB_LP(3) SPB_LP(4) SPB_LP(5) SPB_LP(6) SPB_LP(7) SPB_LP(8)
+            SPB_LP(9) SPB_LP(10) SPB_LP(11) SPB_LP(12) SPB_LP(13) SPB_LP(14) SPB_LP(15) SPB_LP(16)
+#undef SPB_LP
+            default: break;
+        }
+#undef SPB_LONG
+#undef SPB_ARGS_LONG
+    }
 #undef SPB_CASE
 #undef SPB_LAUNCH
+#undef SPB_ARGS
     HIP_TRY(hipGetLastError());
     return 0;
 }
@@ -464,6 +493,9 @@ extern "C" int mxm_set_fused_coded_grid(int32_t nwg) {
     return tune_set([nwg](mxm_tuning &t) { t.fused_coded_wg = nwg > 0 ? nwg : 0; });
 }
 
+extern "C" int mxm_set_sparse_long_rows(int32_t on) {
+    return tune_set([on](mxm_tuning &t) { t.sparse_long = on ? 1 : 0; });
+}
 extern "C" int mxm_set_coded_batch_tile(int32_t bt) {
     if (bt != 1 && bt != 3) return fail(-1, "mxm_set_coded_batch_tile: 1 or 3, got %s%lld", "", bt);
     return tune_set([bt](mxm_tuning &t) { t.coded_bt = bt; });

@@ -81,6 +81,21 @@ def broadcast_inits(n_runs, n_haps, alpha, device, group=None, src=0):
     return buf.cpu().numpy()
 
 
+class ExchangeUnavailable(RuntimeError):
+    """The one-shot exchange could not be set up on at least one rank; EVERY rank of the group raises this together
+    (the outcome of create / connect is agreed with a MIN all-reduce), so a caller may fall back to the all-reduce."""
+
+
+def _agree(ok, group, device):
+    """True iff `ok` holds on every rank of the group (one tiny MIN all-reduce; every rank must call it)."""
+    if not _collective(group):
+        return bool(ok)
+    on_gpu = dist.get_backend(group) == "nccl"
+    flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=device if on_gpu else "cpu")
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=group)
+    return bool(int(flag.item()))
+
+
 class OneShotExchange(object):
     """
     The library's one-shot exchange (include/mixemt_hip.h, mxm_exchange_*; csrc/exchange.hpp) for a process group: every
@@ -88,6 +103,12 @@ class OneShotExchange(object):
     reduce(colsum, state): push + pull on the current stream -- colsum becomes the sum over the ranks in rank order, the
     same bits everywhere.  Opt-in: sharded_em_loop(exchange="oneshot"); RCCL's all-reduce is the default.  Exercised with
     several processes on one GPU; UNMEASURED over xGMI.
+    Setting it up cannot leave the group half way (round 6): a rank whose mxm_exchange_create / _connect fails does not
+    raise on its own while its peers wait in a collective -- after each of the two steps all ranks agree on the outcome
+    (MIN all-reduce) and, if any failed, ALL release what they hold and raise ExchangeUnavailable (sharded_em_loop then
+    warns and uses the all-reduce).  The library itself retries with ordinary device memory when the runtime will not
+    export a fine-grained buffer (`fine_grained` says which one it got).  A pull waits at most 3 s for a peer
+    (MXM_EXCHANGE_TIMEOUT_MS in the environment sets another bound), then poisons the sums and raises error 2.
     """
 
     def __init__(self, n_doubles, group=None, split=False):
@@ -95,23 +116,39 @@ class OneShotExchange(object):
         self.split = bool(split)
         from . import _lib
         self.lib = _lib.load()
+        self.handle = None
         rank, world = _world(group)
         self.rank, self.world = rank, world
+        dev = require_gpu()
         hb = int(self.lib.mxm_exchange_handle_bytes())
         mine = ctypes.create_string_buffer(hb)
         handle = ctypes.c_void_p()
-        _lib.check(self.lib.mxm_exchange_create(world, rank, int(n_doubles), ctypes.byref(handle), mine), "mxm_exchange_create")
-        self.handle = handle
+        rc = self.lib.mxm_exchange_create(world, rank, int(n_doubles), ctypes.byref(handle), mine)
+        why = self.lib.mxm_last_error().decode("utf-8", "replace") if rc != 0 else ""
+        if rc == 0:
+            self.handle = handle
+        if not _agree(rc == 0, group, dev):
+            self.close()
+            raise ExchangeUnavailable("one-shot exchange: mxm_exchange_create failed on %s" % ("this rank (%d): %s" % (rank, why) if rc != 0 else "another rank"))
         every = [None] * world
         if world > 1:
             dist.all_gather_object(every, bytes(mine.raw), group=group)
         else:
             every = [bytes(mine.raw)]
         blob = ctypes.create_string_buffer(b"".join(every), hb * world)
-        _lib.check(self.lib.mxm_exchange_connect(handle, blob), "mxm_exchange_connect")
+        rc = self.lib.mxm_exchange_connect(handle, blob)
+        why = self.lib.mxm_last_error().decode("utf-8", "replace") if rc != 0 else ""
+        if not _agree(rc == 0, group, dev):
+            if world > 1:
+                dist.barrier(group=group)              # (nobody unmaps a buffer a peer is still mapping)
+            self.close()
+            raise ExchangeUnavailable("one-shot exchange: mxm_exchange_connect failed on %s" % ("this rank (%d): %s" % (rank, why) if rc != 0 else "another rank"))
         if world > 1:
             dist.barrier(group=group)                  # nobody pushes into a buffer its owner has not finished setting up
         self.n_doubles = int(n_doubles)
+        fine, nbytes = ctypes.c_int32(0), ctypes.c_int64(0)
+        self.lib.mxm_exchange_info(handle, ctypes.byref(fine), ctypes.byref(nbytes))
+        self.fine_grained, self.bytes = bool(fine.value), int(nbytes.value)
 
     def reduce(self, colsum, state=None):
         from . import _lib
@@ -184,149 +221,184 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
     one-shot exchange (OneShotExchange: every rank writes its sums into every rank's buffer, each sums them in rank order;
     kernels only, so a burst is capturable whatever the group's backend) -- an OneShotExchange may also be passed in, to be
     reused over several loops.  Opt-in; exercised with several processes on one GPU, unmeasured over xGMI.
+    If the exchange cannot be set up on ANY rank (hipIpc refused, a device without peer access), every rank falls back to
+    the all-reduce together, with a RuntimeWarning (OneShotExchange / ExchangeUnavailable; sharded_em_loop.last_exchange
+    says which one ran).  A pull waits at most 3 s for a peer's sums before it poisons them and the loop raises
+    (MXM_EXCHANGE_TIMEOUT_MS in the environment, read when the exchange is created, sets another bound -- a rank under a
+    debugger, a host stalled in a graph instantiation); an exchange this call created is released on every exit, after
+    draining the stream and a bounded wait for the peers.
     """
     oneshot, own_exchange = None, False
     if exchange == "oneshot":
         if not hasattr(plan, "lib"):
             raise ValueError("the one-shot exchange needs a device plan")
-        oneshot = OneShotExchange(int(numpy.asarray(inits).shape[0]) * int(numpy.asarray(inits).shape[1]), group)
-        own_exchange = True
+        try:
+            oneshot = OneShotExchange(int(numpy.asarray(inits).shape[0]) * int(numpy.asarray(inits).shape[1]), group)
+            own_exchange = True
+        except ExchangeUnavailable as exc:             # raised on EVERY rank together: all take the all-reduce instead
+            warnings.warn("sharded EM loop: %s; using the group's all-reduce" % (exc,), RuntimeWarning, stacklevel=2)
+            exchange = "rccl"
+        sharded_em_loop.last_exchange = "oneshot" if oneshot is not None else "rccl (one-shot exchange unavailable)"
     elif isinstance(exchange, OneShotExchange):
         oneshot = exchange
-    elif exchange != "rccl":
+    if exchange != "rccl" and oneshot is None:
         raise ValueError("exchange must be 'rccl', 'oneshot' or an OneShotExchange")
     grouped = _collective(group)                       # a process group exists: decisions are agreed over it
     exchange = grouped or oneshot is not None
-    # This loop always runs the per-iteration kernels (the exchange sits between the row pass and the finalize), so over
-    # records a quad dictionary has no one-launch loop to beat and pays from far fewer rows than in run_em's own loop
-    # (em.EmPlan.attach_quads; SHARD_QUADS_MIN_ROWS byte-coded rows in the shard)
-    if getattr(plan, "coded", None) is not None and hasattr(plan, "attach_quads") and _em.QUADS == "auto":
-        plan.attach_quads("auto", min_rows=SHARD_QUADS_MIN_ROWS)
-    ln0, p0 = _em.log_inits(inits)
-    n_runs = ln0.shape[0]
-    if window is None:
-        window = plan.restart_tile() if (compact and hasattr(plan, "restart_tile")) else n_runs
-    window = max(1, int(window))
-    props_cur = plan.alloc_props(p0)
-    ln_cur = plan.alloc_props(ln0)
-    ln_new = plan.alloc_props(ln0)
-    colsum = plan.alloc_props(numpy.zeros_like(ln0))
-    state = plan.alloc_state(n_runs).view(n_runs, -1)          # one row per restart
-    vectors = (props_cur, ln_cur, ln_new, colsum, state)
-    slot_run = list(range(n_runs))                             # slot -> caller's run index
-    states = plan.read_state(state)
-    if max_iter <= 0:
-        if own_exchange:
+    try:
+        # This loop always runs the per-iteration kernels (the exchange sits between the row pass and the finalize), so over
+        # records a quad dictionary has no one-launch loop to beat and pays from far fewer rows than in run_em's own loop
+        # (em.EmPlan.attach_quads; SHARD_QUADS_MIN_ROWS byte-coded rows in the shard)
+        if getattr(plan, "coded", None) is not None and hasattr(plan, "attach_quads") and _em.QUADS == "auto":
+            plan.attach_quads("auto", min_rows=SHARD_QUADS_MIN_ROWS)
+        ln0, p0 = _em.log_inits(inits)
+        n_runs = ln0.shape[0]
+        if window is None:
+            window = plan.restart_tile() if (compact and hasattr(plan, "restart_tile")) else n_runs
+        window = max(1, int(window))
+        props_cur = plan.alloc_props(p0)
+        ln_cur = plan.alloc_props(ln0)
+        ln_new = plan.alloc_props(ln0)
+        colsum = plan.alloc_props(numpy.zeros_like(ln0))
+        state = plan.alloc_state(n_runs).view(n_runs, -1)          # one row per restart
+        vectors = (props_cur, ln_cur, ln_new, colsum, state)
+        slot_run = list(range(n_runs))                             # slot -> caller's run index
+        states = plan.read_state(state)
+        if max_iter <= 0:
+            if own_exchange:
+                oneshot.close()
+            return ln_cur, ln_new, states
+        first = True
+        eager_bursts = 0                                   # graph="auto" takes its decision from the second eager burst
+        captured = None                                    # None: nothing captured yet; False: capture refused; (lead, graph)
+        graph_bursts = 0
+        sharded_em_loop.last_issue_share = None
+        sharded_em_loop.last_issue_burst = None
+        # The loop ends when `finalize` has marked every restart done (converged, or at its own max_iter).  A plan whose
+        # finalize never does that must not spin for ever: a restart needs at most ceil(max_iter / check_every) bursts, and
+        # at most ceil(n_runs / window) groups of restarts take turns.
+        bursts_left = -(-n_runs // window) * (-(-int(max_iter) // int(check_every)) + 1) + 1
+        while True:
+            running = [s for s in range(n_runs) if states[s][0] == 0]        # slot order = round-robin order
+            if not running:
+                break
+            bursts_left -= 1
+            if bursts_left < 0:
+                raise RuntimeError("sharded EM loop: restarts %s are still running after every burst max_iter=%d allows "
+                                   "(the plan's finalize() must stop a restart at its max_iter)"
+                                   % ([slot_run[s] for s in running], max_iter))
+            lead = min(len(running), window) if compact else n_runs
+            if compact:
+                # one full tile per iteration, dealt round-robin chunk by chunk: the tile that just ran goes
+                # to the back of the queue, so all restarts advance at the same rate and every pass over the
+                # shard carries a full tile until fewer than a tile's worth are left (as mxm_em_loop does)
+                if not first and len(running) > window:
+                    was = [s for s in range(window) if states[s][0] == 0]   # the tile that just ran, still running
+                    rest = [s for s in running if s >= window]
+                    running = rest + was
+                order = running + [s for s in range(n_runs) if states[s][0] != 0]
+                if order != list(range(n_runs)):
+                    idx = torch.as_tensor(order, device=props_cur.device)
+                    for vec in vectors:
+                        vec.copy_(vec[idx])
+                    slot_run = [slot_run[s] for s in order]
+                    states = [states[s] for s in order]
+            def burst():
+                for _ in range(check_every):
+                    plan.em_iter(props_cur[:lead], ln_cur[:lead], state[:lead], colsum[:lead])
+                    if oneshot is not None:
+                        oneshot.reduce(colsum[:lead], state[:lead])
+                    elif exchange:
+                        dist.all_reduce(colsum[:lead], op=dist.ReduceOp.SUM, group=group)
+                    plan.finalize(colsum[:lead], ln_cur[:lead], ln_new[:lead], props_cur[:lead], state[:lead],
+                                  tolerance, max_iter)
+
+            use_graph = (graph is True and not first and captured is not False and props_cur.is_cuda
+                         and (not exchange or oneshot is not None or dist.get_backend(group) == "nccl"))
+            if use_graph and (captured is None or captured[0] != lead):
+                # (re)capture: the burst's launches are recorded, not run; a failure leaves the loop eager for good
+                # (ADVICE r3) only what a refused CAPTURE raises is taken as "not capturable here" -- torch reports those as
+                # RuntimeError (hipErrorStreamCapture*), RCCL as DistBackendError (a RuntimeError); argument / library errors
+                # of the plan (ValueError from _lib.check) are real and propagate.  The fallback is logged once.
+                try:
+                    torch.cuda.synchronize()
+                    cg = torch.cuda.CUDAGraph()
+                    with torch.cuda.graph(cg, capture_error_mode="thread_local"):
+                        burst()
+                    captured = (lead, cg, _burst_ptrs(vectors, plan))
+                except RuntimeError as exc:
+                    captured = False
+                    torch.cuda.synchronize()
+                    warnings.warn("sharded EM loop: hipGraph capture of a burst was refused (%s); staying eager" % (exc,),
+                                  RuntimeWarning, stacklevel=2)
+            first = False
+            if use_graph and captured:
+                # a captured burst replays raw pointers: the loop vectors and the plan's buffers must still be the ones
+                # it recorded (they are never reallocated inside this loop; this makes the convention a check)
+                if captured[2] != _burst_ptrs(vectors, plan):
+                    raise RuntimeError("sharded EM loop: a buffer of the captured burst was reallocated between bursts")
+                captured[1].replay()
+                graph_bursts += 1
+                states = plan.read_state(state)
+            else:
+                t_burst = time.perf_counter()
+                burst()
+                t_issue = time.perf_counter() - t_burst
+                states = plan.read_state(state)                  # (synchronises: the burst's state is back)
+                t_wall = time.perf_counter() - t_burst
+                eager_bursts += 1
+                if eager_bursts == 2 and graph == "auto":
+                    share = t_issue / max(t_wall, 1e-9)
+                    if grouped:                                  # one decision for all ranks
+                        agreed = torch.tensor([share], dtype=torch.float64, device=props_cur.device)
+                        dist.all_reduce(agreed, op=dist.ReduceOp.MAX, group=group)
+                        share = float(agreed.item())
+                    graph = bool(share > GRAPH_AUTO_ISSUE_SHARE and props_cur.is_cuda
+                                 and (not grouped or oneshot is not None or dist.get_backend(group) == "nccl"))
+                    sharded_em_loop.last_issue_share = share
+                    sharded_em_loop.last_issue_burst = eager_bursts
+            if grouped and verify:
+                _assert_ranks_agree(states, props_cur.device, group)
+        if slot_run != list(range(n_runs)):                        # back to the caller's run order
+            back = [0] * n_runs
+            for slot, run in enumerate(slot_run):
+                back[run] = slot
+            idx = torch.as_tensor(back, device=props_cur.device)
+            for vec in vectors:
+                vec.copy_(vec[idx])
+            states = [states[s] for s in back]
+        sharded_em_loop.last_graph_bursts = graph_bursts
+        if own_exchange:                                   # made here: unmapped here, once every rank is through its last pull
+            torch.cuda.synchronize()
+            if grouped:
+                dist.barrier(group=group)
             oneshot.close()
         return ln_cur, ln_new, states
-    first = True
-    eager_bursts = 0                                   # graph="auto" takes its decision from the second eager burst
-    captured = None                                    # None: nothing captured yet; False: capture refused; (lead, graph)
-    graph_bursts = 0
-    sharded_em_loop.last_issue_share = None
-    sharded_em_loop.last_issue_burst = None
-    # The loop ends when `finalize` has marked every restart done (converged, or at its own max_iter).  A plan whose
-    # finalize never does that must not spin for ever: a restart needs at most ceil(max_iter / check_every) bursts, and
-    # at most ceil(n_runs / window) groups of restarts take turns.
-    bursts_left = -(-n_runs // window) * (-(-int(max_iter) // int(check_every)) + 1) + 1
-    while True:
-        running = [s for s in range(n_runs) if states[s][0] == 0]        # slot order = round-robin order
-        if not running:
-            break
-        bursts_left -= 1
-        if bursts_left < 0:
-            raise RuntimeError("sharded EM loop: restarts %s are still running after every burst max_iter=%d allows "
-                               "(the plan's finalize() must stop a restart at its max_iter)"
-                               % ([slot_run[s] for s in running], max_iter))
-        lead = min(len(running), window) if compact else n_runs
-        if compact:
-            # one full tile per iteration, dealt round-robin chunk by chunk: the tile that just ran goes
-            # to the back of the queue, so all restarts advance at the same rate and every pass over the
-            # shard carries a full tile until fewer than a tile's worth are left (as mxm_em_loop does)
-            if not first and len(running) > window:
-                was = [s for s in range(window) if states[s][0] == 0]   # the tile that just ran, still running
-                rest = [s for s in running if s >= window]
-                running = rest + was
-            order = running + [s for s in range(n_runs) if states[s][0] != 0]
-            if order != list(range(n_runs)):
-                idx = torch.as_tensor(order, device=props_cur.device)
-                for vec in vectors:
-                    vec.copy_(vec[idx])
-                slot_run = [slot_run[s] for s in order]
-                states = [states[s] for s in order]
-        def burst():
-            for _ in range(check_every):
-                plan.em_iter(props_cur[:lead], ln_cur[:lead], state[:lead], colsum[:lead])
-                if oneshot is not None:
-                    oneshot.reduce(colsum[:lead], state[:lead])
-                elif exchange:
-                    dist.all_reduce(colsum[:lead], op=dist.ReduceOp.SUM, group=group)
-                plan.finalize(colsum[:lead], ln_cur[:lead], ln_new[:lead], props_cur[:lead], state[:lead],
-                              tolerance, max_iter)
+    except BaseException:
+        # (ADVICE r5) an exchange made here is never left to __del__: that would unmap this rank's buffer, with no
+        # barrier, while peers may still push into it -- a fault on THEIR side.  Best effort: drain this rank's stream,
+        # meet the peers if they can still be met (bounded), then release.
+        if own_exchange and oneshot is not None:
+            _release_exchange(oneshot, grouped, group)
+        raise
 
-        use_graph = (graph is True and not first and captured is not False and props_cur.is_cuda
-                     and (not exchange or oneshot is not None or dist.get_backend(group) == "nccl"))
-        if use_graph and (captured is None or captured[0] != lead):
-            # (re)capture: the burst's launches are recorded, not run; a failure leaves the loop eager for good
-            # (ADVICE r3) only what a refused CAPTURE raises is taken as "not capturable here" -- torch reports those as
-            # RuntimeError (hipErrorStreamCapture*), RCCL as DistBackendError (a RuntimeError); argument / library errors
-            # of the plan (ValueError from _lib.check) are real and propagate.  The fallback is logged once.
-            try:
-                torch.cuda.synchronize()
-                cg = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(cg, capture_error_mode="thread_local"):
-                    burst()
-                captured = (lead, cg, _burst_ptrs(vectors, plan))
-            except RuntimeError as exc:
-                captured = False
-                torch.cuda.synchronize()
-                warnings.warn("sharded EM loop: hipGraph capture of a burst was refused (%s); staying eager" % (exc,),
-                              RuntimeWarning, stacklevel=2)
-        first = False
-        if use_graph and captured:
-            # a captured burst replays raw pointers: the loop vectors and the plan's buffers must still be the ones
-            # it recorded (they are never reallocated inside this loop; this makes the convention a check)
-            if captured[2] != _burst_ptrs(vectors, plan):
-                raise RuntimeError("sharded EM loop: a buffer of the captured burst was reallocated between bursts")
-            captured[1].replay()
-            graph_bursts += 1
-            states = plan.read_state(state)
-        else:
-            t_burst = time.perf_counter()
-            burst()
-            t_issue = time.perf_counter() - t_burst
-            states = plan.read_state(state)                  # (synchronises: the burst's state is back)
-            t_wall = time.perf_counter() - t_burst
-            eager_bursts += 1
-            if eager_bursts == 2 and graph == "auto":
-                share = t_issue / max(t_wall, 1e-9)
-                if grouped:                                  # one decision for all ranks
-                    agreed = torch.tensor([share], dtype=torch.float64, device=props_cur.device)
-                    dist.all_reduce(agreed, op=dist.ReduceOp.MAX, group=group)
-                    share = float(agreed.item())
-                graph = bool(share > GRAPH_AUTO_ISSUE_SHARE and props_cur.is_cuda
-                             and (not grouped or oneshot is not None or dist.get_backend(group) == "nccl"))
-                sharded_em_loop.last_issue_share = share
-                sharded_em_loop.last_issue_burst = eager_bursts
-        if grouped and verify:
-            _assert_ranks_agree(states, props_cur.device, group)
-    if slot_run != list(range(n_runs)):                        # back to the caller's run order
-        back = [0] * n_runs
-        for slot, run in enumerate(slot_run):
-            back[run] = slot
-        idx = torch.as_tensor(back, device=props_cur.device)
-        for vec in vectors:
-            vec.copy_(vec[idx])
-        states = [states[s] for s in back]
-    sharded_em_loop.last_graph_bursts = graph_bursts
-    if own_exchange:                                   # made here: unmapped here, once every rank is through its last pull
+
+def _release_exchange(oneshot, grouped, group, seconds=5.0):
+    import datetime
+    try:
         torch.cuda.synchronize()
-        if grouped:
-            dist.barrier(group=group)
-        oneshot.close()
-    return ln_cur, ln_new, states
+    except Exception:
+        pass
+    if grouped:
+        try:
+            work = dist.barrier(group=group, async_op=True)
+            work.wait(timeout=datetime.timedelta(seconds=seconds))
+        except Exception:
+            pass
+    oneshot.close()
 
 
+sharded_em_loop.last_exchange = None         # "oneshot" / "rccl (one-shot exchange unavailable)" when the last call asked for the one-shot exchange
 sharded_em_loop.last_graph_bursts = 0        # bursts the last call replayed from a captured graph (diagnostic)
 sharded_em_loop.last_issue_share = None      # graph="auto": host enqueue time / wall time of the burst it decided on (max over ranks)
 sharded_em_loop.last_issue_burst = None      # ... which eager burst that was (2: the first warm one); None = the loop ended before

@@ -605,12 +605,18 @@ REST_SLAB_BYTES = 2 << 30             # (46 000 rows at 5408 columns: one slab a
                                       # host read-back of its byte count, so fewer, larger slabs: 8192 rows cost 41 round trips at 10^7)
 
 
-def record_buffer_bytes(n_rows, n_haps):
-    """Size of the record buffer build_em_records_device asks for first (a guess; an overflow repeats the build once)."""
+def record_buffer_bytes(n_rows, n_haps, mean_sites=None):
+    """Size of the record buffer build_em_records_device asks for first (a guess; an overflow repeats the build once).
+    mean_sites: observed sites per row, when known -- a row's distinct values grow with them (37 sites: 61 table entries'
+    worth of bytes per row, wide records included; 72 sites, merged mates: ~150), so longer rows get more room at once
+    instead of paying for the build twice."""
     ldc = (n_haps + 7) // 8 * 8
     one = 2 * ldc + 16 * 1024
     worst = int(n_rows) * one
-    return max(one, min(worst, int(n_rows) * (ldc + RECORD_BYTES_GUESS) + (1 << 20)))
+    guess = RECORD_BYTES_GUESS
+    if mean_sites is not None and mean_sites > 40.0:
+        guess = int(RECORD_BYTES_GUESS * (mean_sites / 40.0) ** 1.5) // 16 * 16
+    return max(one, min(worst, int(n_rows) * (ldc + guess) + (1 << 20)))
 
 
 def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, rec=None):
@@ -651,7 +657,7 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
     if rec is not None:
         cap = rec.numel()
     elif cap is None:
-        cap = record_buffer_bytes(n_rows, n_haps)
+        cap = record_buffer_bytes(n_rows, n_haps, mean_sites=site_d.numel() / float(n_rows))
     cap = max(int(cap), one)
     mat = device_empty((n_rows, n_haps), torch.float64, dev, "the EM input matrix") if dense else None
     rec_off = torch.empty(n_rows, dtype=torch.int64, device=dev)

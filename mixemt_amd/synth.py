@@ -66,16 +66,77 @@ def synth_reads(tables, ref_len, n_reads, seed=1, contrib=DEFAULT_CONTRIB,
     return row_ptr, site.astype(numpy.uint16), obs, who
 
 
+def synth_pairs(tables, ref_len, n_frag, seed=1, contrib=DEFAULT_CONTRIB, props=DEFAULT_PROPS, read_len=READ_LEN,
+                insert=(350, 500), err=ERR_RATE):
+    """
+    synth-pe-v1 (round 6): paired-end FRAGMENTS as matrix rows -- two reads of `read_len` bp at the ends of an insert of
+    insert[0] .. insert[1] bp (outer distance, uniform), merged into ONE row as the reference merges mates
+    (preprocess.py:118-138: one observation dict per query name): the row observes every variant site under either
+    read, in ascending position.  With 2 x 150 bp and inserts of 350-500 the mates do not overlap, so no site is seen
+    twice; a row holds ~74 sites on Build 17, two thirds of the rows more than 64.
+    Draw order (the definition, rng = numpy.random.default_rng(seed)):
+        1. contributor per fragment        rng.choice(len(props), R, p=props)
+        2. start per fragment              rng.integers(0, ref_len - insert[1], R)
+        3. insert per fragment             rng.integers(insert[0], insert[1] + 1, R)
+           (fragments covering no site: start and insert redrawn, all of them at once, until none)
+        4. error flag per observation      rng.random(nnz) < err
+        5. substitution offset per obs.    rng.integers(1, 4, nnz)
+    -> (row_ptr[R+1] int64, site[nnz] uint16, obs[nnz] uint8, who[R] int64) like synth_reads.
+    """
+    if insert[0] < 2 * read_len:
+        raise ValueError("synth_pairs: overlapping mates are not modelled (insert[0] >= 2 * read_len)")
+    rng = numpy.random.default_rng(seed)
+    sites = tables.sites
+    who = rng.choice(len(props), size=n_frag, p=numpy.asarray(props, dtype=float))
+    start = rng.integers(0, ref_len - insert[1], size=n_frag)
+    size = rng.integers(insert[0], insert[1] + 1, size=n_frag)
+
+    def windows(st, sz):
+        lo1 = numpy.searchsorted(sites, st, side="left")
+        hi1 = numpy.searchsorted(sites, st + read_len, side="left")
+        lo2 = numpy.searchsorted(sites, st + sz - read_len, side="left")
+        hi2 = numpy.searchsorted(sites, st + sz, side="left")
+        return lo1, hi1, lo2, hi2
+
+    lo1, hi1, lo2, hi2 = windows(start, size)
+    empty = numpy.flatnonzero((hi1 - lo1) + (hi2 - lo2) == 0)
+    while empty.size:
+        start[empty] = rng.integers(0, ref_len - insert[1], size=empty.size)
+        size[empty] = rng.integers(insert[0], insert[1] + 1, size=empty.size)
+        a, b, c, d = windows(start[empty], size[empty])
+        lo1[empty], hi1[empty], lo2[empty], hi2[empty] = a, b, c, d
+        empty = empty[(b - a) + (d - c) == 0]
+    n1 = (hi1 - lo1).astype(numpy.int64)
+    counts = n1 + (hi2 - lo2).astype(numpy.int64)
+    row_ptr = numpy.zeros(n_frag + 1, dtype=numpy.int64)
+    numpy.cumsum(counts, out=row_ptr[1:])
+    nnz = int(row_ptr[-1])
+    row_of = numpy.repeat(numpy.arange(n_frag, dtype=numpy.int64), counts)
+    within = numpy.arange(nnz, dtype=numpy.int64) - row_ptr[row_of]
+    first = within < n1[row_of]
+    site = numpy.where(first, lo1[row_of] + within, lo2[row_of] + (within - n1[row_of])).astype(numpy.int64)
+    hap_col = numpy.asarray(contrib, dtype=numpy.int64)[who][row_of]
+    truth = tables.expected[site, hap_col]
+    flip = rng.random(nnz) < err
+    shift = rng.integers(1, 4, size=nnz)
+    code = numpy.zeros(nnz, dtype=numpy.int64)
+    for i, base in enumerate(ALPHABET):
+        code[truth == base] = i
+    wrong = ALPHABET[(code + shift) % 4]
+    obs = numpy.where(flip, wrong, truth).astype(numpy.uint8)
+    return row_ptr, site.astype(numpy.uint16), obs, who
+
+
 GEN_BLOCK = 125000          # rows per independently seeded block of synth_rows
 
 
-def synth_rows(tables, ref_len, lo, hi, seed=1, block=GEN_BLOCK, **kw):
+def synth_rows(tables, ref_len, lo, hi, seed=1, block=GEN_BLOCK, pairs=False, **kw):
     """
     Rows [lo, hi) of a synth-v1 read set of any size, without generating the rest:
     the set is defined block by block -- block k (rows k*block ... (k+1)*block - 1) is
     synth_reads(..., n_reads=block, seed=[seed, k]) -- so that every rank of a row-sharded
     run builds its own shard of ONE global problem, whatever the number of ranks
-    (bench.py strong scaling; SURVEY.md section 8 d/e).
+    (bench.py strong scaling; SURVEY.md section 8 d/e).  pairs=True: blocks of synth_pairs (synth-pe-v1) instead.
     -> (row_ptr[hi-lo+1], site, obs, who) like synth_reads.
     """
     lo, hi = int(lo), int(hi)
@@ -85,7 +146,7 @@ def synth_rows(tables, ref_len, lo, hi, seed=1, block=GEN_BLOCK, **kw):
     ptrs, sites, obss, whos = [], [], [], []
     base = 0
     for k in range(lo // block, (hi - 1) // block + 1):
-        rp, st, ob, who = synth_reads(tables, ref_len, block, seed=[int(seed), k], **kw)
+        rp, st, ob, who = (synth_pairs if pairs else synth_reads)(tables, ref_len, block, seed=[int(seed), k], **kw)
         a = max(lo - k * block, 0)
         b = min(hi - k * block, block)
         ptrs.append(rp[a:b] - rp[a] + base)

@@ -200,6 +200,9 @@ def test_bench_starts_its_own_ranks_and_reports_the_world_it_ran():
     assert line["config"]["total_rows"] == 30000 and line["config"]["rows_per_gpu"] == 15000
     assert line["all_reduce_us"] is not None and line["all_reduce_us"] > 0
     assert line["steps"] == 4 and line["roofline"]["kernel_ms"] > 0
+    # what the collective itself saw (round 6): two ranks answered an all-reduce of ones, each names its device
+    assert line["ranks_seen"] == 2 and line["backend"] == "gloo" and [d["rank"] for d in line["devices"]] == [0, 1]
+    assert all(d["name"] for d in line["devices"])
 
 
 def test_bench_four_ranks_on_the_metrics_own_problem():
@@ -281,6 +284,7 @@ def test_bench_line_carries_parity_observables():
     assert par["max_abs_dprops"] < 1e-9 and line["sanity_ok"]
     assert line["cpu_baseline"]["kind"] == "port" and line["cpu_baseline"]["cores"] == 1
     assert line["n_gpus"] == 1 and line["config"]["total_rows"] == 20000
+    assert line["ranks_seen"] == 1 and len(line["devices"]) == 1 and line["backend"] is None
 
 
 def test_bench_reports_row_dictionaries_beside_the_dense_line_and_alone():

@@ -182,3 +182,62 @@ def test_a_silent_rank_times_the_others_out(tmp_path):
     mp.spawn(_sum_worker, args=(2, _free_port(), str(tmp_path), 1), nprocs=2, join=True)
     res = numpy.load(str(tmp_path / "rank0.npz"))
     assert int(res["nan"]) == 1 and int(res["raised"]) == 1
+
+
+def _fallback_worker(rank, world, port, out_dir, mode):
+    """mode "fail": rank 1's mxm_exchange_create fails (fault injection) -- ALL ranks must take the all-reduce together;
+    mode "coarse": the runtime "refuses" to export the fine-grained buffer -- the library retries with ordinary device memory."""
+    _paths()
+    import warnings
+    import torch
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    if mode == "fail":
+        os.environ["MXM_EXCHANGE_FAIL_RANK"] = "1"
+    else:
+        os.environ["MXM_EXCHANGE_REFUSE_FINE"] = "1"
+    os.environ["MXM_EXCHANGE_TIMEOUT_MS"] = "5000"
+    from mixemt_amd import _lib, dist as mdist, em
+    torch.cuda.set_device(0)
+    _lib.load().mxm_set_loop_fused(0, 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        rng = numpy.random.default_rng(7)                                # the same matrix on every rank; each takes its rows
+        n_rows, n_haps = 600, 130
+        mat = numpy.log(rng.dirichlet([0.3] * n_haps, size=n_rows))
+        wts = rng.integers(1, 4, size=n_rows).astype(numpy.float64)
+        inits = rng.dirichlet([1.0] * n_haps, size=2)
+        lo, hi = mdist.shard_bounds(n_rows, rank, world)
+        plan = em.EmPlan(torch.from_numpy(mat[lo:hi]).cuda(), torch.from_numpy(wts[lo:hi]).cuda(), n_runs=2)
+        plain = mdist.sharded_em_loop(plan, inits, 1e-5, 400, check_every=8)
+        with warnings.catch_warnings(record=True) as caught:
+            warnings.simplefilter("always")
+            got = mdist.sharded_em_loop(plan, inits, 1e-5, 400, check_every=8, exchange="oneshot", graph=False)
+        warned = int(any("one-shot exchange" in str(w.message) and "all-reduce" in str(w.message) for w in caught))
+        fine = -1
+        if mode == "coarse":
+            x = mdist.OneShotExchange(2 * n_haps)
+            fine = int(x.fine_grained)
+            x.close()
+        numpy.savez(os.path.join(out_dir, "rank%d.npz" % rank), warned=warned, fine=fine,
+                    equal=int(torch.equal(got[1], plain[1]) and got[2] == plain[2]), iters=numpy.array([s[1] for s in got[2]]),
+                    ln=got[1].cpu().numpy(), route=str(mdist.sharded_em_loop.last_exchange))
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("mode", ["fail", "coarse"])
+def test_a_rank_that_cannot_set_the_exchange_up_takes_every_rank_to_the_all_reduce(tmp_path, mode):
+    """the first 8-GPU attempt must not hang -- one rank raising while its peers wait in a barrier would.  With
+    the failure injected on rank 1 both ranks warn, run the loop over the group's all-reduce and get the plain run's bits;
+    with the fine-grained export refused the exchange itself still runs, on ordinary device memory."""
+    import torch.multiprocessing as mp
+    mp.spawn(_fallback_worker, args=(2, _free_port(), str(tmp_path), mode), nprocs=2, join=True)
+    res = [numpy.load(str(tmp_path / ("rank%d.npz" % r))) for r in range(2)]
+    for r in res:
+        assert int(r["equal"]) == 1 and list(r["iters"]) == list(res[0]["iters"]) and numpy.array_equal(r["ln"], res[0]["ln"])
+        if mode == "fail":
+            assert int(r["warned"]) == 1 and str(r["route"]).startswith("rccl")
+        else:
+            assert int(r["warned"]) == 0 and str(r["route"]) == "oneshot" and int(r["fine"]) == 0

@@ -344,3 +344,75 @@ def test_committed_profiles_name_the_kernel_instances_this_source_builds():
         assert name in stats, "%s: not in %s/bench_1m_kernel_stats.csv -- regenerate the profiles from this binary" % (name, latest)
     assert stream_kernel in traffic and traffic["_workload"]["storage"] == "f64"
     assert abs(traffic[stream_kernel]["hbm_bytes_per_launch"] / (1e6 * 5408 * 8) - 1.0) < 0.02
+
+
+def test_synth_pe_v1_is_pinned(b17):
+    """synth-pe-v1 (round 6; 2 x 150 paired-end fragments, mates merged into one row as preprocess.py:118-138 merges
+    them): the draw order is the definition -- same seed, same bytes; two thirds of the rows observe more than 64 sites."""
+    refseq, phy, haps, tables = b17
+    row_ptr, site, obs, who = synth.synth_pairs(tables, len(refseq), 4000, seed=5)
+    lens = numpy.diff(row_ptr)
+    assert lens.min() >= 1 and 0.6 < (lens > 64).mean() < 0.75 and (lens > 128).mean() < 0.04
+    # ascending sites inside every row (no overlap between the mates at inserts >= 2 x 150)
+    step = numpy.diff(site.astype(numpy.int64))
+    inner = numpy.ones(len(step), dtype=bool)
+    inner[row_ptr[1:-1] - 1] = False
+    assert (step[inner] > 0).all()
+    digest = hashlib.sha256(row_ptr.tobytes() + site.tobytes() + obs.tobytes() + who.tobytes()).hexdigest()
+    again = synth.synth_pairs(tables, len(refseq), 4000, seed=5)
+    assert hashlib.sha256(b"".join(a.tobytes() for a in again)).hexdigest() == digest
+    assert digest[:16] == SYNTH_PE_V1_DIGEST, digest[:16]
+    # blocks of synth_rows: one global fragment set whatever the slice
+    a = synth.synth_rows(tables, len(refseq), 100, 700, seed=3, block=256, pairs=True)
+    b = synth.synth_rows(tables, len(refseq), 0, 1024, seed=3, block=256, pairs=True)
+    assert numpy.array_equal(a[1], b[1][b[0][100]:b[0][700]]) and numpy.array_equal(a[3], b[3][100:700])
+    with pytest.raises(ValueError):
+        synth.synth_pairs(tables, len(refseq), 10, insert=(200, 300))
+
+
+SYNTH_PE_V1_DIGEST = "54e74634cdf719fa"
+
+
+def test_bench_rank_census_rules():
+    """bench.rank_census: a multi-GPU line is only sane when the all-reduce of ones saw --gpus ranks and, under
+    RCCL, no two ranks sit on one PCI address."""
+    import importlib.util
+    import types
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    spec = importlib.util.spec_from_file_location("bench_under_test", os.path.join(root, "bench.py"))
+    bench = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(bench)
+
+    class Ones(object):
+        def __init__(self, total):
+            self.total = total
+
+        def item(self):
+            return self.total
+
+    def fake(world_seen, devices):
+        props = types.SimpleNamespace(name="AMD Instinct MI355X", pci_domain_id=0, pci_bus_id=5, pci_device_id=0, uuid="u0")
+        torch = types.SimpleNamespace(cuda=types.SimpleNamespace(get_device_properties=lambda dev: props),
+                                      ones=lambda n, dtype=None, device=None: Ones(float(world_seen)), float64=None)
+
+        def gather(out, mine):
+            for i, d in enumerate(devices):
+                out[i] = d
+
+        dist = types.SimpleNamespace(all_reduce=lambda t, op=None: None, ReduceOp=types.SimpleNamespace(SUM=0), all_gather_object=gather)
+        return torch, dist
+
+    dev = types.SimpleNamespace(index=0)
+    eight = [{"rank": r, "name": "x", "pci": "0000:%02x:00" % (5 + r), "uuid": None} for r in range(8)]
+    torch, dist = fake(8, eight)
+    ok = bench.rank_census(torch, dist, dev, 0, 8, True, "nccl", 8)
+    assert ok["ok"] and ok["ranks_seen"] == 8 and len(ok["devices"]) == 8 and ok["backend"] == "nccl"
+    torch, dist = fake(7, eight)
+    assert not bench.rank_census(torch, dist, dev, 0, 8, True, "nccl", 8)["ok"]
+    shared = [dict(d, pci="0000:05:00") if d["rank"] in (2, 3) else d for d in eight]
+    torch, dist = fake(8, shared)
+    bad = bench.rank_census(torch, dist, dev, 0, 8, True, "nccl", 8)
+    assert not bad["ok"] and "share a GPU" in bad["note"]
+    assert bench.rank_census(torch, dist, dev, 0, 8, True, "gloo", 8)["ok"]       # (test set-ups share the one GPU over gloo)
+    one = bench.rank_census(torch, dist, dev, 0, 1, False, "nccl", 1)
+    assert one["ok"] and one["ranks_seen"] == 1 and one["backend"] is None

@@ -7,6 +7,7 @@ synthetic reads, device-resident end to end:
     -> refinement EM on the contributor columns -> read assignment -> contributor table
 
     python tools/run_pipeline.py [--reads N] [--seed S] [--multi M] [--dense [--storage f64|f32|coded|auto]] [--alignments]
+                                 [--pairs | --read-len L]
 
 --alignments (round 5): start one step earlier, from ALIGNMENTS -- N synthetic fragments (synth-aln-v1: mates, indels,
 clips, low qualities, duplicates) as columns -> the library's batched front end (alignments.encode_alignments =
@@ -43,6 +44,10 @@ def main():
     ap.add_argument("--bam", action="store_true",
                     help="with --alignments: write them as a BAM file first (tests/_bam_writer.py, untimed) and start from "
                          "the FILE: the library's reader (alignments.read_bam) in front of the encoder")
+    ap.add_argument("--pairs", action="store_true",
+                    help="rows = paired-end fragments (synth-pe-v1: 2 x 150 bp, insert 350-500, mates merged as preprocess.py:118-138 "
+                         "merges them): two thirds of them observe more than 64 sites")
+    ap.add_argument("--read-len", type=int, default=150, help="length of the single-end reads (synth-v1; 250: 38 %% of the rows above 64 sites)")
     ap.add_argument("--threads", type=int, default=0, help="with --alignments: host threads of the encoder (0 = its default)")
     ap.add_argument("--storage", default="auto", choices=["f64", "f32", "coded", "auto"],
                     help="with --dense: form of the matrix the EM loop streams (EmPlan): coded = lossless row dictionaries, "
@@ -96,7 +101,14 @@ def main():
                             len(enc.dropped)))
         opts.reads = enc.n_rows
     else:
-        row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), opts.reads, seed=1)
+        if opts.pairs:                                    # synth-pe-v1: 2 x 150 fragments, mates merged into one row
+            row_ptr, site, obs, who = synth.synth_pairs(tables, len(refseq), opts.reads, seed=1)
+        else:
+            row_ptr, site, obs, who = synth.synth_reads(tables, len(refseq), opts.reads, seed=1, read_len=opts.read_len)
+        lens = numpy.diff(row_ptr)
+        sys.stderr.write("[pipeline] rows: %s, %.1f sites per row, %.1f %% above 64, %.2f %% above 128\n"
+                         % ("synth-pe-v1 (2 x 150, insert 350-500, mates merged)" if opts.pairs else "synth-v1, %d bp" % opts.read_len,
+                            lens.mean(), 100.0 * (lens > 64).mean(), 100.0 * (lens > 128).mean()))
         reads = [[str(i)] for i in range(opts.reads)]     # the read ids behind each row (synthetic input, like the fragments)
         sys.stderr.write("Using %d variant sites from %d haplogroups; %d synthetic fragments (%.1f s)\n"
                          % (len(tables.sites), len(haps), opts.reads, time.perf_counter() - t0))

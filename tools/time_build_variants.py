@@ -17,6 +17,17 @@ from mixemt_amd import _lib, phylotree, preprocess, synth
 from oracle import c_oracle
 
 args = sys.argv[1:]
+pairs = "--pairs" in args                                 # synth-pe-v1 rows (2 x 150 merged mates) instead of synth-v1
+if pairs:
+    args.remove("--pairs")
+read_len = 150
+if "--read-len" in args:
+    at = args.index("--read-len")
+    read_len = int(args[at + 1])
+    del args[at:at + 2]
+long_off = "--no-long" in args                            # round 5's routing: rows beyond 64 observations to the fallback list
+if long_off:
+    args.remove("--no-long")
 rows = int(args.pop(0)) if args and args[0].isdigit() else 1000000
 paths = args or [_lib.LIB_PATH]
 _lib.load()
@@ -24,7 +35,9 @@ refseq = phylotree.load_rsrs()
 phy = phylotree.load_build17(refseq)
 haps = sorted(phy.hap_var)
 tables = preprocess.HapVarTables.build(refseq, phy, haps)
-row_ptr, site, obs, _ = synth.synth_rows(tables, len(refseq), 0, rows, seed=1)
+row_ptr, site, obs, _ = (synth.synth_rows(tables, len(refseq), 0, rows, seed=1, pairs=True) if pairs else
+                         synth.synth_rows(tables, len(refseq), 0, rows, seed=1, read_len=read_len))
+lens = numpy.diff(row_ptr)
 dev = torch.device("cuda")
 rp = torch.from_numpy(row_ptr).to(dev)
 si = torch.from_numpy(site.view(numpy.int16)).to(dev)
@@ -40,11 +53,15 @@ sub_ptr[1:] = numpy.cumsum(row_ptr[pick + 1] - row_ptr[pick])
 sub_site = numpy.concatenate([site[row_ptr[r]:row_ptr[r + 1]] for r in pick])
 sub_obs = numpy.concatenate([obs[row_ptr[r]:row_ptr[r + 1]] for r in pick])
 want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, sub_ptr, sub_site, sub_obs, len(haps))
-print("one MI355X; %d synth-v1 reads x %d haplogroups; the marker kernel alone, HIP events" % (rows, len(haps)))
+print("one MI355X; %d %s x %d haplogroups (%.1f sites per row, %.1f %% above 64, %.2f %% above 128); the marker kernel%s alone, HIP events"
+      % (rows, "synth-pe-v1 fragments" if pairs else "synth-v1 reads of %d bp" % read_len, len(haps), lens.mean(),
+         100.0 * (lens > 64).mean(), 100.0 * (lens > 128).mean(), " (rows beyond 64 observations to the fallback list)" if long_off else "s"))
 for path in paths:
     lib = ctypes.CDLL(os.path.abspath(path))
     fn = lib.mxm_build_em_matrix_sparse
     fn.restype, fn.argtypes = _lib.SIGNATURES["mxm_build_em_matrix_sparse"]
+    if hasattr(lib, "mxm_set_sparse_long_rows"):
+        lib.mxm_set_sparse_long_rows(0 if long_off else 1)
     out.fill_(7.0)
     times = []
     for rep in range(9):
