@@ -117,6 +117,9 @@ int mxm_set_quad_left_grid(int32_t nwg);
  * row beyond 64 observations did before.  The same bits either way.
  */
 int mxm_set_sparse_long_rows(int32_t on);
+/* ... and the most marker entries (sum of the marker-list lengths of its sites) a row of that launch may have; rows beyond go
+ * to the fallback list (0 = no limit).  The same bits either way. */
+int mxm_set_sparse_long_entries(int32_t n);
 
 /*
  * Restarts per pass over records beside a quad dictionary: 3 (default; em_iter_quad_batched_kernel takes full tiles of

@@ -48,7 +48,9 @@
 #ifndef SPB_GATHER
 #define SPB_GATHER 4                  // marker entries a thread looks up and keeps (x 256 threads = the 1024 entries that 79 % of the rows stay below; 8: no gain)
 #endif
-#define SPB_GATHER_LONG 8             // ... of the long rows' instance (their marker lists are twice as long)
+#ifndef SPB_GATHER_LONG
+#define SPB_GATHER_LONG 16            // ... of the long rows' instance (their marker lists are twice as long and more: 4096 kept)
+#endif
 #ifndef SPB_SLOTS_LONG
 #define SPB_SLOTS_LONG 1024           // ... and its table: merged mates hold twice the distinct values (median 52; 3.7 % of the
 #endif
@@ -87,7 +89,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
     const int64_t *__restrict__ row_ptr, const uint16_t *__restrict__ site, const uint8_t *__restrict__ obs,
     const int64_t *__restrict__ order, int64_t R, int H, double *__restrict__ M, int64_t ldm, int vec_ok,
     int64_t *__restrict__ fallback, unsigned long long *__restrict__ n_fallback, int max_distinct, spb_records out,
-    int long_follows) {
+    int long_follows, int max_entries) {
     // W = 1: the rows of up to 64 observations (longer ones: the fallback list, or -- long_follows -- left to the W = 2
     // launch behind this one); W = 2: the rows of 65 .. 128 observations (longer: fallback; shorter: skipped)
     static_assert(W == 1 || W == 2, "64 or 128 observations per row");
@@ -165,6 +167,16 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
         }
         __syncthreads();
         const int total = s_cum[n];
+        if (W > 1 && max_entries > 0 && total > max_entries) {
+            // a long row over the control region: thousands of marker entries (rows of 65+ sites among 150-bp reads: 6000-12000)
+            // -- the cell-by-cell kernel, whose cost does not depend on them, is the faster one there
+            __syncthreads();                                 // (everyone has read the row's total before wave 0 moves on)
+            if (t == 0) {
+                fallback[atomicAdd(n_fallback, 1ull)] = r;
+                no_record(r);
+            }
+            return;
+        }
         // table slot of the thread's two haplogroups per chunk, PACKED (low / high 16 bits; 0xffff = the majority value):
         // eleven registers instead of twenty-two at H = 5408 -- the kernel is compiled for 80 VGPRs (six rows per CU)
         // and used to spill 34 of them
@@ -175,7 +187,8 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
         // filters and ORs them.  79 % of the rows have no more entries than that; the rest of a longer row's entries
         // are walked per range as before.
         unsigned int cached[GATHER];
-        {
+        int lo_keep = 0;                                     // the site of this thread's last kept entry: where its walk over
+        {                                                    // a long row's further entries starts (they lie behind it)
             int jj[GATHER];
             unsigned int hap[GATHER], base[GATHER];
             // thread t takes entries GATHER * t ..: one search for the first, the others a few steps further on
@@ -211,6 +224,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
                     if ((hit ? 1 : 0) != s_hit[jj[u]]) cached[u] = hap[u] | ((unsigned int)jj[u] << 13);
                 }
             }
+            lo_keep = lo;
         }
 #pragma unroll
         for (int pass = 0; pass < PASSES; ++pass) {
@@ -232,19 +246,18 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
                     atomicOr(&s_dev[local * W + (W > 1 ? (jb >> 6) : 0u)], 1ull << (jb & 63u));
                 }
             }
+            // (a thread's further entries t + 256 i come in ascending order, all behind its kept ones: their sites are found
+            // by walking on from lo_keep -- a binary search per entry and column range was most of a long row's time:
+            // rows over the control region hold 6000-12000 entries, profiles/r06/build_long_rows.txt)
+            int lo = lo_keep;
             for (int e0 = t + SPB_THREADS * GATHER; e0 < total; e0 += SPB_THREADS * GATHER) {
                 int jj[GATHER];
                 unsigned int hap[GATHER], base[GATHER];
 #pragma unroll
                 for (int u = 0; u < GATHER; ++u) {
                     const int e = e0 + u * SPB_THREADS;
-                    int lo = 0, hi = n;                     // s_cum[lo] <= e < s_cum[hi]
                     if (e < total) {
-                        while (hi - lo > 1) {
-                            const int mid = (lo + hi) >> 1;
-                            if (s_cum[mid] <= e) lo = mid;
-                            else hi = mid;
-                        }
+                        while (s_cum[lo + 1] <= e) ++lo;    // e < total = s_cum[n]: stops at lo < n
                     }
                     jj[u] = (e < total) ? lo : -1;
                     const int idx = (e < total) ? s_beg[lo] + (e - s_cum[lo]) : 0;

@@ -85,6 +85,7 @@ struct mxm_tuning {
     int fused_cols = 1;             // matrices of up to 1536 rows take the transposed form (columns split)
     int fused_coded_wg = 0;         // workgroups of the one-launch loop over records (0 = by size)
     int quad_left_wg = 0;           // workgroups of the leftover pass beside the quad pass (0 = by the rows' measured cost)
+    int sparse_long_entries = 5120; // ... whose rows with more marker entries than this go to the fallback list (0: no limit)
     int sparse_long = 1;            // the marker build's second launch for rows of 65 .. 128 observations (0: they go to the fallback list)
     int coded_bt = 3;               // restarts per pass over records beside a quad dictionary (1 = one per pass, 3 = the batched kernel)
     int fused_force_abort = 0;      // test hook: the one-launch loop starts with its abort flag raised (as if starved)
@@ -355,8 +356,8 @@ static int build_sparse_impl(const char *who, const uint8_t *maj, const double *
     spb_records none = {};
     const spb_records rec = out != nullptr ? *out : none;
 #define SPB_ARGS maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), maxd, rec
-#define SPB_LAUNCH(n, p) do { if (out != nullptr) hipLaunchKernelGGL((build_sparse_kernel<n, p, true, 1>), dim3(grid), dim3(SPB_THREADS), 0, s, SPB_ARGS, long_too); \
-                          else hipLaunchKernelGGL((build_sparse_kernel<n, p, false, 1>), dim3(grid), dim3(SPB_THREADS), 0, s, SPB_ARGS, long_too); } while (0)
+#define SPB_LAUNCH(n, p) do { if (out != nullptr) hipLaunchKernelGGL((build_sparse_kernel<n, p, true, 1>), dim3(grid), dim3(SPB_THREADS), 0, s, SPB_ARGS, long_too, 0); \
+                          else hipLaunchKernelGGL((build_sparse_kernel<n, p, false, 1>), dim3(grid), dim3(SPB_THREADS), 0, s, SPB_ARGS, long_too, 0); } while (0)
     // (only the instances of the column-range count this build runs with are compiled: the other three quarters of them
     // were a third of the library's build time)
 #define SPB_CASE(n) case n: if constexpr (SPB_PASSES == 1) { if constexpr (n <= 7) SPB_LAUNCH(n, 1); else return fail(-1, "%s: one pass covers H <= 3584", who); } else if constexpr (SPB_PASSES == 2) SPB_LAUNCH(n, 2); else if constexpr (SPB_PASSES == 3) SPB_LAUNCH(n, 3); else SPB_LAUNCH(n, 4); break;
@@ -370,11 +371,12 @@ static int build_sparse_impl(const char *who, const uint8_t *maj, const double *
         // the rows of 65 .. 128 observations (merged mates, long reads): 128-bit masks, one column range per 512 haplogroups
         // and a table of 1024 slots (build_sparse_kernels.hpp, W = 2); its grid looks at the rows 64 at a time
 #define SPB_ARGS_LONG maj, lhit, lmiss, mk_ptr, mk_hap, mk_base, row_ptr, site, obs, order, R, (int)H, M, ldm, vec_ok, fallback, reinterpret_cast<unsigned long long *>(n_fallback), maxd_long, rec
-#define SPB_LONG(n, p) case n: if (out != nullptr) hipLaunchKernelGGL((build_sparse_kernel<n, p, true, 2>), dim3(grid_long), dim3(SPB_THREADS), 0, s, SPB_ARGS_LONG, 0); \
-                               else hipLaunchKernelGGL((build_sparse_kernel<n, p, false, 2>), dim3(grid_long), dim3(SPB_THREADS), 0, s, SPB_ARGS_LONG, 0); break;
+#define SPB_LONG(n, p) case n: if (out != nullptr) hipLaunchKernelGGL((build_sparse_kernel<n, p, true, 2>), dim3(grid_long), dim3(SPB_THREADS), 0, s, SPB_ARGS_LONG, 0, T.sparse_long_entries); \
+                               else hipLaunchKernelGGL((build_sparse_kernel<n, p, false, 2>), dim3(grid_long), dim3(SPB_THREADS), 0, s, SPB_ARGS_LONG, 0, T.sparse_long_entries); break;
         switch (nch) {
 #ifndef SPB_LONG_KPP
-#define SPB_LONG_KPP 1                // 512-haplogroup chunks per column range of the long rows' instance
+#define SPB_LONG_KPP 2                // 512-haplogroup chunks per column range of the long rows' instance (1: 34.9, 2: 34.5, 4: 36.5 ms
+                                      // per 10^6 paired-end fragments before the walk over a long row's further entries was fixed)
 #endif
 #define SPB_LP(n) SPB_LONG(n, ((n + SPB_LONG_KPP - 1) / SPB_LONG_KPP))
             SPB_LP(1) SPB_LP(2) SPB_LP(3) SPB_LP(4) SPB_LP(5) SPB_LP(6) SPB_LP(7) SPB_LP(8)
@@ -495,6 +497,9 @@ extern "C" int mxm_set_fused_coded_grid(int32_t nwg) {
 
 extern "C" int mxm_set_sparse_long_rows(int32_t on) {
     return tune_set([on](mxm_tuning &t) { t.sparse_long = on ? 1 : 0; });
+}
+extern "C" int mxm_set_sparse_long_entries(int32_t n) {
+    return tune_set([n](mxm_tuning &t) { t.sparse_long_entries = n > 0 ? n : 0; });
 }
 extern "C" int mxm_set_coded_batch_tile(int32_t bt) {
     if (bt != 1 && bt != 3) return fail(-1, "mxm_set_coded_batch_tile: 1 or 3, got %s%lld", "", bt);

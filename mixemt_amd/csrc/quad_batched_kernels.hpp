@@ -125,7 +125,9 @@ __device__ __forceinline__ void quadb_class_pass(const uint8_t *__restrict__ rba
     auto publish = [&](auto SLOT) {
         constexpr int slot = decltype(SLOT)::value;
         if constexpr (CLS == 0) {
-            *reinterpret_cast<quad_d2 *>(&s_tbl[slot][t * 2]) = tring[slot];
+            // the table in LDS: first halves of the entries, then second halves (quad_kernels.hpp, QUAD_SPLIT_TABLE); this
+            // thread holds half t & 1 of entry t >> 1
+            *reinterpret_cast<quad_d2 *>(&s_tbl[slot][(t & 1) * (QUAD_MAX * 2) + (t >> 1) * 2]) = tring[slot];
         } else if constexpr (CLS == 1) {
             if (t < ENC_MAX_CODES) s_tbl[slot][t] = tring[slot].x;
         } else {
@@ -139,10 +141,10 @@ __device__ __forceinline__ void quadb_class_pass(const uint8_t *__restrict__ rba
             // the thread's code bytes: 0, 2, 4 of the word shifted down by `half` bytes
             const unsigned long long word = (((unsigned long long)c[1] << 32) | c[0]) >> (8 * half);
             const unsigned int lo = (unsigned int)word, hi = (unsigned int)(word >> 32);
-            unsigned int off[3] = {quad_byte_x32<0>(lo), quad_byte_x32<2>(lo), quad_byte_x32<0>(hi)};
+            unsigned int off[3] = {quad_byte_x16<0>(lo), quad_byte_x16<2>(lo), quad_byte_x16<0>(hi)};
 #pragma unroll
             for (int k = 0; k < NCH; ++k) {
-                const quad_d2 a = *reinterpret_cast<const quad_d2 *>(tb + off[k]), b = *reinterpret_cast<const quad_d2 *>(tb + off[k] + 16);
+                const quad_d2 a = *reinterpret_cast<const quad_d2 *>(tb + off[k]), b = *reinterpret_cast<const quad_d2 *>(tb + off[k] + QUAD_MAX * 16);
                 v[k][0] = a.x;
                 v[k][1] = a.y;
                 v[k][2] = b.x;

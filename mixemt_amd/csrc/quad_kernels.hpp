@@ -36,7 +36,8 @@ typedef double quad_d2 __attribute__((ext_vector_type(2)));
 // K3q-enc  quad_encode_kernel: one workgroup per byte-coded row.  The row's quads (4 code bytes = one dword; code bytes
 // of columns past H are cleared so that equal quads compare equal) are de-duplicated in an LDS hash table (64-bit slots:
 // a tag bit + the quad, so that the quad 0xFFFFFFFF is an ordinary key), the distinct ones ranked by value (each counts
-// the smaller ones) -- the codes are those ranks, so a record's bytes do not depend on which thread won a slot -- and the
+// the smaller ones; QUAD_RANK_BY_COUNT: by occurrences first -- built and measured in round 6, no gain) -- the codes are
+// those ranks, so a record's bytes do not depend on which thread won a slot -- and the
 // record goes to a bump-allocated place in `qrec` (a workgroup reserves 64 KB at a time: stats[0] = bytes RESERVED, an upper
 // bound of what is in use; a record that does not fit any more is not written and the row keeps nquad = 0: the caller sees
 // stats[0] > capacity and may repeat with that much and a chunk per workgroup to spare).
@@ -48,7 +49,12 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
                                                                    uint8_t *__restrict__ qrec, unsigned long long qcap,
                                                                    int64_t *__restrict__ qoff, int32_t *__restrict__ nquad,
                                                                    unsigned long long *__restrict__ stats) {
+#ifndef QUAD_RANK_BY_COUNT
+#define QUAD_RANK_BY_COUNT 0              // 1: codes = ranks by (occurrences descending, quad ascending) -- the round-6 A/B build:
+#endif                                    // the pass's LDS bank conflicts (24.9 %) and its time did not move (profiles/r06/ab_quad_ranking_1m.txt)
     __shared__ unsigned long long s_tab[QUAD_HASH];
+    __shared__ int s_cnt[QUAD_RANK_BY_COUNT ? QUAD_HASH : 1];       // occurrences of the quad in slot i among the row's quads
+    __shared__ int s_kcnt[QUAD_RANK_BY_COUNT ? QUAD_MAX : 1];
     __shared__ unsigned int s_keys[QUAD_MAX], s_sorted[QUAD_MAX];
     __shared__ unsigned short s_slot[QUAD_MAX];
     __shared__ unsigned char s_rank[QUAD_HASH];
@@ -66,7 +72,10 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
             }
             continue;
         }
-        for (int i = t; i < QUAD_HASH; i += QUAD_THREADS) s_tab[i] = 0ull;
+        for (int i = t; i < QUAD_HASH; i += QUAD_THREADS) {
+            s_tab[i] = 0ull;
+            if constexpr (QUAD_RANK_BY_COUNT != 0) s_cnt[i] = 0;
+        }
         if (t == 0) s_n = s_n2 = 0;
         __syncthreads();
         const uint8_t *base = rec + rec_off[r];
@@ -105,6 +114,20 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
                     slot = (slot + 1) & (QUAD_HASH - 1);
                 }
                 if (!placed) atomicAdd(&s_n, QUAD_MAX + 1);                  // too many distinct quads (or a full table)
+#if QUAD_RANK_BY_COUNT
+                // how often the quad occurs: the wave's lanes that hold the same quad add their number ONCE (a row is
+                // mostly one quad: an atomic per lane would queue a thousand adds on one LDS word)
+                if (placed) {
+                    unsigned long long todo = __ballot(1);
+                    while (todo != 0ull) {
+                        const int lead = __ffsll((long long)todo) - 1;
+                        const unsigned int k0 = (unsigned int)__builtin_amdgcn_readlane((int)key, lead);
+                        const unsigned long long same = __ballot(key == k0) & todo;
+                        if ((t & 63) == lead) atomicAdd(&s_cnt[slot], __popcll(same));
+                        todo &= ~same;
+                    }
+                }
+#endif
             }
             q[j] = key;
         }
@@ -128,6 +151,7 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
                 const int at_i = atomicAdd(&s_n2, 1);
                 s_keys[at_i] = (unsigned int)v;
                 s_slot[at_i] = (unsigned short)i;
+                if constexpr (QUAD_RANK_BY_COUNT != 0) s_kcnt[at_i] = s_cnt[i];
             }
         }
         __syncthreads();
@@ -135,7 +159,19 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
         if (t < n) {
             my_key = s_keys[t];
             int rank = 0;
+#if QUAD_RANK_BY_COUNT
+            // by occurrences (descending), then by quad: the row's most frequent entries get the codes 0, 1, 2, ... -- their
+            // 32-byte table entries then sit in DIFFERENT bank groups of the LDS table the pass looks them up in (ranked by
+            // value alone, which groups two hot entries shared was left to chance: 24.8 % of the quad pass's LDS cycles
+            // were bank conflicts, profiles/r05/coded_pmc_sq_summary.txt)
+            const int my_cnt = s_kcnt[t];
+            for (int j = 0; j < n; ++j) {
+                const int cj = s_kcnt[j];
+                rank += (cj > my_cnt || (cj == my_cnt && s_keys[j] < my_key)) ? 1 : 0;
+            }
+#else
             for (int j = 0; j < n; ++j) rank += (s_keys[j] < my_key) ? 1 : 0;
+#endif
             s_rank[s_slot[t]] = (unsigned char)rank;
             s_sorted[rank] = my_key;
         }
@@ -328,7 +364,18 @@ __global__ __launch_bounds__(QLIST_THREADS) void quad_list_fill_kernel(const int
     }
 }
 
-// code byte B of a word x 32 = the byte offset of the quad's table entry: one SDWA shift
+// code byte B of a word x 16 = the byte offset of the quad's entry in EACH of the two half tables in LDS: one SDWA shift
+template <int B>
+__device__ __forceinline__ unsigned int quad_byte_x16(unsigned int word) {
+    const unsigned int four = 4;
+    unsigned int r;
+    if constexpr (B == 0) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_0" : "=v"(r) : "v"(four), "v"(word));
+    else if constexpr (B == 1) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_1" : "=v"(r) : "v"(four), "v"(word));
+    else if constexpr (B == 2) asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_2" : "=v"(r) : "v"(four), "v"(word));
+    else asm("v_lshlrev_b32_sdwa %0, %1, %2 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:DWORD src1_sel:BYTE_3" : "=v"(r) : "v"(four), "v"(word));
+    return r;
+}
+// (x 32: the entry's offset in the record's own table -- QUAD_SPLIT_TABLE = 0 builds look it up in that layout)
 template <int B>
 __device__ __forceinline__ unsigned int quad_byte_x32(unsigned int word) {
     const unsigned int five = 5;
@@ -415,19 +462,37 @@ __device__ __forceinline__ void quad_row_pass(const uint8_t *__restrict__ qrec, 
         tring[slot][2] = __hiloint2double((int)b.y, (int)b.x);
         tring[slot][3] = __hiloint2double((int)b.w, (int)b.z);
     };
+    // In LDS a row's table is kept as TWO arrays of 16-byte elements (the entries' first halves, then their second halves)
+    // instead of the record's 32-byte entries: a ds_read_b128 per half at a 32-byte stride used only every other bank
+    // group, so lanes on different entries collided twice as often and the publishing writes always did -- 24.9 % of the
+    // pass's LDS cycles were bank conflicts, 7.3 % with the split (profiles/r06/ab_quad_split_1m.txt: step 1.33 -> 1.30 ms).
+#ifndef QUAD_SPLIT_TABLE
+#define QUAD_SPLIT_TABLE 1
+#endif
     auto publish = [&](auto SLOT) {
         constexpr int slot = decltype(SLOT)::value;
+#if QUAD_SPLIT_TABLE
+        *reinterpret_cast<quad_d2 *>(&s_tbl[slot][t * 2]) = quad_d2{tring[slot][0], tring[slot][1]};
+        *reinterpret_cast<quad_d2 *>(&s_tbl[slot][QUAD_MAX * 2 + t * 2]) = quad_d2{tring[slot][2], tring[slot][3]};
+#else
         quad_d2 *dst = reinterpret_cast<quad_d2 *>(&s_tbl[slot][t * 4]);
         dst[0] = quad_d2{tring[slot][0], tring[slot][1]};
         dst[1] = quad_d2{tring[slot][2], tring[slot][3]};
+#endif
     };
     double v[NCH][4];
     auto lookup_quad = [&](const char *tb, auto K, const quad_u2 &c) {
         constexpr int k = decltype(K)::value;
         unsigned int off;
+#if QUAD_SPLIT_TABLE
+        if constexpr (k < 4) off = quad_byte_x16<k>(c.x);
+        else off = quad_byte_x16<k - 4>(c.y);
+        const quad_d2 a = *reinterpret_cast<const quad_d2 *>(tb + off), b = *reinterpret_cast<const quad_d2 *>(tb + off + QUAD_MAX * 16);
+#else
         if constexpr (k < 4) off = quad_byte_x32<k>(c.x);
         else off = quad_byte_x32<k - 4>(c.y);
         const quad_d2 a = *reinterpret_cast<const quad_d2 *>(tb + off), b = *reinterpret_cast<const quad_d2 *>(tb + off + 16);
+#endif
         v[k][0] = a.x;
         v[k][1] = a.y;
         v[k][2] = b.x;

@@ -221,7 +221,7 @@ def test_lut_kernel_long_reads_unusual_bases_and_strided_output(b17):
 @pytest.mark.parametrize("n_cols", [1, 2, 3, 255, 1024, 1025, 2050, 5408])
 def test_sparse_kernel_ragged_widths_and_rows(b17, n_cols):
     """The marker kernel (one in-order sum per distinct cell value of a row): the oracle's bits at every width,
-    from one row to a few thousand, rows longer than its 64-observation mask included (they take the
+    from one row to a few thousand, rows longer than its masks (128 observations) included (they take the
     lookup-table kernel through the fallback list)."""
     from mixemt_amd import preprocess, synth
     refseq, phy, haps, tables = b17
@@ -234,8 +234,8 @@ def test_sparse_kernel_ragged_widths_and_rows(b17, n_cols):
         got = preprocess.build_em_matrix_device(sub_tables, row_ptr, site, obs, kernel="sparse").cpu().numpy()
         assert numpy.array_equal(got, want), (n_cols, n_rows)
         left = preprocess.build_em_matrix_device.last_fallback
-        long_rows = int((numpy.diff(row_ptr) > 64).sum())
-        assert long_rows <= left <= long_rows + max(2, n_rows // 50)      # + the odd row with more than 352 distinct masks
+        long_rows = int((numpy.diff(row_ptr) > 128).sum())                # (round 6: rows of 65 .. 128 observations stay)
+        assert long_rows <= left <= long_rows + max(2, n_rows // 50)      # + the odd row with more than 352 / 704 distinct masks
         if read_len == 400:
             assert 0 < left < n_rows                      # both paths in one call
 

@@ -350,8 +350,12 @@ def test_records_straight_from_the_build(b17, name, read_len):
     long_rows = numpy.flatnonzero(numpy.diff(row_ptr) > 64)                   # beyond the marker kernel's mask: built
     for r in rest:                                                             # densely, then coded from there
         assert len(numpy.unique(want[r])) > 1024                               # only rows with too many values stay dense
-    for r in numpy.flatnonzero(nd > 256):                                      # wide records: one entry per distinct value
-        assert nd[r] == len(numpy.unique(want[r]))
+    n_obs = numpy.diff(row_ptr)
+    for r in numpy.flatnonzero(nd > 256):        # wide records: from the encoder (rows beyond 128 observations) one entry per
+        if n_obs[r] > 128:                       # distinct value; from the marker kernel (round 6) one per distinct mask
+            assert nd[r] == len(numpy.unique(want[r]))
+        else:
+            assert nd[r] >= len(numpy.unique(want[r]))
     if read_len == 260:
         assert len(long_rows) > 100 and (nd[long_rows] > 0).sum() > 50         # long rows with records of their own
     for r in numpy.flatnonzero(nd > 0)[:40]:
@@ -382,14 +386,14 @@ def test_rows_from_alignments_keep_their_dense_rows(b17):
     enc = alignments.encode_alignments(cols, tables.sites, len(refseq), 30, 30)
     want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, enc.row_ptr, enc.site, enc.obs, len(haps))
     old = preprocess.REST_SLAB_ROWS
-    preprocess.REST_SLAB_ROWS = 150                                            # several slabs
+    preprocess.REST_SLAB_ROWS = 60                                             # several slabs
     try:
         cm = preprocess.build_em_records_device(tables, enc.row_ptr, enc.site, enc.obs)
     finally:
         preprocess.REST_SLAB_ROWS = old
     nd = cm.ndist.cpu().numpy()
     rest = cm.rest_rows.cpu().numpy()
-    assert preprocess.build_em_matrix_device.last_fallback > 300               # (three slabs at least)
+    assert preprocess.build_em_matrix_device.last_fallback > 150               # (three slabs at least: the rows beyond 128 observations)
     assert len(rest) >= 5 and numpy.array_equal(rest, numpy.flatnonzero(nd == 0))
     assert all(len(numpy.unique(want[r])) > 1024 for r in rest)
     assert numpy.array_equal(cm.m_rest.cpu().numpy(), want[rest])

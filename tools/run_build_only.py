@@ -23,6 +23,11 @@ if "--read-len" in argv:
     at = argv.index("--read-len")
     read_len = int(argv[at + 1])
     del argv[at:at + 2]
+max_entries = None
+if "--max-entries" in argv:
+    at = argv.index("--max-entries")
+    max_entries = int(argv[at + 1])
+    del argv[at:at + 2]
 long_off = "--no-long" in argv            # round 5's routing: rows beyond 64 observations to the fallback list
 if long_off:
     argv.remove("--no-long")
@@ -44,6 +49,9 @@ rowmax = torch.empty(rows, dtype=torch.float64, device=dev)
 tables.device(); tables.lut_device(); tables.sparse_device()
 lib = _lib.load()
 lib.mxm_set_sparse_long_rows(0 if long_off else 1)
+if max_entries is not None:
+    lib.mxm_set_sparse_long_entries(max_entries)
+    print("(rows of the long launch with more than %d marker entries -> fallback list)" % max_entries)
 cells = rows * len(haps)
 lens = numpy.diff(row_ptr)
 print("one MI355X; %d %s x %d haplogroups (%.1f observed sites per row, %.1f %% above 64, %.2f %% above 128)%s; wall time per call, "

@@ -25,6 +25,11 @@ if "--read-len" in args:
     at = args.index("--read-len")
     read_len = int(args[at + 1])
     del args[at:at + 2]
+max_entries = None
+if "--max-entries" in args:
+    at = args.index("--max-entries")
+    max_entries = int(args[at + 1])
+    del args[at:at + 2]
 long_off = "--no-long" in args                            # round 5's routing: rows beyond 64 observations to the fallback list
 if long_off:
     args.remove("--no-long")
@@ -62,6 +67,11 @@ for path in paths:
     fn.restype, fn.argtypes = _lib.SIGNATURES["mxm_build_em_matrix_sparse"]
     if hasattr(lib, "mxm_set_sparse_long_rows"):
         lib.mxm_set_sparse_long_rows(0 if long_off else 1)
+        if max_entries is not None and hasattr(lib, "mxm_set_sparse_long_entries"):
+            lib.mxm_set_sparse_long_entries(max_entries)
+if max_entries is not None:
+    lib.mxm_set_sparse_long_entries(max_entries)
+    print("(rows of the long launch with more than %d marker entries -> fallback list)" % max_entries)
     out.fill_(7.0)
     times = []
     for rep in range(9):
