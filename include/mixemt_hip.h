@@ -53,7 +53,8 @@ extern "C" {
  * 504: mxm_exchange_* (the optional one-shot exchange of a row-sharded loop); mxm_em_state.error may be 2;
  * 505: mxm_exchange_reduce; 506: mxm_expand_tables;
  * 600 round 6: mxm_restart_tile_coded (three restarts share a pass over records beside a quad dictionary:
- * mxm_em_iter_coded / mxm_em_loop_coded take full tiles of three through em_iter_quad_batched_kernel). */
+ * mxm_em_iter_coded / mxm_em_loop_coded take full tiles of three through em_iter_quad_batched_kernel),
+ * mxm_quad_loop_min_rows. */
 #define MXM_VERSION 600
 
 /* per-restart loop state, written by mxm_m_finalize (24 bytes); allocate it ZEROED */
@@ -359,6 +360,10 @@ int mxm_gather_columns_coded(const mxm_coded *c, int32_t H, const int32_t *cols,
 int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, int32_t H, int32_t B,
                       mxm_em_state *state /* nullable; only .error is ever written */, double *colsum, void *ws,
                       size_t ws_bytes, void *stream);
+/* Rows WITH quads from which mxm_em_loop_coded iterates with the per-iteration kernels over the quad dictionary instead of
+ * the one-launch loop over the records alone: a binding that attaches a dictionary "where it pays" must test the same
+ * quantity (n_quad_rows after mxm_build_quads), or it builds one the loop never looks at. */
+int64_t mxm_quad_loop_min_rows(void);
 /* Restarts that share one pass over THIS coded matrix in mxm_em_iter_coded / mxm_em_loop_coded: 3 beside a quad dictionary
  * (width within the quad pass's range, no dense leftover rows), else 1.  B restarts take floor(B / 3) shared passes and
  * B mod 3 single ones; per-restart sums differ from the one-per-pass kernel's by the rounding of another order only. */

@@ -60,6 +60,11 @@ class AlignmentColumns(object):
                   or (self.qual is not None and len(self.qual) < len(self.seq))
                   or (self.has_qual is not None and len(self.has_qual) != n)):
             raise ValueError("alignment columns: offsets run past their arrays")
+        #  the C ABI carries no array lengths: an offset array that starts elsewhere than 0 or steps backwards
+        # would make the encoder's walk read cigar[] / seq[] / qual[] outside their arrays
+        for name, ptr in (("cig_ptr", self.cig_ptr), ("seq_ptr", self.seq_ptr)):
+            if int(ptr[0]) != 0 or (n and int(numpy.diff(ptr).min()) < 0):
+                raise ValueError("alignment columns: %s must start at 0 and never step backwards" % name)
 
     def __len__(self):
         return len(self.ref_start)

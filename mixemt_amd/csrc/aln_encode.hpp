@@ -29,6 +29,7 @@
 #include <stdlib.h>
 #include <algorithm>
 #include <chrono>
+#include <exception>
 #include <functional>
 #include <memory>
 #include <thread>
@@ -106,20 +107,50 @@ struct walker {
     }
 };
 
+// Worker threads must not let an exception escape: a std::bad_alloc thrown inside a std::thread body -- the
+// per-thread lists and vectors below grow there -- would call std::terminate and take the Python process down, where
+// mxm_aln_encode / mxm_bam_read are written to return -5.  Every body runs under a catch-all; the threads are always
+// joined; the first exception is rethrown on the calling thread, inside the entry point's own try block.
+template <typename F>
+static void run_threads(int nt, F &&body) {
+    if (nt <= 1) {
+        body(0);
+        return;
+    }
+    std::vector<std::exception_ptr> err((size_t)nt);
+    std::vector<std::thread> pool;
+    std::exception_ptr spawn_err;
+    try {
+        pool.reserve((size_t)nt);
+        for (int t = 0; t < nt; ++t)
+            pool.emplace_back([&body, &err, t]() {
+                try {
+                    body(t);
+                } catch (...) {
+                    err[(size_t)t] = std::current_exception();
+                }
+            });
+    } catch (...) {
+        spawn_err = std::current_exception();               // (a thread could not be started: join the ones that were)
+    }
+    for (auto &th : pool) th.join();
+    if (spawn_err) std::rethrow_exception(spawn_err);
+    for (auto &e : err)
+        if (e) std::rethrow_exception(e);
+}
+
 template <typename F>
 static void parallel_for(int64_t n, int n_threads, F &&body, int64_t serial_below = 4096) {
     if (n_threads <= 1 || n < serial_below) {
         body(0, n, 0);
         return;
     }
-    std::vector<std::thread> pool;
     const int64_t per = (n + n_threads - 1) / n_threads;
-    for (int t = 0; t < n_threads; ++t) {
+    const int used = (int)((n + per - 1) / per);
+    run_threads(used, [&](int t) {
         const int64_t lo = t * per, hi = std::min(n, lo + per);
-        if (lo >= hi) break;
-        pool.emplace_back([&body, lo, hi, t]() { body(lo, hi, t); });
-    }
-    for (auto &th : pool) th.join();
+        if (lo < hi) body(lo, hi, t);
+    });
 }
 
 static inline uint64_t mix64(uint64_t h) {
@@ -301,15 +332,7 @@ static int aln_encode_impl(const mxm_aln_columns *c, const int32_t *site_of_pos,
         const int nt = (n_threads > 1 && n_seen >= 4096) ? n_threads : 1;
         std::vector<int64_t> first_k((size_t)n_seen, -1), cnt_k((size_t)n_seen, 0);
         std::vector<std::vector<int64_t>> lists((size_t)nt * NPART);
-        auto run = [&](const std::function<void(int)> &body) {
-            if (nt == 1) {
-                body(0);
-                return;
-            }
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nt; ++t) pool.emplace_back(body, t);
-            for (auto &th : pool) th.join();
-        };
+        auto run = [&](const std::function<void(int)> &body) { run_threads(nt, body); };
         run([&](int t) {
             const int64_t per = (n_seen + nt - 1) / nt, lo = t * per, hi = std::min(n_seen, lo + per);
             for (int64_t k = lo; k < hi; ++k) {

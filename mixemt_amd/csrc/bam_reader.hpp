@@ -201,9 +201,7 @@ static int bam_read_impl(const char *path, int n_threads, mxm_bam *out) {
             n_threads = 1;
             work(0);
         } else {
-            std::vector<std::thread> pool;
-            for (int t = 0; t < n_threads; ++t) pool.emplace_back(work, t);
-            for (auto &th : pool) th.join();
+            aln_detail::run_threads(n_threads, work);                    // (aln_encode.hpp: no exception leaves a worker thread)
         }
         for (int t = 0; t < n_threads; ++t)
             if (bad[t] >= 0) return fail(-4, "mxm_bam_read: BGZF block %s%lld does not inflate to its recorded size and CRC", "", bad[t]);
@@ -308,9 +306,7 @@ static int bam_read_impl(const char *path, int n_threads, mxm_bam *out) {
         fill(0);
         n_threads = keep;
     } else {
-        std::vector<std::thread> pool;
-        for (int t = 0; t < n_threads; ++t) pool.emplace_back(fill, t);
-        for (auto &th : pool) th.join();
+        aln_detail::run_threads(n_threads, fill);
     }
     for (size_t t = 0; t < too_long.size(); ++t)
         if (too_long[t] >= 0) return fail(-4, "mxm_bam_read: alignment %s%lld keeps its CIGAR in a CG tag (more than 65535 operations)", "", too_long[t]);
@@ -362,15 +358,7 @@ static int bam_read_impl(const char *path, int n_threads, mxm_bam *out) {
                 }
             }
         };
-        auto run = [&](const std::function<void(int)> &body) {
-            if (nt == 1) {
-                body(0);
-                return;
-            }
-            std::vector<std::thread> pool;
-            for (int t = 0; t < nt; ++t) pool.emplace_back(body, t);
-            for (auto &th : pool) th.join();
-        };
+        auto run = [&](const std::function<void(int)> &body) { aln_detail::run_threads(nt, body); };
         run(split);
         run(dedup);
         // (3) number the first records in file order; the names' offsets

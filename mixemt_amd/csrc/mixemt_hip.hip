@@ -1397,6 +1397,8 @@ static int fused_coded_grid(int64_t R) {
     return nwg < 1 ? 1 : nwg;
 }
 #define QUAD_PER_ITER_MIN_ROWS 300000
+// the floor a binding's "auto" rule must use too: a dictionary of fewer quad rows is never looked at by mxm_em_loop_coded
+extern "C" int64_t mxm_quad_loop_min_rows(void) { return QUAD_PER_ITER_MIN_ROWS; }
 static bool fused_coded_eligible(const mxm_coded *c, int H, int B, size_t ws_bytes) {
     if (T.loop_fused == 0 || c == nullptr || c->R_rest > 0 || !mxm_linear_supported(H) || (H & 1)) return false;
     // beside a quad dictionary the per-iteration kernels are the faster loop from a few 10^5 rows (1.35 against 1.45 ms per
