@@ -338,7 +338,7 @@ def test_committed_profiles_name_the_kernel_instances_this_source_builds():
     passes = int(re.search(r"#define SPB_PASSES (\d+)", src).group(1))
     lut = open(os.path.join(root, "mixemt_amd", "csrc", "build_lut_kernels.hpp")).read()
     cpl = int(re.search(r"#define LUT_CPL (\d+)", lut).group(1))
-    expected = [stream_kernel, "build_sparse_kernel<11, %d, false>" % passes, "build_lut_kernel<6, %d>" % cpl,
+    expected = [stream_kernel, "build_sparse_kernel<11, %d, false, 1>" % passes, "build_lut_kernel<6, %d>" % cpl,
                 "em_iter_coded_kernel<256, 6, 4, 2>", "em_fused_coded_kernel<6, 4, false>", "encode_wide_rows_kernel<6>"]
     for name in expected:
         assert name in stats, "%s: not in %s/bench_1m_kernel_stats.csv -- regenerate the profiles from this binary" % (name, latest)

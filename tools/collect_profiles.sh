@@ -2,7 +2,7 @@
 # Copy the summaries of a tools/profile_round.sh run from gpurun_out/<round>/ (scratch) into
 # profiles/<round>/ (tracked).  usage: bash tools/collect_profiles.sh r02
 set -u
-round=${1:-r05}
+round=${1:-r06}
 src=gpurun_out/$round
 dst=profiles/$round
 mkdir -p $dst
@@ -19,7 +19,10 @@ for f in bench_1m.json bench_1m_under_rocprof.json bench_1m_10restarts.json benc
          frontend_1m.txt pipeline_1m_alignments.txt row_pass_experiments.txt \
          bam_reader_1m.txt pipeline_1m_bam.txt quad_1m.txt quads_product_1m.txt quad_build_1m.txt step_sequence.txt \
          alloc_big.txt records_build_alignments.txt stress_parity_707.txt stress_parity_808.txt stress_parity_909.txt stress_parity_1111.txt \
-         bench_125k_records_one_rank_rccl.json bench_125k_records_one_rank_oneshot.json exchange_tests.txt; do
+         bench_125k_records_one_rank_rccl.json bench_125k_records_one_rank_oneshot.json exchange_tests.txt \
+         quads_batched_1m.txt bench_1m_coded_10restarts_48steps.json quads_step_1m.txt pipeline_1m_pe.txt pipeline_1m_250bp.txt \
+         pipeline_1m_pe_under_rocprof.txt build_kernels_pe.txt build_kernels_250bp.txt build_kernel_alone_pe.txt \
+         build_pe_pmc_sq_summary.txt config5_one_rank.txt stress_parity_606.txt; do
   [ -f $src/$f ] && cp $src/$f $dst/$f
 done
 [ -f $src/bench_1m.log ] && cp $src/bench_1m.log $dst/bench_1m.log
@@ -31,6 +34,7 @@ cp $src/pmc_fetch_quads/f_counter_collection.csv $dst/pmc_fetch_size_quads.csv 2
 cp $src/pmc_sq_coded/sq_counter_collection.csv $dst/pmc_sq_coded.csv 2>/dev/null
 [ -f $src/bench_1m_coded.log ] && cp $src/bench_1m_coded.log $dst/bench_1m_coded.log
 cp $src/kt_build/kt_kernel_stats.csv $dst/build_kernel_stats.csv 2>/dev/null
+cp $src/kt_pe/kt_kernel_stats.csv $dst/pipeline_1m_pe_kernel_stats.csv 2>/dev/null
 cp $src/pmc_fetch/f_counter_collection.csv $dst/pmc_fetch_size.csv 2>/dev/null
 cp $src/pmc_write/w_counter_collection.csv $dst/pmc_write_size.csv 2>/dev/null
 cp $src/pmc_sq/sq_counter_collection.csv $dst/pmc_sq.csv 2>/dev/null

@@ -5,8 +5,8 @@
 # rocprofv3 gets the program itself after `--` (python3 <script>), never a shell or env hop, and
 # counter passes (--pmc) are separate runs with --kernel-trace only.
 set -u
-round=${1:-r05}
-part=${2:-all}        # a: headline + counters + row dictionaries; b: pipelines, other configurations, small runs, build; all: both
+round=${1:-r06}
+part=${2:-all}        # a: headline + counters + row dictionaries; b: pipelines, other configurations, small runs, build; c (round 6): paired-end rows, config 5; all
 repo=$PWD
 out=$repo/gpurun_out/$round
 mkdir -p "$out"
@@ -70,6 +70,11 @@ python3 $repo/bench.py --records > $out/bench_1m_records.json 2> /dev/null
 echo "[profile_round] step 20 done"
 python3 $repo/bench.py --records --total-rows 125000 --force-dist --no-cpu-baseline > $out/bench_125k_records_one_rank_rccl.json 2> /dev/null
 echo "[profile_round] step 21 done"
+# --- round 6: three restarts per pass over the records (configs 3 and 5) -------------------------------
+python3 $repo/tools/time_quads_batched.py 1000000 > $out/quads_batched_1m.txt 2>&1
+python3 $repo/bench.py --storage coded --restarts 10 --steps 48 --no-cpu-baseline > $out/bench_1m_coded_10restarts_48steps.json 2> /dev/null
+python3 $repo/tools/ab_quad_ranking.py 1000000 > $out/quads_step_1m.txt 2>&1
+echo "[profile_round] step 21b done"
 fi
 if [ "$part" = b ] || [ "$part" = all ]; then
 python3 $repo/tools/run_pipeline.py --reads 1000000 > $out/pipeline_1m_records.txt 2>&1
@@ -121,5 +126,26 @@ python3 $repo/tools/run_pipeline.py --reads 1000000 --alignments > $out/pipeline
 echo "[profile_round] step 43 done"
 python3 $repo/tools/experiments/time_coded3.py 1000000 > $out/row_pass_experiments.txt 2>&1
 echo "[profile_round] step 44 done"
+fi
+if [ "$part" = c ] || [ "$part" = all ]; then
+# --- round 6: paired-end fragments (synth-pe-v1) and 250-bp reads through the default route; config 5 on one rank ------
+MXM_PIPELINE_TIMING=1 python3 $repo/tools/run_pipeline.py --reads 1000000 --pairs > $out/pipeline_1m_pe.txt 2>&1
+echo "[profile_round] step 45 done"
+MXM_PIPELINE_TIMING=1 python3 $repo/tools/run_pipeline.py --reads 1000000 --read-len 250 > $out/pipeline_1m_250bp.txt 2>&1
+echo "[profile_round] step 46 done"
+rocprofv3 --output-format csv --kernel-trace --stats -d $out/kt_pe -o kt -- python3 $repo/tools/run_pipeline.py --reads 1000000 --pairs > $out/pipeline_1m_pe_under_rocprof.txt 2> $out/kt_pe.log
+echo "[profile_round] step 47 done"
+python3 $repo/tools/run_build_only.py --pairs 1000000 sparse records > $out/build_kernels_pe.txt 2>&1
+python3 $repo/tools/run_build_only.py --pairs --no-long 1000000 sparse records >> $out/build_kernels_pe.txt 2>&1
+python3 $repo/tools/run_build_only.py --read-len 250 1000000 sparse records > $out/build_kernels_250bp.txt 2>&1
+python3 $repo/tools/time_build_variants.py --pairs 1000000 > $out/build_kernel_alone_pe.txt 2>&1
+echo "[profile_round] step 48 done"
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $out/pmc_sq_build_pe -o sq -- python3 $repo/tools/time_build_variants.py --pairs 400000 > /dev/null 2> $out/pmc_sq_build_pe.log
+python3 $repo/tools/sq_summary.py $out/pmc_sq_build_pe/sq_counter_collection.csv > $out/build_pe_pmc_sq_summary.txt 2>&1
+echo "[profile_round] step 49 done"
+python3 $repo/tools/time_config5_one_rank.py > $out/config5_one_rank.txt 2>&1
+echo "[profile_round] step 50 done"
+python3 $repo/tools/stress_parity.py --seed 606 --budget 420 > $out/stress_parity_606.txt 2>&1
+echo "[profile_round] step 51 done"
 fi
 find $out -name "*.csv" | head -60

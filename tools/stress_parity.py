@@ -129,8 +129,13 @@ for case in range(20):
     tables = preprocess.HapVarTables.build(refseq, phy, sub)
     n_rows = int(rng.choice([1, 9, 130, 1000, 5000]))
     read_len = int(rng.choice([30, 150, 150, 600, 3000]))
-    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=int(rng.integers(1, 1 << 30)),
-                                              read_len=read_len, contrib=(0, n_cols // 2, n_cols - 1))
+    if rng.random() < 0.3:                                    # round 6: merged mates (two thirds of the rows above 64 sites)
+        read_len = 0
+        row_ptr, site, obs, _ = synth.synth_pairs(tables, len(refseq), n_rows, seed=int(rng.integers(1, 1 << 30)),
+                                                  contrib=(0, n_cols // 2, n_cols - 1))
+    else:
+        row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=int(rng.integers(1, 1 << 30)),
+                                                  read_len=read_len, contrib=(0, n_cols // 2, n_cols - 1))
     obs = obs.copy()
     obs[rng.random(obs.size) < 0.02] = ord("N")
     want = c_oracle.build_em_matrix(tables.expected, tables.lhit, tables.lmiss, row_ptr, site, obs, n_cols)
@@ -149,7 +154,7 @@ for case in range(20):
     # against the oracle's run_em on the reference-exact matrix (even widths in the streaming kernel's range)
     if n_cols % 2 == 0 and 66 <= n_cols and n_rows * n_cols <= 6.0e6 and tables.lut() is not None:
         wts = rng.integers(1, 5, size=n_rows).astype(numpy.float64)
-        args = ns(max_iter=int(rng.choice([5, 40])))
+        args = ns(max_iter=int(rng.choice([5, 40])), n_multi=int(rng.choice([1, 1, 3, 4])))     # (3, 4: a shared pass of three + one)
         seed = int(rng.integers(1, 1 << 30))
         trace = []
         numpy.random.seed(seed)
