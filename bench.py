@@ -510,9 +510,7 @@ def main(argv=None):
     tables = preprocess.HapVarTables.build(refseq, phy, haps)
     n_haps = len(haps)
     if opts.records:
-        if opts.mode != "rows":
-            raise SystemExit("bench: --records goes with --mode rows")
-        opts.storage = "coded"
+        opts.storage = "coded"                        # (round 6: --mode restarts takes records too -- config 5 on the default route)
     need_gb = (2.0 + (1.0 if opts.mode == "rows" else 0.0)) * n_rows * n_haps * 8 / 1e9
     if opts.records:
         need_gb = n_rows * (8.0 + 0.07 * 2 * n_haps * 8 / 1024.0) * 1024 / 1e9       # records + ~7 % dense rows twice
@@ -937,6 +935,7 @@ def bench_restarts(opts, env):
     from mixemt_amd import dist as mdist
     (dev, rank, world, use_dist, mat, wts, n_rows, n_haps, build_s) = (
         env[k] for k in ("dev", "rank", "world", "use_dist", "mat", "wts", "n_rows", "n_haps", "build_s"))
+    as_records = env.get("records") is not None
     args = _ap.Namespace(init_alpha=1.0, tolerance=1e-4, max_iter=10000, n_multi=opts.restarts, verbose=False)
     numpy.random.seed(7)
     timing = {}
@@ -944,7 +943,7 @@ def bench_restarts(opts, env):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    res = mdist.run_em_restart_parallel(mat, wts, args, timing=timing)
+    res = mdist.run_em_restart_parallel(mat, wts, args, timing=timing, records=env.get("records"))
     torch.cuda.synchronize()
     wall = time.perf_counter() - t0
     stats = torch.tensor([timing["loop_s"], timing["fold_s"], timing["combine_s"], wall],
@@ -976,11 +975,13 @@ def bench_restarts(opts, env):
         "restart_iters_per_s": total_iters / float(loop_s.max()),
         "n_gpus": world, "steps": total_iters, "warmup": 0,
         "ms_per_step": float(loop_s.max()) / max(total_iters, 1) * 1e3,
-        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "f64 (matrix stored as lossless row dictionaries: opt-in variant)" if as_records else "f64",
         "data": "synthetic (synth-v1 reads in blocks of %d, matrix built on device)" % 125000,
         "config": {"workload": "%d EM restarts (sequential Dirichlet inits after seed 7) on %d reads x %d "
-                               "haplogroups replicated per GPU, dealt over %d rank(s), tile %d with slot refill"
-                               % (opts.restarts, n_rows, n_haps, world, opts.batch_tile),
+                               "haplogroups replicated per GPU%s, dealt over %d rank(s), tile %d with slot refill"
+                               % (opts.restarts, n_rows, n_haps, " as row-dictionary records + quad dictionary" if as_records else "",
+                                  world, 3 if as_records else opts.batch_tile),
                    "rows_per_gpu": n_rows, "haps": n_haps, "restarts": opts.restarts, "mode": "restarts"},
         "iters_per_restart": [int(x) for x in iters],
         "loop_s_per_rank": [float(x) for x in loop_s],

@@ -312,6 +312,11 @@ def test_bench_restart_mode_runs_to_convergence():
     assert line["sanity_ok"] and len(line["iters_per_restart"]) == 5
     assert line["steps"] == sum(line["iters_per_restart"]) and line["restart_iters_per_s"] > 0
     assert line["idle_tail_s_per_rank"] == [0.0]
+    # round 6: the same over records straight from the build (config 5 on the default route) -- the same iteration counts
+    proc2, line2 = _run_bench(["--mode", "restarts", "--restarts", "5", "--rows", "3000", "--no-cpu-baseline", "--records"])
+    assert proc2.returncode == 0, proc2.stderr[-2000:]
+    assert line2["sanity_ok"] and line2["iters_per_restart"] == line["iters_per_restart"]
+    assert "records" in line2["config"]["workload"] and line2["dtype"].startswith("f64 (matrix stored")
 
 
 def test_bench_refuses_a_world_that_differs_from_gpus():
