@@ -57,6 +57,7 @@
 #define SPB_MAXD_LONG (SPB_SLOTS_LONG * 11 / 16)   //     rows above 256, which the 512-slot table's 352 would hand to the fallback kernel)
 #define SPB_LONG_CHUNK 64             // rows the long instance examines at a time
 
+
 // NCH column pairs per thread (ceil(H / 2 / 256)); the haplogroups are taken in PASSES column ranges so that the
 // mask array is 1 / PASSES of a row (LDS per workgroup decides how many rows a CU has in flight, and a row is
 // mostly latency: dependent table loads, LDS atomics, eight barriers)
@@ -187,15 +188,20 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
         // filters and ORs them.  79 % of the rows have no more entries than that; the rest of a longer row's entries
         // are walked per range as before.
         unsigned int cached[GATHER];
+        int e_per = 0;                                       // kept entries per thread (uniform): ceil(kept / 256) <= GATHER
         int lo_keep = 0;                                     // the site of this thread's last kept entry: where its walk over
         {                                                    // a long row's further entries starts (they lie behind it)
             int jj[GATHER];
             unsigned int hap[GATHER], base[GATHER];
             // thread t takes entries GATHER * t ..: one search for the first, the others a few steps further on
             const int tot_c = total < GATHER * SPB_THREADS ? total : GATHER * SPB_THREADS;
+            e_per = (tot_c + SPB_THREADS - 1) / SPB_THREADS;
+            // (round 6) e_per entries per thread, just enough for the row's kept ones: the unrolled loops over the kept entries
+            // -- here and once per column range below -- leave at a uniform branch instead of running all GATHER rounds
+            // masked (a median row keeps 600 of its 1024 / 1500 of its 4096 slots)
             int lo = 0;
             {
-                const int e = GATHER * t;
+                const int e = e_per * t;
                 int hi = n;
                 if (e < tot_c) {
                     while (hi - lo > 1) {
@@ -207,7 +213,13 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
             }
 #pragma unroll
             for (int u = 0; u < GATHER; ++u) {
-                const int e = GATHER * t + u;
+                jj[u] = -1;
+                hap[u] = base[u] = 0u;
+            }
+#pragma unroll
+            for (int u = 0; u < GATHER; ++u) {
+                if (u >= e_per) break;                      // uniform
+                const int e = e_per * t + u;
                 if (e < tot_c) {
                     while (s_cum[lo + 1] <= e) ++lo;        // e < total = s_cum[n]: stops at lo < n
                 }
@@ -219,6 +231,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
 #pragma unroll
             for (int u = 0; u < GATHER; ++u) {
                 cached[u] = 0xffffffffu;
+                if (u >= e_per) continue;
                 if (jj[u] >= 0) {
                     const bool hit = (s_obs[jj[u]] == base[u]);
                     if ((hit ? 1 : 0) != s_hit[jj[u]]) cached[u] = hap[u] | ((unsigned int)jj[u] << 13);
@@ -240,6 +253,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
             // rows), the per-site table loads then queue up behind each other
 #pragma unroll
             for (int u = 0; u < GATHER; ++u) {
+                if (u >= e_per) break;                      // uniform
                 const unsigned int local = (cached[u] & 0x1fffu) - (unsigned int)h_lo;
                 if (cached[u] != 0xffffffffu && local < (unsigned int)SPAN) {
                     const unsigned int jb = cached[u] >> 13;
@@ -345,6 +359,8 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
                                 if (tag == 0ull) tag = 1ull;
                                 unsigned int hs = (unsigned int)(tag >> 40) & (SLOTS - 1);
                                 for (int probes = 0;; ++probes) {
+                                    // (reading the slot before the compare-and-swap -- equal masks of a clade queue up on one
+                                    // LDS word -- measured 3 % SLOWER here, unlike in the quad encoder: profiles/r06/experiments.md 2)
                                     const unsigned long long old = atomicCAS(&s_key[hs], 0ull, tag);
                                     if (old == 0ull) {
                                         *reinterpret_cast<ull2 *>(&s_wide[2 * hs]) = m;

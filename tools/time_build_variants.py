@@ -69,9 +69,6 @@ for path in paths:
         lib.mxm_set_sparse_long_rows(0 if long_off else 1)
         if max_entries is not None and hasattr(lib, "mxm_set_sparse_long_entries"):
             lib.mxm_set_sparse_long_entries(max_entries)
-if max_entries is not None:
-    lib.mxm_set_sparse_long_entries(max_entries)
-    print("(rows of the long launch with more than %d marker entries -> fallback list)" % max_entries)
     out.fill_(7.0)
     times = []
     for rep in range(9):
