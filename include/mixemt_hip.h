@@ -363,7 +363,7 @@ int mxm_em_iter_coded(const mxm_coded *c, const double *w, const double *props, 
 /* Rows WITH quads from which mxm_em_loop_coded iterates with the per-iteration kernels over the quad dictionary instead of
  * the one-launch loop over the records alone: a binding that attaches a dictionary "where it pays" must test the same
  * quantity (n_quad_rows after mxm_build_quads), or it builds one the loop never looks at. */
-int64_t mxm_quad_loop_min_rows(void);
+int64_t mxm_quad_loop_min_rows(int32_t B /* restarts of the run: from three on, tiles of three share a pass and the floor is far lower */);
 /* Restarts that share one pass over THIS coded matrix in mxm_em_iter_coded / mxm_em_loop_coded: 3 beside a quad dictionary
  * (width within the quad pass's range, no dense leftover rows), else 1.  B restarts take floor(B / 3) shared passes and
  * B mod 3 single ones; per-restart sums differ from the one-per-pass kernel's by the rounding of another order only. */

@@ -59,7 +59,7 @@ SIGNATURES = {
     "mxm_workspace_bytes": (c_size, [c_i64, c_i32, c_i32]),
     "mxm_restart_tile": (ctypes.c_int, [c_i32]),
     "mxm_restart_tile_coded": (ctypes.c_int, [ctypes.POINTER(Coded), c_i32]),
-    "mxm_quad_loop_min_rows": (c_i64, []),
+    "mxm_quad_loop_min_rows": (c_i64, [c_i32]),
     "mxm_build_em_matrix": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,
                                            c_i64, c_i32, c_i32, c_ptr, c_i64, c_ptr]),
     "mxm_build_em_matrix_lut": (ctypes.c_int, [c_ptr, c_i64, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr, c_ptr,

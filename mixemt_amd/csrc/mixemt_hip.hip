@@ -1397,9 +1397,12 @@ static int fused_coded_grid(int64_t R) {
     return nwg < 1 ? 1 : nwg;
 }
 #define QUAD_PER_ITER_MIN_ROWS 300000
+#define QUAD_BATCH_MIN_ROWS 15000     // ... with three or more restarts running: tiles of three share a pass, which beats the one-launch
+                                      // loop (restarts one after another) from the smallest record plans on: 45 against 55 us per
+                                      // restart-iteration at 2*10^4 rows, 172 against 244 at 1.5*10^5 (profiles/r06/multi_restart_routes.txt)
 // the floor a binding's "auto" rule must use too: a dictionary of fewer quad rows is never looked at by mxm_em_loop_coded
-extern "C" int64_t mxm_quad_loop_min_rows(void) { return QUAD_PER_ITER_MIN_ROWS; }
-static bool fused_coded_eligible(const mxm_coded *c, int H, int B, size_t ws_bytes) {
+extern "C" int64_t mxm_quad_loop_min_rows(int32_t B) { return B >= 3 ? QUAD_BATCH_MIN_ROWS : QUAD_PER_ITER_MIN_ROWS; }
+static bool fused_coded_eligible(const mxm_coded *c, int H, int B, size_t ws_bytes, int running = 1) {
     if (T.loop_fused == 0 || c == nullptr || c->R_rest > 0 || !mxm_linear_supported(H) || (H & 1)) return false;
     // beside a quad dictionary the per-iteration kernels are the faster loop from a few 10^5 rows (1.35 against 1.45 ms per
     // iteration at 10^6: the quad pass saves 0.13 ms of the row pass, the one-launch loop ~0.04 ms of launches and tail;
@@ -1408,6 +1411,8 @@ static bool fused_coded_eligible(const mxm_coded *c, int H, int B, size_t ws_byt
     if (c->qrec != nullptr && c->n_quad_rows >= QUAD_PER_ITER_MIN_ROWS && T.loop_fused != 1 &&
         (coded_ld(H) / 4 + QUAD_THREADS - 1) / QUAD_THREADS <= QUAD_MAX_NCH)
         return false;
+    // ... and with a full tile of restarts still running, from far fewer rows (round 6)
+    if (running >= 3 && T.loop_fused != 1 && c->n_quad_rows >= QUAD_BATCH_MIN_ROWS && coded_batch_ok(c, H)) return false;
     const int nwg = fused_coded_grid(c->R);
     const int ncol2 = H / 2;
     if ((ncol2 + nwg - 1) / nwg > 16 * FCODED_MAX_M) return false;           // slice wider than the column reduce covers
@@ -1705,7 +1710,7 @@ static int em_loop_impl(const double *M, int64_t ldm, const double *P, int64_t l
     HIP_TRY(hipStreamSynchronize(caller));
     int running = 0;
     for (int b = 0; b < B; ++b) running += (state_host[b].done == 0) ? 1 : 0;
-    if (coded != nullptr && running > 0 && max_iter > 0 && fused_coded_eligible(coded, (int)H, (int)B, ws_bytes)) {
+    if (coded != nullptr && running > 0 && max_iter > 0 && fused_coded_eligible(coded, (int)H, (int)B, ws_bytes, running)) {
         // records: the whole loop in persistent launches on the caller's stream, restarts one after another.  A launch
         // is kept to about half a second (a 10^7-row matrix takes 15 ms per iteration): `chunk` iterations each.
         int chunk = T.fused_chunk > 0 ? T.fused_chunk : max_iter;

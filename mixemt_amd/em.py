@@ -114,6 +114,8 @@ AUTO_CODED_MIN_CELLS = 1.5e7        # storage="auto": measured break-even of the
 # sets the start value: A/B runs of the tools without editing them)
 QUADS = {"off": False, "0": False, "on": True, "1": True}.get(os.environ.get("MXM_QUADS", "auto").strip().lower(), "auto")
 QUADS_MIN_ROWS = 300000             # ... "auto": from this many byte-coded rows (below, the one-launch loop over the records is faster)
+QUADS_MIN_ROWS_MULTI = 20000        # ... with three or more restarts: tiles of three share a pass over the records (round 6), which beats the
+                                    #     one-launch loop from the smallest record plans on (profiles/r06/multi_restart_routes.txt)
 QUADS_MAX_FOOTPRINT = 60e9          # ... and only while records + dictionary stay under this many bytes
 AUTO_CODED_MIN_CELLS_MULTI = 5e7    # ... with SEVERAL restarts: the one-launch records loop runs them one after
                                     # another while the dense path shares each pass of the matrix among up to four, so the
@@ -279,7 +281,8 @@ class EmPlan(object):
             # (fixed orders, but different ones), and the same call must take the same route every time
             # (min_rows: a caller whose loop runs the per-iteration kernels anyway -- dist.sharded_em_loop -- names its own
             # floor, and one restart is reason enough there)
-            floor_ok = n_byte >= (min_rows if min_rows is not None else QUADS_MIN_ROWS)
+            floor_ok = n_byte >= (min_rows if min_rows is not None else
+                                  (QUADS_MIN_ROWS_MULTI if getattr(self, "n_runs", 1) >= 3 else QUADS_MIN_ROWS))
             # ... and not where it would take the process's device footprint past ~64 GB: the driver charges a process's
             # first growth past that mark with 2-6 s (profiles/r05/alloc_big.txt), more than the dictionary earns back
             if not floor_ok or int(rec.numel()) + guess > QUADS_MAX_FOOTPRINT:
@@ -334,7 +337,7 @@ class EmPlan(object):
         # mxm_quad_loop_min_rows() rows WITH quads -- "auto" decides by that same quantity, now that it is known, instead of
         # keeping a dictionary (11 ms, 4.8 KB per row) the loop would never look at; a caller that named its own floor
         # (dist.sharded_em_loop: its only loop is the per-iteration kernels) keeps what it asked for
-        if mode == "auto" and min_rows is None and n_quad < int(lib.mxm_quad_loop_min_rows()):
+        if mode == "auto" and min_rows is None and n_quad < int(lib.mxm_quad_loop_min_rows(int(getattr(self, "n_runs", 1)))):
             return False
         quad_rows_d, byte_rows_d = quad_rows_d[:n_quad], byte_rows_d[:n_byte_left]
         self._quad_keep = (qrec, qoff, nquad, quad_rows_d, byte_rows_d)

@@ -266,3 +266,40 @@ def test_seven_restarts_to_convergence_with_every_schedule(b17):
             continue
         assert got[1] == ref[1] and got[2] == ref[2], (tile, sched)
         assert numpy.abs(numpy.exp(got[0]) - numpy.exp(ref[0])).max() < 1e-12
+
+
+def test_several_restarts_take_the_shared_passes_from_twenty_thousand_rows(b17, monkeypatch):
+    """`"auto"` (profiles/r06/multi_restart_routes.txt): with three or more restarts the quad dictionary is attached from 2*10^4
+    byte-coded rows and mxm_em_loop_coded leaves the one-launch loop (restarts one after another) for tiles of three --
+    45 against 55 us per restart-iteration at that size; with one restart the plan stays without quads.  Same iteration
+    counts and proportions as the one-launch loop."""
+    from mixemt_amd import _lib, em
+    refseq, phy, haps, tables = b17
+    n_rows = 24000
+    cm, _ = _records(tables, len(refseq), n_rows, 51)
+    wts = numpy.ones(n_rows)
+    lib = _lib.load()
+    assert lib.mxm_quad_loop_min_rows(1) == 300000 and lib.mxm_quad_loop_min_rows(3) < 20000
+    made = []
+    real = em.EmPlan.attach_quads
+
+    def spy(self, mode=None, cap=None, min_rows=None):
+        ok = real(self, mode, cap, min_rows)
+        made.append((self.n_runs, bool(ok)))
+        return ok
+
+    monkeypatch.setattr(em.EmPlan, "attach_quads", spy)
+    monkeypatch.setattr(em, "QUADS", "auto")
+    args3 = em_args(n_multi=4, max_iter=40)
+    numpy.random.seed(5)
+    shared = em.run_em_ex(None, wts, args3, want_read_mix=False, records=cm)
+    assert made and made[-1] == (4, True)
+    em.QUADS = False                                                 # the one-launch loop over the records alone
+    numpy.random.seed(5)
+    plain = em.run_em_ex(None, wts, args3, want_read_mix=False, records=cm)
+    em.QUADS = "auto"
+    assert shared["iters"] == plain["iters"] == [40, 40, 40, 40]
+    assert numpy.abs(shared["run_props"] - plain["run_props"]).max() < 1e-12
+    numpy.random.seed(5)
+    one = em.run_em_ex(None, wts, em_args(n_multi=1, max_iter=10), want_read_mix=False, records=cm)
+    assert made[-1] == (1, False) and one["iters"] == [10]
