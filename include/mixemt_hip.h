@@ -148,11 +148,14 @@ int mxm_build_em_matrix_lut_rows(const uint8_t *Ecode, int64_t lde, const double
  *                     differ from maj[s]  (Build 17: 113 027 entries)
  *   obs[]             the observation's byte itself (it hits where it equals the expected base's byte)
  * A haplogroup's cell is decided by the set of the row's sites where its term differs from the
- * majority's (a 64-bit mask OR-ed together from the marker lists); the row's distinct masks are
- * deduplicated and each one's sum is formed in signature order from 0.0, as prob_for_vars does
- * (preprocess.py:86-96).  Rows with more than 64 observations (or more than 352 distinct values) are NOT
- * written: their indices are appended to fallback[] (device int64[R], *n_fallback = how many, device) and
- * the caller builds them with mxm_build_em_matrix_lut (order = fallback, R = *n_fallback; any order of the list).
+ * majority's (a mask OR-ed together from the marker lists: 64 bits for rows of up to 64 observations, 128 bits --
+ * round 6, a second launch over the same rows -- for rows of 65 .. 128: the reference merges mates into one
+ * fragment, preprocess.py:118-138, and two thirds of 2 x 150 paired-end fragments observe more than 64 sites);
+ * the row's distinct masks are deduplicated and each one's sum is formed in signature order from 0.0, as
+ * prob_for_vars does (preprocess.py:86-96).  Rows with more than 128 observations, more than 352 (long rows:
+ * 704) distinct values, or -- long rows -- more than 5120 marker entries are NOT written: their indices are
+ * appended to fallback[] (device int64[R], *n_fallback = how many, device) and the caller builds them with
+ * mxm_build_em_matrix_lut (order = fallback, R = *n_fallback; any order of the list; every row at most once).
  */
 int mxm_build_em_matrix_sparse(const uint8_t *maj, const double *lhit, const double *lmiss,
                                const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,
@@ -166,9 +169,9 @@ int mxm_build_em_matrix_sparse(const uint8_t *maj, const double *lhit, const dou
  * (mxm_encode_rows) is needed, and with M == NULL no dense matrix is written at all:
  *     record = codes[ldc] ++ P table[ndist] ++ table of the log sums themselves [ndist]
  * (P = exp(sum - rowmax[r]); code 0 = the value of a haplogroup without a deviating marker in the window).
- * Rows that get no record have ndist[r] = 0: with M given, rows of more than 256 distinct values (their dense
- * row is written); rows on the fallback list (more than 64 observations, more than 352 distinct masks, and --
- * when M is NULL -- more than 256 values), which the caller builds densely.  stats[0] = bytes used,
+ * Rows of 257 .. 705 distinct values get a record with 16-bit codes ("wide", round 6; 2 * ldc bytes of codes).
+ * Rows that get no record have ndist[r] = 0: the rows on the fallback list (as above), which the caller builds
+ * densely; with M given their dense row is NOT written either (the list says which).  stats[0] = bytes used,
  * stats[1] = rows without a record (device int64[2]); rec_bytes >= mxm_record_bytes(R, H) never overflows.
  */
 size_t mxm_record_bytes(int64_t R, int32_t H);

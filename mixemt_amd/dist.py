@@ -250,7 +250,9 @@ def sharded_em_loop(plan, inits, tolerance, max_iter, group=None, check_every=8,
         # records a quad dictionary has no one-launch loop to beat and pays from far fewer rows than in run_em's own loop
         # (em.EmPlan.attach_quads; SHARD_QUADS_MIN_ROWS byte-coded rows in the shard)
         if getattr(plan, "coded", None) is not None and hasattr(plan, "attach_quads") and _em.QUADS == "auto":
-            plan.attach_quads("auto", min_rows=SHARD_QUADS_MIN_ROWS)
+            # (three or more restarts: tiles of three share a pass -- worth the dictionary from far fewer rows, em.QUADS_MIN_ROWS_MULTI)
+            few = int(numpy.asarray(inits).shape[0]) < 3
+            plan.attach_quads("auto", min_rows=SHARD_QUADS_MIN_ROWS if few else min(SHARD_QUADS_MIN_ROWS, _em.QUADS_MIN_ROWS_MULTI))
         ln0, p0 = _em.log_inits(inits)
         n_runs = ln0.shape[0]
         if window is None:

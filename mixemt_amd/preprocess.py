@@ -356,7 +356,7 @@ def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto", 
       "lut"    hit / miss by LDS lookup (mxm_build_em_matrix_lut): the fastest cell-by-cell kernel
       "bytes"  the byte-table kernel (mxm_build_em_matrix), any alphabet, any width
       "sparse" the marker kernel (mxm_build_em_matrix_sparse): one in-order sum per distinct cell value of a
-               row instead of one per cell; rows with more than 64 observations go through "lut"
+               row instead of one per cell; rows with more than 128 observations (or 5120 marker entries) go through "lut"
       "auto"   "sparse" where the tables qualify for "lut" (at most 14 distinct bases, H <= 8192), else "bytes"
     All give the same bits (profiles/r02/build_kernels.txt has the timings).
     sort_rows: take the rows in position order ("lut" only; True / False / "auto" = from
@@ -391,7 +391,7 @@ def build_em_matrix_device(tables, row_ptr, site, obs, out=None, kernel="auto", 
         left = int(n_fallback.item())
         build_em_matrix_device.last_fallback = left
         if left:
-            # rows with more than 64 observations (or thousands of distinct values): cell by cell
+            # rows with more than 128 observations (or hundreds of distinct values, or thousands of marker entries): cell by cell
             lut = tables.lut_device()
             rows = fallback[:left].sort().values          # any order gives the same rows; sorted = reproducible launch
             _lib.check(lib.mxm_build_em_matrix_lut(
@@ -625,7 +625,7 @@ def build_em_records_device(tables, row_ptr, site, obs, dense=False, cap=None, r
     (one byte per haplogroup + the row's distinct values) -- what em.EmPlan(storage="coded") otherwise
     makes from the dense matrix with a pass of its own.  dense=False: NO dense matrix is written (5.5 GB
     instead of 43 GB at 10^6 x 5408; 10^7 rows fit one GPU); rows the marker kernel cannot take (more than
-    64 observations, more than 256 distinct values: ~3.5 %) are built densely by the lookup-table kernel and
+    128 observations, more than 5120 marker entries, more than 704 distinct values: 2 % of 150-bp reads, 4 % of merged mates) are built densely by the lookup-table kernel and
     coded from there (mxm_encode_rows: byte codes up to 256 values, 16-bit codes up to 1024) a slab (REST_SLAB_BYTES) at a
     time, so the detour never holds more than one slab of dense rows (round 4 built all of them at once: 1.4 GB at
     10^6 rows, 14 GB at 10^7); what remains (more than 1024 values: none on build_em_matrix's rows) stays dense in `m_rest`.
