@@ -1,3 +1,7 @@
+"""Round 6: where a cold process spends the plan stage (EmPlan over records + quad dictionary) -- host time stamps of
+its parts without synchronising between them (profiles/r06/experiments.md; DESIGN section 6: a 25 ms stall at the plan's
+synchronize on some boxes' first process, absent under rocprofv3).  python tools/experiments/time_plan2.py
+"""
 import os, sys, time, argparse
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import numpy, torch
