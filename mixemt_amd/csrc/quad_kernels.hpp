@@ -59,17 +59,43 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
     __shared__ unsigned short s_slot[QUAD_MAX];
     __shared__ unsigned char s_rank[QUAD_HASH];
     __shared__ int s_n, s_n2;
+    __shared__ double s_ptab[ENC_MAX_CODES];
     __shared__ unsigned long long s_base, s_chunk_at, s_chunk_left;
     const int t = threadIdx.x;
     const int nqc = ldc >> 2;                              // quads per row
     if (t == 0) s_chunk_at = s_chunk_left = 0ull;          // (ordered before its first use by the row loop's barriers)
-    for (int64_t r = blockIdx.x; r < R; r += gridDim.x) {
-        const int nd = ndist[r];
-        if (nd <= 0 || nd > ENC_MAX_CODES) {               // uniform: wide rows and rows without a record have no quads
+    // The row loop is a chain of dependent steps (six barriers, ~17 us per row and workgroup, SQ: parked 74 %): the next row's
+    // record offset / size are asked for at the top of a row and its code words once they are back, after the inserts'
+    // barrier, so that neither load's latency sits in front of the next row's first step (round 6).
+    const auto codes_ok = [](int nd) { return nd > 0 && nd <= ENC_MAX_CODES; };
+    auto load_codes = [&](long long off, int nd, unsigned int(&dst)[8]) {
+        const unsigned int *codes = reinterpret_cast<const unsigned int *>(rec + off);
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+            const int idx = t + QUAD_THREADS * j;
+            dst[j] = (codes_ok(nd) && idx < nqc) ? codes[idx] : 0u;
+        }
+    };
+    int64_t r = blockIdx.x;
+    int nd_nx = r < R ? ndist[r] : 0;
+    long long off_nx = r < R ? rec_off[r] : 0;
+    unsigned int q_nx[8];
+    load_codes(off_nx, nd_nx, q_nx);
+    for (; r < R; r += gridDim.x) {
+        const int nd = nd_nx;
+        const long long off_r = off_nx;
+        unsigned int q[8];
+#pragma unroll
+        for (int j = 0; j < 8; ++j) q[j] = q_nx[j];
+        const int64_t r2 = r + gridDim.x;
+        nd_nx = r2 < R ? ndist[r2] : 0;                   // (in flight under this row's first steps)
+        off_nx = r2 < R ? rec_off[r2] : 0;
+        if (!codes_ok(nd)) {                               // uniform: wide rows and rows without a record have no quads
             if (t == 0) {
                 nquad[r] = 0;
                 qoff[r] = 0;
             }
+            load_codes(off_nx, nd_nx, q_nx);
             continue;
         }
         for (int i = t; i < QUAD_HASH; i += QUAD_THREADS) {
@@ -78,15 +104,16 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
         }
         if (t == 0) s_n = s_n2 = 0;
         __syncthreads();
-        const uint8_t *base = rec + rec_off[r];
-        const unsigned int *codes = reinterpret_cast<const unsigned int *>(base);
-        unsigned int q[8];
+        const uint8_t *base = rec + off_r;
+        // this thread's entry of the record's P table: asked for now, parked in LDS behind the ranking's barrier, so that the
+        // four values of a table entry are LDS reads at the end of the row instead of dependent global loads
+        const double ptab_mine = (t < nd) ? reinterpret_cast<const double *>(base + ldc)[t] : 0.0;
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int idx = t + QUAD_THREADS * j;
             unsigned int key = 0;
             if (idx < nqc) {
-                key = codes[idx];
+                key = q[j];
                 const int c0 = idx * 4;                    // columns past H (ldc - H <= 7 of them): code 0
                 if (c0 + 3 >= H) {
                     if (c0 + 0 >= H) key &= ~0x000000ffu;
@@ -128,9 +155,11 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
                     }
                 }
 #endif
+                key = slot;                                // from here on the thread only needs where its quad sits
             }
             q[j] = key;
         }
+        load_codes(off_nx, nd_nx, q_nx);                   // the next row's code words: back by the time this row is written
         __syncthreads();
         const int n = s_n;                                 // uniform
         if (n > QUAD_MAX) {
@@ -145,16 +174,22 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
         // the distinct quads, numbered by RANK (ascending quad): compact them, count for each how many are smaller (n
         // broadcast reads), and leave the rank in the quad's hash slot for the threads' own quads to pick up -- no sort,
         // four barriers per row
-        for (int i = t; i < QUAD_HASH; i += QUAD_THREADS) {
+        for (int i = t; i < QUAD_HASH; i += QUAD_THREADS) {   // (four rounds, every thread in each: the ballots are whole)
             const unsigned long long v = s_tab[i];
+            // one reservation per wave and round instead of one atomic per occupied slot (a row's ~93 on one LDS word)
+            const unsigned long long votes = __ballot(v != 0ull);
+            int first = 0;
+            if ((t & 63) == 0 && votes != 0ull) first = atomicAdd(&s_n2, __popcll(votes));
+            first = __builtin_amdgcn_readfirstlane(first);
             if (v != 0ull) {
-                const int at_i = atomicAdd(&s_n2, 1);
+                const int at_i = first + __popcll(votes & ((1ull << (t & 63)) - 1ull));
                 s_keys[at_i] = (unsigned int)v;
                 s_slot[at_i] = (unsigned short)i;
                 if constexpr (QUAD_RANK_BY_COUNT != 0) s_kcnt[at_i] = s_cnt[i];
             }
         }
         __syncthreads();
+        s_ptab[t] = ptab_mine;                              // (read after the next barrier)
         unsigned int my_key = 0;
         if (t < n) {
             my_key = s_keys[t];
@@ -180,12 +215,7 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
             const int idx = t + QUAD_THREADS * j;
-            if (idx < nqc) {
-                const unsigned long long tagged = (1ull << 32) | q[j];
-                unsigned int slot = (q[j] * 2654435761u) >> 22;
-                while (s_tab[slot] != tagged) slot = (slot + 1) & (QUAD_HASH - 1);      // it is there: inserted above
-                word |= (unsigned long long)s_rank[slot] << (8 * j);
-            }
+            if (idx < nqc) word |= (unsigned long long)s_rank[q[j]] << (8 * j);      // (q[j]: the quad's SLOT, kept from its insert)
         }
         const unsigned long long bytes = QUAD_CODE_BYTES + 32ull * (unsigned long long)n;
 #ifdef QUAD_FIXED_SLOTS                                     // (timing experiment: no shared bump pointer)
@@ -212,7 +242,7 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
         if (fits) {
             *reinterpret_cast<unsigned long long *>(qrec + at + (unsigned long long)t * 8ull) = word;
             if (t < n) {
-                const double *tbl = reinterpret_cast<const double *>(base + ldc);
+                const double *tbl = s_ptab;
                 const unsigned int key = s_sorted[t];
                 quad_d2 *dst = reinterpret_cast<quad_d2 *>(qrec + at + QUAD_CODE_BYTES + (unsigned long long)t * 32ull);
                 dst[0] = quad_d2{tbl[key & 255u], tbl[(key >> 8) & 255u]};
