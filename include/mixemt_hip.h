@@ -309,7 +309,8 @@ size_t mxm_coded_bytes(int64_t R, int32_t H);
 /*
  * mxm_build_quads    records -> quad records (device work on `stream`, no allocation): qoff[R] / nquad[R] for EVERY row
  *                    (0 for rows without a byte-coded record and for rows with more than 256 distinct quads); the
- *                    records go to qrec[0 .. qrec_bytes) by a bump allocator (64 KB reserved per workgroup at a time),
+ *                    records go to qrec[0 .. qrec_bytes) by a bump allocator (64 KB reserved at a time by each of at most
+ *                    5120 waves: up to 5120 x 64 KB are open, i.e. reserved and partly unused, when the call ends),
  *                    stats[0] = bytes reserved (a record that no longer fits is not written and its row keeps
  *                    nquad = 0: repeat with stats[0] bytes and some room to spare),
  *                    stats[1] = byte-coded rows left without quads (device uint64[2], zeroed by the call).  qrec must be

@@ -122,6 +122,12 @@ int mxm_set_sparse_long_rows(int32_t on);
 int mxm_set_sparse_long_entries(int32_t n);
 
 /*
+ * The quad dictionary's encoder (mxm_build_quads): 1 (default) = a wave per row (quad_encode_wave_kernel, round 6),
+ * 0 = a workgroup per row (quad_encode_kernel).  The same record bytes for every row either way.
+ */
+int mxm_set_quad_encoder(int32_t kind);
+
+/*
  * Restarts per pass over records beside a quad dictionary: 3 (default; em_iter_quad_batched_kernel takes full tiles of
  * three) or 1 (every restart its own pass, as before round 6).  Results differ by the rounding of another summation
  * order only.

@@ -129,6 +129,7 @@ SIGNATURES = {
     "mxm_set_quad_left_grid": (ctypes.c_int, [c_i32]),
     "mxm_set_coded_batch_tile": (ctypes.c_int, [c_i32]),
     "mxm_set_sparse_long_rows": (ctypes.c_int, [c_i32]),
+    "mxm_set_quad_encoder": (ctypes.c_int, [c_i32]),
     "mxm_set_sparse_long_entries": (ctypes.c_int, [c_i32]),
     "mxm_diag_fused_stamps": (ctypes.c_int, [c_ptr, ctypes.POINTER(ctypes.c_ulonglong)]),
     "mxm_set_timing_events": (ctypes.c_int, [c_ptr, c_ptr]),

@@ -86,6 +86,7 @@ struct mxm_tuning {
     int fused_coded_wg = 0;         // workgroups of the one-launch loop over records (0 = by size)
     int quad_left_wg = 0;           // workgroups of the leftover pass beside the quad pass (0 = by the rows' measured cost)
     int sparse_long_entries = 5120; // ... whose rows with more marker entries than this go to the fallback list (0: no limit)
+    int quad_encoder = 1;           // the quad dictionary's encoder: 1 = a wave per row (quad_encode_wave_kernel), 0 = a workgroup per row
     int sparse_long = 1;            // the marker build's second launch for rows of 65 .. 128 observations (0: they go to the fallback list)
     int coded_bt = 3;               // restarts per pass over records beside a quad dictionary (1 = one per pass, 3 = the batched kernel)
     int fused_force_abort = 0;      // test hook: the one-launch loop starts with its abort flag raised (as if starved)
@@ -504,6 +505,10 @@ extern "C" int mxm_set_sparse_long_entries(int32_t n) {
 extern "C" int mxm_set_coded_batch_tile(int32_t bt) {
     if (bt != 1 && bt != 3) return fail(-1, "mxm_set_coded_batch_tile: 1 or 3, got %s%lld", "", bt);
     return tune_set([bt](mxm_tuning &t) { t.coded_bt = bt; });
+}
+extern "C" int mxm_set_quad_encoder(int32_t kind) {
+    if (kind != 0 && kind != 1) return fail(-1, "mxm_set_quad_encoder: 0 or 1, got %s%lld", "", kind);
+    return tune_set([kind](mxm_tuning &t) { t.quad_encoder = kind; });
 }
 extern "C" int mxm_set_quad_left_grid(int32_t nwg) {
     return tune_set([nwg](mxm_tuning &t) { t.quad_left_wg = nwg > 0 ? nwg : 0; });
@@ -982,9 +987,15 @@ extern "C" int mxm_build_quads(const mxm_coded *c, int32_t H, uint8_t *qrec, siz
     const int ldc = coded_ld(H);
     if (ldc / 4 > 8 * QUAD_THREADS) return fail(-1, "mxm_build_quads: H=%s%lld beyond eight quads per thread", "", H);
     HIP_TRY(hipMemsetAsync(stats, 0, 2 * sizeof(uint64_t), (hipStream_t)stream));
-    hipLaunchKernelGGL(quad_encode_kernel, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(QUAD_THREADS), 0, (hipStream_t)stream,
-                       c->rec, c->rec_off, c->ndist, ldc, (int)H, c->R, qrec, (unsigned long long)qrec_bytes, qoff, nquad,
-                       reinterpret_cast<unsigned long long *>(stats));
+    // (either way at most 5120 pieces of QUAD_CHUNK bytes are open at the end: what the caller's first guess leaves room for)
+    if (T.quad_encoder == 1 && ldc / 4 <= 64 * QW_K)
+        hipLaunchKernelGGL(quad_encode_wave_kernel, dim3(clamp_grid((c->R + QW_WAVES - 1) / QW_WAVES, std::min(num_cu() * QW_MIN_WAVES, 5120 / QW_WAVES))), dim3(QUAD_THREADS),
+                           0, (hipStream_t)stream, c->rec, c->rec_off, c->ndist, ldc, (int)H, c->R, qrec,
+                           (unsigned long long)qrec_bytes, qoff, nquad, reinterpret_cast<unsigned long long *>(stats));
+    else
+        hipLaunchKernelGGL(quad_encode_kernel, dim3(clamp_grid(c->R, num_cu() * 8)), dim3(QUAD_THREADS), 0, (hipStream_t)stream,
+                           c->rec, c->rec_off, c->ndist, ldc, (int)H, c->R, qrec, (unsigned long long)qrec_bytes, qoff, nquad,
+                           reinterpret_cast<unsigned long long *>(stats));
     HIP_TRY(hipGetLastError());
     return 0;
 }

@@ -127,7 +127,7 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
                 for (int probe = 0; probe < QUAD_HASH && s_n <= QUAD_MAX; ++probe) {
                     // most of a row's quads are ONE quad (the row's majority value four times): look before the atomic, or
                     // a thousand compare-and-swaps queue up on one LDS word
-                    unsigned long long old = *reinterpret_cast<volatile unsigned long long *>(&s_tab[slot]);
+                    unsigned long long old = __hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);   // (a ds_read: a volatile access went the flat way)
                     if (old == 0ull) old = atomicCAS(&s_tab[slot], 0ull, tagged);
                     if (old == 0ull) {
                         atomicAdd(&s_n, 1);
@@ -255,6 +255,281 @@ __global__ __launch_bounds__(QUAD_THREADS) void quad_encode_kernel(const uint8_t
             if (!fits) atomicAdd(&stats[1], 1ull);
         }
         __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// K3q-encw  quad_encode_wave_kernel: the same records, one WAVE per row (round 6).  The workgroup-per-row encoder above is
+// a chain of six barriers per row with five or six quads per thread between them (SQ: parked 74 %, issuing 17 %); a wave
+// that owns its row needs no barrier at all -- a wave's LDS instructions are carried out in the order it issued them, so a
+// compiler fence is all that stands between the steps -- and a CU holds sixteen rows instead of eight.  Lane l owns the
+// quads l + 64 k (k < 24), i.e. the code words of the threads l, l + 64, l + 128, l + 192 of the pass; the distinct quads
+// are counted by ballots as they are inserted (no shared counter), the hash has 512 slots (a round adds at most 64 to at
+// most 256: it never fills), the bump pointer's chunk is the wave's own, in registers.  The bytes written for a row are
+// those of the kernel above (codes = ranks by value); where the record lies in `qrec` differs from run to run in both.
+// ------------------------------------------------------------------------------------------
+#define QW_HASH 512
+#define QW_K 24
+#define QW_WAVES (QUAD_THREADS / 64)
+#ifndef QW_MIN_WAVES
+#define QW_MIN_WAVES 5                    // waves per SIMD the encoder is compiled for (20 rows per CU; LDS: 26 KB per workgroup)
+#endif
+
+__device__ __forceinline__ void wave_lds_fence() {
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+    __builtin_amdgcn_wave_barrier();
+    __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+}
+
+// body(integral_constant<int, 0>) ... body(integral_constant<int, N - 1>): a loop whose index is a constant where the
+// source is parsed.  (Arrays indexed inside `#pragma unroll` loops become ONE 24-wide vector value once they are carried
+// round the row loop -- spilled and reloaded as a block; indexed by constants from the start they are 24 registers.)
+template <class F, int... K>
+__device__ __forceinline__ void quad_static_for_impl(F &&body, std::integer_sequence<int, K...>) {
+    (body(std::integral_constant<int, K>{}), ...);
+}
+template <int N, class F>
+__device__ __forceinline__ void quad_static_for(F &&body) {
+    quad_static_for_impl(body, std::make_integer_sequence<int, N>{});
+}
+
+__global__ __launch_bounds__(QUAD_THREADS, QW_MIN_WAVES) void quad_encode_wave_kernel(const uint8_t *__restrict__ rec,
+                                                                        const int64_t *__restrict__ rec_off,
+                                                                        const int32_t *__restrict__ ndist, int ldc, int H, int64_t R,
+                                                                        uint8_t *__restrict__ qrec, unsigned long long qcap,
+                                                                        int64_t *__restrict__ qoff, int32_t *__restrict__ nquad,
+                                                                        unsigned long long *__restrict__ stats) {
+    __shared__ __attribute__((aligned(16))) unsigned long long s_tab_all[QW_WAVES][QW_HASH];
+    __shared__ unsigned char s_rank_all[QW_WAVES][QW_HASH];
+    __shared__ double s_ptab_all[QW_WAVES][ENC_MAX_CODES];
+    int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+    unsigned long long *s_tab = s_tab_all[wv];
+    // once the table has been read out (into registers), its 4 KB hold the distinct quads in slot order (+ 4: read four at a
+    // time), the same in rank order, and their slots
+    unsigned int *s_keys = reinterpret_cast<unsigned int *>(s_tab), *s_sorted = s_keys + QUAD_MAX + 4;
+    unsigned short *s_slot = reinterpret_cast<unsigned short *>(s_sorted + QUAD_MAX);
+    static_assert((2 * QUAD_MAX + 4) * 4 + QUAD_MAX * 2 <= QW_HASH * 8, "the lists live in the table's LDS");
+    unsigned char *s_rank = s_rank_all[wv];
+    double *s_ptab = s_ptab_all[wv];
+    const int nqc = ldc >> 2;                              // quads per row (<= 64 QW_K, checked by the host)
+    unsigned long long chunk_at = 0ull, chunk_left = 0ull; // the wave's piece of `qrec` (uniform)
+    const auto codes_ok = [](int nd) { return nd > 0 && nd <= ENC_MAX_CODES; };
+    // a row's code words and its record's P table (lane l: entries l, l + 64, ...), asked for during the row before
+    auto load_row = [&](long long off, int nd, unsigned int(&dst)[QW_K], double(&tab)[4]) {
+        const unsigned int *codes = reinterpret_cast<const unsigned int *>(rec + off);
+        const double *ptab = reinterpret_cast<const double *>(rec + off + ldc);
+        const bool ok = codes_ok(nd);
+        quad_static_for<QW_K>([&](auto K) {
+            constexpr int k = decltype(K)::value;
+            dst[k] = (ok && lane + 64 * k < nqc) ? codes[lane + 64 * k] : 0u;
+        });
+        quad_static_for<4>([&](auto M) {
+            constexpr int m = decltype(M)::value;
+            tab[m] = (ok && lane + 64 * m < nd) ? ptab[lane + 64 * m] : 0.0;
+        });
+    };
+    // a wave takes a run of consecutive rows: their sizes and offsets come 64 rows at a time, one per lane (a row's own
+    // scalar loads would put a trip to memory in front of every row: they share the LDS instructions' counter), and what
+    // the wave found goes back the same way
+    const int64_t waves = (int64_t)gridDim.x * QW_WAVES;
+    const int64_t per = (R + waves - 1) / waves;
+    const int64_t row_lo = ((int64_t)blockIdx.x * QW_WAVES + wv) * per;
+    const int64_t row_hi = row_lo + per < R ? row_lo + per : R;
+    if (row_lo >= row_hi) return;
+    const auto meta_nd = [&](int64_t first) { return first + lane < row_hi ? ndist[first + lane] : 0; };
+    const auto meta_off = [&](int64_t first) { return first + lane < row_hi ? (long long)rec_off[first + lane] : 0ll; };
+    const auto lane_i32 = [](int v, int i) { return __builtin_amdgcn_readlane(v, i); };
+    const auto lane_i64 = [](long long v, int i) {
+        const unsigned int lo = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)v, i);
+        const unsigned int hi = (unsigned int)__builtin_amdgcn_readlane((int)(unsigned int)((unsigned long long)v >> 32), i);
+        return (long long)(((unsigned long long)hi << 32) | lo);
+    };
+    int nd_v = meta_nd(row_lo), nd_v2 = 0;
+    long long off_v = meta_off(row_lo), off_v2 = 0;
+    unsigned int q[QW_K];
+    double pt[4];
+    load_row(lane_i64(off_v, 0), lane_i32(nd_v, 0), q, pt);
+    int nq_v = 0;                                          // lane i: what row first + i got
+    long long at_v = 0;
+    for (int64_t first = row_lo; first < row_hi; first += 64) {
+        nd_v2 = meta_nd(first + 64);                       // (back long before the chunk's last row asks for them)
+        off_v2 = meta_off(first + 64);
+        const int rows_here = row_hi - first < 64 ? (int)(row_hi - first) : 64;
+        for (int i = 0; i < rows_here; ++i) {
+            const int nd = lane_i32(nd_v, i);
+            const int nd_nx = i + 1 < 64 ? lane_i32(nd_v, (i + 1) & 63) : lane_i32(nd_v2, 0);     // (0 past the wave's last row)
+            const long long off_nx = i + 1 < 64 ? lane_i64(off_v, (i + 1) & 63) : lane_i64(off_v2, 0);
+            int n_out = 0;
+            long long at_out = 0;
+            // (the lane number made opaque once per row: what is derived from it -- 24 indices, 24 predicates, 24 addresses
+            // -- is otherwise kept in registers across the whole row loop)
+            asm volatile("" : "+v"(lane));
+            int h4 = H >> 2, nqc_r = nqc;                  // (the same for the 24 rounds' uniform conditions)
+            asm volatile("" : "+s"(h4), "+s"(nqc_r));
+            do {                                           // (one pass: `break` = the row keeps no quads)
+                if (!codes_ok(nd)) {                       // uniform: wide rows and rows without a record have no quads
+                    load_row(off_nx, nd_nx, q, pt);
+                    break;
+                }
+                wave_lds_fence();                          // (the row before is done with the arrays)
+                quad_static_for<QW_HASH / 64>([&](auto Z) { s_tab[lane + 64 * decltype(Z)::value] = 0ull; });
+                quad_static_for<4>([&](auto M) { s_ptab[lane + 64 * decltype(M)::value] = pt[decltype(M)::value]; });
+                wave_lds_fence();
+                int n = 0;                                 // distinct quads so far (uniform)
+                quad_static_for<QW_K>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    if (64 * k < nqc_r && n <= QUAD_MAX) { // uniform
+                        const int idx = lane + 64 * k;
+                        bool fresh = false;
+                        if (idx < nqc) {
+                            unsigned int key = q[k];
+                            const int c0 = idx * 4;        // columns past H (ldc - H <= 7 of them): code 0
+                            if (64 * k + 64 >= h4) {       // uniform, false for all rounds but the last
+                                asm volatile("");          // (a branch, not twelve instructions with no lane enabled)
+                                if (c0 + 0 >= H) key &= ~0x000000ffu;
+                                if (c0 + 1 >= H) key &= ~0x0000ff00u;
+                                if (c0 + 2 >= H) key &= ~0x00ff0000u;
+                                if (c0 + 3 >= H) key &= ~0xff000000u;
+                            }
+                            const unsigned long long tagged = (1ull << 32) | key;
+                            unsigned int slot = (key * 2654435761u) >> 23;       // 9 bits
+                            for (;;) {                     // (ends: the table holds at most 256 + 64 of 512)
+                                // most of a row's quads are ONE quad: look before the atomic
+                                unsigned long long old = __hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (old == 0ull) old = atomicCAS(&s_tab[slot], 0ull, tagged);
+                                if (old == 0ull) {
+                                    fresh = true;
+                                    break;
+                                }
+                                if (old == tagged) break;
+                                slot = (slot + 1) & (QW_HASH - 1);
+                            }
+                            q[k] = slot;                   // from here on the lane only needs where its quad sits
+                        }
+                        n += __popcll(__ballot(fresh));
+                    }
+                });
+                // where the lane's quads sit, two to a register, so that the code words of the NEXT row can be on their
+                // way while this row is ranked and written
+                unsigned int where[QW_K / 2];
+                quad_static_for<QW_K / 2>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    where[k] = q[2 * k] | (q[2 * k + 1] << 16);
+                });
+                asm volatile("" : "+v"(lane));
+                load_row(off_nx, nd_nx, q, pt);
+                asm volatile("" : "+v"(lane));
+                if (n > QUAD_MAX) {
+                    if (lane == 0) atomicAdd(&stats[1], 1ull);
+                    break;
+                }
+                wave_lds_fence();
+                // the distinct quads in slot order, then each counts the smaller ones: its rank is its code
+                int cnt = 0;
+                unsigned long long held[QW_HASH / 64];
+                quad_static_for<QW_HASH / 64>([&](auto Z) { held[decltype(Z)::value] = s_tab[lane + 64 * decltype(Z)::value]; });
+                wave_lds_fence();                          // (the lists below are written where the table was)
+                quad_static_for<QW_HASH / 64>([&](auto Z) {
+                    constexpr int z = decltype(Z)::value;
+                    const unsigned long long votes = __ballot(held[z] != 0ull);
+                    if (held[z] != 0ull) {
+                        // (mbcnt: the votes of the lanes below this one)
+                        const int at_i = cnt + (int)__builtin_amdgcn_mbcnt_hi((unsigned int)(votes >> 32),
+                                                                              __builtin_amdgcn_mbcnt_lo((unsigned int)votes, 0u));
+                        s_keys[at_i] = (unsigned int)held[z];
+                        s_slot[at_i] = (unsigned short)(lane + 64 * z);
+                    }
+                    cnt += __popcll(votes);
+                });
+                if (lane < 4) s_keys[cnt + lane] = 0xffffffffu;        // (smaller than nothing: the ranking reads four keys at a time)
+                wave_lds_fence();
+                unsigned int mine0 = (lane < n) ? s_keys[lane] : 0u, mine1 = (lane + 64 < n) ? s_keys[lane + 64] : 0u;
+                unsigned int mine2 = (lane + 128 < n) ? s_keys[lane + 128] : 0u, mine3 = (lane + 192 < n) ? s_keys[lane + 192] : 0u;
+                int rank0 = 0, rank1 = 0, rank2 = 0, rank3 = 0;
+                const quad_u4 *keys4 = reinterpret_cast<const quad_u4 *>(s_keys);
+                const int n4 = (n + 3) >> 2;
+                const auto smaller = [](quad_u4 kk, unsigned int me) {
+                    return ((kk.x < me) ? 1 : 0) + ((kk.y < me) ? 1 : 0) + ((kk.z < me) ? 1 : 0) + ((kk.w < me) ? 1 : 0);
+                };
+                if (n <= 64) {
+                    for (int j = 0; j < n4; ++j) rank0 += smaller(keys4[j], mine0);
+                } else if (n <= 128) {
+                    for (int j = 0; j < n4; ++j) {
+                        const quad_u4 kk = keys4[j];
+                        rank0 += smaller(kk, mine0);
+                        rank1 += smaller(kk, mine1);
+                    }
+                } else {
+                    for (int j = 0; j < n4; ++j) {
+                        const quad_u4 kk = keys4[j];
+                        rank0 += smaller(kk, mine0);
+                        rank1 += smaller(kk, mine1);
+                        rank2 += smaller(kk, mine2);
+                        rank3 += smaller(kk, mine3);
+                    }
+                }
+                const auto place = [&](int e, unsigned int me, int rk) {
+                    if (e < n) {
+                        s_rank[s_slot[e]] = (unsigned char)rk;
+                        s_sorted[rk] = me;
+                    }
+                };
+                place(lane, mine0, rank0);
+                place(lane + 64, mine1, rank1);
+                place(lane + 128, mine2, rank2);
+                place(lane + 192, mine3, rank3);
+                wave_lds_fence();
+                unsigned long long word[4] = {0ull, 0ull, 0ull, 0ull};
+                quad_static_for<QW_K>([&](auto K) {
+                    constexpr int k = decltype(K)::value;
+                    const unsigned int slot = (k & 1) ? (where[k >> 1] >> 16) : (where[k >> 1] & 0xffffu);
+                    if (lane + 64 * k < nqc) word[k & 3] |= (unsigned long long)s_rank[slot] << (8 * (k >> 2));
+                });
+                const unsigned long long bytes = QUAD_CODE_BYTES + 32ull * (unsigned long long)n;
+                if (chunk_left < bytes) {                  // uniform: one global atomic per QUAD_CHUNK bytes and wave
+                    const unsigned long long grab = bytes > QUAD_CHUNK ? bytes : QUAD_CHUNK;
+                    unsigned long long got = 0ull;
+                    if (lane == 0) got = atomicAdd(&stats[0], grab);
+                    const unsigned int lo = __builtin_amdgcn_readfirstlane((unsigned int)got);
+                    const unsigned int hi = __builtin_amdgcn_readfirstlane((unsigned int)(got >> 32));
+                    chunk_at = ((unsigned long long)hi << 32) | lo;
+                    chunk_left = grab;
+                }
+                const unsigned long long at = chunk_at;
+                chunk_at += bytes;
+                chunk_left -= bytes;
+                if (at + bytes > qcap) {                   // uniform: no room left in `qrec` (the caller sees stats[0] > capacity)
+                    if (lane == 0) atomicAdd(&stats[1], 1ull);
+                    break;
+                }
+                quad_static_for<4>([&](auto M) {
+                    constexpr int m = decltype(M)::value;
+                    *reinterpret_cast<unsigned long long *>(qrec + at + (unsigned long long)(lane + 64 * m) * 8ull) = word[m];
+                });
+                quad_static_for<4>([&](auto M) {
+                    constexpr int m = decltype(M)::value;
+                    if (lane + 64 * m < n) {
+                        const unsigned int key = s_sorted[lane + 64 * m];
+                        quad_d2 *dst = reinterpret_cast<quad_d2 *>(qrec + at + QUAD_CODE_BYTES + (unsigned long long)(lane + 64 * m) * 32ull);
+                        dst[0] = quad_d2{s_ptab[key & 255u], s_ptab[(key >> 8) & 255u]};
+                        dst[1] = quad_d2{s_ptab[(key >> 16) & 255u], s_ptab[key >> 24]};
+                    }
+                });
+                n_out = n;
+                at_out = (long long)at;
+            } while (false);
+            if (lane == i) {
+                nq_v = n_out;
+                at_v = at_out;
+            }
+        }
+        if (lane < rows_here) {
+            nquad[first + lane] = nq_v;
+            qoff[first + lane] = at_v;
+        }
+        nd_v = nd_v2;
+        off_v = off_v2;
     }
 }
 

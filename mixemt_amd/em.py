@@ -273,9 +273,12 @@ class EmPlan(object):
         ldc = (self.n_haps + 7) // 8 * 8
         if n_byte == 0 or ldc // 4 > 6 * 256:         # (the quad pass is instantiated up to H = 6144)
             return False
-        # room for 112 quads per row (mean on build_em_matrix rows: 93) + the 64 KB chunk every workgroup of the encoder may
-        # leave half empty at the end
-        guess = n_byte * (2048 + 32 * 112) + min(self.n_rows, 4096) * 65536 + (1 << 20)
+        # room for >= 112 quads per row (mean on build_em_matrix rows: 93) + the 64 KB chunk every wave of the encoder (at most
+        # 5120 of them) may leave half empty at the end
+        # (a row's distinct quads go with its table entries: ~2 per entry on 150-bp reads -- 44 entries, 93 quads -- and on
+        # merged pairs alike; a flat 112 made every paired-end build overflow and run twice)
+        per_row = int(min(256, max(112, 2.3 * float(nd_h[byte_coded].mean()) + 12)))
+        guess = n_byte * (2048 + 32 * per_row) + min(self.n_rows, 5120) * 65536 + (1 << 20)
         if mode == "auto":
             # by the card's TOTAL memory, not by what happens to be free: which loop runs decides the last bits of the sums
             # (fixed orders, but different ones), and the same call must take the same route every time
@@ -344,20 +347,39 @@ class EmPlan(object):
         self.coded.qrec, self.coded.qoff, self.coded.nquad = qrec.data_ptr(), qoff.data_ptr(), nquad.data_ptr()
         self.coded.quad_rows, self.coded.n_quad_rows = quad_rows_d.data_ptr(), n_quad
         self.coded.byte_rows, self.coded.n_byte_rows = (byte_rows_d.data_ptr() if n_byte_left else None), n_byte_left
-        # what an iteration reads now: the quad records, and of the records only the rows without quads (codes + P table)
-        nq_h = nquad.cpu().numpy()
-        left = byte_coded & (nq_h == 0)
-        wide_h = nd_h > 256
-        rec_left = int((ldc + 8 * nd_h[left].astype(numpy.int64)).sum() + (2 * ldc + 8 * nd_h[wide_h].astype(numpy.int64)).sum())
-        lap("byte counts (host)")
-        quad_rows = quad_rows_d                       # (len() below)
         if laps is not None:
+            laps["quads per row (room for / used, table entries)"] = "%d / %.1f, %.1f" % (
+                per_row, (used / max(1, n_quad) - 2048) / 32.0, float(nd_h[byte_coded].mean()))
             sys.stderr.write("[attach_quads] %s\n" % laps)
-        quad_exact = int((2048 + 32 * nq_h[nq_h > 0].astype(numpy.int64)).sum())       # (`used` includes the allocator's slack)
-        self.quad_rows_n, self.quad_bytes = len(quad_rows), quad_exact
-        self.coded_record_bytes = quad_exact + rec_left
-        self.coded_bytes = self.coded_record_bytes + self.coded_rest * self.n_haps * 8
+        self.quad_rows_n = n_quad
+        # what an iteration reads now -- the quad records, and of the records only the rows without quads (codes + P table):
+        # reporting figures (bench.py, the tools), counted from nquad on the host when somebody asks; the plan itself does
+        # not need them (1.3 ms of a 12 ms plan stage at 10^6 rows)
+        rest_bytes = self.coded_rest * self.n_haps * 8
+
+        def account():
+            nq_h = nquad.cpu().numpy()
+            left = byte_coded & (nq_h == 0)
+            wide_h = nd_h > 256
+            rec_left = int((ldc + 8 * nd_h[left].astype(numpy.int64)).sum() + (2 * ldc + 8 * nd_h[wide_h].astype(numpy.int64)).sum())
+            quad_exact = int((2048 + 32 * nq_h[nq_h > 0].astype(numpy.int64)).sum())   # (`used` includes the allocator's slack)
+            return {"quad_bytes": quad_exact, "coded_record_bytes": quad_exact + rec_left,
+                    "coded_bytes": quad_exact + rec_left + rest_bytes}
+
+        self._accounting = account
+        for name in ("quad_bytes", "coded_record_bytes", "coded_bytes"):
+            self.__dict__.pop(name, None)             # (the records' own figures: replaced by the ones counted on demand)
         return True
+
+    def __getattr__(self, name):
+        # quad_bytes / coded_record_bytes / coded_bytes after attach_quads: counted on first use (see there)
+        if name in ("quad_bytes", "coded_record_bytes", "coded_bytes"):
+            account = self.__dict__.get("_accounting")
+            if account is not None:
+                self.__dict__.update(account())
+                self.__dict__["_accounting"] = None
+                return self.__dict__[name]
+        raise AttributeError(name)
 
     def encode(self):
         """Row-dictionary form of this plan's matrix (mxm_encode_rows) + the dense rest."""

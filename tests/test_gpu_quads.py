@@ -374,3 +374,40 @@ def test_the_bare_reader_of_the_quad_records(b17):
     assert torch.equal(qrec, plan._quad_keep[0]) and int(sink.abs().sum()) == 0
     assert numpy.array_equal(_iterate(plan, props)[0][0], before)
     assert lib.mxm_diag_stream_quads(ctypes.byref(plan.coded), plan.n_haps, 0, sink.data_ptr(), current_stream()) == -1
+
+
+def _quad_blobs(plan):
+    qrec, qoff, nquad = (x.cpu().numpy() for x in plan._quad_keep[:3])
+    return nquad, {int(r): qrec[int(qoff[r]):int(qoff[r]) + 2048 + 32 * int(nquad[r])].copy() for r in numpy.flatnonzero(nquad > 0)}
+
+
+@pytest.mark.parametrize("n_cols,n_rows,read_len", [(None, 2600, 150), (None, 700, 260), (2050, 900, 150), (130, 300, 600), (1021, 5, 150)])
+def test_the_two_encoders_write_the_same_records(b17, n_cols, n_rows, read_len):
+    """mxm_set_quad_encoder: a wave per row (default, round 6) against a workgroup per row -- nquad for every row and every
+    quad record byte for byte (codes = ranks by value: nothing depends on which lane won a hash slot); full width, narrow
+    and odd tables (rounds past the row's last quad, pad columns inside the last quad), fewer rows than waves."""
+    from mixemt_amd import _lib, em, phylotree, preprocess, synth
+    refseq, phy, haps, tables = b17
+    if n_cols is not None:
+        tables = preprocess.HapVarTables.build(refseq, phy, haps[400:400 + n_cols])
+    width = len(haps) if n_cols is None else n_cols
+    row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), n_rows, seed=n_rows, read_len=read_len,
+                                              contrib=(0, width // 2, width - 1))
+    cm = preprocess.build_em_records_device(tables, row_ptr, site, obs)
+    lib = _lib.load()
+    got = {}
+    try:
+        for kind in (0, 1):
+            _lib.check(lib.mxm_set_quad_encoder(kind), "mxm_set_quad_encoder")
+            plan = em.EmPlan(None, numpy.ones(n_rows), records=cm)
+            attached = plan.attach_quads(True)
+            got[kind] = _quad_blobs(plan) if attached else (None, {})
+    finally:
+        lib.mxm_set_quad_encoder(1)
+    assert lib.mxm_set_quad_encoder(2) != 0
+    assert (got[0][0] is None) == (got[1][0] is None)
+    if got[0][0] is not None:
+        assert numpy.array_equal(got[0][0], got[1][0])
+        assert len(got[0][1]) > 0 and got[0][1].keys() == got[1][1].keys()
+        for r, blob in got[0][1].items():
+            assert numpy.array_equal(blob, got[1][1][r]), r
