@@ -257,8 +257,9 @@ class EmPlan(object):
         mode: True / False / "auto" (None = QUADS): auto builds them from QUADS_MIN_ROWS byte-coded rows while records +
         dictionary stay under QUADS_MAX_FOOTPRINT.  Measured at 10^6 x 5408 (profiles/r05/quads_product_1m.txt,
         pipeline_1m_records_quads.txt): the step 1.46 -> 1.32 ms, run_em's loop 1.44 (one-launch loop over the records) ->
-        1.35 ms per iteration (the per-iteration kernels), the build 11 ms cold or warm (encoder 8.6 ms; the row lists are
-        formed on the device): a restart of ~400 iterations gains 35 ms for it.
+        1.35 ms per iteration (the per-iteration kernels), the build 11 ms cold or warm in round 5 (encoder 8.6 ms; the row
+        lists are formed on the device) and 4.3 ms since round 6 (a wave per row: 3.5 ms): a restart of ~400 iterations gains
+        35 ms for it.
         cap: bytes of the first buffer (default: room for 112 quads per row; the kernel counts what it needs and an
         overflow repeats the build once with exactly that much).
         """
