@@ -9,7 +9,7 @@ from mixemt_amd import _lib, em, phylotree, preprocess, synth
 refseq = phylotree.load_rsrs(); phy = phylotree.load_build17(refseq); haps = sorted(phy.hap_var)
 tables = preprocess.HapVarTables.build(refseq, phy, haps)
 rows = 1000000
-row_ptr, site, obs, _ = synth.synth_reads(tables, len(refseq), rows, seed=1)
+row_ptr, site, obs, _ = synth.synth_rows(tables, len(refseq), 0, rows, seed=1, pairs="--pairs" in sys.argv)
 torch.zeros(1, device="cuda"); _lib.load(); torch.cuda.synchronize()
 tables.sparse_device(); tables.lut_device(); torch.cuda.synchronize()
 T0 = time.perf_counter()
@@ -24,7 +24,7 @@ def wrap(obj, name):
         return r
     setattr(obj, name, inner)
 wrap(em, "_workspace"); wrap(em.EmPlan, "attach_quads"); wrap(preprocess.CodedMatrix, "ndist_host"); wrap(preprocess.CodedMatrix, "wide_rows")
-wrap(em, "device_empty")
+wrap(em, "device_empty"); wrap(em.EmPlan, "encode") if hasattr(em.EmPlan, "encode") else None
 wts = torch.ones(rows, dtype=torch.float64, device="cuda")
 stamp("build records")
 cm = preprocess.build_em_records_device(tables, row_ptr, site, obs)

@@ -124,6 +124,8 @@ python3 $repo/tools/time_frontend.py > $out/frontend_1m.txt 2>&1
 echo "[profile_round] step 42 done"
 python3 $repo/tools/run_pipeline.py --reads 1000000 --alignments > $out/pipeline_1m_alignments.txt 2>&1
 echo "[profile_round] step 43 done"
+# (the experiment's own library: built here when the snapshot did not bring it)
+[ -f $repo/tools/experiments/_build/libcoded3.so ] || { mkdir -p $repo/tools/experiments/_build && /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -shared -fPIC -I $repo/include -I $repo/mixemt_amd/csrc $repo/tools/experiments/coded3_experiment.hip -o $repo/tools/experiments/_build/libcoded3.so; }
 python3 $repo/tools/experiments/time_coded3.py 1000000 > $out/row_pass_experiments.txt 2>&1
 echo "[profile_round] step 44 done"
 fi
