@@ -22,7 +22,8 @@ for f in bench_1m.json bench_1m_under_rocprof.json bench_1m_10restarts.json benc
          bench_125k_records_one_rank_rccl.json bench_125k_records_one_rank_oneshot.json exchange_tests.txt \
          quads_batched_1m.txt bench_1m_coded_10restarts_48steps.json quads_step_1m.txt pipeline_1m_pe.txt pipeline_1m_250bp.txt \
          pipeline_1m_pe_under_rocprof.txt build_kernels_pe.txt build_kernels_250bp.txt build_kernel_alone_pe.txt \
-         build_pe_pmc_sq_summary.txt config5_one_rank.txt stress_parity_606.txt; do
+         build_pe_pmc_sq_summary.txt config5_one_rank.txt stress_parity_606.txt \
+         ab_quad_encoder_1m.txt ab_quad_encoder_pe.txt quad_encoder_pmc_sq_summary.txt loop_gaps_1m.txt pipeline_1m_records_under_rocprof.txt; do
   [ -f $src/$f ] && cp $src/$f $dst/$f
 done
 [ -f $src/bench_1m.log ] && cp $src/bench_1m.log $dst/bench_1m.log

@@ -149,5 +149,13 @@ python3 $repo/tools/time_config5_one_rank.py > $out/config5_one_rank.txt 2>&1
 echo "[profile_round] step 50 done"
 python3 $repo/tools/stress_parity.py --seed 606 --budget 420 > $out/stress_parity_606.txt 2>&1
 echo "[profile_round] step 51 done"
+# --- the quad dictionary's two encoders (a workgroup / a wave per row), their counters, and the loop's idle gaps --------------
+python3 $repo/tools/ab_quad_encoder.py > $out/ab_quad_encoder_1m.txt 2>&1
+python3 $repo/tools/ab_quad_encoder.py --pairs > $out/ab_quad_encoder_pe.txt 2>&1
+rocprofv3 --output-format csv --kernel-trace --pmc SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE GRBM_GUI_ACTIVE -d $out/pmc_sq_qenc -o sq -- python3 $repo/tools/ab_quad_encoder.py > /dev/null 2> $out/pmc_sq_qenc.log
+python3 $repo/tools/sq_summary.py $out/pmc_sq_qenc/sq_counter_collection.csv > $out/quad_encoder_pmc_sq_summary.txt 2>&1
+rocprofv3 --output-format csv --kernel-trace -d $out/kt_loop -o kt -- python3 $repo/tools/run_pipeline.py --reads 1000000 > $out/pipeline_1m_records_under_rocprof.txt 2> $out/kt_loop.log
+python3 $repo/tools/loop_gaps.py $(find $out/kt_loop -name "kt_kernel_trace.csv" | head -1) > $out/loop_gaps_1m.txt 2>&1
+echo "[profile_round] step 52 done"
 fi
 find $out -name "*.csv" | head -60
