@@ -315,7 +315,8 @@ size_t mxm_coded_bytes(int64_t R, int32_t H);
  *                    nquad = 0: repeat with stats[0] bytes and some room to spare),
  *                    stats[1] = byte-coded rows left without quads (device uint64[2], zeroed by the call).  qrec must be
  *                    32-byte aligned.  The caller forms quad_rows / byte_rows from nquad and ndist.
- * mxm_quad_bytes     a buffer size that can never overflow: R * (2048 + 256 * 32)
+ * mxm_quad_bytes     a buffer size that can never overflow: 64 KB pieces of at least six largest records (2048 + 256 * 32
+ *                    bytes) each, + the 5120 pieces that may be open at the end
  */
 size_t mxm_quad_bytes(int64_t R, int32_t H);
 /* mxm_quad_lists     the two row lists from ndist / nquad, on the device, ASCENDING: quad_rows[R] / byte_rows[R] (room for

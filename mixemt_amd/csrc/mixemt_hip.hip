@@ -942,7 +942,11 @@ static int coded_check(const mxm_coded *c, int32_t H, const char *who) {
 
 extern "C" size_t mxm_quad_bytes(int64_t R, int32_t H) {
     (void)H;
-    return R > 0 ? (size_t)R * (size_t)(QUAD_CODE_BYTES + QUAD_MAX * 32) : 0;
+    // the encoders hand `qrec` out in pieces of QUAD_CHUNK bytes: a piece holds at least six records of the largest size
+    // (2048 + 256 x 32 bytes) and at most 5120 pieces are open -- reserved, partly unused -- when the call ends
+    // (R x the largest record alone, the figure until round 6, left the pieces' tails out)
+    constexpr size_t largest = QUAD_CODE_BYTES + QUAD_MAX * 32, per_piece = (size_t)QUAD_CHUNK / largest;
+    return R > 0 ? (((size_t)R + per_piece - 1) / per_piece + 5120) * (size_t)QUAD_CHUNK : 0;
 }
 
 extern "C" int mxm_expand_tables(const uint8_t *maj, const int32_t *mk_ptr, const uint16_t *mk_hap, const uint8_t *mk_base,

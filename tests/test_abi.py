@@ -57,6 +57,11 @@ def test_binding_table_matches_header(lib_path):
     assert lib.mxm_linear_supported(5408) == 1 and lib.mxm_linear_supported(3) == 0
     assert lib.mxm_linear_supported(8192) == 1 and lib.mxm_linear_supported(8193) == 0
     assert lib.mxm_workspace_bytes(1000000, 5408, 1) >= 1024 * 5408 * 8
+    # the quad dictionary's never-overflows size counts the 64 KB pieces the encoder hands out (six of the largest records
+    # fit one; 5120 may be open at the end), not the records alone
+    for rows in (1, 7, 1000000):
+        assert lib.mxm_quad_bytes(rows, 5408) >= (-(-rows // 6) + 5120) * 65536 > rows * (2048 + 256 * 32)
+    assert lib.mxm_quad_bytes(0, 5408) == 0
 
 
 def test_binding_refuses_a_library_of_another_abi_version(lib_path, monkeypatch):
@@ -73,6 +78,7 @@ def test_tuning_knobs_reset_and_take_their_ranges(lib_path):
     from mixemt_amd import _lib
     lib = _lib.load()
     assert lib.mxm_set_batch_tile(7) < 0 and lib.mxm_set_batch_tile(2) == 0
+    assert lib.mxm_set_quad_encoder(2) < 0 and lib.mxm_set_quad_encoder(0) == 0 and lib.mxm_set_quad_encoder(1) == 0
     assert lib.mxm_restart_tile(5408) == 2
     assert lib.mxm_reset_tuning() == 0
     assert lib.mxm_restart_tile(5408) == 4
