@@ -394,16 +394,18 @@ __global__ __launch_bounds__(QUAD_THREADS, QW_MIN_WAVES) void quad_encode_wave_k
                             }
                             const unsigned long long tagged = (1ull << 32) | key;
                             unsigned int slot = (key * 2654435761u) >> 23;       // 9 bits
-                            for (;;) {                     // (ends: the table holds at most 256 + 64 of 512)
-                                // most of a row's quads are ONE quad: look before the atomic
-                                unsigned long long old = __hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
-                                if (old == 0ull) old = atomicCAS(&s_tab[slot], 0ull, tagged);
-                                if (old == 0ull) {
-                                    fresh = true;
-                                    break;
-                                }
-                                if (old == tagged) break;
+                            // the first look straight-line: most of a row's quads are ONE quad (look before the atomic), and
+                            // a table a fifth full rarely needs a second probe -- the loop below is skipped by most rounds
+                            unsigned long long old = __hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                            if (old == 0ull) old = atomicCAS(&s_tab[slot], 0ull, tagged);
+                            fresh = old == 0ull;
+                            bool more = !fresh && old != tagged;
+                            while (more) {                 // (ends: the table holds at most 256 + 64 of 512)
                                 slot = (slot + 1) & (QW_HASH - 1);
+                                old = __hip_atomic_load(&s_tab[slot], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+                                if (old == 0ull) old = atomicCAS(&s_tab[slot], 0ull, tagged);
+                                fresh = old == 0ull;
+                                more = !fresh && old != tagged;
                             }
                             q[k] = slot;                   // from here on the lane only needs where its quad sits
                         }
