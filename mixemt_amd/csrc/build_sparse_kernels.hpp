@@ -130,11 +130,18 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
     if (t == 0) s_flag = 0;
 
     auto do_row = [&](const int64_t r) {
+        // the thread's number, in the long rows' instance opaque once per row: what is derived from it and from the kernel's
+        // arguments alone (three predicates per column chunk: `h < H`, `h + 1 < H`, `h < ldc`) is otherwise computed before
+        // the row loop and KEPT -- scalar registers parked in vector lanes and read back by v_readlane pairs in front of
+        // every store (137 -> 13 spilled SGPRs in the short rows' record instance, which nevertheless ran 4 % SLOWER with it:
+        // 16.4 -> 17.1 ms; the long rows' 38.4 -> 37.6 ms on fragments: profiles/r06/opaque_thread_index_ab.txt)
+        int tr = t;
+        if constexpr (W > 1) asm volatile("" : "+v"(tr));
         const int64_t beg = row_ptr[r];
         const int64_t n64 = row_ptr[r + 1] - beg;
         if (n64 > MAXN) {                                   // uniform: the whole workgroup skips the row
             if (W == 1 && long_follows != 0) return;        // (the long rows' launch takes it, or hands it to the fallback list)
-            if (t == 0) {
+            if (tr == 0) {
                 fallback[atomicAdd(n_fallback, 1ull)] = r;
                 no_record(r);
             }
@@ -142,11 +149,11 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
         }
         const int n = (int)n64;
         // ---- 1. the row's term lists -----------------------------------------------------------------
-        if (t < 64) {                                        // wave 0, lane j = observation j (W = 2: and j + 64)
+        if (tr < 64) {                                        // wave 0, lane j = observation j (W = 2: and j + 64)
             int carry = 0;
 #pragma unroll
             for (int j0 = 0; j0 < MAXN; j0 += 64) {
-                const int j = j0 + t;
+                const int j = j0 + tr;
                 int len = 0;
                 if (j < n) {
                     const int s0 = site[beg + j];
@@ -164,7 +171,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
                 s_cum[j + 1] = incl;
                 if constexpr (W > 1) carry = __builtin_amdgcn_readlane(incl, 63);
             }
-            if (t == 0) s_cum[0] = 0;
+            if (tr == 0) s_cum[0] = 0;
         }
         __syncthreads();
         const int total = s_cum[n];
@@ -172,7 +179,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
             // a long row over the control region: thousands of marker entries (rows of 65+ sites among 150-bp reads: 6000-12000)
             // -- the cell-by-cell kernel, whose cost does not depend on them, is the faster one there
             __syncthreads();                                 // (everyone has read the row's total before wave 0 moves on)
-            if (t == 0) {
+            if (tr == 0) {
                 fallback[atomicAdd(n_fallback, 1ull)] = r;
                 no_record(r);
             }
@@ -201,7 +208,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
             // masked (a median row keeps 600 of its 1024 / 1500 of its 4096 slots)
             int lo = 0;
             {
-                const int e = e_per * t;
+                const int e = e_per * tr;
                 int hi = n;
                 if (e < tot_c) {
                     while (hi - lo > 1) {
@@ -219,7 +226,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
 #pragma unroll
             for (int u = 0; u < GATHER; ++u) {
                 if (u >= e_per) break;                      // uniform
-                const int e = e_per * t + u;
+                const int e = e_per * tr + u;
                 if (e < tot_c) {
                     while (s_cum[lo + 1] <= e) ++lo;        // e < total = s_cum[n]: stops at lo < n
                 }
@@ -264,7 +271,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
             // by walking on from lo_keep -- a binary search per entry and column range was most of a long row's time:
             // rows over the control region hold 6000-12000 entries, profiles/r06/build_long_rows.txt)
             int lo = lo_keep;
-            for (int e0 = t + SPB_THREADS * GATHER; e0 < total; e0 += SPB_THREADS * GATHER) {
+            for (int e0 = tr + SPB_THREADS * GATHER; e0 < total; e0 += SPB_THREADS * GATHER) {
                 int jj[GATHER];
                 unsigned int hap[GATHER], base[GATHER];
 #pragma unroll
@@ -295,7 +302,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
                 // the thread's two haplogroups are neighbours: both masks in one 16-byte read, zeroed by one write;
                 // the second one takes the first one's slot when they are equal (haplogroups of one clade)
                 typedef unsigned long long ull2 __attribute__((ext_vector_type(2)));
-                const int h0 = 2 * (t + k * SPB_THREADS);
+                const int h0 = 2 * (tr + k * SPB_THREADS);
                 ull2 both = {0ull, 0ull};
                 if (h0 < H) {
                     both = *reinterpret_cast<const ull2 *>(&s_dev[h0 - h_lo]);
@@ -305,7 +312,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
                 int sl_pair[2];
 #pragma unroll
                 for (int e = 0; e < 2; ++e) {
-                    const int h = 2 * (t + k * SPB_THREADS) + e;
+                    const int h = 2 * (tr + k * SPB_THREADS) + e;
                     int sl = -1;
                     if (h < H) {
                         const unsigned long long mask = e == 0 ? both.x : both.y;
@@ -345,7 +352,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
                 for (int e = 0; e < 2; ++e) {
                     keep[kq][e] = ull2{0ull, 0ull};
                     mine_claim[kq][e] = true;
-                    const int h = 2 * (t + k * SPB_THREADS) + e;
+                    const int h = 2 * (tr + k * SPB_THREADS) + e;
                     if (k < NCH && h < H) {
                         const ull2 m = *reinterpret_cast<const ull2 *>(&s_dev[(h - h_lo) * 2]);
                         if ((m.x | m.y) != 0ull) {
@@ -405,7 +412,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
         int cnt = 0;
 #pragma unroll
         for (int q = 0; q < SPT; ++q) {
-            kk[q] = s_key[SPT * t + q];
+            kk[q] = s_key[SPT * tr + q];
             cnt += (kk[q] != 0ull) ? 1 : 0;
         }
         const int incl = wave_inclusive_scan_i32(cnt);
@@ -428,8 +435,8 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
 #pragma unroll
             for (int q = 0; q < SPT; ++q) {
                 if (kk[q] != 0ull) {
-                    if constexpr (EMIT) s_code[SPT * t + q] = (unsigned short)(d + 1);
-                    s_list[d++] = (unsigned short)(SPT * t + q);
+                    if constexpr (EMIT) s_code[SPT * tr + q] = (unsigned short)(d + 1);
+                    s_list[d++] = (unsigned short)(SPT * tr + q);
                 }
             }
         }
@@ -437,8 +444,8 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
         if (bad) {
             // more distinct values than the table is sized for: clear it, hand the row to the cell-by-cell kernel
 #pragma unroll
-            for (int q = 0; q < SPT; ++q) s_key[SPT * t + q] = 0ull;
-            if (t == 0) {
+            for (int q = 0; q < SPT; ++q) s_key[SPT * tr + q] = 0ull;
+            if (tr == 0) {
                 fallback[atomicAdd(n_fallback, 1ull)] = r;
                 s_flag = 0;
                 no_record(r);
@@ -450,7 +457,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
         double wmax = -INFINITY;
 #pragma unroll
         for (int q = 0; q < (MAXD + SPB_THREADS - 1) / SPB_THREADS; ++q) {
-            const int d = t + q * SPB_THREADS;
+            const int d = tr + q * SPB_THREADS;
             double a = 0.0;
             if (d < D) {
                 if constexpr (W == 1) {
@@ -477,7 +484,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
             }
             mine[q] = a;
         }
-        if (t == SPB_THREADS - 1) {
+        if (tr == SPB_THREADS - 1) {
             double a = 0.0;
 #pragma unroll 4
             for (int j = 0; j < n; ++j) a += s_t2[j].x;
@@ -488,10 +495,10 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
             if (codable) {                                  // uniform
 #pragma unroll
                 for (int q = 0; q < (MAXD + SPB_THREADS - 1) / SPB_THREADS; ++q)
-                    if (t + q * SPB_THREADS < D) wmax = fmax(wmax, mine[q]);
+                    if (tr + q * SPB_THREADS < D) wmax = fmax(wmax, mine[q]);
                 wmax = wave_max(wmax);
                 if (lane == 0) s_wmax[wv] = wmax;
-                if (t == 0) {                               // the record: codes ++ P table ++ table of the sums
+                if (tr == 0) {                               // the record: codes ++ P table ++ table of the sums
                     const long long bytes = (long long)out.ldc * (wide_rec ? 2 : 1) + 16ll * (D + 1);
 #ifdef RECORDS_FIXED_SLOTS                                  // (timing experiment: no shared bump pointer)
                     long long off = (long long)r * ((long long)out.ldc + 16ll * (MAXD + 1));
@@ -506,7 +513,7 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
         __syncthreads();                                     // every mask has been read
 #pragma unroll
         for (int q = 0; q < (MAXD + SPB_THREADS - 1) / SPB_THREADS; ++q) {
-            const int d = t + q * SPB_THREADS;
+            const int d = tr + q * SPB_THREADS;
             if (d < D) s_key[s_list[d]] = (unsigned long long)__double_as_longlong(mine[q]);
         }
         __syncthreads();
@@ -520,13 +527,13 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
                 double *mtab = ptab + (D + 1);
 #pragma unroll
                 for (int q = 0; q < (MAXD + SPB_THREADS - 1) / SPB_THREADS; ++q) {
-                    const int d = t + q * SPB_THREADS;
+                    const int d = tr + q * SPB_THREADS;
                     if (d < D) {
                         ptab[d + 1] = exp(mine[q] - shift);
                         mtab[d + 1] = mine[q];
                     }
                 }
-                if (t == SPB_THREADS - 1) {
+                if (tr == SPB_THREADS - 1) {
                     ptab[0] = exp(sum0 - shift);
                     mtab[0] = sum0;
                 }
@@ -534,21 +541,21 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
                 unsigned int *cw32 = reinterpret_cast<unsigned int *>(out.rec + off);
 #pragma unroll
                 for (int k = 0; k < NCH; ++k) {
-                    const int h = 2 * (t + k * SPB_THREADS);
+                    const int h = 2 * (tr + k * SPB_THREADS);
                     if (h < out.ldc) {
                         const unsigned int sa = slot2[k] & 0xffffu, sb = slot2[k] >> 16;
                         const unsigned int c0 = (h < H && sa != 0xffffu) ? s_code[sa] : 0u;
                         const unsigned int c1 = (h + 1 < H && sb != 0xffffu) ? s_code[sb] : 0u;
-                        if (wide_rec) cw32[t + k * SPB_THREADS] = c0 | (c1 << 16);      // (uniform)
-                        else cw[t + k * SPB_THREADS] = (unsigned short)(c0 | (c1 << 8));
+                        if (wide_rec) cw32[tr + k * SPB_THREADS] = c0 | (c1 << 16);      // (uniform)
+                        else cw[tr + k * SPB_THREADS] = (unsigned short)(c0 | (c1 << 8));
                     }
                 }
-                if (t == 0) {
+                if (tr == 0) {
                     out.rec_off[r] = off;
                     out.ndist[r] = D + 1;
                     out.rowmax[r] = shift;
                 }
-            } else if (t == 0) {
+            } else if (tr == 0) {
                 no_record(r);                               // the record buffer is full: the dense row below is its form
             }
         }
@@ -565,15 +572,15 @@ __global__ __launch_bounds__(SPB_THREADS, (W > 1 ? 4 : (EMIT ? SPB_WAVES_EMIT : 
                 const double v0 = sa == 0xffffu ? sum0 : __longlong_as_double((long long)s_key[sa]);
                 const double v1 = sb == 0xffffu ? sum0 : __longlong_as_double((long long)s_key[sb]);
                 if (vec_ok && ((H & 1) == 0)) {
-                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(su4, d2{v0, v1}), mrs, t * 16, k * SPB_THREADS * 16, 2 /* nt */);
+                    __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(su4, d2{v0, v1}), mrs, tr * 16, k * SPB_THREADS * 16, 2 /* nt */);
                 } else {
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(su2, v0), mrs, t * 16, k * SPB_THREADS * 16, 0);
-                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(su2, v1), mrs, t * 16, k * SPB_THREADS * 16 + 8, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(su2, v0), mrs, tr * 16, k * SPB_THREADS * 16, 0);
+                    __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(su2, v1), mrs, tr * 16, k * SPB_THREADS * 16 + 8, 0);
                 }
             }
         }
         __syncthreads();                                     // everyone has its values: the table can be zeroed
-        for (int d = t; d < D; d += SPB_THREADS) s_key[s_list[d]] = 0ull;
+        for (int d = tr; d < D; d += SPB_THREADS) s_key[s_list[d]] = 0ull;
         __syncthreads();
     };
 
