@@ -180,19 +180,39 @@ class HapVarTables(object):
                 lde = self.expected.shape[1]
                 k_u, j_u = self._marker_flat // lde, self._marker_flat % lde
                 v_u = self.expected.reshape(-1)[self._marker_flat]
-                cnt = numpy.bincount(k_u * 256 + v_u, minlength=n_sites * 256).reshape(n_sites, 256)
-                cnt[numpy.arange(n_sites), self._ref_codes] += self.n_haps - numpy.bincount(k_u, minlength=n_sites)
-                maj = cnt.argmax(axis=1).astype(numpy.uint8)
+                # (the bytes that occur -- a handful -- numbered in ascending order: a histogram of n_sites x 8 instead of
+                # n_sites x 256 counters, and argmax still breaks ties towards the smallest byte)
+                present = numpy.zeros(256, dtype=bool)
+                present[v_u] = True
+                present[self._ref_codes] = True
+                alphabet = numpy.flatnonzero(present)
+                small = numpy.zeros(256, dtype=numpy.int64)
+                small[alphabet] = numpy.arange(alphabet.size)
+                n_a = int(alphabet.size)
+                cnt = numpy.bincount(k_u * n_a + small[v_u], minlength=n_sites * n_a).reshape(n_sites, n_a)
+                cnt[numpy.arange(n_sites), small[self._ref_codes]] += self.n_haps - numpy.bincount(k_u, minlength=n_sites)
+                maj = alphabet[cnt.argmax(axis=1)].astype(numpy.uint8)
                 keep = v_u != maj[k_u]
                 site_i, hap_i = k_u[keep], j_u[keep]
                 special = numpy.flatnonzero(maj != self._ref_codes)  # sites where most haplogroups carry a marker
                 if special.size:
-                    drop = numpy.isin(site_i, special)
+                    # their lists are the haplogroups that differ from the new majority; both lists are sorted by (site,
+                    # haplogroup) and a site is wholly in one of them: merged by counting, without a sort
+                    stay = ~numpy.isin(site_i, special)
+                    site_n, hap_n = site_i[stay], hap_i[stay]
                     xs, xh = numpy.nonzero(exp[special] != maj[special, None])
-                    site_i = numpy.concatenate([site_i[~drop], special[xs]])
-                    hap_i = numpy.concatenate([hap_i[~drop], xh])
-                    order = numpy.lexsort((hap_i, site_i))
-                    site_i, hap_i = site_i[order], hap_i[order]
+                    site_x = special[xs]
+                    before_n = numpy.zeros(n_sites + 1, dtype=numpy.int64)     # special-site entries in sites below s
+                    numpy.cumsum(numpy.bincount(site_x, minlength=n_sites), out=before_n[1:])
+                    before_x = numpy.zeros(n_sites + 1, dtype=numpy.int64)     # ordinary entries in sites below s
+                    numpy.cumsum(numpy.bincount(site_n, minlength=n_sites), out=before_x[1:])
+                    total = site_n.size + site_x.size
+                    site_i = numpy.empty(total, dtype=site_n.dtype)
+                    hap_i = numpy.empty(total, dtype=hap_n.dtype)
+                    at_n = numpy.arange(site_n.size) + before_n[site_n]
+                    at_x = numpy.arange(site_x.size) + before_x[site_x]
+                    site_i[at_n], hap_i[at_n] = site_n, hap_n
+                    site_i[at_x], hap_i[at_x] = site_x, xh
             else:
                 maj = numpy.zeros(n_sites, dtype=numpy.uint8)
                 for s in range(n_sites):
