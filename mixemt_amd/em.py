@@ -339,7 +339,7 @@ class EmPlan(object):
             return False
         #  run_em's loop only leaves the one-launch loop over the records for a dictionary of at least
         # mxm_quad_loop_min_rows() rows WITH quads -- "auto" decides by that same quantity, now that it is known, instead of
-        # keeping a dictionary (11 ms, 4.8 KB per row) the loop would never look at; a caller that named its own floor
+        # keeping a dictionary (4 ms, 4.8 KB per row) the loop would never look at; a caller that named its own floor
         # (dist.sharded_em_loop: its only loop is the per-iteration kernels) keeps what it asked for
         if mode == "auto" and min_rows is None and n_quad < int(lib.mxm_quad_loop_min_rows(int(getattr(self, "n_runs", 1)))):
             return False
