@@ -232,7 +232,15 @@ class EmPlan(object):
             _lib.check(self.lib.mxm_linearize(cm.m_rest.data_ptr(), cm.m_rest.stride(0), n_rest, self.n_haps,
                                               p_rest.data_ptr(), p_rest.stride(0), rm.data_ptr(), current_stream()),
                        "mxm_linearize")
-            w_rest = self.wts.index_select(0, cm.rest_rows).contiguous()
+            # the rest rows' weights: the library's own column gather over the weights as a 1 x R matrix (a torch
+            # index_select here was the operator's first use in the process: ~5 ms of a paired-end plan's 14)
+            if self.n_rows < 2 ** 31:
+                cols = torch.from_numpy(cm.rest_rows.cpu().numpy().astype(numpy.int32)).to(self.dev)
+                w_rest = torch.empty(n_rest, dtype=torch.float64, device=self.dev)
+                _lib.check(self.lib.mxm_gather_columns(self.wts.data_ptr(), self.n_rows, 1, self.n_rows, cols.data_ptr(), n_rest,
+                                                       w_rest.data_ptr(), n_rest, current_stream()), "mxm_gather_columns")
+            else:
+                w_rest = self.wts.index_select(0, cm.rest_rows).contiguous()
         self.coded_record_bytes = cm.used - 8 * int(cm.ndist_host().sum(dtype=numpy.int64))     # codes + P tables: the loop's read
         self.coded_bytes = self.coded_record_bytes + n_rest * self.n_haps * 8
         self.coded_rest = n_rest
